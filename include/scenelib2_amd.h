@@ -1,0 +1,225 @@
+/*
+ * scenelib2_amd — C ABI of the MI355X-native MonoSLAM per-frame engine.
+ *
+ * The reference (hanmekim/SceneLib2) has no plugin/FFI layer: its boundary is the
+ * public C++ class SceneLib2::MonoSLAM (scenelib2/monoslam.h:69-219) used by
+ * examples/MonoSlamSceneLib1.cpp:132-142.  This header is the C-ABI a maintainer
+ * binds instead: plain pointers and sizes, int status codes,
+ * no exceptions, no torch/Eigen/OpenCV types.  Each entry point cites the
+ * reference interface it replaces (paths relative to the reference's scenelib2/).
+ *
+ * One engine = B independent image sequences ("batch"), each an independent
+ * MonoSLAM instance with its own state vector, covariance, map and templates,
+ * stepped together on one HIP stream of one GPU.  All *_dev pointers are device
+ * pointers valid on the engine's device; host pointers are plain host memory.
+ * All matrices crossing the ABI are row-major FP64 unless stated.
+ *
+ * Threading: one engine per host thread / stream; calls are asynchronous on the
+ * engine's stream unless they return data to host memory (those synchronise).
+ */
+#ifndef SCENELIB2_AMD_H
+#define SCENELIB2_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SL2_OK 0
+#define SL2_ERR_INVALID 1   /* bad argument */
+#define SL2_ERR_HIP 2       /* HIP runtime error (sl2_last_error() has the text) */
+#define SL2_ERR_CAPACITY 3  /* feature / batch capacity exceeded */
+#define SL2_ERR_NO_DEVICE 4 /* no HIP device: the engine has NO CPU fallback */
+
+#define SL2_STATE_SIZE 13    /* MotionModel::kStateSize_, motion_model.cpp:44 */
+#define SL2_POSITION_SIZE 7  /* MotionModel::kPositionStateSize_ */
+#define SL2_PATCH_SIZE 11    /* MonoSLAM::kBoxSize_, monoslam.cpp:48 */
+#define SL2_PATCH_BYTES 121
+
+typedef struct sl2_engine sl2_engine;
+
+/* Camera::SetCameraParameters(width,height,fku,fkv,u0,v0,kd1,sd) — camera.cpp:49-62.
+ * cfg keys cam.* (data/SceneLib2.cfg:24-31); fku,fkv,u0,v0,sd are read as ints by
+ * the reference (monoslam.cpp:1597-1602) but stored as doubles/ints as below. */
+typedef struct sl2_camera {
+  int32_t width, height;
+  double fku, fkv, u0, v0, kd1;
+  int32_t sd;
+} sl2_camera;
+
+/* cfg keys params.* (data/SceneLib2.cfg:59-69, monoslam.cpp:1583-1593) plus the two
+ * hard-wired deletion constants (monoslam.cpp:1875-1876). */
+typedef struct sl2_params {
+  double delta_t;
+  int32_t number_of_features_to_select;
+  int32_t number_of_features_to_keep_visible;
+  int32_t max_features_to_init_at_once;
+  double min_lambda, max_lambda;
+  int32_t number_of_particles;
+  double standard_deviation_depth_ratio;
+  int32_t min_number_of_particles;
+  double prune_probability_threshold;
+  int32_t erase_partially_init_feature_after_this_many_attempts;
+  int32_t minimum_attempted_measurements_of_feature; /* 10 */
+  double successful_match_fraction;                  /* 0.5 */
+} sl2_params;
+
+/* Per-feature record returned by sl2_get_features — the public members of
+ * SceneLib2::Feature that GraphicTool / the example read (feature.h:78-142). */
+typedef struct sl2_feature_info {
+  int32_t label;                               /* Feature::label_ */
+  int32_t active;                              /* 0 once delete_feature() removed it */
+  int32_t selected_flag;                       /* Feature::selected_flag_ */
+  int32_t successful_measurement_flag;         /* Feature::successful_measurement_flag_ */
+  int32_t attempted_measurements_of_feature;   /* Feature::attempted_measurements_of_feature_ */
+  int32_t successful_measurements_of_feature;  /* Feature::successful_measurements_of_feature_ */
+  int32_t position_in_total_state_vector;      /* as the reference would report it (deleted features removed) */
+  int32_t visible;                             /* visibility_test()==0 in the last auto_select_n_features */
+  double y[3];                                 /* Feature::y_ */
+  double h[2], z[2], nu[2];                    /* h_, z_, nu_ */
+  double R;                                    /* R_ = R * I2 */
+  double S[4];                                 /* S_ (2x2) */
+  double dh_by_dxp[14];                        /* first 7 columns of dh_by_dxv_ (rest are zero) */
+  double dh_by_dy[6];                          /* dh_by_dy_ (2x3) */
+  double xp_org[7];                            /* xp_org_ */
+} sl2_feature_info;
+
+/* ------------------------------------------------------------------ lifecycle */
+
+/* Number of HIP devices visible (0 => every other call fails with SL2_ERR_NO_DEVICE). */
+int sl2_device_count(void);
+
+/* Replaces `new MonoSLAM` + the object wiring of MonoSLAM::Init (monoslam.cpp:1852-1885)
+ * for `batch` sequences with room for `max_features` features each.  `stream` is a
+ * hipStream_t (NULL => the engine creates its own). */
+int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int max_features, int device,
+               void* stream, sl2_engine** out);
+void sl2_destroy(sl2_engine* e);
+const char* sl2_last_error(void);
+int sl2_synchronize(sl2_engine* e);
+int sl2_batch(const sl2_engine* e);
+int sl2_max_features(const sl2_engine* e);
+
+/* xv_ and Pxx_ as MonoSLAM::Init sets them (monoslam.cpp:1881-1938): xv [nseq][13] in
+ * the order r(3) q(w,x,y,z) v(3) omega(3); Pxx [nseq][13][13]. */
+int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx);
+int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double* Pxx);
+
+/* MonoSLAM::AddNewKnownFeature(y, xp, identifier) (monoslam.cpp:1278-1291 ->
+ * Feature ctor feature.cpp:108-149), batched: `nfeat` features appended to each of
+ * sequences [seq0, seq0+nseq).  y [nseq][nfeat][3], xp_org [nseq][nfeat][7],
+ * patches [nseq][nfeat][121] = the 11x11 8-bit template the reference would
+ * cv::imread from `identifier`. */
+int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const double* y, const double* xp_org,
+                           const uint8_t* patches);
+
+/* ------------------------------------------------------------------- stepping */
+
+/* MonoSLAM::GoOneStep(frame, save_trajectory, enable_mapping) (monoslam.cpp:108-180)
+ * for every sequence.  frames: [batch] images of width*height bytes, 8-bit single
+ * channel, row pitch == width (Q25); seq_stride = bytes between consecutive
+ * sequences' frames.  frames_on_device != 0 => `frames` is a device pointer
+ * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
+ * enable_mapping must be 0 in this release (feature initialisation: SURVEY §8(f)). */
+int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
+                    int save_trajectory, int enable_mapping);
+
+/* The seams of GoOneStep, individually callable (same order as the reference):
+ *   Kalman::KalmanFilterPredict(monoslam,u=0)            kalman.cpp:50-69
+ *   MonoSLAM::auto_select_n_features(n)                  monoslam.cpp:187-254
+ *   MonoSLAM::make_measurements(image)                   monoslam.cpp:336-359
+ *   Kalman::KalmanFilterUpdate(monoslam)+normalise_state kalman.cpp:72-119, monoslam.cpp:616-637
+ *   delete_bad_features + symmetrise                     monoslam.cpp:141-150
+ */
+int sl2_kalman_filter_predict(sl2_engine* e);
+int sl2_auto_select_n_features(sl2_engine* e, int n);
+int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device);
+int sl2_kalman_filter_update(sl2_engine* e);
+int sl2_finish_step(sl2_engine* e, int save_trajectory);
+
+/* MonoSLAM::elliptical_search (monoslam.cpp:401-477) as a stateless batch: `count`
+ * independent searches.  image_index[i] selects one of `nimages` images (all
+ * width x height).  patches [count][121]; centre [count][2]; puinv [count][3] =
+ * (PuInv(0,0), PuInv(0,1), PuInv(1,1)).  Outputs: ok[count] (the bool return),
+ * uv[count][2] (left untouched where no candidate qualified, Q4), score[count]
+ * (corrmax).  All pointers are HOST pointers; variant 0 = default kernel. */
+int sl2_elliptical_search_batch(int device, const uint8_t* images, int nimages, int width, int height,
+                                const int32_t* image_index, const uint8_t* patches, const double* centre,
+                                const double* puinv, int count, int32_t* ok, int32_t* uv, double* score,
+                                int variant);
+
+/* ----------------------------------------------------------------- state access */
+
+/* total_state_size_ per sequence (13 + 3 * live features). */
+int sl2_get_total_state_sizes(sl2_engine* e, int seq0, int nseq, int32_t* sizes);
+/* construct_total_state / construct_total_covariance (monoslam.cpp:501-546) for one
+ * sequence, deleted features removed: x [n], P [n][n], n = total state size. */
+int sl2_get_total_state(sl2_engine* e, int seq, double* x, int capacity);
+int sl2_get_total_covariance(sl2_engine* e, int seq, double* P, int capacity_n);
+/* feature_list_ of one sequence in list order (deleted features skipped unless
+ * include_deleted).  Returns the number written through *count. */
+int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity, int include_deleted, int* count);
+/* selected_feature_list_ (labels, selection order) and per-step counters:
+ * counters[0] = number_of_visible_features_, [1] = #selected,
+ * [2] = successful_measurement_vector_size_. */
+int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int32_t counters[3]);
+/* trajectory_store_ (monoslam.cpp:172-177; keeps the reference's stale-scratch
+ * behaviour): up to `capacity` most recent entries of 3 doubles. */
+int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count);
+/* Feature::attempted_/successful_measurements (test hook for delete_bad_features). */
+int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful);
+/* Non-zero bits: 1 = NaN/Inf seen in the state (e.g. the omega == 0 hazard, Q10). */
+int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
+
+/* ------------------------------------------------------------------- profiling */
+
+/* When enabled, every kernel launch of a step is bracketed by HIP events on the
+ * engine's stream; sl2_get_kernel_times returns accumulated milliseconds and
+ * launch counts per kernel name since the last reset. */
+int sl2_set_profiling(sl2_engine* e, int enabled);
+int sl2_reset_kernel_times(sl2_engine* e);
+int sl2_kernel_count(sl2_engine* e);
+int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total_ms, int64_t* launches);
+/* Algorithmic work of the last completed step summed over the batch:
+ * out[0] = search window bytes sum_f (2hw+11)(2hh+11) capped per sequence at W*H,
+ * out[1] = number of searched features, out[2] = in-ellipse candidates,
+ * out[3] = sum over sequences of m (measurement rows), out[4] = sum of m^2,
+ * out[5] = sum of m^3, out[6] = sum of n (state size) , out[7] = sum n*m, out[8] = sum n*n*m, out[9] = sum n*m*m */
+int sl2_get_step_work(sl2_engine* e, double out[10]);
+
+/* ------------------------------------------------------------- synthetic input */
+
+/* Render `count` frames of the synthetic textured plane z = 0:
+ * poses [count][7] = camera r(3), q(w,x,y,z); tex = tex_size^2 8-bit texture
+ * covering tex_extent metres (torus-wrapped), shifted by tex_origin[count][2].
+ * out [count][height][width].  The device and host versions run the SAME source
+ * (scenelib2_amd/csrc/sl2_synth.hpp) and produce identical bytes. */
+int sl2_synth_render_host(const sl2_camera* cam, const uint8_t* tex, int tex_size, double tex_extent,
+                          const double* tex_origin, const double* poses, int count, uint8_t* out);
+int sl2_synth_render_device(int device, void* stream, const sl2_camera* cam, const uint8_t* tex_dev, int tex_size,
+                            double tex_extent, const double* tex_origin_dev, const double* poses_dev, int count,
+                            uint8_t* out_dev);
+
+/* ------------------------------------------------------ device-memory helpers */
+/* For hosts without their own HIP binding (the Python tests use these; a torch
+ * caller passes tensor.data_ptr() instead). */
+int sl2_dev_malloc(int device, size_t bytes, void** out);
+int sl2_dev_free(int device, void* p);
+int sl2_dev_upload(int device, void* dst_dev, const void* src_host, size_t bytes);
+int sl2_dev_download(int device, void* dst_host, const void* src_dev, size_t bytes);
+
+/* ------------------------------------------------------------ debug / test hooks */
+/* FP64 epilogue of correlate2_warning (improc.cpp:99-133) evaluated ON THE DEVICE
+ * for `count` tuples of the five integer sums: checks IEEE div/sqrt parity. */
+int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* score, double* sd0, double* sd1);
+/* C[M][N] = sum_k XT[k][m] * YT[k][n] on the FP64 MFMA tile path used by the EKF
+ * kernels (k-major operands): XT [K][ldx], YT [K][ldy], C [M][ldc].  Host pointers. */
+int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const double* YT, int ldy, int M, int N, int K,
+                      double* C, int ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCENELIB2_AMD_H */

@@ -1,0 +1,750 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
+//
+// CPU FP64 restatement of the SceneLib2 per-frame path
+//   MonoSLAM::GoOneStep -> KalmanFilterPredict -> auto_select_n_features ->
+//   make_measurements (elliptical_search / correlate2_warning) ->
+//   KalmanFilterUpdate -> normalise_state -> delete_bad_features -> symmetrise
+// written from the behaviour of the reference (paths relative to
+// /root/reference/scenelib2/; every function cites the lines it follows).
+//
+// PARITY STATUS: the reference ships no tests, golden vectors or KATs and cannot
+// be built in this image (Eigen3/OpenCV/Pangolin absent), so
+// this oracle is "parity unpinned" in the strict sense.  It is pinned instead by
+// (i) the reference's only fixtures (data/SceneLib2.cfg values and
+// data/known_patch{0..3}.pgm), (ii) the derived known answers K1-K3 of SURVEY.md
+// §8(c) and (iii) invariants (finite-difference Jacobians, score == 2(1-rho),
+// S_i == block of H P H^T + R ...) — see tests/test_oracle_*.py.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+// anything in this directory.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "dense.hpp"
+
+namespace oracle {
+
+// ----------------------------------------------------------------------------
+// Camera — camera.cpp:49-300.  Stateful like the reference: the Jacobian uses
+// the point cached by the previous Project() (Q14).
+// ----------------------------------------------------------------------------
+struct Camera {
+  int width = 0, height = 0;
+  double fku = 0, fkv = 0, u0 = 0, v0 = 0, kd1 = 0;
+  int sd = 0;  // measurement_sd_ is an int in the reference (camera.cpp:52, Q15)
+  double last_cam[3] = {0, 0, 1};
+  double last_centred[2] = {0, 0};
+
+  // camera.cpp:90-114
+  void Project(const double cam[3], double h[2]) {
+    last_cam[0] = cam[0]; last_cam[1] = cam[1]; last_cam[2] = cam[2];
+    double ic0 = -fku * cam[0] / cam[2];
+    double ic1 = -fkv * cam[1] / cam[2];
+    last_centred[0] = ic0; last_centred[1] = ic1;
+    const double radius2 = (ic0 * ic0 + ic1 * ic1);
+    const double factor = std::sqrt(1 + 2 * kd1 * radius2);
+    h[0] = ic0 / factor + u0;
+    h[1] = ic1 / factor + v0;
+  }
+
+  // camera.cpp:133-154
+  void Unproject(const double image[2], double cam[3]) {
+    const double c0 = image[0] - u0, c1 = image[1] - v0;
+    last_centred[0] = c0; last_centred[1] = c1;
+    const double radius2 = (c0 * c0 + c1 * c1);
+    const double factor = std::sqrt(1 - 2 * kd1 * radius2);
+    const double und0 = c0 / factor, und1 = c1 / factor;
+    cam[0] = und0 / -fku;
+    cam[1] = und1 / -fkv;
+    cam[2] = 1.0;
+  }
+
+  // camera.cpp:183-215 — 2x3, row-major in J[r*3+c]
+  void ProjectionJacobian(double J[6]) const {
+    const double fku_yz = fku / last_cam[2];
+    const double fkv_yz = fkv / last_cam[2];
+    const double du[6] = {-fku_yz, 0.0, fku_yz * last_cam[0] / last_cam[2],
+                          0.0, -fkv_yz, fkv_yz * last_cam[1] / last_cam[2]};
+    double d00 = last_centred[0] * last_centred[0];
+    double d01 = last_centred[0] * last_centred[1];
+    double d10 = last_centred[1] * last_centred[0];
+    double d11 = last_centred[1] * last_centred[1];
+    const double radius2 = d00 + d11;
+    const double distor = 1 + 2 * kd1 * radius2;
+    const double distor1_2 = std::sqrt(distor);
+    const double distor3_2 = distor1_2 * distor;
+    const double s = -2 * kd1 / distor3_2;
+    d00 *= s; d01 *= s; d10 *= s; d11 *= s;
+    d00 += (1 / distor1_2);
+    d11 += (1 / distor1_2);
+    for (int c = 0; c < 3; ++c) {
+      J[0 * 3 + c] = d00 * du[0 * 3 + c] + d01 * du[1 * 3 + c];
+      J[1 * 3 + c] = d10 * du[0 * 3 + c] + d11 * du[1 * 3 + c];
+    }
+  }
+
+  // camera.cpp:282-300 — returns the diagonal value of R = value * I2
+  double MeasurementNoise(const double h[2]) const {
+    const double dx = h[0] - u0, dy = h[1] - v0;
+    const double distance = std::sqrt(dx * dx + dy * dy);
+    const double max_distance = std::sqrt(u0 * u0 + v0 * v0);
+    const double ratio = distance / max_distance;
+    const double sd_use = sd * (1.0 + ratio);
+    return sd_use * sd_use;
+  }
+};
+
+// ----------------------------------------------------------------------------
+// Motion model — motion_model.cpp:84-380, support/math_util.cpp:61-114.
+// ----------------------------------------------------------------------------
+struct MotionModel {
+  static constexpr double kSdA = 4.0, kSdAlpha = 6.0;  // motion_model.cpp:45
+  Vec fvRES;       // 13
+  Mat dfv_by_dxv;  // 13x13
+  Mat Qx;          // 13x13
+  double rRES[3] = {0, 0, 0};  // scratch written by func_r (Q12)
+
+  MotionModel() : fvRES(13, 1), dfv_by_dxv(13, 13), Qx(13, 13) {}
+
+  // math_util.cpp:61-80
+  static Quat QuaternionFromAngularVelocity(const double av[3]) {
+    Quat q;
+    const double angle = std::sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+    if (angle > 0.0) {
+      const double s = std::sin(angle / 2.0) / angle;
+      const double c = std::cos(angle / 2.0);
+      q.x = s * av[0]; q.y = s * av[1]; q.z = s * av[2]; q.w = c;
+    } else {
+      q.x = q.y = q.z = 0.0; q.w = 1.0;
+    }
+    return q;
+  }
+  // math_util.cpp:82-97
+  static Mat dq3_by_dq1(const Quat& q) {
+    Mat m(4, 4);
+    const double x = q.x, y = q.y, z = q.z, w = q.w;
+    const double v[16] = {w, -x, -y, -z, x, w, -z, y, y, z, w, -x, z, -y, x, w};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = v[i * 4 + j];
+    return m;
+  }
+  // math_util.cpp:99-114
+  static Mat dq3_by_dq2(const Quat& q) {
+    Mat m(4, 4);
+    const double x = q.x, y = q.y, z = q.z, w = q.w;
+    const double v[16] = {w, -x, -y, -z, x, w, z, -y, y, -z, w, x, z, y, -x, w};
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) m(i, j) = v[i * 4 + j];
+    return m;
+  }
+  // motion_model.cpp:318-349 (no |omega|==0 guard: Q10)
+  static double dq0_by_domegaA(double omegaA, double omega, double dt) {
+    return (-dt / 2.0) * (omegaA / omega) * std::sin(omega * dt / 2.0);
+  }
+  static double dqA_by_domegaA(double omegaA, double omega, double dt) {
+    return (dt / 2.0) * omegaA * omegaA / (omega * omega) * std::cos(omega * dt / 2.0) +
+           (1.0 / omega) * (1.0 - omegaA * omegaA / (omega * omega)) * std::sin(omega * dt / 2.0);
+  }
+  static double dqA_by_domegaB(double omegaA, double omegaB, double omega, double dt) {
+    return (omegaA * omegaB / (omega * omega)) *
+           ((dt / 2.0) * std::cos(omega * dt / 2.0) - (1.0 / omega) * std::sin(omega * dt / 2.0));
+  }
+  // motion_model.cpp:290-312
+  static Mat dqomegadt_by_domega(const double om[3], double dt) {
+    Mat D(4, 3);
+    const double omegamod = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    D(0, 0) = dq0_by_domegaA(om[0], omegamod, dt);
+    D(0, 1) = dq0_by_domegaA(om[1], omegamod, dt);
+    D(0, 2) = dq0_by_domegaA(om[2], omegamod, dt);
+    D(1, 0) = dqA_by_domegaA(om[0], omegamod, dt);
+    D(1, 1) = dqA_by_domegaB(om[0], om[1], omegamod, dt);
+    D(1, 2) = dqA_by_domegaB(om[0], om[2], omegamod, dt);
+    D(2, 0) = dqA_by_domegaB(om[1], om[0], omegamod, dt);
+    D(2, 1) = dqA_by_domegaA(om[1], omegamod, dt);
+    D(2, 2) = dqA_by_domegaB(om[1], om[2], omegamod, dt);
+    D(3, 0) = dqA_by_domegaB(om[2], om[0], omegamod, dt);
+    D(3, 1) = dqA_by_domegaB(om[2], om[1], omegamod, dt);
+    D(3, 2) = dqA_by_domegaA(om[2], omegamod, dt);
+    return D;
+  }
+  // motion_model.cpp:351-380 — note qq is the SQUARED norm (Q9)
+  static Mat dqnorm_by_dq(const Quat& q) {
+    Mat M(4, 4);
+    const double qq = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    const double e[4] = {q.w, q.x, q.y, q.z};
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        M(i, j) = (i == j) ? (1 - e[i] * e[i] / (qq * qq)) / qq : -e[i] * e[j] / (qq * qq * qq);
+    return M;
+  }
+
+  // motion_model.cpp:84-146
+  void func_fv_and_dfv_by_dxv(const Vec& xv, const double u[3], double dt) {
+    const double rold[3] = {xv(0), xv(1), xv(2)};
+    const Quat qold(xv(3), xv(4), xv(5), xv(6));
+    const double vold[3] = {xv(7), xv(8), xv(9)};
+    const double omold[3] = {xv(10), xv(11), xv(12)};
+    double rnew[3], vnew[3], av[3];
+    for (int i = 0; i < 3; ++i) rnew[i] = rold[i] + vold[i] * dt;
+    for (int i = 0; i < 3; ++i) av[i] = omold[i] * dt;
+    const Quat qwt = QuaternionFromAngularVelocity(av);
+    const Quat qnew = qmul(qold, qwt);
+    for (int i = 0; i < 3; ++i) vnew[i] = vold[i] + u[i] * dt;
+    fvRES(0) = rnew[0]; fvRES(1) = rnew[1]; fvRES(2) = rnew[2];
+    fvRES(3) = qnew.w; fvRES(4) = qnew.x; fvRES(5) = qnew.y; fvRES(6) = qnew.z;
+    fvRES(7) = vnew[0]; fvRES(8) = vnew[1]; fvRES(9) = vnew[2];
+    fvRES(10) = omold[0]; fvRES(11) = omold[1]; fvRES(12) = omold[2];
+
+    dfv_by_dxv.setIdentity();
+    for (int i = 0; i < 3; ++i) dfv_by_dxv(i, 7 + i) = dt;
+    set_block(dfv_by_dxv, 3, 3, dq3_by_dq2(qwt));
+    const Mat T44 = dq3_by_dq1(qold);
+    const Mat T43 = dqomegadt_by_domega(omold, dt);
+    set_block(dfv_by_dxv, 3, 10, mul(T44, T43));
+  }
+
+  // motion_model.cpp:148-217
+  void func_Q(const Vec& xv, double dt) {
+    const double lin = kSdA * kSdA * dt * dt;
+    const double ang = kSdAlpha * kSdAlpha * dt * dt;
+    Mat Pnn(6, 6);
+    for (int i = 0; i < 3; ++i) { Pnn(i, i) = lin; Pnn(3 + i, 3 + i) = ang; }
+    Mat G(13, 6);
+    for (int i = 0; i < 3; ++i) { G(7 + i, i) = 1.0; G(10 + i, 3 + i) = 1.0; G(i, i) = dt; }
+    const Quat qold(xv(3), xv(4), xv(5), xv(6));
+    const double omold[3] = {xv(10), xv(11), xv(12)};
+    set_block(G, 3, 3, mul(dq3_by_dq1(qold), dqomegadt_by_domega(omold, dt)));
+    Qx = mul(mul(G, Pnn), transpose(G));
+  }
+};
+
+// ----------------------------------------------------------------------------
+// Full (3-D point) feature measurement model — full_feature_model.cpp:67-200,
+// feature_model.cpp:99-238.
+// ----------------------------------------------------------------------------
+struct FullFeatureModel {
+  Camera* cam = nullptr;
+  MotionModel* mm = nullptr;
+  double zeroedyi[3];
+  Mat dzeroedyi_by_dxp;  // 3x7
+  Mat dzeroedyi_by_dyi;  // 3x3
+  double hi[2];
+  Mat dhi_by_dxp;  // 2x7
+  Mat dhi_by_dyi;  // 2x3
+  Mat Si;          // 2x2
+
+  static constexpr double kMaximumLengthRatio = 2.0;          // full_feature_model.cpp:49
+  static constexpr double kImageSearchBoundary = 20.0;        // :51
+  static double kMaximumAngleDifference() { return M_PI * 45.0 / 180.0; }  // :50
+
+  FullFeatureModel() : dzeroedyi_by_dxp(3, 7), dzeroedyi_by_dyi(3, 3), dhi_by_dxp(2, 7), dhi_by_dyi(2, 3), Si(2, 2) {}
+
+  // feature_model.cpp:196-238 (k = 0: d/dq0, 1: d/dqx, 2: d/dqy, 3: d/dqz)
+  static Mat dR_by_dqk(const Quat& q, int k) {
+    Mat M(3, 3);
+    const double w = q.w, x = q.x, y = q.y, z = q.z;
+    const double t[4][9] = {
+        {2 * w, -2 * z, 2 * y, 2 * z, 2 * w, -2 * x, -2 * y, 2 * x, 2 * w},
+        {2 * x, 2 * y, 2 * z, 2 * y, -2 * x, -2 * w, 2 * z, 2 * w, -2 * x},
+        {-2 * y, 2 * x, 2 * w, 2 * x, 2 * y, 2 * z, -2 * w, 2 * z, -2 * y},
+        {-2 * z, -2 * w, 2 * x, 2 * w, -2 * z, 2 * y, 2 * x, 2 * y, 2 * z}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M(i, j) = t[k][i * 3 + j];
+    return M;
+  }
+
+  // full_feature_model.cpp:67-101
+  void func_zeroedyi(const double yi[3], const double xp[7]) {
+    mm->rRES[0] = xp[0]; mm->rRES[1] = xp[1]; mm->rRES[2] = xp[2];  // func_r (motion_model.cpp:63)
+    const Quat q(xp[3], xp[4], xp[5], xp[6]);                       // func_q (:81)
+    Mat d(3, 1);
+    for (int i = 0; i < 3; ++i) d(i) = yi[i] - mm->rRES[i];
+    const Quat qRW = qinverse(q);
+    const Mat RRW = qrot(qRW);
+    const Mat z = mul(RRW, d);
+    for (int i = 0; i < 3; ++i) zeroedyi[i] = z(i);
+    dzeroedyi_by_dyi = RRW;
+    const Mat dr = scaled(RRW, -1.0);
+    Mat dqRW(3, 4);  // dRq_times_a_by_dq(qRW, d): feature_model.cpp:164-194
+    for (int k = 0; k < 4; ++k) set_block(dqRW, 0, k, mul(dR_by_dqk(qRW, k), d));
+    Mat dqbar(4, 4);  // feature_model.cpp:152-162
+    dqbar(0, 0) = 1.0; dqbar(1, 1) = -1.0; dqbar(2, 2) = -1.0; dqbar(3, 3) = -1.0;
+    const Mat dq = mul(dqRW, dqbar);
+    set_block(dzeroedyi_by_dxp, 0, 0, dr);
+    set_block(dzeroedyi_by_dxp, 0, 3, dq);
+  }
+
+  // full_feature_model.cpp:178-195
+  void func_hi_and_jacobians(const double yi[3], const double xp[7]) {
+    func_zeroedyi(yi, xp);
+    cam->Project(zeroedyi, hi);
+    double J[6];
+    cam->ProjectionJacobian(J);
+    Mat Jm(2, 3);
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) Jm(r, c) = J[r * 3 + c];
+    dhi_by_dxp = mul(Jm, dzeroedyi_by_dxp);
+    dhi_by_dyi = mul(Jm, dzeroedyi_by_dyi);
+  }
+
+  // feature_model.cpp:99-116
+  void func_Si(const Mat& Pxx, const Mat& Pxyi, const Mat& Pyiyi, const Mat& dhi_by_dxv,
+               const Mat& dhi_by_dyi_, double Ri) {
+    Si.setZero();
+    Si = add(Si, mul(mul(dhi_by_dxv, Pxx), transpose(dhi_by_dxv)));
+    const Mat T = mul(mul(dhi_by_dxv, Pxyi), transpose(dhi_by_dyi_));
+    Si = add(Si, T);
+    Si = add(Si, transpose(T));
+    Si = add(Si, mul(mul(dhi_by_dyi_, Pyiyi), transpose(dhi_by_dyi_)));
+    Si(0, 0) += Ri;
+    Si(1, 1) += Ri;
+  }
+
+  // full_feature_model.cpp:103-170
+  int visibility_test(const double xp[7], const double yi[3], const double xp_orig[7], const double h[2]) {
+    int cant_see = 0;
+    if (h[0] < 0.0 + kImageSearchBoundary || h[0] > (double)(cam->width - 1 - kImageSearchBoundary)) cant_see |= 1;
+    if (h[1] < 0.0 + kImageSearchBoundary || h[1] > (double)(cam->height - 1 - kImageSearchBoundary)) cant_see |= 2;
+    func_zeroedyi(yi, xp);
+    if (zeroedyi[2] <= 0) cant_see |= 4;
+    Mat z(3, 1);
+    for (int i = 0; i < 3; ++i) z(i) = zeroedyi[i];
+    const Mat hLWi = mul(qrot(Quat(xp[3], xp[4], xp[5], xp[6])), z);
+    func_zeroedyi(yi, xp_orig);
+    for (int i = 0; i < 3; ++i) z(i) = zeroedyi[i];
+    const Mat hLWi_orig = mul(qrot(Quat(xp_orig[3], xp_orig[4], xp_orig[5], xp_orig[6])), z);
+    const double mod = std::sqrt(hLWi(0) * hLWi(0) + hLWi(1) * hLWi(1) + hLWi(2) * hLWi(2));
+    const double mod_o = std::sqrt(hLWi_orig(0) * hLWi_orig(0) + hLWi_orig(1) * hLWi_orig(1) + hLWi_orig(2) * hLWi_orig(2));
+    const double length_ratio = mod / mod_o;
+    if (length_ratio > kMaximumLengthRatio || length_ratio < (1.0 / kMaximumLengthRatio)) cant_see |= 8;
+    const double dot = hLWi(0) * hLWi_orig(0) + hLWi(1) * hLWi_orig(1) + hLWi(2) * hLWi_orig(2);
+    double angle = std::acos(dot / (mod * mod_o));
+    angle = (angle >= 0.0 ? angle : -angle);
+    if (angle > kMaximumAngleDifference()) cant_see |= 16;
+    return cant_see;
+  }
+};
+
+// ----------------------------------------------------------------------------
+// Patch score — improc/improc.cpp:55-134.  p0 = patch (row pitch w0), p1 = image
+// (row pitch w1); both raw 8-bit raster buffers (Q25).
+// ----------------------------------------------------------------------------
+inline double correlate2_warning(int x0, int y0, int x0lim, int y0lim, int x1, int y1,
+                                 const uint8_t* p0, int w0, const uint8_t* p1, int w1,
+                                 double* sd0ptr, double* sd1ptr) {
+  const int patchwidth = x0lim - x0;
+  const int p0skip = w0 - patchwidth;
+  const int p1skip = w1 - patchwidth;
+  int Sg0 = 0, Sg1 = 0, Sg0g1 = 0, Sg0sq = 0, Sg1sq = 0;
+  const double n = (x0lim - x0) * (y0lim - y0);
+  const uint8_t* a = p0 + w0 * y0 + x0;
+  const uint8_t* b = p1 + w1 * y1 + x1;
+  // trip counts follow the reference exactly: x0lim/y0lim, not lim-start (a12)
+  for (int yc = y0lim - 1; yc >= 0; --yc) {
+    for (int xc = x0lim - 1; xc >= 0; --xc) {
+      Sg0 += *a; Sg1 += *b; Sg0g1 += *a * *b; Sg0sq += *a * *a; Sg1sq += *b * *b;
+      ++a; ++b;
+    }
+    a += p0skip; b += p1skip;
+  }
+  const double Sg0d = Sg0, Sg1d = Sg1, Sg0g1d = Sg0g1, Sg0sqd = Sg0sq, Sg1sqd = Sg1sq;
+  const double g0bar = Sg0d / n, g1bar = Sg1d / n;
+  const double varg0 = Sg0sqd / n - (g0bar * g0bar);
+  const double varg1 = Sg1sqd / n - (g1bar * g1bar);
+  const double sigmag0 = std::sqrt(varg0), sigmag1 = std::sqrt(varg1);
+  *sd0ptr = sigmag0; *sd1ptr = sigmag1;
+  if (sigmag0 == 0.0) { if (sigmag1 == 0.0) return 0.0; else return 1.0; }
+  if (sigmag1 == 0.0) return 1.0;
+  const double k = g0bar / sigmag0 - g1bar / sigmag1;
+  const double C = Sg0sqd / varg0 + Sg1sqd / varg1 + n * (k * k) - Sg0g1d * 2.0 / (sigmag0 * sigmag1) -
+                   Sg0d * 2.0 * k / sigmag0 + Sg1d * 2.0 * k / sigmag1;
+  return C / n;
+}
+
+// monoslam.cpp:401-477.  PuInv given as (a, b, c) = (PuInv(0,0), PuInv(0,1), PuInv(1,1)).
+// Optional n_candidates counts in-ellipse candidates (diagnostic, not in the reference).
+inline bool elliptical_search(const uint8_t* image, int width, int height, const uint8_t* patch,
+                              const double centre[2], double a, double b, double c,
+                              int* u, int* v, int BOXSIZE = 11, int* n_candidates = nullptr,
+                              double* best_corr = nullptr, int* hw_out = nullptr, int* hh_out = nullptr) {
+  const double kNoSigma = 3.0, kCorrThresh2 = 0.40, kSigmaThr = 10.0;  // monoslam.cpp:48-49
+  const int halfwidth = (int)(kNoSigma / std::sqrt(a - b * b / c));
+  const int halfheight = (int)(kNoSigma / std::sqrt(c - b * b / a));
+  if (hw_out) *hw_out = halfwidth;
+  if (hh_out) *hh_out = halfheight;
+  const int ucentre = int(centre[0] + 0.5);
+  const int vcentre = int(centre[1] + 0.5);
+  int urelstart = -halfwidth, urelfinish = halfwidth, vrelstart = -halfheight, vrelfinish = halfheight;
+  if (ucentre + urelstart - (BOXSIZE - 1) / 2 < 0) urelstart = (BOXSIZE - 1) / 2 - ucentre;
+  if (ucentre + urelfinish - (BOXSIZE - 1) / 2 > width - BOXSIZE) urelfinish = width - BOXSIZE - ucentre + (BOXSIZE - 1) / 2;
+  if (vcentre + vrelstart - (BOXSIZE - 1) / 2 < 0) vrelstart = (BOXSIZE - 1) / 2 - vcentre;
+  if (vcentre + vrelfinish - (BOXSIZE - 1) / 2 > height - BOXSIZE) vrelfinish = height - BOXSIZE - vcentre + (BOXSIZE - 1) / 2;
+  double corrmax = 1000000.0, corr, sdpatch, sdimage;
+  int ncand = 0;
+  for (int urel = urelstart; urel <= urelfinish; ++urel) {
+    for (int vrel = vrelstart; vrel <= vrelfinish; ++vrel) {
+      if (a * urel * urel + 2 * b * urel * vrel + c * vrel * vrel < kNoSigma * kNoSigma) {
+        ++ncand;
+        corr = correlate2_warning(0, 0, BOXSIZE, BOXSIZE, ucentre + urel - (BOXSIZE - 1) / 2,
+                                  vcentre + vrel - (BOXSIZE - 1) / 2, patch, BOXSIZE, image, width,
+                                  &sdpatch, &sdimage);
+        if (corr <= corrmax) {  // ties: the LAST candidate wins (Q2)
+          if (sdpatch < kSigmaThr) {
+          } else if (sdimage < kSigmaThr) {
+          } else {
+            corrmax = corr;
+            *u = urel + ucentre;
+            *v = vrel + vcentre;
+          }
+        }
+      }
+    }
+  }
+  if (n_candidates) *n_candidates = ncand;
+  if (best_corr) *best_corr = corrmax;
+  if (corrmax > kCorrThresh2) return false;
+  return true;
+}
+
+// ----------------------------------------------------------------------------
+// Feature record — feature.h:78-142, feature.cpp:108-171 (known-feature ctor).
+// ----------------------------------------------------------------------------
+struct Feature {
+  double y[3];
+  double xp_org[7];
+  Mat Pyy;                           // 3x3
+  Mat Pxy;                           // 13x3
+  std::vector<Mat> matrix_block_list;  // P_{yj yi}, j < i
+  uint8_t patch[121];
+  double h[2] = {0, 0}, z[2] = {0, 0}, nu[2] = {0, 0};
+  Mat dh_by_dxv;  // 2x13
+  Mat dh_by_dy;   // 2x3
+  double R = 0;   // R_ = R * I2
+  Mat S;          // 2x2
+  int label = 0, position_in_list = 0, position_in_total_state_vector = 0;
+  int attempted = 0, successful = 0;
+  bool selected_flag = false, scheduled_for_termination_flag = false;
+  bool successful_measurement_flag = false, fully_initialised_flag = true;
+  Feature() : Pyy(3, 3), Pxy(13, 3), dh_by_dxv(2, 13), dh_by_dy(2, 3), S(2, 2) {}
+};
+
+// ----------------------------------------------------------------------------
+// MonoSLAM — monoslam.cpp:108-812 (known features only; the feature
+// initialisation path, monoslam.cpp:823-1533, is SURVEY.md §8(f) "next").
+// ----------------------------------------------------------------------------
+struct StageTimes { double predict = 0, select = 0, search = 0, update = 0, rest = 0; };
+
+struct MonoSLAM {
+  Camera camera;
+  MotionModel motion_model;
+  FullFeatureModel full_feature_model;
+  Vec xv;   // 13
+  Mat Pxx;  // 13x13
+  std::vector<Feature*> feature_list;
+  std::vector<Feature*> selected_feature_list;
+  std::vector<double> trajectory_store;  // 3 doubles per entry (Q12: pushes stale rRES_)
+  int number_of_visible_features = 0, next_free_label = 0, marked_feature_label = -1;
+  int total_state_size = 13, successful_measurement_vector_size = 0;
+  double kDeltaT = 0;
+  int kNumberOfFeaturesToSelect = 0;
+  int minimum_attempted_measurements_of_feature = 10;  // monoslam.cpp:1875
+  double successful_match_fraction = 0.5;              // :1876
+  // diagnostics (not in the reference)
+  long long total_candidates = 0;
+  long long total_window_bytes = 0;
+  StageTimes times;
+
+  MonoSLAM() : xv(13, 1), Pxx(13, 13) {
+    full_feature_model.cam = &camera;
+    full_feature_model.mm = &motion_model;
+  }
+  ~MonoSLAM() { for (Feature* f : feature_list) delete f; }
+  MonoSLAM(const MonoSLAM&) = delete;
+  MonoSLAM& operator=(const MonoSLAM&) = delete;
+
+  // monoslam.cpp:1278-1291 + feature.cpp:108-149 (patch bytes instead of cv::imread path)
+  void AddNewKnownFeature(const double y[3], const double xp[7], const uint8_t patch[121]) {
+    Feature* nf = new Feature();
+    std::memcpy(nf->patch, patch, 121);
+    nf->label = next_free_label;
+    nf->position_in_list = (int)feature_list.size();
+    nf->position_in_total_state_vector = total_state_size;
+    for (int i = 0; i < 7; ++i) nf->xp_org[i] = xp[i];
+    for (int i = 0; i < 3; ++i) nf->y[i] = y[i];
+    for (int i = 0; i < nf->position_in_list; ++i) nf->matrix_block_list.push_back(Mat(3, 3));
+    feature_list.push_back(nf);
+    total_state_size += 3;
+    ++next_free_label;
+  }
+
+  // kalman.cpp:50-69
+  void KalmanFilterPredict(const double u[3]) {
+    motion_model.func_fv_and_dfv_by_dxv(xv, u, kDeltaT);
+    motion_model.func_Q(xv, kDeltaT);
+    xv = motion_model.fvRES;
+    const Mat& F = motion_model.dfv_by_dxv;
+    Pxx = add(mul(mul(F, Pxx), transpose(F)), motion_model.Qx);
+    for (Feature* f : feature_list) f->Pxy = mul(F, f->Pxy);
+  }
+
+  // monoslam.cpp:289-308
+  void predict_single_feature_measurements(Feature* sfp) {
+    double xp[7];
+    for (int i = 0; i < 7; ++i) xp[i] = xv(i);  // func_xp
+    full_feature_model.func_hi_and_jacobians(sfp->y, xp);
+    sfp->h[0] = full_feature_model.hi[0]; sfp->h[1] = full_feature_model.hi[1];
+    sfp->dh_by_dy = full_feature_model.dhi_by_dyi;
+    Mat dxp_by_dxv(7, 13);  // motion_model.cpp:224-235
+    for (int i = 0; i < 7; ++i) dxp_by_dxv(i, i) = 1.0;
+    sfp->dh_by_dxv = mul(full_feature_model.dhi_by_dxp, dxp_by_dxv);
+    sfp->R = camera.MeasurementNoise(sfp->h);
+    full_feature_model.func_Si(Pxx, sfp->Pxy, sfp->Pyy, sfp->dh_by_dxv, sfp->dh_by_dy, sfp->R);
+    sfp->S = full_feature_model.Si;
+  }
+
+  // monoslam.cpp:258-281 / 312-323
+  bool deselect_feature(Feature* fp) {
+    if (!fp->selected_flag) return true;
+    for (size_t i = 0; i < selected_feature_list.size(); ++i)
+      if (selected_feature_list[i] == fp) {
+        fp->selected_flag = false;
+        selected_feature_list.erase(selected_feature_list.begin() + i);
+        return true;
+      }
+    return false;
+  }
+  bool select_feature(Feature* fp) {
+    if (fp->selected_flag) return true;
+    fp->selected_flag = true;
+    selected_feature_list.push_back(fp);
+    return true;
+  }
+
+  // monoslam.cpp:187-254
+  int auto_select_n_features(int n) {
+    while (selected_feature_list.size() != 0) deselect_feature(selected_feature_list.front());
+    struct FAS { double score; Feature* fp; };
+    std::vector<FAS> fas;
+    double xp[7];
+    for (Feature* f : feature_list) {
+      if (!f->fully_initialised_flag) continue;
+      predict_single_feature_measurements(f);
+      for (int i = 0; i < 7; ++i) xp[i] = xv(i);
+      const int cant_see = full_feature_model.visibility_test(xp, f->y, f->xp_org, f->h);
+      if (cant_see == 0) {
+        const double score = trace(full_feature_model.Si);  // selection_score, full_feature_model.cpp:172
+        bool added = false;
+        for (size_t k = 0; k < fas.size(); ++k)
+          if (score > fas[k].score) { fas.insert(fas.begin() + k, FAS{score, f}); added = true; break; }
+        if (!added) fas.push_back(FAS{score, f});
+      }
+    }
+    int n_actual = 0;
+    if (fas.size() == 0) return 0;
+    for (size_t k = 0; k < fas.size(); ++k) {
+      if (fas[k].score == 0.0 || n_actual == n) return (int)fas.size();
+      select_feature(fas[k].fp);
+      ++n_actual;
+    }
+    return (int)fas.size();
+  }
+
+  // monoslam.cpp:368-386 (S^-1 through the lower Cholesky factor)
+  static void sinv_from_S(const Mat& S, double& a, double& b, double& c) {
+    Mat L;
+    llt_lower(S, L);
+    const Mat Li = lower_inverse(L);
+    const Mat Sinv = mul(transpose(Li), Li);
+    a = Sinv(0, 0); b = Sinv(0, 1); c = Sinv(1, 1);
+  }
+
+  // monoslam.cpp:336-359, 479-496
+  int make_measurements(const uint8_t* image) {
+    int count = 0;
+    if (selected_feature_list.size() == 0) return 0;
+    successful_measurement_vector_size = 0;
+    for (Feature* f : selected_feature_list) {
+      double a, b, c;
+      sinv_from_S(f->S, a, b, c);
+      int u_found = 0, v_found = 0, ncand = 0, hw = 0, hh = 0;
+      const bool ok = elliptical_search(image, camera.width, camera.height, f->patch, f->h, a, b, c,
+                                        &u_found, &v_found, 11, &ncand, nullptr, &hw, &hh);
+      total_candidates += ncand;
+      total_window_bytes += (long long)(2 * hw + 11) * (2 * hh + 11);
+      if (!ok) {
+        f->successful_measurement_flag = false;
+        ++f->attempted;
+      } else {
+        f->z[0] = (double)u_found; f->z[1] = (double)v_found;
+        f->successful_measurement_flag = true;
+        successful_measurement_vector_size += 2;
+        f->nu[0] = f->z[0] - f->h[0]; f->nu[1] = f->z[1] - f->h[1];  // func_nui
+        ++f->successful; ++f->attempted;
+        ++count;
+      }
+    }
+    return count;
+  }
+
+  // monoslam.cpp:501-512
+  void construct_total_state(Vec& V) const {
+    int pos = 0;
+    for (int i = 0; i < 13; ++i) V(pos + i) = xv(i);
+    pos += 13;
+    for (const Feature* f : feature_list) { for (int i = 0; i < 3; ++i) V(pos + i) = f->y[i]; pos += 3; }
+  }
+  // monoslam.cpp:518-546
+  void construct_total_covariance(Mat& M) const {
+    set_block(M, 0, 0, Pxx);
+    int x_position = 13;
+    for (const Feature* f : feature_list) {
+      int y_position = 0;
+      set_block(M, y_position, x_position, f->Pxy);
+      set_block(M, x_position, y_position, transpose(f->Pxy));
+      y_position += 13;
+      for (const Mat& blk : f->matrix_block_list) {
+        set_block(M, y_position, x_position, blk);
+        set_block(M, x_position, y_position, transpose(blk));
+        y_position += blk.r;
+      }
+      set_block(M, y_position, x_position, f->Pyy);
+      x_position += 3;
+    }
+  }
+  // monoslam.cpp:548-572
+  void construct_total_measurement_stuff(Vec& nu_tot, Mat& H, Mat& R_tot) const {
+    nu_tot.setZero(); H.setZero(); R_tot.setZero();
+    int vp = 0;
+    for (const Feature* f : selected_feature_list) {
+      if (!f->successful_measurement_flag) continue;
+      nu_tot(vp) = f->nu[0]; nu_tot(vp + 1) = f->nu[1];
+      set_block(H, vp, 0, f->dh_by_dxv);
+      set_block(H, vp, f->position_in_total_state_vector, f->dh_by_dy);
+      R_tot(vp, vp) = f->R; R_tot(vp + 1, vp + 1) = f->R;
+      vp += 2;
+    }
+  }
+  // monoslam.cpp:574-586
+  void fill_states(const Vec& V) {
+    int pos = 0;
+    for (int i = 0; i < 13; ++i) xv(i) = V(pos + i);
+    pos += 13;
+    for (Feature* f : feature_list) {
+      if (pos >= V.size()) break;
+      for (int i = 0; i < 3; ++i) f->y[i] = V(pos + i);
+      pos += 3;
+    }
+  }
+  // monoslam.cpp:588-614 — reads only the upper block triangle
+  void fill_covariances(const Mat& M) {
+    Pxx = get_block(M, 0, 0, 13, 13);
+    int x_position = 13;
+    for (Feature* f : feature_list) {
+      if (x_position >= M.c) break;
+      int y_position = 0;
+      f->Pxy = get_block(M, y_position, x_position, 13, 3);
+      y_position += 13;
+      for (Mat& blk : f->matrix_block_list) {
+        blk = get_block(M, y_position, x_position, blk.r, blk.c);
+        y_position += blk.r;
+      }
+      f->Pyy = get_block(M, y_position, x_position, 3, 3);
+      x_position += 3;
+    }
+  }
+
+  // kalman.cpp:72-119 — evaluation order as Eigen parses the expressions:
+  // (H*P)*H^T, (P*H^T)*Sinv, (W*S)*W^T.
+  void KalmanFilterUpdate() {
+    const int size = successful_measurement_vector_size, size2 = total_state_size;
+    Vec x(size2, 1);
+    Mat P(size2, size2);
+    construct_total_state(x);
+    construct_total_covariance(P);
+    Vec nu_tot(size, 1);
+    Mat H(size, size2), R_tot(size, size);
+    construct_total_measurement_stuff(nu_tot, H, R_tot);
+    const Mat Ht = transpose(H);
+    Mat S = mul(mul(H, P), Ht);
+    S = add(S, R_tot);
+    Mat S_L;
+    llt_lower(S, S_L);
+    const Mat S_Linv = lower_inverse(S_L);
+    const Mat Sinv = mul(transpose(S_Linv), S_Linv);
+    const Mat W = mul(mul(P, Ht), Sinv);
+    x = add(x, mul(W, nu_tot));
+    P = sub(P, mul(mul(W, S), transpose(W)));
+    fill_states(x);
+    fill_covariances(P);
+  }
+
+  // monoslam.cpp:616-637 + motion_model.cpp:237-263: xv is NOT normalised (Q9)
+  void normalise_state() {
+    Mat J(13, 13);
+    J.setIdentity();
+    set_block(J, 3, 3, MotionModel::dqnorm_by_dq(Quat(xv(3), xv(4), xv(5), xv(6))));
+    Pxx = mul(mul(J, Pxx), transpose(J));
+    for (Feature* f : feature_list) f->Pxy = mul(J, f->Pxy);
+  }
+
+  // monoslam.cpp:743-766 (Q21)
+  void mark_feature_by_lab(int lab) {
+    size_t found = 0;
+    if (lab > 0) for (; found < feature_list.size(); ++found) if (feature_list[found]->label == lab) break;
+    if (found == feature_list.size() && lab != -1) return;
+    marked_feature_label = lab;
+  }
+  // monoslam.cpp:770-812
+  bool delete_feature() {
+    if (marked_feature_label == -1) return false;
+    size_t k = 0;
+    for (; k < feature_list.size(); ++k) if (feature_list[k]->label == marked_feature_label) break;
+    if (k == feature_list.size()) return false;
+    Feature* del = feature_list[k];
+    for (size_t i = k + 1; i < feature_list.size(); ++i) {
+      Feature* f = feature_list[i];
+      --f->position_in_list;
+      f->matrix_block_list.erase(f->matrix_block_list.begin() + del->position_in_list);
+      f->position_in_total_state_vector -= 3;
+    }
+    if (del->selected_flag) deselect_feature(del);
+    total_state_size -= 3;
+    delete del;
+    feature_list.erase(feature_list.begin() + k);
+    marked_feature_label = -1;
+    return true;
+  }
+  // monoslam.cpp:644-703
+  void delete_bad_features() {
+    for (Feature* f : feature_list)
+      if (f->attempted >= minimum_attempted_measurements_of_feature &&
+          double(f->successful) / double(f->attempted) < successful_match_fraction)
+        f->scheduled_for_termination_flag = true;
+    for (size_t i = 0; i < feature_list.size();) {
+      if (feature_list[i]->scheduled_for_termination_flag) {
+        const bool last = (i + 1 == feature_list.size());
+        int currently_marked = marked_feature_label;
+        if (currently_marked == feature_list[i]->label) currently_marked = -1;
+        mark_feature_by_lab(feature_list[i]->label);
+        delete_feature();
+        if (currently_marked != -1) mark_feature_by_lab(currently_marked);
+        if (last) break;
+        // Q27: the reference advances its iterator BEFORE vector::erase
+        // (monoslam.cpp:670-671), so after the erase it points one element
+        // further: the feature that followed the deleted one is not examined in
+        // this pass (it keeps its scheduled flag and goes next frame).
+        ++i;
+      } else {
+        ++i;
+      }
+    }
+  }
+
+  // monoslam.cpp:108-180 (steps 8-9, feature initialisation and partially
+  // initialised features, are §8(f) "next": with enable_mapping == false and no
+  // partial features they are no-ops in the reference too).
+  bool GoOneStep(const uint8_t* frame, bool save_trajectory, bool enable_mapping);
+};
+
+double now_seconds();
+
+}  // namespace oracle

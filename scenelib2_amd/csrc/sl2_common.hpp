@@ -1,0 +1,149 @@
+// Engine-internal declarations shared by the HIP translation units.
+// gfx950 (MI355X / CDNA4) only; wavefront = 64.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scenelib2_amd.h"
+#include "sl2_math.hpp"
+
+namespace sl2 {
+
+void set_error(const std::string& s);
+const char* hip_err_text(hipError_t e);
+
+#define SL2_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (call);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      char _buf[512];                                                                          \
+      snprintf(_buf, sizeof(_buf), "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      sl2::set_error(_buf);                                                                    \
+      return SL2_ERR_HIP;                                                                      \
+    }                                                                                          \
+  } while (0)
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+// feature flag bits (f_flags)
+enum : int {
+  FF_ACTIVE = 1,      // slot holds a live feature
+  FF_SCHEDULED = 2,   // scheduled_for_termination_flag_
+  FF_SELECTED = 4,    // selected_flag_
+  FF_SUCCESS = 8,     // successful_measurement_flag_
+  FF_VISIBLE = 16,    // passed visibility_test in the last selection
+  FF_USED = 32,       // slot was ever used (deleted features keep FF_USED)
+};
+
+constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
+constexpr int kCholBlock = 32;       // block size of the blocked Cholesky / forward substitution
+constexpr int kPatchStride = 128;    // bytes per stored template (121 + pad)
+
+struct KernelTimer {
+  std::string name;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+struct PendingEvent {
+  int timer;
+  hipEvent_t start, stop;
+};
+
+}  // namespace sl2
+
+// The opaque engine object of the C ABI.
+struct sl2_engine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  sl2::CameraParams cam;
+  sl2_params prm;
+  int B = 0;         // sequences
+  int N = 0;         // feature capacity per sequence
+  int ld = 0;        // leading dimension of x / P / At / Vt rows (>= 13 + 3N + 1, multiple of 64)
+  int nsel_max = 0;  // max features measured per frame
+  int mld = 0;       // leading dimension of the innovation system (>= 2 nsel_max, multiple of 32)
+  int nblk_max = 0;  // mld / 32
+
+  // ---- persistent SLAM state (device) ----
+  double* x = nullptr;        // [B][ld]        total state: xv(13), y_0(3), y_1(3) ... ; x[ld-1] unused
+  double* P = nullptr;        // [B][ld][ld]    total covariance, dense; row/col ld-1 always zero
+  uint8_t* patch = nullptr;   // [B][N][128]    11x11 templates
+  int* patch_sums = nullptr;  // [B][N][2]      (sum g0, sum g0^2) of each template
+  double* xp_org = nullptr;   // [B][N][8]      xp_org_ (7 used)
+  int* f_flags = nullptr;     // [B][N]
+  int* n_slots = nullptr;     // [B]            slots used so far == next_free_label_
+  int* attempted = nullptr;   // [B][N]
+  int* successful = nullptr;  // [B][N]
+  double* traj = nullptr;     // [B][kTrajCapacity][3]
+  int* traj_count = nullptr;  // [B]  total pushes
+  double* last_r = nullptr;   // [B][3] scratch motion_model_->rRES_ (Q12)
+  int* status = nullptr;      // [B]
+
+  // ---- per-frame feature scratch (device), indexed [B][N] ----
+  double* f_h = nullptr;      // [..][2]
+  double* f_Hx = nullptr;     // [..][14]
+  double* f_Hy = nullptr;     // [..][6]
+  double* f_R = nullptr;      // [..]
+  double* f_S = nullptr;      // [..][4]
+  double* f_score = nullptr;  // [..]
+  double* f_z = nullptr;      // [..][2]  (persistent: untouched on failure, Q4)
+  double* f_nu = nullptr;     // [..][2]
+  int* sel_idx = nullptr;     // [B][N]   selected feature slots in selection order
+  int* n_sel = nullptr;       // [B]
+  int* n_vis = nullptr;       // [B]
+  int* meas_ok = nullptr;     // [B][N]   per selected position k
+  double* meas_score = nullptr;  // [B][N]
+  int* succ_idx = nullptr;    // [B][N]   successful feature slots in selection order
+  int* m_count = nullptr;     // [B]      number of successful features (m = 2 * m_count)
+  double* work = nullptr;     // [B][4]   window bytes, searched, candidates, (unused)
+
+  // ---- EKF update workspaces (device) ----
+  double* At = nullptr;    // [B][mld][ld]   (P H^T)^T, k-major; column ld-1 carries nu
+  double* Vt = nullptr;    // [B][mld][ld]   L^-1 (P H^T)^T
+  double* St = nullptr;    // [B][mld][mld]  St[c][r] = S[r][c]; overwritten by L (same layout)
+  double* LinvT = nullptr; // [B][nblk_max][32][32]  LinvT[p][k] = (L_JJ^-1)[k][p]
+
+  uint8_t* frames_buf = nullptr;  // [B][W*H] staging for host frames
+  const uint8_t* cur_frames = nullptr;
+  size_t cur_stride = 0;
+
+  // profiling
+  bool profiling = false;
+  std::vector<sl2::KernelTimer> timers;
+  std::vector<sl2::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  int timer_id(const char* name);
+  void prof_begin(int id);
+  void prof_end();
+  int fold_events();
+};
+
+namespace sl2 {
+
+// RAII-less helper: bracket a launch with events when profiling is on.
+struct LaunchScope {
+  sl2_engine* e;
+  bool on;
+  LaunchScope(sl2_engine* eng, const char* name) : e(eng), on(eng->profiling) {
+    if (on) e->prof_begin(e->timer_id(name));
+  }
+  ~LaunchScope() {
+    if (on) e->prof_end();
+  }
+};
+
+// launchers implemented in the kernel translation units (all asynchronous on e->stream)
+int launch_predict(sl2_engine* e);
+int launch_feature_prediction(sl2_engine* e);
+int launch_select(sl2_engine* e, int n);
+int launch_search(sl2_engine* e);
+int launch_update(sl2_engine* e);
+int launch_finalize(sl2_engine* e, int save_trajectory);
+
+}  // namespace sl2

@@ -1,0 +1,634 @@
+// Engine object, state access and step orchestration behind the C ABI
+// (include/scenelib2_amd.h).  Host side of MonoSLAM::GoOneStep
+// (monoslam.cpp:108-180): a fixed sequence of batch-wide kernel launches on one
+// HIP stream, no host synchronisation inside a step.
+#include "sl2_common.hpp"
+
+#include <mutex>
+
+namespace sl2 {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+// ------------------------------------------------------------------ small kernels
+
+__global__ void k_add_features(double* __restrict__ x, double* __restrict__ xp_org, uint8_t* __restrict__ patch,
+                               int* __restrict__ patch_sums, int* __restrict__ f_flags, int* __restrict__ n_slots,
+                               int* __restrict__ attempted, int* __restrict__ successful, const double* __restrict__ y_in,
+                               const double* __restrict__ xp_in, const uint8_t* __restrict__ patch_in, int seq0, int nfeat,
+                               int N, int ld) {
+  // one block per sequence, threads over features
+  const int s = blockIdx.x, b = seq0 + s;
+  const int base = n_slots[b];
+  for (int f = threadIdx.x; f < nfeat; f += blockDim.x) {
+    const int slot = base + f;
+    const size_t fi = (size_t)b * N + slot;
+    const size_t src = (size_t)s * nfeat + f;
+    for (int k = 0; k < 3; ++k) x[(size_t)b * ld + 13 + 3 * slot + k] = y_in[src * 3 + k];
+    for (int k = 0; k < 7; ++k) xp_org[fi * 8 + k] = xp_in[src * 7 + k];
+    xp_org[fi * 8 + 7] = 0.0;
+    int s0 = 0, s0sq = 0;
+    for (int p = 0; p < 121; ++p) {
+      const int g = patch_in[src * 121 + p];
+      patch[fi * kPatchStride + p] = (uint8_t)g;
+      s0 += g; s0sq += g * g;
+    }
+    for (int p = 121; p < kPatchStride; ++p) patch[fi * kPatchStride + p] = 0;
+    patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
+    f_flags[fi] = FF_ACTIVE | FF_USED;
+    attempted[fi] = 0; successful[fi] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) n_slots[b] = base + nfeat;
+}
+
+__global__ void k_set_vehicle(double* __restrict__ x, double* __restrict__ P, const double* __restrict__ xv,
+                              const double* __restrict__ Pxx, int seq0, int ld) {
+  const int s = blockIdx.x, b = seq0 + s;
+  for (int e = threadIdx.x; e < 169; e += blockDim.x) P[(size_t)b * ld * ld + (size_t)(e / 13) * ld + (e % 13)] = Pxx[s * 169 + e];
+  if (threadIdx.x < 13) x[(size_t)b * ld + threadIdx.x] = xv[s * 13 + threadIdx.x];
+}
+
+__global__ void k_get_vehicle(const double* __restrict__ x, const double* __restrict__ P, double* __restrict__ xv,
+                              double* __restrict__ Pxx, int seq0, int ld) {
+  const int s = blockIdx.x, b = seq0 + s;
+  for (int e = threadIdx.x; e < 169; e += blockDim.x) Pxx[s * 169 + e] = P[(size_t)b * ld * ld + (size_t)(e / 13) * ld + (e % 13)];
+  if (threadIdx.x < 13) xv[s * 13 + threadIdx.x] = x[(size_t)b * ld + threadIdx.x];
+}
+
+__global__ void k_ncc_score(const int* __restrict__ sums5, int count, double* __restrict__ score, double* __restrict__ sd0,
+                            double* __restrict__ sd1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a, b;
+  score[i] = ncc_score(sums5[i * 5], sums5[i * 5 + 1], sums5[i * 5 + 2], sums5[i * 5 + 3], sums5[i * 5 + 4], &a, &b);
+  sd0[i] = a; sd1[i] = b;
+}
+
+static int check_device() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    set_error("no HIP device visible: scenelib2_amd has no CPU fallback");
+    return SL2_ERR_NO_DEVICE;
+  }
+  return SL2_OK;
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+  SL2_HIP(hipMalloc((void**)p, sizeof(T) * (count ? count : 1)));
+  SL2_HIP(hipMemset(*p, 0, sizeof(T) * (count ? count : 1)));
+  return SL2_OK;
+}
+
+template <typename T>
+static int fetch_vec(std::vector<T>& v, const T* dev, size_t off, size_t n) {
+  v.resize(n);
+  SL2_HIP(hipMemcpy(v.data(), dev + off, sizeof(T) * n, hipMemcpyDeviceToHost));
+  return SL2_OK;
+}
+
+}  // namespace sl2
+
+using namespace sl2;
+
+int sl2_engine::timer_id(const char* name) {
+  for (size_t i = 0; i < timers.size(); ++i)
+    if (timers[i].name == name) return (int)i;
+  KernelTimer t;
+  t.name = name;
+  timers.push_back(t);
+  return (int)timers.size() - 1;
+}
+
+void sl2_engine::prof_begin(int id) {
+  PendingEvent pe;
+  pe.timer = id;
+  for (int k = 0; k < 2; ++k) {
+    hipEvent_t ev;
+    if (!event_pool.empty()) { ev = event_pool.back(); event_pool.pop_back(); }
+    else hipEventCreate(&ev);
+    if (k == 0) pe.start = ev; else pe.stop = ev;
+  }
+  hipEventRecord(pe.start, stream);
+  pending.push_back(pe);
+}
+
+void sl2_engine::prof_end() { hipEventRecord(pending.back().stop, stream); }
+
+int sl2_engine::fold_events() {
+  if (pending.empty()) return SL2_OK;
+  SL2_HIP(hipStreamSynchronize(stream));
+  for (auto& pe : pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
+      timers[pe.timer].total_ms += ms;
+      timers[pe.timer].launches += 1;
+    }
+    event_pool.push_back(pe.start);
+    event_pool.push_back(pe.stop);
+  }
+  pending.clear();
+  return SL2_OK;
+}
+
+extern "C" {
+
+const char* sl2_last_error(void) { return g_err.c_str(); }
+
+int sl2_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int max_features, int device, void* stream,
+               sl2_engine** out) {
+  if (!cam || !params || !out || batch <= 0 || max_features <= 0) { set_error("sl2_create: bad argument"); return SL2_ERR_INVALID; }
+  if (cam->width < 2 * SL2_PATCH_SIZE || cam->height < 2 * SL2_PATCH_SIZE) { set_error("sl2_create: image too small"); return SL2_ERR_INVALID; }
+  int rc = check_device();
+  if (rc != SL2_OK) return rc;
+  SL2_HIP(hipSetDevice(device));
+  sl2_engine* e = new sl2_engine();
+  e->device = device;
+  if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
+  else { SL2_HIP(hipStreamCreate(&e->stream)); e->own_stream = true; }
+  e->cam.width = cam->width; e->cam.height = cam->height; e->cam.fku = cam->fku; e->cam.fkv = cam->fkv;
+  e->cam.u0 = cam->u0; e->cam.v0 = cam->v0; e->cam.kd1 = cam->kd1; e->cam.sd = cam->sd;
+  e->prm = *params;
+  if (e->prm.minimum_attempted_measurements_of_feature <= 0) e->prm.minimum_attempted_measurements_of_feature = 10;
+  if (!(e->prm.successful_match_fraction > 0.0)) e->prm.successful_match_fraction = 0.5;
+  e->B = batch; e->N = max_features;
+  e->ld = round_up(13 + 3 * max_features + 1, 64);
+  int nsel = params->number_of_features_to_select;
+  if (nsel < 1) nsel = 1;
+  if (nsel > max_features) nsel = max_features;
+  e->nsel_max = nsel;
+  e->mld = round_up(2 * nsel, 32);
+  e->nblk_max = e->mld / 32;
+  const size_t B = batch, N = max_features, ld = e->ld, mld = e->mld;
+  int r = SL2_OK;
+#define A(call) do { r = (call); if (r != SL2_OK) { return r; } } while (0)
+  A(dmalloc(&e->x, B * ld));
+  A(dmalloc(&e->P, B * ld * ld));
+  A(dmalloc(&e->patch, B * N * kPatchStride));
+  A(dmalloc(&e->patch_sums, B * N * 2));
+  A(dmalloc(&e->xp_org, B * N * 8));
+  A(dmalloc(&e->f_flags, B * N));
+  A(dmalloc(&e->n_slots, B));
+  A(dmalloc(&e->attempted, B * N));
+  A(dmalloc(&e->successful, B * N));
+  A(dmalloc(&e->traj, B * kTrajCapacity * 3));
+  A(dmalloc(&e->traj_count, B));
+  A(dmalloc(&e->last_r, B * 3));
+  A(dmalloc(&e->status, B));
+  A(dmalloc(&e->f_h, B * N * 2));
+  A(dmalloc(&e->f_Hx, B * N * 14));
+  A(dmalloc(&e->f_Hy, B * N * 6));
+  A(dmalloc(&e->f_R, B * N));
+  A(dmalloc(&e->f_S, B * N * 4));
+  A(dmalloc(&e->f_score, B * N));
+  A(dmalloc(&e->f_z, B * N * 2));
+  A(dmalloc(&e->f_nu, B * N * 2));
+  A(dmalloc(&e->sel_idx, B * N));
+  A(dmalloc(&e->n_sel, B));
+  A(dmalloc(&e->n_vis, B));
+  A(dmalloc(&e->meas_ok, B * N));
+  A(dmalloc(&e->meas_score, B * N));
+  A(dmalloc(&e->succ_idx, B * N));
+  A(dmalloc(&e->m_count, B));
+  A(dmalloc(&e->work, B * 4));
+  A(dmalloc(&e->At, B * mld * ld));
+  A(dmalloc(&e->Vt, B * mld * ld));
+  A(dmalloc(&e->St, B * mld * mld));
+  A(dmalloc(&e->LinvT, B * (size_t)e->nblk_max * 1024));
+#undef A
+  SL2_HIP(hipDeviceSynchronize());
+  *out = e;
+  return SL2_OK;
+}
+
+void sl2_destroy(sl2_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
+                  e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
+                  e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
+  for (auto ev : e->event_pool) hipEventDestroy(ev);
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+}
+
+int sl2_synchronize(sl2_engine* e) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  return SL2_OK;
+}
+int sl2_batch(const sl2_engine* e) { return e ? e->B : 0; }
+int sl2_max_features(const sl2_engine* e) { return e ? e->N : 0; }
+
+static int range_ok(sl2_engine* e, int seq0, int nseq) { return e && seq0 >= 0 && nseq > 0 && seq0 + nseq <= e->B; }
+
+int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx) {
+  if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  double *dxv = nullptr, *dP = nullptr;
+  SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
+  SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
+  SL2_HIP(hipMemcpyAsync(dxv, xv, sizeof(double) * 13 * nseq, hipMemcpyHostToDevice, e->stream));
+  SL2_HIP(hipMemcpyAsync(dP, Pxx, sizeof(double) * 169 * nseq, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_set_vehicle, dim3(nseq), dim3(64), 0, e->stream, e->x, e->P, dxv, dP, seq0, e->ld);
+  SL2_HIP(hipGetLastError());
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  hipFree(dxv); hipFree(dP);
+  return SL2_OK;
+}
+
+int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double* Pxx) {
+  if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  double *dxv = nullptr, *dP = nullptr;
+  SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
+  SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
+  hipLaunchKernelGGL(k_get_vehicle, dim3(nseq), dim3(64), 0, e->stream, e->x, e->P, dxv, dP, seq0, e->ld);
+  SL2_HIP(hipGetLastError());
+  SL2_HIP(hipMemcpyAsync(xv, dxv, sizeof(double) * 13 * nseq, hipMemcpyDeviceToHost, e->stream));
+  SL2_HIP(hipMemcpyAsync(Pxx, dP, sizeof(double) * 169 * nseq, hipMemcpyDeviceToHost, e->stream));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  hipFree(dxv); hipFree(dP);
+  return SL2_OK;
+}
+
+int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const double* y, const double* xp_org,
+                           const uint8_t* patches) {
+  if (!range_ok(e, seq0, nseq) || nfeat <= 0 || !y || !xp_org || !patches) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  std::vector<int> slots(nseq);
+  SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
+  for (int s = 0; s < nseq; ++s)
+    if (slots[s] + nfeat > e->N) { set_error("sl2_add_known_features: feature capacity exceeded"); return SL2_ERR_CAPACITY; }
+  double *dy = nullptr, *dxp = nullptr;
+  uint8_t* dp = nullptr;
+  const size_t cnt = (size_t)nseq * nfeat;
+  SL2_HIP(hipMalloc(&dy, sizeof(double) * 3 * cnt));
+  SL2_HIP(hipMalloc(&dxp, sizeof(double) * 7 * cnt));
+  SL2_HIP(hipMalloc(&dp, 121 * cnt));
+  SL2_HIP(hipMemcpyAsync(dy, y, sizeof(double) * 3 * cnt, hipMemcpyHostToDevice, e->stream));
+  SL2_HIP(hipMemcpyAsync(dxp, xp_org, sizeof(double) * 7 * cnt, hipMemcpyHostToDevice, e->stream));
+  SL2_HIP(hipMemcpyAsync(dp, patches, 121 * cnt, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_add_features, dim3(nseq), dim3(64), 0, e->stream, e->x, e->xp_org, e->patch, e->patch_sums, e->f_flags,
+                     e->n_slots, e->attempted, e->successful, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
+  SL2_HIP(hipGetLastError());
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  hipFree(dy); hipFree(dxp); hipFree(dp);
+  return SL2_OK;
+}
+
+// ------------------------------------------------------------------- stepping
+
+static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int on_device) {
+  const size_t fb = (size_t)e->cam.width * e->cam.height;
+  if (!frames || seq_stride < fb) { set_error("frames: null pointer or seq_stride < width*height"); return SL2_ERR_INVALID; }
+  if (on_device) {
+    e->cur_frames = frames;
+    e->cur_stride = seq_stride;
+    return SL2_OK;
+  }
+  if (!e->frames_buf) SL2_HIP(hipMalloc((void**)&e->frames_buf, fb * e->B));
+  SL2_HIP(hipMemcpy2DAsync(e->frames_buf, fb, frames, seq_stride, fb, e->B, hipMemcpyHostToDevice, e->stream));
+  e->cur_frames = e->frames_buf;
+  e->cur_stride = fb;
+  return SL2_OK;
+}
+
+int sl2_kalman_filter_predict(sl2_engine* e) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  return launch_predict(e);
+}
+
+int sl2_auto_select_n_features(sl2_engine* e, int n) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  int rc = launch_feature_prediction(e);
+  if (rc != SL2_OK) return rc;
+  return launch_select(e, n);
+}
+
+int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  int rc = bind_frames(e, frames, seq_stride, frames_on_device);
+  if (rc != SL2_OK) return rc;
+  return launch_search(e);
+}
+
+int sl2_kalman_filter_update(sl2_engine* e) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  return launch_update(e);
+}
+
+int sl2_finish_step(sl2_engine* e, int save_trajectory) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  return launch_finalize(e, save_trajectory);
+}
+
+int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int save_trajectory,
+                    int enable_mapping) {
+  if (!e) return SL2_ERR_INVALID;
+  if (enable_mapping) { set_error("enable_mapping: feature initialisation is not implemented in this release (SURVEY 8(f))"); return SL2_ERR_INVALID; }
+  SL2_HIP(hipSetDevice(e->device));
+  int rc;
+  if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
+  if ((rc = launch_predict(e)) != SL2_OK) return rc;
+  if ((rc = launch_feature_prediction(e)) != SL2_OK) return rc;
+  if ((rc = launch_select(e, e->prm.number_of_features_to_select)) != SL2_OK) return rc;
+  if ((rc = launch_search(e)) != SL2_OK) return rc;
+  if ((rc = launch_update(e)) != SL2_OK) return rc;
+  if ((rc = launch_finalize(e, save_trajectory)) != SL2_OK) return rc;
+  if (e->profiling && e->pending.size() > 8192) return e->fold_events();
+  return SL2_OK;
+}
+
+// ----------------------------------------------------------------- state access
+
+struct HostSeq {
+  std::vector<double> x, P;
+  std::vector<int> flags;
+  int n_slots = 0;
+};
+
+static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  SL2_HIP(hipMemcpy(&hs.n_slots, e->n_slots + seq, sizeof(int), hipMemcpyDeviceToHost));
+  hs.flags.resize(e->N);
+  SL2_HIP(hipMemcpy(hs.flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  hs.x.resize(e->ld);
+  SL2_HIP(hipMemcpy(hs.x.data(), e->x + (size_t)seq * e->ld, sizeof(double) * e->ld, hipMemcpyDeviceToHost));
+  if (want_P) {
+    hs.P.resize((size_t)e->ld * e->ld);
+    SL2_HIP(hipMemcpy(hs.P.data(), e->P + (size_t)seq * e->ld * e->ld, sizeof(double) * e->ld * e->ld, hipMemcpyDeviceToHost));
+  }
+  return SL2_OK;
+}
+
+// dense index list of the live state entries (deleted features removed)
+static std::vector<int> live_index(const sl2_engine* e, const HostSeq& hs) {
+  (void)e;
+  std::vector<int> idx;
+  for (int i = 0; i < 13; ++i) idx.push_back(i);
+  for (int f = 0; f < hs.n_slots; ++f)
+    if (hs.flags[f] & FF_ACTIVE) for (int k = 0; k < 3; ++k) idx.push_back(13 + 3 * f + k);
+  return idx;
+}
+
+int sl2_get_total_state_sizes(sl2_engine* e, int seq0, int nseq, int32_t* sizes) {
+  if (!range_ok(e, seq0, nseq) || !sizes) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  std::vector<int> flags((size_t)nseq * e->N), slots(nseq);
+  SL2_HIP(hipMemcpy(flags.data(), e->f_flags + (size_t)seq0 * e->N, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
+  for (int s = 0; s < nseq; ++s) {
+    int n = 13;
+    for (int f = 0; f < slots[s]; ++f) if (flags[(size_t)s * e->N + f] & FF_ACTIVE) n += 3;
+    sizes[s] = n;
+  }
+  return SL2_OK;
+}
+
+int sl2_get_total_state(sl2_engine* e, int seq, double* x, int capacity) {
+  if (!range_ok(e, seq, 1) || !x) return SL2_ERR_INVALID;
+  HostSeq hs;
+  int rc = fetch_seq(e, seq, false, hs);
+  if (rc != SL2_OK) return rc;
+  const std::vector<int> idx = live_index(e, hs);
+  if ((int)idx.size() > capacity) return SL2_ERR_CAPACITY;
+  for (size_t i = 0; i < idx.size(); ++i) x[i] = hs.x[idx[i]];
+  return SL2_OK;
+}
+
+int sl2_get_total_covariance(sl2_engine* e, int seq, double* P, int capacity_n) {
+  if (!range_ok(e, seq, 1) || !P) return SL2_ERR_INVALID;
+  HostSeq hs;
+  int rc = fetch_seq(e, seq, true, hs);
+  if (rc != SL2_OK) return rc;
+  const std::vector<int> idx = live_index(e, hs);
+  const int n = (int)idx.size();
+  if (n > capacity_n) return SL2_ERR_CAPACITY;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) P[(size_t)i * n + j] = hs.P[(size_t)idx[i] * e->ld + idx[j]];
+  return SL2_OK;
+}
+
+int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity, int include_deleted, int* count) {
+  if (!range_ok(e, seq, 1) || !out || !count) return SL2_ERR_INVALID;
+  HostSeq hs;
+  int rc = fetch_seq(e, seq, false, hs);
+  if (rc != SL2_OK) return rc;
+  const size_t N = e->N, o = (size_t)seq * N;
+  std::vector<double> h, z, nu, R, S, Hx, Hy, xo;
+  std::vector<int> att, suc;
+  if ((rc = fetch_vec(h, e->f_h, o * 2, N * 2))) return rc;
+  if ((rc = fetch_vec(z, e->f_z, o * 2, N * 2))) return rc;
+  if ((rc = fetch_vec(nu, e->f_nu, o * 2, N * 2))) return rc;
+  if ((rc = fetch_vec(R, e->f_R, o, N))) return rc;
+  if ((rc = fetch_vec(S, e->f_S, o * 4, N * 4))) return rc;
+  if ((rc = fetch_vec(Hx, e->f_Hx, o * 14, N * 14))) return rc;
+  if ((rc = fetch_vec(Hy, e->f_Hy, o * 6, N * 6))) return rc;
+  if ((rc = fetch_vec(xo, e->xp_org, o * 8, N * 8))) return rc;
+  if ((rc = fetch_vec(att, e->attempted, o, N))) return rc;
+  if ((rc = fetch_vec(suc, e->successful, o, N))) return rc;
+  int n = 0, pos = 13;
+  for (int f = 0; f < hs.n_slots; ++f) {
+    const int fl = hs.flags[f];
+    const bool active = fl & FF_ACTIVE;
+    if (!active && !include_deleted) continue;
+    if (n >= capacity) return SL2_ERR_CAPACITY;
+    sl2_feature_info& fi = out[n++];
+    memset(&fi, 0, sizeof(fi));
+    fi.label = f;
+    fi.active = active ? 1 : 0;
+    fi.selected_flag = (fl & FF_SELECTED) ? 1 : 0;
+    fi.successful_measurement_flag = (fl & FF_SUCCESS) ? 1 : 0;
+    fi.visible = (fl & FF_VISIBLE) ? 1 : 0;
+    fi.attempted_measurements_of_feature = att[f];
+    fi.successful_measurements_of_feature = suc[f];
+    fi.position_in_total_state_vector = active ? pos : -1;
+    if (active) pos += 3;
+    for (int k = 0; k < 3; ++k) fi.y[k] = hs.x[13 + 3 * f + k];
+    for (int k = 0; k < 2; ++k) { fi.h[k] = h[f * 2 + k]; fi.z[k] = z[f * 2 + k]; fi.nu[k] = nu[f * 2 + k]; }
+    fi.R = R[f];
+    for (int k = 0; k < 4; ++k) fi.S[k] = S[f * 4 + k];
+    for (int k = 0; k < 14; ++k) fi.dh_by_dxp[k] = Hx[f * 14 + k];
+    for (int k = 0; k < 6; ++k) fi.dh_by_dy[k] = Hy[f * 6 + k];
+    for (int k = 0; k < 7; ++k) fi.xp_org[k] = xo[f * 8 + k];
+  }
+  *count = n;
+  return SL2_OK;
+}
+
+int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int32_t counters[3]) {
+  if (!range_ok(e, seq, 1) || !labels || !counters) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  int ns = 0, nv = 0, mc = 0;
+  SL2_HIP(hipMemcpy(&ns, e->n_sel + seq, sizeof(int), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(&nv, e->n_vis + seq, sizeof(int), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(&mc, e->m_count + seq, sizeof(int), hipMemcpyDeviceToHost));
+  if (ns > capacity) return SL2_ERR_CAPACITY;
+  if (ns > 0) SL2_HIP(hipMemcpy(labels, e->sel_idx + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
+  counters[0] = nv; counters[1] = ns; counters[2] = 2 * mc;
+  return SL2_OK;
+}
+
+int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count) {
+  if (!range_ok(e, seq, 1) || !out || !count) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  int total = 0;
+  SL2_HIP(hipMemcpy(&total, e->traj_count + seq, sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<double> ring((size_t)kTrajCapacity * 3);
+  SL2_HIP(hipMemcpy(ring.data(), e->traj + (size_t)seq * kTrajCapacity * 3, sizeof(double) * ring.size(), hipMemcpyDeviceToHost));
+  int have = total < kTrajCapacity ? total : kTrajCapacity;
+  int n = have < capacity ? have : capacity;
+  // oldest-first among the n most recent
+  for (int i = 0; i < n; ++i) {
+    const int logical = total - n + i;
+    const int slot = logical % kTrajCapacity;
+    for (int k = 0; k < 3; ++k) out[i * 3 + k] = ring[(size_t)slot * 3 + k];
+  }
+  *count = n;
+  return SL2_OK;
+}
+
+int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful) {
+  if (!range_ok(e, seq, 1) || label < 0 || label >= e->N) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  SL2_HIP(hipMemcpy(e->attempted + (size_t)seq * e->N + label, &attempted, sizeof(int), hipMemcpyHostToDevice));
+  SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + label, &successful, sizeof(int), hipMemcpyHostToDevice));
+  return SL2_OK;
+}
+
+int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags) {
+  if (!range_ok(e, seq0, nseq) || !flags) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  SL2_HIP(hipMemcpy(flags, e->status + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
+  return SL2_OK;
+}
+
+// ------------------------------------------------------------------- profiling
+
+int sl2_set_profiling(sl2_engine* e, int enabled) {
+  if (!e) return SL2_ERR_INVALID;
+  if (!enabled && e->profiling) { int rc = e->fold_events(); if (rc) return rc; }
+  e->profiling = enabled != 0;
+  return SL2_OK;
+}
+int sl2_reset_kernel_times(sl2_engine* e) {
+  if (!e) return SL2_ERR_INVALID;
+  int rc = e->fold_events();
+  if (rc) return rc;
+  for (auto& t : e->timers) { t.total_ms = 0; t.launches = 0; }
+  return SL2_OK;
+}
+int sl2_kernel_count(sl2_engine* e) {
+  if (!e) return 0;
+  e->fold_events();
+  return (int)e->timers.size();
+}
+int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total_ms, int64_t* launches) {
+  if (!e || idx < 0 || idx >= (int)e->timers.size()) return SL2_ERR_INVALID;
+  int rc = e->fold_events();
+  if (rc) return rc;
+  if (name) *name = e->timers[idx].name.c_str();
+  if (total_ms) *total_ms = e->timers[idx].total_ms;
+  if (launches) *launches = e->timers[idx].launches;
+  return SL2_OK;
+}
+
+int sl2_get_step_work(sl2_engine* e, double out[10]) {
+  if (!e || !out) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  std::vector<double> w((size_t)e->B * 4);
+  std::vector<int> mc(e->B), flags((size_t)e->B * e->N), slots(e->B);
+  SL2_HIP(hipMemcpy(w.data(), e->work, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(mc.data(), e->m_count, sizeof(int) * e->B, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(flags.data(), e->f_flags, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(slots.data(), e->n_slots, sizeof(int) * e->B, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 10; ++k) out[k] = 0.0;
+  const double frame_bytes = (double)e->cam.width * e->cam.height;
+  for (int b = 0; b < e->B; ++b) {
+    const double win = w[(size_t)b * 4 + 0];
+    out[0] += win < frame_bytes ? win : frame_bytes;
+    out[1] += w[(size_t)b * 4 + 1];
+    out[2] += w[(size_t)b * 4 + 2];
+    double n = 13;
+    for (int f = 0; f < slots[b]; ++f) if (flags[(size_t)b * e->N + f] & FF_ACTIVE) n += 3;
+    const double m = 2.0 * mc[b];
+    out[3] += m; out[4] += m * m; out[5] += m * m * m; out[6] += n; out[7] += n * m; out[8] += n * n * m; out[9] += n * m * m;
+  }
+  return SL2_OK;
+}
+
+// ------------------------------------------------------ device-memory helpers
+
+int sl2_dev_malloc(int device, size_t bytes, void** out) {
+  if (!out) return SL2_ERR_INVALID;
+  int rc = check_device();
+  if (rc) return rc;
+  SL2_HIP(hipSetDevice(device));
+  SL2_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return SL2_OK;
+}
+int sl2_dev_free(int device, void* p) {
+  SL2_HIP(hipSetDevice(device));
+  SL2_HIP(hipFree(p));
+  return SL2_OK;
+}
+int sl2_dev_upload(int device, void* dst_dev, const void* src_host, size_t bytes) {
+  SL2_HIP(hipSetDevice(device));
+  SL2_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+  return SL2_OK;
+}
+int sl2_dev_download(int device, void* dst_host, const void* src_dev, size_t bytes) {
+  SL2_HIP(hipSetDevice(device));
+  SL2_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+  return SL2_OK;
+}
+
+int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* score, double* sd0, double* sd1) {
+  if (!sums5 || !score || !sd0 || !sd1 || count <= 0) return SL2_ERR_INVALID;
+  int rc = check_device();
+  if (rc) return rc;
+  SL2_HIP(hipSetDevice(device));
+  int* ds = nullptr;
+  double *dsc = nullptr, *d0 = nullptr, *d1 = nullptr;
+  SL2_HIP(hipMalloc(&ds, sizeof(int) * 5 * count));
+  SL2_HIP(hipMalloc(&dsc, sizeof(double) * count));
+  SL2_HIP(hipMalloc(&d0, sizeof(double) * count));
+  SL2_HIP(hipMalloc(&d1, sizeof(double) * count));
+  SL2_HIP(hipMemcpy(ds, sums5, sizeof(int) * 5 * count, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_ncc_score, dim3((count + 255) / 256), dim3(256), 0, 0, ds, count, dsc, d0, d1);
+  SL2_HIP(hipGetLastError());
+  SL2_HIP(hipDeviceSynchronize());
+  SL2_HIP(hipMemcpy(score, dsc, sizeof(double) * count, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(sd0, d0, sizeof(double) * count, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(sd1, d1, sizeof(double) * count, hipMemcpyDeviceToHost));
+  hipFree(ds); hipFree(dsc); hipFree(d0); hipFree(d1);
+  return SL2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+// Front-end kernels of the per-frame step (all FP64, one launch per stage over the
+// whole batch):
+//   k_predict            Kalman::KalmanFilterPredict          kalman.cpp:50-69
+//   k_feature_prediction predict_single_feature_measurements   monoslam.cpp:289-308
+//                        + visibility_test + selection_score   full_feature_model.cpp:103-176
+//   k_select             auto_select_n_features (ordering)     monoslam.cpp:187-254
+//   k_finalize           normalise_state, delete_bad_features, symmetrise,
+//                        trajectory_store_                      monoslam.cpp:137-177,616-703
+// Data layout: see sl2_common.hpp (dense P[B][ld][ld], x[B][ld]).
+#include "sl2_common.hpp"
+
+namespace sl2 {
+
+// ---------------------------------------------------------------------------
+// k_predict: one workgroup per sequence.  Only the first 13 rows/cols of P change
+// (static map): Pxx <- (F Pxx) F^T + Q, strip P[0:13, j] <- F P[0:13, j], mirrored.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
+                                                 int ld, double dt) {
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  double* xb = x + (size_t)b * ld;
+  double* Pb = P + (size_t)b * ld * ld;
+  __shared__ double s_f[13], s_A[16], s_B[12], s_P[169], s_T[169];
+  if (tid == 0) {
+    double xv[13];
+    for (int i = 0; i < 13; ++i) xv[i] = xb[i];
+    double f[13], A44[16], B43[12];
+    motion_f_and_blocks(xv, dt, f, A44, B43);
+    for (int i = 0; i < 13; ++i) s_f[i] = f[i];
+    for (int i = 0; i < 16; ++i) s_A[i] = A44[i];
+    for (int i = 0; i < 12; ++i) s_B[i] = B43[i];
+  }
+  for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
+  __syncthreads();
+  for (int e = tid; e < 169; e += blockDim.x) {
+    const int i = e / 13, j = e % 13;
+    double v[13];
+    for (int k = 0; k < 13; ++k) v[k] = s_P[k * 13 + j];
+    s_T[e] = frow_dot(i, dt, s_A, s_B, v);
+  }
+  __syncthreads();
+  for (int e = tid; e < 169; e += blockDim.x) {
+    const int i = e / 13, j = e % 13;
+    double v[13];
+    for (int k = 0; k < 13; ++k) v[k] = s_T[i * 13 + k];
+    Pb[(size_t)i * ld + j] = frow_dot(j, dt, s_A, s_B, v) + process_noise_entry(i, j, dt, s_B);
+  }
+  const int n_used = 13 + 3 * n_slots[b];
+  for (int j = 13 + tid; j < n_used; j += blockDim.x) {
+    double v[13], w[13];
+    for (int k = 0; k < 13; ++k) v[k] = Pb[(size_t)k * ld + j];
+    for (int i = 0; i < 13; ++i) w[i] = frow_dot(i, dt, s_A, s_B, v);
+    for (int i = 0; i < 13; ++i) {
+      Pb[(size_t)i * ld + j] = w[i];
+      Pb[(size_t)j * ld + i] = w[i];
+    }
+  }
+  if (tid < 13) xb[tid] = s_f[tid];
+}
+
+// ---------------------------------------------------------------------------
+// k_feature_prediction: one thread per (sequence, feature slot).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_feature_prediction(const double* __restrict__ x, const double* __restrict__ P,
+                                                           const double* __restrict__ xp_org, int* __restrict__ f_flags,
+                                                           const int* __restrict__ n_slots, double* __restrict__ f_h,
+                                                           double* __restrict__ f_Hx, double* __restrict__ f_Hy,
+                                                           double* __restrict__ f_R, double* __restrict__ f_S,
+                                                           double* __restrict__ f_score, CameraParams cam, int N, int ld) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots[b]) return;
+  const size_t fi = (size_t)b * N + i;
+  int flags = f_flags[fi] & ~(FF_SELECTED | FF_VISIBLE);
+  if (!(flags & FF_ACTIVE)) { f_flags[fi] = flags; return; }
+  const double* xb = x + (size_t)b * ld;
+  const double* Pb = P + (size_t)b * ld * ld;
+  double xp[7], y[3], xo[7];
+  for (int k = 0; k < 7; ++k) xp[k] = xb[k];
+  const int pos = 13 + 3 * i;
+  for (int k = 0; k < 3; ++k) y[k] = xb[pos + k];
+  for (int k = 0; k < 7; ++k) xo[k] = xp_org[fi * 8 + k];
+  double zeroed[3], h[2], Hx[14], Hy[6], Rn;
+  measurement_model(cam, xp, y, zeroed, h, Hx, Hy, &Rn);
+  double Pxx7[49], Pxy7[21], Pyy[9], S[4];
+  for (int r = 0; r < 7; ++r) {
+    for (int c = 0; c < 7; ++c) Pxx7[r * 7 + c] = Pb[(size_t)r * ld + c];
+    for (int c = 0; c < 3; ++c) Pxy7[r * 3 + c] = Pb[(size_t)r * ld + pos + c];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Pyy[r * 3 + c] = Pb[(size_t)(pos + r) * ld + pos + c];
+  innovation_cov(Hx, Hy, Rn, Pxx7, Pxy7, Pyy, S);
+  const int cant_see = visibility_test(cam, xp, y, xo, h);
+  f_h[fi * 2 + 0] = h[0]; f_h[fi * 2 + 1] = h[1];
+  for (int k = 0; k < 14; ++k) f_Hx[fi * 14 + k] = Hx[k];
+  for (int k = 0; k < 6; ++k) f_Hy[fi * 6 + k] = Hy[k];
+  f_R[fi] = Rn;
+  for (int k = 0; k < 4; ++k) f_S[fi * 4 + k] = S[k];
+  f_score[fi] = S[0] + S[3];  // trace (selection_score, full_feature_model.cpp:172-176)
+  if (cant_see == 0) flags |= FF_VISIBLE;
+  f_flags[fi] = flags;
+}
+
+// ---------------------------------------------------------------------------
+// k_select: one workgroup per sequence.  The reference's descending insertion
+// (strict '>' => ties keep list order) is a stable sort by score; a feature's
+// position is its rank = #{visible j : score_j > score_i or (== and j < i)}.
+// Selection stops at the first zero score or after n (monoslam.cpp:241-249).
+// Also records rRES_ as left by the last visibility_test (Q12).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_score, int* __restrict__ f_flags,
+                                                const int* __restrict__ n_slots, const double* __restrict__ xp_org,
+                                                int* __restrict__ sel_idx, int* __restrict__ n_sel, int* __restrict__ n_vis,
+                                                double* __restrict__ last_r, int N, int n_want) {
+  extern __shared__ double s_dyn[];
+  double* s_score = s_dyn;                 // [N]
+  int* s_vis = (int*)(s_dyn + N);          // [N]
+  __shared__ int s_nvis, s_zero_rank, s_last;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ns = n_slots[b];
+  if (tid == 0) { s_nvis = 0; s_zero_rank = 0x7fffffff; s_last = -1; }
+  __syncthreads();
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const int fl = f_flags[(size_t)b * N + i];
+    s_score[i] = f_score[(size_t)b * N + i];
+    s_vis[i] = (fl & FF_VISIBLE) ? 1 : 0;
+    if (fl & FF_ACTIVE) atomicMax(&s_last, i);
+  }
+  __syncthreads();
+  for (int i = tid; i < ns; i += blockDim.x) {
+    if (!s_vis[i]) continue;
+    const double si = s_score[i];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j)
+      if (s_vis[j] && (s_score[j] > si || (s_score[j] == si && j < i))) ++rank;
+    s_vis[i] = 1 + rank;  // store rank+1
+    atomicAdd(&s_nvis, 1);
+    if (si == 0.0) atomicMin(&s_zero_rank, rank);
+  }
+  __syncthreads();
+  int limit = n_want;
+  if (s_zero_rank < limit) limit = s_zero_rank;
+  if (s_nvis < limit) limit = s_nvis;
+  for (int i = tid; i < ns; i += blockDim.x) {
+    if (!s_vis[i]) continue;
+    const int rank = s_vis[i] - 1;
+    if (rank < limit) {
+      sel_idx[(size_t)b * N + rank] = i;
+      f_flags[(size_t)b * N + i] |= FF_SELECTED;
+    }
+  }
+  if (tid == 0) {
+    n_sel[b] = limit;
+    n_vis[b] = s_nvis;
+    if (s_last >= 0)
+      for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xp_org[((size_t)b * N + s_last) * 8 + k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_finalize: one workgroup per sequence.
+//  (1) if an update happened (m > 0): normalise_state — Pxx <- (Jn Pxx) Jn^T,
+//      strip rows 3..6 <- N * strip rows 3..6 (xv itself unchanged, Q9);
+//  (2) delete_bad_features with the reference's skip-after-erase iteration (Q27):
+//      a deleted feature's rows/cols of P are zeroed and its slot deactivated —
+//      arithmetically identical to removing them;
+//  (3) symmetrise: only the 13x13 block can be asymmetric in this layout (every
+//      other block is stored mirrored), P <- P*0.5 + P^T*0.5;
+//  (4) trajectory_store_ push (stale rRES_, Q12); NaN check.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double* __restrict__ P, int* __restrict__ f_flags,
+                                                  const int* __restrict__ n_slots, int* __restrict__ attempted,
+                                                  int* __restrict__ successful, const int* __restrict__ m_count,
+                                                  const int* __restrict__ n_sel, double* __restrict__ traj,
+                                                  int* __restrict__ traj_count, const double* __restrict__ last_r,
+                                                  int* __restrict__ status, int N, int ld, int min_attempts,
+                                                  double match_fraction, int save_trajectory) {
+  extern __shared__ int s_del[];  // [N] slots deleted this frame
+  __shared__ double s_N[16], s_P[169], s_T[169];
+  __shared__ int s_ndel;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* xb = x + (size_t)b * ld;
+  double* Pb = P + (size_t)b * ld * ld;
+  const int ns = n_slots[b];
+  const int n_used = 13 + 3 * ns;
+  const bool updated = (n_sel[b] > 0) && (m_count[b] > 0);
+  if (updated) {
+    if (tid == 0) {
+      double q[4] = {xb[3], xb[4], xb[5], xb[6]}, Nn[16];
+      dqnorm_by_dq(q, Nn);
+      for (int i = 0; i < 16; ++i) s_N[i] = Nn[i];
+    }
+    for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
+    __syncthreads();
+    // T = Jn * Pxx
+    for (int e = tid; e < 169; e += blockDim.x) {
+      const int i = e / 13, j = e % 13;
+      double v;
+      if (i >= 3 && i < 7) {
+        v = 0.0;
+        for (int k = 0; k < 4; ++k) v += s_N[(i - 3) * 4 + k] * s_P[(3 + k) * 13 + j];
+      } else v = s_P[e];
+      s_T[e] = v;
+    }
+    __syncthreads();
+    // Pxx = T * Jn^T
+    for (int e = tid; e < 169; e += blockDim.x) {
+      const int i = e / 13, j = e % 13;
+      double v;
+      if (j >= 3 && j < 7) {
+        v = 0.0;
+        for (int k = 0; k < 4; ++k) v += s_T[i * 13 + 3 + k] * s_N[(j - 3) * 4 + k];
+      } else v = s_T[e];
+      s_P[e] = v;
+    }
+    // strip
+    for (int j = 13 + tid; j < n_used; j += blockDim.x) {
+      double v[4], w[4];
+      for (int k = 0; k < 4; ++k) v[k] = Pb[(size_t)(3 + k) * ld + j];
+      for (int a = 0; a < 4; ++a) {
+        double acc = 0.0;
+        for (int k = 0; k < 4; ++k) acc += s_N[a * 4 + k] * v[k];
+        w[a] = acc;
+      }
+      for (int a = 0; a < 4; ++a) {
+        Pb[(size_t)(3 + a) * ld + j] = w[a];
+        Pb[(size_t)j * ld + 3 + a] = w[a];
+      }
+    }
+    __syncthreads();
+  } else {
+    for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
+    __syncthreads();
+  }
+  // (2) deletion bookkeeping, serial like the reference's list walk
+  if (tid == 0) {
+    int nd = 0;
+    for (int i = 0; i < ns; ++i) {
+      const size_t fi = (size_t)b * N + i;
+      int fl = f_flags[fi];
+      if (!(fl & FF_ACTIVE)) continue;
+      const int att = attempted[fi], suc = successful[fi];
+      if (att >= min_attempts && double(suc) / double(att) < match_fraction) f_flags[fi] = fl | FF_SCHEDULED;
+    }
+    bool skip_next = false;
+    for (int i = 0; i < ns; ++i) {
+      const size_t fi = (size_t)b * N + i;
+      const int fl = f_flags[fi];
+      if (!(fl & FF_ACTIVE)) continue;
+      if (skip_next) { skip_next = false; continue; }
+      if (fl & FF_SCHEDULED) {
+        f_flags[fi] = FF_USED;  // inactive, deselected
+        s_del[nd++] = i;
+        skip_next = true;
+      }
+    }
+    s_ndel = nd;
+  }
+  __syncthreads();
+  for (int d = 0; d < s_ndel; ++d) {
+    const int pos = 13 + 3 * s_del[d];
+    for (int j = tid; j < n_used; j += blockDim.x)
+      for (int r = 0; r < 3; ++r) {
+        Pb[(size_t)(pos + r) * ld + j] = 0.0;
+        Pb[(size_t)j * ld + pos + r] = 0.0;
+      }
+  }
+  // (3) symmetrise the vehicle block
+  for (int e = tid; e < 169; e += blockDim.x) {
+    const int i = e / 13, j = e % 13;
+    Pb[(size_t)i * ld + j] = s_P[i * 13 + j] * 0.5 + s_P[j * 13 + i] * 0.5;
+  }
+  if (tid == 0) {
+    if (save_trajectory) {
+      const int c = traj_count[b];
+      double* t = traj + ((size_t)b * kTrajCapacity + (c % kTrajCapacity)) * 3;
+      for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
+      traj_count[b] = c + 1;
+    }
+    bool bad = false;
+    for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]);
+    if (bad) status[b] |= 1;
+  }
+}
+
+int launch_predict(sl2_engine* e) {
+  LaunchScope ls(e, "k_predict");
+  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(128), 0, e->stream, e->x, e->P, e->n_slots, e->ld, e->prm.delta_t);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+int launch_feature_prediction(sl2_engine* e) {
+  LaunchScope ls(e, "k_feature_prediction");
+  dim3 grid((e->N + 63) / 64, e->B);
+  hipLaunchKernelGGL(k_feature_prediction, grid, dim3(64), 0, e->stream, e->x, e->P, e->xp_org, e->f_flags, e->n_slots,
+                     e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score, e->cam, e->N, e->ld);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+int launch_select(sl2_engine* e, int n) {
+  LaunchScope ls(e, "k_select");
+  if (n > e->nsel_max) n = e->nsel_max;
+  const size_t shm = (size_t)e->N * (sizeof(double) + sizeof(int));
+  hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->N, n);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+int launch_finalize(sl2_engine* e, int save_trajectory) {
+  LaunchScope ls(e, "k_finalize");
+  const size_t shm = (size_t)e->N * sizeof(int);
+  hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
+                     e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->N, e->ld,
+                     e->prm.minimum_attempted_measurements_of_feature, e->prm.successful_match_fraction, save_trajectory);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+}  // namespace sl2

@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's MonoSLAM / Kalman / Feature interface over the
+C ABI (include/scenelib2_amd.h).
+
+* `Engine` — the batched engine: B independent sequences stepped together.
+* `MonoSLAM` — a single-sequence object with the reference's member names
+  (scenelib2/monoslam.h:69-219): Init(cfg), GoOneStep(frame, save_trajectory,
+  enable_mapping), xv_, Pxx_, feature_list_, selected_feature_list_,
+  trajectory_store_, AddNewKnownFeature, print_robot_state ... so that tests read
+  like the reference's own usage (examples/MonoSlamSceneLib1.cpp:132-142).
+
+All numerical work happens in the HIP library; nothing here computes SLAM math.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import load_config, read_pgm, resolve_identifier
+
+
+class Engine:
+    """B independent MonoSLAM instances on one GPU (one HIP stream)."""
+
+    def __init__(self, cam, params, batch, max_features, device=0, stream=None):
+        self.L = _lib.load()
+        self.cam = dict(cam)
+        self.params = dict(params)
+        self.batch = int(batch)
+        self.max_features = int(max_features)
+        self.device = int(device)
+        self.frame_bytes = int(cam["width"]) * int(cam["height"])
+        self._cam = _lib.make_camera(cam)
+        self._prm = _lib.make_params(params)
+        h = _lib.vp()
+        _lib.check(self.L.sl2_create(C.byref(self._cam), C.byref(self._prm), self.batch, self.max_features,
+                                     self.device, _lib.vp(stream) if stream else None, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.sl2_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------
+    def set_vehicle_state(self, xv, Pxx, seq0=0):
+        xv = np.ascontiguousarray(xv, dtype=np.float64).reshape(-1, 13)
+        Pxx = np.ascontiguousarray(Pxx, dtype=np.float64).reshape(-1, 13, 13)
+        assert xv.shape[0] == Pxx.shape[0]
+        _lib.check(self.L.sl2_set_vehicle_state(self.h, seq0, xv.shape[0], _lib.dp(xv), _lib.dp(Pxx)))
+
+    def get_vehicle_state(self, seq0=0, nseq=None):
+        nseq = self.batch - seq0 if nseq is None else nseq
+        xv = np.zeros((nseq, 13))
+        Pxx = np.zeros((nseq, 13, 13))
+        _lib.check(self.L.sl2_get_vehicle_state(self.h, seq0, nseq, _lib.dp(xv), _lib.dp(Pxx)))
+        return xv, Pxx
+
+    def add_known_features(self, y, xp_org, patches, seq0=0):
+        """y [nseq][nfeat][3], xp_org [nseq][nfeat][7], patches [nseq][nfeat][11][11] uint8."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        nseq, nfeat = y.shape[0], y.shape[1]
+        xp = np.ascontiguousarray(xp_org, dtype=np.float64).reshape(nseq, nfeat, 7)
+        p = np.ascontiguousarray(patches, dtype=np.uint8).reshape(nseq, nfeat, 121)
+        _lib.check(self.L.sl2_add_known_features(self.h, seq0, nseq, nfeat, _lib.dp(y), _lib.dp(xp), _lib.u8p(p)))
+
+    # ---- stepping ----------------------------------------------------------
+    def _frames_arg(self, frames, seq_stride, on_device):
+        if on_device:
+            return _lib.vp(int(frames)), int(seq_stride if seq_stride else self.frame_bytes), 1, None
+        f = np.ascontiguousarray(frames, dtype=np.uint8).reshape(self.batch, self.frame_bytes)
+        return f.ctypes.data_as(_lib.vp), self.frame_bytes, 0, f
+
+    def go_one_step(self, frames, save_trajectory=False, enable_mapping=False, on_device=False, seq_stride=0):
+        ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
+        _lib.check(self.L.sl2_go_one_step(self.h, ptr, stride, dev, int(save_trajectory), int(enable_mapping)))
+        if keep is not None:
+            self.synchronize()  # host buffer must outlive the async H2D copy
+
+    def kalman_filter_predict(self):
+        _lib.check(self.L.sl2_kalman_filter_predict(self.h))
+
+    def auto_select_n_features(self, n):
+        _lib.check(self.L.sl2_auto_select_n_features(self.h, int(n)))
+
+    def make_measurements(self, frames, on_device=False, seq_stride=0):
+        ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
+        _lib.check(self.L.sl2_make_measurements(self.h, ptr, stride, dev))
+        if keep is not None:
+            self.synchronize()
+
+    def kalman_filter_update(self):
+        _lib.check(self.L.sl2_kalman_filter_update(self.h))
+
+    def finish_step(self, save_trajectory=False):
+        _lib.check(self.L.sl2_finish_step(self.h, int(save_trajectory)))
+
+    def synchronize(self):
+        _lib.check(self.L.sl2_synchronize(self.h))
+
+    # ---- state access ------------------------------------------------------
+    def total_state_sizes(self, seq0=0, nseq=None):
+        nseq = self.batch - seq0 if nseq is None else nseq
+        out = np.zeros(nseq, dtype=np.int32)
+        _lib.check(self.L.sl2_get_total_state_sizes(self.h, seq0, nseq, _lib.ip(out)))
+        return out
+
+    def total_state(self, seq):
+        n = int(self.total_state_sizes(seq, 1)[0])
+        x = np.zeros(n)
+        _lib.check(self.L.sl2_get_total_state(self.h, seq, _lib.dp(x), n))
+        return x
+
+    def total_covariance(self, seq):
+        n = int(self.total_state_sizes(seq, 1)[0])
+        P = np.zeros((n, n))
+        _lib.check(self.L.sl2_get_total_covariance(self.h, seq, _lib.dp(P), n))
+        return P
+
+    def features(self, seq, include_deleted=False):
+        arr = (_lib.sl2_feature_info * self.max_features)()
+        cnt = C.c_int(0)
+        _lib.check(self.L.sl2_get_features(self.h, seq, arr, self.max_features, int(include_deleted), C.byref(cnt)))
+        out = []
+        for i in range(cnt.value):
+            f = arr[i]
+            out.append(dict(label=f.label, active=bool(f.active), selected=bool(f.selected_flag),
+                            success=bool(f.successful_measurement_flag),
+                            attempted=f.attempted_measurements_of_feature,
+                            successful=f.successful_measurements_of_feature,
+                            pos=f.position_in_total_state_vector, visible=bool(f.visible),
+                            y=np.array(f.y[:]), h=np.array(f.h[:]), z=np.array(f.z[:]), nu=np.array(f.nu[:]),
+                            R=float(f.R), S=np.array(f.S[:]).reshape(2, 2),
+                            dh_by_dxp=np.array(f.dh_by_dxp[:]).reshape(2, 7),
+                            dh_by_dy=np.array(f.dh_by_dy[:]).reshape(2, 3), xp_org=np.array(f.xp_org[:])))
+        return out
+
+    def selection(self, seq):
+        labels = np.zeros(self.max_features, dtype=np.int32)
+        counters = np.zeros(3, dtype=np.int32)
+        _lib.check(self.L.sl2_get_selection(self.h, seq, _lib.ip(labels), self.max_features, _lib.ip(counters)))
+        return labels[:counters[1]].copy(), dict(visible=int(counters[0]), selected=int(counters[1]),
+                                                 measurement_size=int(counters[2]))
+
+    def trajectory(self, seq, capacity=1000):
+        out = np.zeros((capacity, 3))
+        cnt = C.c_int(0)
+        _lib.check(self.L.sl2_get_trajectory(self.h, seq, _lib.dp(out), capacity, C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def set_feature_counters(self, seq, label, attempted, successful):
+        _lib.check(self.L.sl2_set_feature_counters(self.h, seq, label, attempted, successful))
+
+    def status_flags(self):
+        out = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(self.L.sl2_get_status_flags(self.h, 0, self.batch, _lib.ip(out)))
+        return out
+
+    # ---- profiling -----------------------------------------------------------
+    def set_profiling(self, on):
+        _lib.check(self.L.sl2_set_profiling(self.h, int(on)))
+
+    def reset_kernel_times(self):
+        _lib.check(self.L.sl2_reset_kernel_times(self.h))
+
+    def kernel_times(self):
+        n = self.L.sl2_kernel_count(self.h)
+        out = {}
+        for i in range(n):
+            name = C.c_char_p()
+            ms = C.c_double(0)
+            cnt = C.c_int64(0)
+            _lib.check(self.L.sl2_get_kernel_time(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            out[name.value.decode()] = dict(total_ms=ms.value, launches=cnt.value)
+        return out
+
+    def step_work(self):
+        w = np.zeros(10)
+        _lib.check(self.L.sl2_get_step_work(self.h, _lib.dp(w)))
+        keys = ["window_bytes", "searched", "candidates", "sum_m", "sum_m2", "sum_m3", "sum_n", "sum_nm", "sum_nnm",
+                "sum_nmm"]
+        return dict(zip(keys, w.tolist()))
+
+
+class Feature:
+    """Read-only view with the member names of SceneLib2::Feature (feature.h:78-142)."""
+
+    def __init__(self, d, patch=None):
+        self.label_ = d["label"]
+        self.y_ = d["y"]
+        self.xp_org_ = d["xp_org"]
+        self.h_ = d["h"]
+        self.z_ = d["z"]
+        self.nu_ = d["nu"]
+        self.S_ = d["S"]
+        self.R_ = np.eye(2) * d["R"]
+        dh = np.zeros((2, 13))
+        dh[:, :7] = d["dh_by_dxp"]
+        self.dh_by_dxv_ = dh
+        self.dh_by_dy_ = d["dh_by_dy"]
+        self.selected_flag_ = d["selected"]
+        self.successful_measurement_flag_ = d["success"]
+        self.attempted_measurements_of_feature_ = d["attempted"]
+        self.successful_measurements_of_feature_ = d["successful"]
+        self.position_in_total_state_vector_ = d["pos"]
+        self.fully_initialised_flag_ = True
+        self.patch_ = patch
+
+
+class MonoSLAM:
+    """Single-sequence MonoSLAM with the reference's public surface (monoslam.h:69-219)."""
+
+    kBoxSize_ = 11
+    kNoSigma_ = 3.0
+    kCorrThresh2_ = 0.40
+    kCorrelationSigmaThreshold_ = 10.0
+
+    def __init__(self, max_features=64, device=0):
+        self._max_features = max_features
+        self._device = device
+        self._engine = None
+        self._patches = {}
+        self.camera_ = None
+
+    # MonoSLAM::Init(config_path) — monoslam.cpp:1574-1969
+    def Init(self, config_path, template_dirs=()):
+        cfg = load_config(config_path)
+        self.InitFromValues(cfg["cam"], cfg["params"], cfg["xv"], cfg["Pxx"])
+        for f in cfg["features"]:
+            self.AddNewKnownFeature(f["y"], f["xp_org"], resolve_identifier(f, template_dirs))
+        return self
+
+    def InitFromValues(self, cam, params, xv, Pxx):
+        self.camera_ = dict(cam)
+        self.kDeltaT_ = params["delta_t"]
+        self.kNumberOfFeaturesToSelect_ = params["number_of_features_to_select"]
+        self._engine = Engine(cam, params, 1, self._max_features, self._device)
+        self._engine.set_vehicle_state(np.asarray(xv).reshape(1, 13), np.asarray(Pxx).reshape(1, 13, 13))
+        return self
+
+    # MonoSLAM::AddNewKnownFeature(y, xp, identifier) — monoslam.cpp:1278-1291
+    def AddNewKnownFeature(self, y, xp, identifier):
+        patch = read_pgm(identifier) if isinstance(identifier, str) else np.asarray(identifier, dtype=np.uint8)
+        if patch.shape != (11, 11):
+            raise ValueError("template must be 11x11")
+        label = len(self._patches)
+        self._engine.add_known_features(np.asarray(y).reshape(1, 1, 3), np.asarray(xp).reshape(1, 1, 7),
+                                        patch.reshape(1, 1, 11, 11))
+        self._patches[label] = patch
+
+    # MonoSLAM::GoOneStep(frame, save_trajectory, enable_mapping) — monoslam.cpp:108-180
+    def GoOneStep(self, frame, save_trajectory=False, enable_mapping=False):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        if f.size != self._engine.frame_bytes:
+            raise ValueError("frame must be %d x %d 8-bit single channel" % (self.camera_["width"], self.camera_["height"]))
+        self._engine.go_one_step(f.reshape(1, -1), save_trajectory, enable_mapping)
+        return True  # the reference always returns true (monoslam.cpp:179)
+
+    @property
+    def xv_(self):
+        return self._engine.get_vehicle_state(0, 1)[0][0]
+
+    @property
+    def Pxx_(self):
+        return self._engine.get_vehicle_state(0, 1)[1][0]
+
+    @property
+    def feature_list_(self):
+        return [Feature(d, self._patches.get(d["label"])) for d in self._engine.features(0)]
+
+    @property
+    def selected_feature_list_(self):
+        labels, _ = self._engine.selection(0)
+        by_label = {f.label_: f for f in self.feature_list_}
+        return [by_label[l] for l in labels if l in by_label]
+
+    @property
+    def number_of_visible_features_(self):
+        return self._engine.selection(0)[1]["visible"]
+
+    @property
+    def successful_measurement_vector_size_(self):
+        return self._engine.selection(0)[1]["measurement_size"]
+
+    @property
+    def total_state_size_(self):
+        return int(self._engine.total_state_sizes(0, 1)[0])
+
+    @property
+    def trajectory_store_(self):
+        return self._engine.trajectory(0)
+
+    def construct_total_state(self):
+        return self._engine.total_state(0)
+
+    def construct_total_covariance(self):
+        return self._engine.total_covariance(0)
+
+    # MonoSLAM::print_robot_state — monoslam.cpp:1543-1549
+    def print_robot_state(self):
+        print("[Robot state]")
+        print(self.xv_)
+        print("[Robot covariance]")
+        print(self.Pxx_)

@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Headline benchmark: batched MonoSLAM frames/s (320x240, 100 features).
+
+A "step" is one MonoSLAM::GoOneStep (monoslam.cpp:108-180: predict -> select ->
+elliptical NCC search -> EKF update -> normalise -> delete -> symmetrise) applied
+to every sequence of the batch.  Workload at N = 1 GPU: BASELINE.json configs[2]
+(batch 1024 independent 320x240 synthetic sequences, 100 features each); with
+--gpus N every rank owns its own 1024 sequences (weak scaling, no collective in
+the data path; RCCL only for the barrier / MAX-reduce and the final state gather).
+
+Inputs (synthetic frames rendered on the device, templates, states) are resident
+in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6   # MI355X FP64 matrix = FP64 vector peak (256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz); SURVEY §8(d)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=1024, help="sequences per GPU")
+    ap.add_argument("--features", type=int, default=100)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--height", type=int, default=240)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per core, max 32; 0: skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch  # first: one shared HIP runtime (scenelib2_amd/_lib.py)
+    import torch.distributed as dist
+    from scenelib2_amd import Engine, _lib, sharding, synth
+
+    rank, world, local_rank = sharding.env_rank_world()
+    if world > 1:
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available() or _lib.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
+    tdev = torch.device("cuda", dev)
+
+    B, N, W, H = args.batch, args.features, args.width, args.height
+    K, Wm = args.steps, args.warmup
+    n_frames = K + Wm
+    cam = synth.default_camera(W, H)
+    params = synth.default_params(N)
+    seq_ids = sharding.global_sequence_ids(B, world, rank)
+
+    # ---- synthetic inputs: specs on the host, frames rendered on the device ----
+    t_setup = time.time()
+    tex = synth.make_texture()
+    specs = [synth.SequenceSpec(cam, N, n_frames, synth.BASE_SEED + int(i)) for i in seq_ids]
+    fb = W * H
+    d_tex = _lib.DeviceBuffer(tex.nbytes, dev); d_tex.upload(tex)
+    # pose k of every sequence, k-major: frames[k][b]
+    poses = np.ascontiguousarray(np.stack([s.poses for s in specs], axis=1))       # [n_frames+1][B][7]
+    origins = np.ascontiguousarray(np.tile(np.stack([s.tex_origin for s in specs])[None], (n_frames + 1, 1, 1)))
+    d_pose = _lib.DeviceBuffer(poses.nbytes, dev); d_pose.upload(poses)
+    d_org = _lib.DeviceBuffer(origins.nbytes, dev); d_org.upload(origins)
+    d_frames = _lib.DeviceBuffer((n_frames + 1) * B * fb, dev)
+    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr, d_pose.ptr, (n_frames + 1) * B,
+                        d_frames.ptr, device=dev)
+    torch.cuda.synchronize()
+    frame0 = d_frames.download((B, H, W), np.uint8)                                  # t = 0 views -> templates
+    templates = np.stack([synth.cut_templates(frame0[b], specs[b].feat_px) for b in range(B)])
+
+    eng = Engine(cam, params, B, N, device=dev)
+    eng.set_vehicle_state(np.stack([s.xv0 for s in specs]), np.stack([s.Pxx0 for s in specs]))
+    eng.add_known_features(np.stack([s.feat_y for s in specs]), np.stack([s.xp_org() for s in specs]), templates)
+    eng.synchronize()
+    setup_s = time.time() - t_setup
+
+    def step(k):  # frame k (0-based) = pose k+1, resident in HBM
+        eng.go_one_step(d_frames.ptr + (k + 1) * B * fb, on_device=True, seq_stride=fb)
+
+    # ---- warm-up ----
+    for k in range(Wm):
+        step(k)
+    eng.synchronize()
+    if not args.no_profile:
+        eng.set_profiling(True)
+        eng.reset_kernel_times()
+
+    # ---- timed region: exactly K steps ----
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(Wm, Wm + K):
+        step(k)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = sharding.max_over_ranks(elapsed, tdev if world > 1 else None)
+
+    ktimes = eng.kernel_times() if not args.no_profile else {}
+    eng.set_profiling(False)
+    work = eng.step_work()       # algorithmic work of the last step, summed over this rank's batch
+    total_frames = sharding.sum_over_ranks(B * K, tdev if world > 1 else None)
+    value = total_frames / elapsed
+
+    # ---- gather of the small results (RCCL all-gather; outside the timed region) ----
+    t_g = time.perf_counter()
+    xv_final, _ = eng.get_vehicle_state()
+    all_xv = sharding.gather_states(xv_final, tdev if world > 1 else None)
+    gather_ms = (time.perf_counter() - t_g) * 1e3
+    status_bad = int(eng.status_flags().any())
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel + the search kernel ----
+        roof = None
+        roof_search = None
+        per_kernel = {}
+        if ktimes:
+            tot_ms = sum(v["total_ms"] for v in ktimes.values())
+            for name, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["total_ms"]):
+                per_kernel[name] = dict(ms_per_step=v["total_ms"] / K, launches_per_step=v["launches"] / K,
+                                        share=v["total_ms"] / tot_ms if tot_ms else 0.0)
+            dom = max(ktimes.items(), key=lambda kv: kv[1]["total_ms"])[0]
+            # algorithmic FLOPs per launch over the rank's batch (executed formulation)
+            flops = {"k_syrk": work["sum_nnm"],                  # P -= V V^T on the symmetric half: n^2 m
+                     "k_fwdsub": work["sum_nmm"],                # V = A L^-T: n m^2
+                     "k_build_A": 20.0 * work["sum_nm"],         # sparse P H^T
+                     "k_build_S": 20.0 * work["sum_m2"]}
+            chol = work["sum_m3"] / 3.0
+            n_chol_launch = sum(ktimes[n]["launches"] for n in ("k_chol_diag", "k_chol_panel", "k_chol_trail") if n in ktimes)
+            bsearch = work["window_bytes"] + (121.0 + 64.0) * work["searched"]   # SURVEY §8(d) B_search, summed over the batch
+            if "k_search" in ktimes:
+                dur = ktimes["k_search"]["total_ms"] / ktimes["k_search"]["launches"] * 1e-3
+                ach = bsearch / dur / 1e9
+                roof_search = dict(kernel="k_search", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=ach / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=bsearch,
+                                   avg_launch_ms=dur * 1e3, candidates_per_launch=work["candidates"])
+            if dom in flops:
+                dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
+                ach = flops[dom] / dur / 1e12
+                roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                            frac=ach / FP64_MFMA_PEAK_TF, traffic=None, algorithmic_flops_per_launch=flops[dom],
+                            avg_launch_ms=dur * 1e3)
+            elif dom == "k_search":
+                roof = roof_search
+            elif dom.startswith("k_chol"):
+                dur_all = sum(ktimes[n]["total_ms"] for n in ("k_chol_diag", "k_chol_panel", "k_chol_trail") if n in ktimes) / K * 1e-3
+                ach = chol / dur_all / 1e12
+                roof = dict(kernel="k_chol_*", bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
+                            frac=ach / FP64_MFMA_PEAK_TF, traffic=None, algorithmic_flops_per_launch=chol,
+                            avg_launch_ms=dur_all * 1e3, launches=n_chol_launch / K)
+            else:
+                dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
+                roof = dict(kernel=dom, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
+                            traffic=None, avg_launch_ms=dur * 1e3)
+
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
+        cpu = None
+        parity = None
+        ncores = os.cpu_count() or 1
+        sample = args.cpu_sample if args.cpu_sample >= 0 else min(ncores, 32, B)
+        if world == 1 and sample > 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_api as oa
+            sample = min(sample, B)
+            # the same bytes the GPU consumed: frames[k][b] for the first `sample` sequences
+            allf = np.stack([d_frames.download((sample, H, W), np.uint8, offset=k * B * fb) for k in range(n_frames + 1)])
+            slams, frames_list = [], []
+            for b in range(sample):
+                s = oa.OracleSLAM(cam, params["delta_t"], N)
+                s.set_state(specs[b].xv0, specs[b].Pxx0)
+                xo = specs[b].xp_org()
+                for i in range(N):
+                    s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
+                slams.append(s)
+                frames_list.append(np.ascontiguousarray(allf[1:, b]))
+            nthreads = min(ncores, sample)
+            secs, traj = oa.run_sequences(slams, frames_list, nthreads=nthreads)
+            cpu = dict(value=sample * n_frames / secs, unit="frames/s", cores=nthreads, kind="port",
+                       sample="%d sequences x %d frames (320x240, %d features) of this run's input, one oracle instance per thread"
+                              % (sample, n_frames, N),
+                       seconds=secs, single_thread_frames_per_s=None)
+            d = slams[0].diag()
+            tt = sum(d["times"].values())
+            cpu["stage_split"] = {k: float(v / tt) for k, v in d["times"].items()}
+            # parity of the trajectories on the sample (BASELINE metric: traj RMSE vs ref <= 1e-4)
+            log = eng.position_log(0, sample, capacity=n_frames)
+            rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
+            parity = dict(traj_rmse_vs_oracle=rmse, sequences=sample, frames=n_frames,
+                          final_state_maxabs=float(np.abs(all_xv[:sample] - np.stack([s.get_state()[0] for s in slams])).max()))
+
+        out = {
+            "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch %d independent %dx%d synthetic sequences per GPU, %d features each, all features selected"
+                                   % (B, W, H, N),
+                       "sequences_per_gpu": B, "features": N, "width": W, "height": H,
+                       "state_dim": 13 + 3 * N, "parallelism": "independent sequences sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": roof, "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity,
+            "kernels": per_kernel,
+            "work_per_step": {k: v for k, v in work.items()},
+            "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,
+            "gathered_states": int(all_xv.shape[0]),
+        }
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

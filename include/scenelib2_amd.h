@@ -168,6 +168,10 @@ int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int
 /* trajectory_store_ (monoslam.cpp:172-177; keeps the reference's stale-scratch
  * behaviour): up to `capacity` most recent entries of 3 doubles. */
 int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count);
+/* xv_(0..2) after each of the last `count` steps (the actual camera trajectory; the
+ * reference's trajectory_store_ holds a stale scratch value instead):
+ * out [nseq][count][3], count = min(capacity, steps done, 1000). */
+int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int capacity, int* count);
 /* Feature::attempted_/successful_measurements (test hook for delete_bad_features). */
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful);
 /* Non-zero bits: 1 = NaN/Inf seen in the state (e.g. the omega == 0 hazard, Q10). */

@@ -66,7 +66,7 @@ EXPORTED_SYMBOLS = [
     "sl2_go_one_step", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
-    "sl2_get_trajectory", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
+    "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
     "sl2_dev_download", "sl2_debug_ncc_score", "sl2_debug_gemm_kt",
@@ -126,6 +126,7 @@ def load():
     L.sl2_get_features.argtypes = [vp, C.c_int, C.POINTER(sl2_feature_info), C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.sl2_get_selection.argtypes = [vp, C.c_int, c_ip, C.c_int, c_ip]
     L.sl2_get_trajectory.argtypes = [vp, C.c_int, c_dp, C.c_int, C.POINTER(C.c_int)]
+    L.sl2_get_position_log.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.POINTER(C.c_int)]
     L.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.sl2_get_status_flags.argtypes = [vp, C.c_int, C.c_int, c_ip]
     L.sl2_set_profiling.argtypes = [vp, C.c_int]

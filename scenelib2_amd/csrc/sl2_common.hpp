@@ -83,6 +83,8 @@ struct sl2_engine {
   int* traj_count = nullptr;  // [B]  total pushes
   double* last_r = nullptr;   // [B][3] scratch motion_model_->rRES_ (Q12)
   int* status = nullptr;      // [B]
+  double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
+  long long steps_done = 0;
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]

@@ -183,6 +183,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->traj_count, B));
   A(dmalloc(&e->last_r, B * 3));
   A(dmalloc(&e->status, B));
+  A(dmalloc(&e->pos_log, B * kTrajCapacity * 3));
   A(dmalloc(&e->f_h, B * N * 2));
   A(dmalloc(&e->f_Hx, B * N * 14));
   A(dmalloc(&e->f_Hy, B * N * 6));
@@ -216,7 +217,7 @@ void sl2_destroy(sl2_engine* e) {
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
-                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf};
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -507,6 +508,24 @@ int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* c
     const int slot = logical % kTrajCapacity;
     for (int k = 0; k < 3; ++k) out[i * 3 + k] = ring[(size_t)slot * 3 + k];
   }
+  *count = n;
+  return SL2_OK;
+}
+
+int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int capacity, int* count) {
+  if (!range_ok(e, seq0, nseq) || !out || !count || capacity <= 0) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  SL2_HIP(hipStreamSynchronize(e->stream));
+  const long long total = e->steps_done;
+  const int have = (int)(total < kTrajCapacity ? total : kTrajCapacity);
+  const int n = have < capacity ? have : capacity;
+  std::vector<double> ring((size_t)nseq * kTrajCapacity * 3);
+  SL2_HIP(hipMemcpy(ring.data(), e->pos_log + (size_t)seq0 * kTrajCapacity * 3, sizeof(double) * ring.size(), hipMemcpyDeviceToHost));
+  for (int s = 0; s < nseq; ++s)
+    for (int i = 0; i < n; ++i) {
+      const int slot = (int)((total - n + i) % kTrajCapacity);
+      for (int k = 0; k < 3; ++k) out[((size_t)s * n + i) * 3 + k] = ring[((size_t)s * kTrajCapacity + slot) * 3 + k];
+    }
   *count = n;
   return SL2_OK;
 }

@@ -174,8 +174,8 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   int* __restrict__ successful, const int* __restrict__ m_count,
                                                   const int* __restrict__ n_sel, double* __restrict__ traj,
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
-                                                  int* __restrict__ status, int N, int ld, int min_attempts,
-                                                  double match_fraction, int save_trajectory) {
+                                                  int* __restrict__ status, double* __restrict__ pos_log, int log_slot, int N, int ld,
+                                                  int min_attempts, double match_fraction, int save_trajectory) {
   extern __shared__ int s_del[];  // [N] slots deleted this frame
   __shared__ double s_N[16], s_P[169], s_T[169];
   __shared__ int s_ndel;
@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
       for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
       traj_count[b] = c + 1;
     }
+    for (int k = 0; k < 3; ++k) pos_log[((size_t)b * kTrajCapacity + log_slot) * 3 + k] = xb[k];
     bool bad = false;
     for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]);
     if (bad) status[b] |= 1;
@@ -314,9 +315,11 @@ int launch_finalize(sl2_engine* e, int save_trajectory) {
   LaunchScope ls(e, "k_finalize");
   const size_t shm = (size_t)e->N * sizeof(int);
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
-                     e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->N, e->ld,
-                     e->prm.minimum_attempted_measurements_of_feature, e->prm.successful_match_fraction, save_trajectory);
+                     e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
+                     (int)(e->steps_done % kTrajCapacity), e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
+                     e->prm.successful_match_fraction, save_trajectory);
   SL2_HIP(hipGetLastError());
+  e->steps_done += 1;
   return SL2_OK;
 }
 

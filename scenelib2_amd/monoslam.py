@@ -153,6 +153,14 @@ class Engine:
         _lib.check(self.L.sl2_get_trajectory(self.h, seq, _lib.dp(out), capacity, C.byref(cnt)))
         return out[:cnt.value].copy()
 
+    def position_log(self, seq0=0, nseq=None, capacity=1000):
+        """xv[0:3] after each of the last steps: [nseq][count][3]."""
+        nseq = self.batch - seq0 if nseq is None else nseq
+        out = np.zeros((nseq, capacity, 3))
+        cnt = C.c_int(0)
+        _lib.check(self.L.sl2_get_position_log(self.h, seq0, nseq, _lib.dp(out), capacity, C.byref(cnt)))
+        return out.reshape(-1)[: nseq * cnt.value * 3].reshape(nseq, cnt.value, 3).copy()
+
     def set_feature_counters(self, seq, label, attempted, successful):
         _lib.check(self.L.sl2_set_feature_counters(self.h, seq, label, attempted, successful))
 

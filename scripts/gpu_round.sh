@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, rocprofv3 summaries.  Everything
+# lands under gpurun_out/ (merged back by gpurun).  Usage: scripts/gpu_round.sh [tag] [stages]
+TAG=${1:-r01}
+STAGES=${2:-"tests smoke bench prof"}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+echo "== env" > $OUT/env.txt
+(rocminfo | grep -E "Marketing Name|gfx|Compute Unit" | head -12; nproc; free -g | head -2; python -c "import torch;print(torch.__version__, torch.cuda.is_available())") >> $OUT/env.txt 2>&1
+for st in $STAGES; do
+case $st in
+tests)
+  timeout 900 python -m pytest tests -q -m gpu -x --timeout=600 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -25 $OUT/pytest_gpu.log ;;
+testsall)
+  timeout 1200 python -m pytest tests -q -m gpu --timeout=600 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_gpu.log
+  tail -40 $OUT/pytest_gpu.log ;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke exit $?" >> $OUT/smoke.log
+  tail -5 $OUT/smoke.log ;;
+benchsmall)
+  timeout 600 python bench.py --batch 64 --steps 3 --warmup 1 --cpu-sample 2 > $OUT/bench_small.json 2> $OUT/bench_small.err; echo "bench small exit $?"
+  tail -c 3000 $OUT/bench_small.json; tail -5 $OUT/bench_small.err ;;
+bench)
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+  tail -c 4000 $OUT/bench.json; tail -5 $OUT/bench.err ;;
+prof)
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
+  find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done ;;
+pmc)
+  for c in FETCH_SIZE WRITE_SIZE; do
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d $OLDPWD/$OUT/pmc_$c -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err ); echo "pmc $c exit $?"
+  done
+  python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; tail -30 $OUT/pmc_summary.txt ;;
+esac
+done
+ls -la $OUT | head -30

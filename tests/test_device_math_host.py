@@ -1,0 +1,175 @@
+"""The scalar FP64 model math that the HIP kernels inline (scenelib2_amd/csrc/
+sl2_math.hpp), compiled here for the HOST purely as a test vehicle, against the
+oracle.  Everything except sin/cos/acos-dependent values must agree bit for bit
+(same operation order, no FP contraction)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import SHIPPED_CAM
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _rand_xv(rng):
+    q = np.array([0.95, 0.1, -0.15, 0.2]) + rng.normal(size=4) * 0.05
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(size=3) * 0.2 + [0, 0, -0.6], q, rng.normal(size=3) * 0.1,
+                           rng.normal(size=3) * 0.2])
+
+
+def test_motion_model_matches_oracle(oracle, devmath):
+    rng = np.random.default_rng(10)
+    for _ in range(20):
+        xv = _rand_xv(rng)
+        f0, F0, Q0 = oracle.motion_model(xv, 1 / 30.0)
+        f = np.zeros(13)
+        F = np.zeros((13, 13))
+        Q = np.zeros((13, 13))
+        devmath.dm_motion(_dp(xv), 1 / 30.0, _dp(f), _dp(F), _dp(Q))
+        assert np.array_equal(f, f0)
+        assert np.array_equal(F, F0)
+        assert np.array_equal(Q, Q0)
+
+
+def test_predict_covariance_matches_dense_product(oracle, devmath):
+    rng = np.random.default_rng(11)
+    xv = _rand_xv(rng)
+    A = rng.normal(size=(13, 13))
+    Pxx = A @ A.T * 1e-3
+    strip = rng.normal(size=(13, 9)) * 1e-3
+    _, F, Q = oracle.motion_model(xv, 1 / 30.0)
+    Po = np.zeros((13, 13))
+    So = np.zeros((13, 9))
+    devmath.dm_predict_cov(_dp(xv), 1 / 30.0, _dp(np.ascontiguousarray(Pxx)), _dp(np.ascontiguousarray(strip)), 9,
+                           _dp(Po), _dp(So))
+    assert np.allclose(Po, F @ Pxx @ F.T + Q, rtol=1e-13, atol=1e-18)
+    assert np.allclose(So, F @ strip, rtol=1e-13, atol=1e-18)
+    # and bit-exact against the oracle's own KalmanFilterPredict on the same numbers
+    s = oracle.OracleSLAM(SHIPPED_CAM, 1 / 30.0, 10)
+    s.set_state(xv, Pxx)
+    s.kalman_filter_predict()
+    _, P1 = s.get_state()
+    assert np.array_equal(Po, P1)
+
+
+def test_measurement_model_matches_oracle_bitwise(oracle, devmath):
+    rng = np.random.default_rng(12)
+    c8 = oracle.cam8(SHIPPED_CAM)
+    for _ in range(50):
+        xv = _rand_xv(rng)
+        xp = xv[:7].copy()
+        y = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2), rng.uniform(-0.05, 0.05)])
+        xo = _rand_xv(rng)[:7]
+        want = oracle.measurement_model(SHIPPED_CAM, xp, y, xo)
+        out = np.zeros(24)
+        devmath.dm_measurement(_dp(c8), _dp(xp), _dp(y), _dp(xo), _dp(out))
+        assert np.array_equal(out[0:2], want["h"])
+        assert np.array_equal(out[2:16].reshape(2, 7), want["dh_by_dxp"])
+        assert np.array_equal(out[16:22].reshape(2, 3), want["dh_by_dy"])
+        assert out[22] == want["R"]
+        assert int(out[23]) == want["vis"]
+
+
+def test_innovation_cov_matches_oracle_bitwise(oracle, devmath):
+    rng = np.random.default_rng(13)
+    s = oracle.OracleSLAM(SHIPPED_CAM, 1 / 30.0, 10)
+    xv = _rand_xv(rng)
+    xv[3:7] = [1, 0, 0, 0]
+    xv[:3] = [0.01, -0.02, -0.6]
+    A = rng.normal(size=(13, 13))
+    s.set_state(xv, A @ A.T * 1e-4)
+    ys = [np.array([0.1, 0.05, 0.0]), np.array([-0.12, 0.02, 0.0])]
+    for y in ys:
+        s.add_known_feature(y, xv[:7], np.zeros((11, 11), np.uint8))
+    img = rng.integers(0, 255, (240, 320), dtype=np.uint8)
+    s.go_one_step(img)
+    s.kalman_filter_predict()
+    s.auto_select_n_features(10)
+    P = s.total_covariance()
+    for i in range(2):
+        f = s.feature(i)
+        pos = f["pos"]
+        S = np.zeros(4)
+        Hx = np.ascontiguousarray(f["dh_by_dxv"][:, :7])
+        devmath.dm_innovation_cov(_dp(Hx), _dp(np.ascontiguousarray(f["dh_by_dy"])), f["R"],
+                                  _dp(np.ascontiguousarray(P[:7, :7])), _dp(np.ascontiguousarray(P[:7, pos:pos + 3])),
+                                  _dp(np.ascontiguousarray(P[pos:pos + 3, pos:pos + 3])), _dp(S))
+        assert np.array_equal(S.reshape(2, 2), f["S"])
+
+
+def test_sinv_and_bounds_match_oracle(oracle, devmath):
+    rng = np.random.default_rng(14)
+    img = np.zeros((240, 320), np.uint8)
+    patch = np.zeros(121, np.uint8)
+    for _ in range(200):
+        s0, s1 = rng.uniform(2, 60, 2)
+        r = rng.uniform(-0.8, 0.8) * np.sqrt(s0 * s1)
+        S = np.array([[s0, r], [r, s1]])
+        abc = np.zeros(3)
+        devmath.dm_sinv(_dp(S.reshape(4).copy()), _dp(abc))
+        assert np.array_equal(abc, oracle.sinv_from_S(S))
+        centre = np.array([rng.uniform(-5, 325), rng.uniform(-5, 245)])
+        out = np.zeros(8, dtype=np.int32)
+        devmath.dm_search_bounds(_dp(centre), abc[0], abc[1], abc[2], 320, 240, out.ctypes.data_as(C.POINTER(C.c_int)))
+        ref = oracle.elliptical_search(img, patch, centre, *abc)
+        assert (out[6], out[7]) == (ref["hw"], ref["hh"])
+        # candidate count by the device's own enumeration == the oracle's
+        n = 0
+        for ur in range(out[2], out[3] + 1):
+            for vr in range(out[4], out[5] + 1):
+                n += devmath.dm_in_ellipse(abc[0], abc[1], abc[2], ur, vr)
+        assert n == ref["ncand"]
+
+
+def test_ncc_score_matches_oracle_bitwise(oracle, devmath):
+    rng = np.random.default_rng(15)
+    for _ in range(300):
+        patch = rng.integers(0, 256, (11, 11), dtype=np.uint8)
+        win = rng.integers(0, 256, (11, 11), dtype=np.uint8)
+        if rng.random() < 0.1:
+            win[:] = rng.integers(0, 256)
+        if rng.random() < 0.1:
+            patch[:] = rng.integers(0, 256)
+        p, w = patch.astype(np.int64), win.astype(np.int64)
+        sd0 = C.c_double(0)
+        sd1 = C.c_double(0)
+        got = devmath.dm_ncc_score(int(p.sum()), int(w.sum()), int((p * w).sum()), int((p * p).sum()),
+                                   int((w * w).sum()), C.byref(sd0), C.byref(sd1))
+        want, w0, w1 = oracle.correlate2_warning(patch, win, 0, 0)
+        assert got == want and sd0.value == w0 and sd1.value == w1
+
+
+def test_search_scan_logic_matches_oracle(oracle, devmath):
+    """The kernel's enumeration + accept/tie rule (scalar re-enactment) against elliptical_search."""
+    rng = np.random.default_rng(16)
+    for trial in range(40):
+        img = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+        if trial % 4 == 0:   # periodic image -> exact ties (Q2: last candidate wins)
+            tile = rng.integers(0, 256, (6, 7), dtype=np.uint8)
+            img = np.tile(tile, (20, 23))[:120, :160].copy()
+        cy, cx = int(rng.integers(10, 110)), int(rng.integers(10, 150))
+        cy, cx = min(max(cy, 5), 114), min(max(cx, 5), 154)
+        patch = img[cy - 5:cy + 6, cx - 5:cx + 6].copy()
+        if trial % 5 == 1:
+            patch = rng.integers(0, 256, (11, 11), dtype=np.uint8)   # no good match -> ok False
+        s0, s1 = rng.uniform(3, 40, 2)
+        r = rng.uniform(-0.7, 0.7) * np.sqrt(s0 * s1)
+        a, b, c = oracle.sinv_from_S(np.array([[s0, r], [r, s1]]))
+        centre = np.array([cx + rng.uniform(-4, 4), cy + rng.uniform(-4, 4)])
+        if trial % 7 == 2:
+            centre = np.array([rng.uniform(-3, 8), rng.uniform(112, 125)])  # clamped at the image border
+        want = oracle.elliptical_search(img, patch, centre, a, b, c)
+        uv = np.array([-1, -1], dtype=np.int32)
+        score = C.c_double(0)
+        nc = C.c_int(0)
+        ok = devmath.dm_search_scan(img.ctypes.data_as(C.POINTER(C.c_uint8)), 160, 120,
+                                    patch.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(centre), a, b, c,
+                                    uv.ctypes.data_as(C.POINTER(C.c_int)), C.byref(score), C.byref(nc))
+        assert bool(ok) == want["ok"]
+        assert nc.value == want["ncand"]
+        assert score.value == want["corr"]
+        assert (int(uv[0]), int(uv[1])) == (want["u"], want["v"])

@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two gloo ranks exercise the sharding / reduce / gather logic
+used by bench.py (the data path itself has no collective)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from scenelib2_amd import sharding, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r, w, lr = sharding.env_rank_world()
+        ids = sharding.global_sequence_ids(3, w, r)
+        # each rank builds its own shard of sequence specs: unique seeds, no overlap
+        cam = synth.default_camera()
+        specs = [synth.SequenceSpec(cam, 6, 2, synth.BASE_SEED + int(i)) for i in ids]
+        local = np.stack([np.concatenate([[float(i)], s.xv0]) for i, s in zip(ids, specs)])
+        allrows = sharding.gather_states(local)
+        tmax = sharding.max_over_ranks(1.0 + r)
+        tsum = sharding.sum_over_ranks(len(ids))
+        dist.barrier()
+        q.put((rank, ids.tolist(), allrows, tmax, tsum, sharding.shard_range(7, w, r)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ids0, rows0, tmax0, tsum0, sh0), (r1, ids1, rows1, tmax1, tsum1, sh1) = res
+    assert ids0 == [0, 1, 2] and ids1 == [3, 4, 5]
+    assert np.array_equal(rows0, rows1) and rows0.shape == (6, 14)
+    assert rows0[:, 0].tolist() == [0, 1, 2, 3, 4, 5]            # gathered in global sequence order
+    assert len({tuple(r) for r in rows0[:, 1:].round(12).tolist()}) == 6   # six different sequences
+    assert tmax0 == tmax1 == 2.0 and tsum0 == tsum1 == 6.0
+    assert sh0 == (0, 4) and sh1 == (4, 3)                       # block partition covers 7 exactly once
+
+
+def test_shard_range_partitions_exactly():
+    from scenelib2_amd.sharding import shard_range
+    for total in (0, 1, 7, 1024, 8192):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                f, c = shard_range(total, world, r)
+                got += list(range(f, f + c))
+            assert got == list(range(total))

@@ -1,0 +1,211 @@
+"""GPU parity of the whole per-frame path against the oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from conftest import SHIPPED_CAM, golden_path, rel_fro
+from slam_helpers import Pair
+from scenelib2_amd import Engine, MonoSLAM, synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_X = 1e-9     # max-abs on the total state (EKF summation order differs from the dense CPU path)
+TOL_P = 1e-8     # relative Frobenius on the total covariance
+
+
+def test_seams_one_frame():
+    """Each seam of GoOneStep on its own (kalman.cpp:50-69, monoslam.cpp:187-254, 336-359, kalman.cpp:72-119)."""
+    pr = Pair(24, 2, batch=2)
+    e = pr.engine
+    for b in range(2):
+        pr.oracles[b].kalman_filter_predict()
+    e.kalman_filter_predict()
+    for b in range(2):
+        xv, Pxx = pr.oracles[b].get_state()
+        xe, Pe = e.get_vehicle_state(b, 1)
+        assert np.allclose(xe[0], xv, rtol=0, atol=1e-15)
+        assert np.allclose(Pe[0], Pxx, rtol=1e-13, atol=1e-20)
+        assert rel_fro(e.total_covariance(b), pr.oracles[b].total_covariance()) < 1e-13
+    for b in range(2):
+        pr.oracles[b].auto_select_n_features(24)
+    e.auto_select_n_features(24)
+    for b in range(2):
+        sel, cnt = e.selection(b)
+        assert cnt["visible"] == pr.oracles[b].num_visible
+        assert list(sel) == list(pr.oracles[b].selected_labels())
+        for i, fe in enumerate(e.features(b)):
+            fo = pr.oracles[b].feature(i)
+            assert np.allclose(fe["h"], fo["h"], rtol=0, atol=1e-11)
+            assert np.allclose(fe["S"], fo["S"], rtol=1e-12)
+            assert np.allclose(fe["dh_by_dxp"], fo["dh_by_dxv"][:, :7], rtol=1e-12, atol=1e-12)
+            assert np.allclose(fe["dh_by_dy"], fo["dh_by_dy"], rtol=1e-12, atol=1e-12)
+    for b in range(2):
+        pr.oracles[b].make_measurements(pr.frames[b][0])
+    e.make_measurements(pr.frame_batch(0))
+    for b in range(2):
+        n_ok = 0
+        for i, fe in enumerate(e.features(b)):
+            fo = pr.oracles[b].feature(i)
+            assert fe["success"] == fo["success"] and fe["attempted"] == fo["attempted"]
+            if fo["success"]:
+                assert np.array_equal(fe["z"], fo["z"])
+                n_ok += 1
+        assert n_ok >= 20
+    for b in range(2):
+        pr.oracles[b].kalman_filter_update()
+        pr.oracles[b].normalise_state()
+    e.kalman_filter_update()
+    e.finish_step(False)          # normalise + (no deletions) + symmetrise
+    for b in range(2):
+        # the oracle symmetrises inside GoOneStep only; do it on its dense P here
+        Po = pr.oracles[b].total_covariance()
+        Po = 0.5 * Po + 0.5 * Po.T
+        assert np.abs(e.total_state(b) - pr.oracles[b].total_state()).max() < TOL_X
+        assert rel_fro(e.total_covariance(b), Po) < TOL_P
+
+
+@pytest.mark.parametrize("n_features,n_frames,batch", [(20, 40, 3), (100, 12, 2)])
+def test_sequences_track_the_oracle(n_features, n_frames, batch):
+    pr = Pair(n_features, n_frames, batch=batch)
+    traj_o = np.zeros((batch, n_frames, 3))
+    traj_e = np.zeros((batch, n_frames, 3))
+    for k in range(n_frames):
+        pr.step_both(k, save_trajectory=True)
+        worst = pr.compare_state(TOL_X, TOL_P)
+        xe, _ = pr.engine.get_vehicle_state()
+        for b in range(batch):
+            traj_o[b, k] = pr.oracles[b].get_state()[0][:3]
+            traj_e[b, k] = xe[b, :3]
+    rmse = np.sqrt(((traj_o - traj_e) ** 2).sum(axis=2).mean())
+    assert rmse <= 1e-4          # BASELINE.json: trajectory RMSE within 1e-4 of the CPU reference
+    assert rmse <= 1e-9          # what FP64 on both sides should actually give
+    truth = np.stack([s.poses[1:, :3] for s in pr.specs])
+    assert np.abs(traj_e - truth).max() < 0.02      # and it actually tracks the camera
+    for b in range(batch):     # trajectory_store_ keeps the reference's stale-scratch semantics (Q12)
+        assert np.array_equal(pr.engine.trajectory(b), pr.oracles[b].trajectory())
+    assert not pr.engine.status_flags().any()
+
+
+def test_ragged_batch_and_empty_map():
+    """Sequences of one batch with different map sizes (incl. zero features) and n_select < N."""
+    pr = Pair(16, 6, batch=4, n_select=10, feature_counts=[16, 0, 7, 11], max_features=16)
+    for k in range(6):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+    sizes = pr.engine.total_state_sizes()
+    assert list(sizes) == [13 + 48, 13, 13 + 21, 13 + 33]
+    sel, cnt = pr.engine.selection(0)
+    assert cnt["selected"] == 10 and cnt["visible"] == 16      # Q8: visible count, not selected count
+
+
+def test_all_measurements_fail_means_pure_prediction():
+    pr = Pair(12, 1, batch=1)
+    flat = np.full((1, 240, 320), 77, np.uint8)
+    xv0 = pr.specs[0].xv0
+    pr.oracles[0].go_one_step(flat[0])
+    pr.engine.go_one_step(flat)
+    f, _, _ = oa.motion_model(xv0, pr.params["delta_t"])
+    xe, _ = pr.engine.get_vehicle_state()
+    assert np.allclose(xe[0], f, rtol=0, atol=1e-15)
+    _, cnt = pr.engine.selection(0)
+    assert cnt["measurement_size"] == 0
+    pr.compare_state(1e-14, 1e-13)
+    assert all(fe["attempted"] == 1 and fe["successful"] == 0 for fe in pr.engine.features(0))
+
+
+def test_delete_bad_features_matches_reference_walk():
+    pr = Pair(10, 3, batch=2)
+    pr.step_both(0)
+    for b in range(2):
+        for lab in (2, 3, 4, 8):
+            pr.oracles[b].set_feature_counters(lab, 12, 3)     # index == label before any deletion
+            pr.engine.set_feature_counters(b, lab, 12, 3)
+    pr.step_both(1)
+    pr.compare_state(TOL_X, TOL_P)
+    labels = [f["label"] for f in pr.engine.features(0)]
+    assert 2 in [f["label"] for f in pr.engine.features(0, include_deleted=True)]
+    assert 2 not in labels and 4 not in labels and 8 not in labels and 3 in labels   # 3 is skipped once (Q27)
+    pr.step_both(2)
+    pr.compare_state(TOL_X, TOL_P)
+    assert 3 not in [f["label"] for f in pr.engine.features(0)]
+
+
+def test_monoslam_api_with_shipped_cfg_and_templates():
+    """MonoSLAM.Init(cfg) + GoOneStep on the reference's own fixtures (cfg values, known_patch*.pgm)."""
+    from scenelib2_amd.config import load_config, read_pgm
+    cfg = load_config(golden_path("scenelib2_shipped.cfg"))
+    patches = [read_pgm(golden_path("known_patch%d.pgm" % i)) for i in range(4)]
+    # a frame showing the four templates where the filter expects them after one prediction
+    o = oa.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], 10)
+    o.set_state(cfg["xv"], cfg["Pxx"])
+    for f, p in zip(cfg["features"], patches):
+        o.add_known_feature(f["y"], f["xp_org"], p)
+    probe = oa.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], 10)
+    probe.set_state(cfg["xv"], cfg["Pxx"])
+    for f, p in zip(cfg["features"], patches):
+        probe.add_known_feature(f["y"], f["xp_org"], p)
+    probe.kalman_filter_predict()
+    probe.auto_select_n_features(10)
+    rng = np.random.default_rng(7)
+    frame = rng.integers(90, 110, (240, 320)).astype(np.uint8)
+    for i, p in enumerate(patches):
+        h = probe.feature(i)["h"]
+        u, v = int(round(h[0])) + (i - 1), int(round(h[1])) + (2 - i)
+        frame[v - 5:v + 6, u - 5:u + 6] = p
+    m = MonoSLAM(max_features=8).Init(golden_path("scenelib2_shipped.cfg"), template_dirs=[golden_path("")])
+    for step in range(3):
+        o.go_one_step(frame, True)
+        assert m.GoOneStep(frame, True, False) is True
+        assert m.total_state_size_ == o.total_state_size == 25
+        assert np.abs(m.construct_total_state() - o.total_state()).max() < TOL_X
+        assert rel_fro(m.construct_total_covariance(), o.total_covariance()) < TOL_P
+        assert m.number_of_visible_features_ == o.num_visible
+        assert [f.label_ for f in m.selected_feature_list_] == list(o.selected_labels())
+        for i, f in enumerate(m.feature_list_):
+            fo = o.feature(i)
+            assert f.successful_measurement_flag_ == fo["success"]
+            if fo["success"]:
+                assert np.array_equal(f.z_, fo["z"])
+    assert o.measurement_size > 0
+    assert np.array_equal(m.trajectory_store_, o.trajectory())
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3 shape (320x240, 100 features) at a batch the oracle cannot follow:
+    size-independent properties — replicas agree bit for bit, P stays symmetric and finite,
+    and sampled sequences still match the oracle."""
+    B, N, F = 96, 100, 4
+    tex = synth.make_texture()
+    cam = synth.default_camera()
+    uniq = 3
+    seqs = [synth.make_sequence(cam, N, F, seq_index=i, tex=tex) for i in range(uniq)]
+    e = Engine(cam, synth.default_params(N), B, N)
+    e.set_vehicle_state(np.stack([seqs[b % uniq][0].xv0 for b in range(B)]), np.stack([seqs[b % uniq][0].Pxx0 for b in range(B)]))
+    for b in range(B):
+        sp, tpl = seqs[b % uniq][0], seqs[b % uniq][1]
+        e.add_known_features(sp.feat_y[None], np.tile(sp.poses[0], (1, N, 1)), tpl[None], seq0=b)
+    orc = []
+    for i in range(uniq):
+        sp, tpl = seqs[i][0], seqs[i][1]
+        s = oa.OracleSLAM(cam, sp.delta_t, N)
+        s.set_state(sp.xv0, sp.Pxx0)
+        for j in range(N):
+            s.add_known_feature(sp.feat_y[j], sp.poses[0], tpl[j])
+        orc.append(s)
+    for k in range(F):
+        e.go_one_step(np.stack([seqs[b % uniq][2][k] for b in range(B)]))
+        for s, q in zip(orc, seqs):
+            s.go_one_step(q[2][k])
+    xv, Pxx = e.get_vehicle_state()
+    assert np.isfinite(xv).all() and np.isfinite(Pxx).all()
+    for b in range(uniq, B):
+        assert np.array_equal(xv[b], xv[b % uniq]) and np.array_equal(Pxx[b], Pxx[b % uniq])   # replicas identical
+    for b in (0, 1, 2, B - 1):
+        P = e.total_covariance(b)
+        assert np.array_equal(P, P.T)
+        assert np.linalg.eigvalsh(P).min() > -1e-12
+        o = orc[b % uniq]
+        assert np.abs(e.total_state(b) - o.total_state()).max() < TOL_X
+        assert rel_fro(P, o.total_covariance()) < TOL_P
+    w = e.step_work()
+    assert w["searched"] > 0.9 * B * N and w["sum_m"] > 1.8 * 0.9 * B * N

@@ -1,0 +1,203 @@
+"""Pins for the CPU oracle (oracle/): the reference's only fixtures (cfg values,
+known_patch*.pgm) and the derived known answers K1-K3 of SURVEY.md §8(c), plus
+invariants.  The reference ships no golden vectors, so these are the anchor."""
+import numpy as np
+import pytest
+
+from conftest import SHIPPED_CAM, SHIPPED_DT, SHIPPED_XV, SHIPPED_Y, shipped_Pxx, shipped_patches
+
+
+def make_shipped(oracle, n_select=10):
+    s = oracle.OracleSLAM(SHIPPED_CAM, SHIPPED_DT, n_select)
+    s.set_state(SHIPPED_XV, shipped_Pxx())
+    for y, p in zip(SHIPPED_Y, shipped_patches()):
+        s.add_known_feature(y, SHIPPED_XV[:7], p)
+    return s
+
+
+def test_fixture_patch_bytes():
+    p = shipped_patches()
+    assert p[0].shape == (11, 11)
+    # first row of known_patch0.pgm as recorded in SURVEY.md §8(c)
+    assert p[0][0].tolist() == [180, 185, 184, 181, 184, 181, 180, 181, 180, 180, 184]
+    assert all(x.dtype == np.uint8 and x.size == 121 for x in p)
+
+
+def test_K1_initial_projections(oracle):
+    want = [(128.399167, 101.239411), (195.600833, 101.239411), (128.399167, 148.760589), (195.600833, 148.760589)]
+    for y, w in zip(SHIPPED_Y, want):
+        h = oracle.measurement_model(SHIPPED_CAM, SHIPPED_XV[:7], y)["h"]
+        assert np.allclose(h, w, atol=5e-7)
+
+
+def test_K2_one_predict(oracle):
+    s = make_shipped(oracle)
+    s.kalman_filter_predict()
+    xv, Pxx = s.get_state()
+    assert np.allclose(xv[:3], [0, 0, -0.6033333333], atol=1e-9)
+    assert np.isclose(xv[6], 1.6667e-4, rtol=1e-3) and np.isclose(xv[3], 1.0, atol=1e-7)
+    assert np.allclose(xv[7:], [0, 0, -0.1, 0, 0, 0.01])
+    d = np.diag(Pxx)
+    assert np.allclose(d[:3], 4.2e-4, rtol=2e-3)
+    assert d[3] < 1e-9
+    assert np.allclose(d[4:7], 1.11e-5, rtol=2e-3)
+    assert np.allclose(d[7:10], 1.7778e-2, rtol=1e-4)
+    assert np.allclose(d[10:13], 4e-2, rtol=1e-6)
+
+
+def test_K3_frame0_prediction(oracle):
+    s = make_shipped(oracle)
+    s.kalman_filter_predict()
+    nvis = s.auto_select_n_features(10)
+    assert nvis == 4 and s.num_selected == 4
+    f1 = s.feature(0)
+    assert np.allclose(f1["h"], [128.571317, 101.377857], atol=5e-7)
+    assert np.isclose(f1["R"], 1.440104, atol=5e-7)
+    assert np.allclose(f1["S"], [[45.187098, -0.347652], [-0.347652, 45.433409]], atol=5e-7)
+    assert np.isclose(np.trace(f1["S"]), 90.620508, atol=1e-6)
+    a, b, c = oracle.sinv_from_S(f1["S"])
+    img = np.full((240, 320), 128, np.uint8)
+    r = oracle.elliptical_search(img, shipped_patches()[0], f1["h"], a, b, c)
+    assert (r["hw"], r["hh"], r["ncand"]) == (20, 20, 1287)
+    assert not r["ok"]  # flat image: sigma test rejects everything, u/v untouched (Q4)
+    f2 = s.feature(1)
+    assert np.allclose(f2["h"], [195.412927, 101.355576], atol=5e-7)
+    assert np.allclose(f2["S"], [[45.187562, 0.347816], [0.347816, 45.432946]], atol=5e-7)
+
+
+def test_score_is_two_one_minus_rho(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        patch = rng.integers(0, 256, (11, 11), dtype=np.uint8)
+        img = rng.integers(0, 256, (40, 50), dtype=np.uint8)
+        x1, y1 = int(rng.integers(0, 39)), int(rng.integers(0, 29))
+        c, sd0, sd1 = oracle.correlate2_warning(patch, img, x1, y1)
+        w = img[y1:y1 + 11, x1:x1 + 11].astype(np.float64)
+        p = patch.astype(np.float64)
+        rho = np.corrcoef(p.ravel(), w.ravel())[0, 1]
+        assert np.isclose(c, 2 * (1 - rho), atol=1e-9)
+        assert np.isclose(sd0, p.std()) and np.isclose(sd1, w.std())  # population sigma
+
+
+def test_score_identity_and_gain_offset_invariance(oracle):
+    rng = np.random.default_rng(2)
+    patch = rng.integers(40, 200, (11, 11), dtype=np.uint8)
+    img = np.zeros((30, 30), np.uint8)
+    img[7:18, 9:20] = patch
+    c, _, _ = oracle.correlate2_warning(patch, img, 9, 7)
+    assert abs(c) < 1e-9
+    base = rng.integers(20, 100, (30, 30))
+    p2 = base[5:16, 5:16]
+    c1, _, _ = oracle.correlate2_warning(p2.astype(np.uint8), base.astype(np.uint8), 8, 8)
+    c2, _, _ = oracle.correlate2_warning(p2.astype(np.uint8), (2 * base + 17).astype(np.uint8), 8, 8)
+    assert np.isclose(c1, c2, atol=1e-9)
+
+
+def test_score_degenerate_sigma(oracle):
+    flat = np.full((11, 11), 77, np.uint8)
+    tex = (np.arange(121).reshape(11, 11) * 2).astype(np.uint8)
+    img_flat = np.full((20, 20), 9, np.uint8)
+    img_tex = np.zeros((20, 20), np.uint8)
+    img_tex[:11, :11] = tex
+    assert oracle.correlate2_warning(flat, img_flat, 0, 0)[0] == 0.0   # improc.cpp:117-119
+    assert oracle.correlate2_warning(flat, img_tex, 0, 0)[0] == 1.0    # :120-121
+    assert oracle.correlate2_warning(tex, img_flat, 0, 0)[0] == 1.0    # :124-125
+
+
+def test_motion_jacobian_matches_finite_differences(oracle):
+    rng = np.random.default_rng(3)
+    xv = np.concatenate([rng.normal(size=3), [0.9, 0.1, -0.2, 0.3], rng.normal(size=3) * 0.2, rng.normal(size=3) * 0.3])
+    xv[3:7] /= np.linalg.norm(xv[3:7])
+    dt = 1.0 / 30
+    f, F, Q = oracle.motion_model(xv, dt)
+    num = np.zeros((13, 13))
+    for j in range(13):
+        e = np.zeros(13)
+        e[j] = 1e-6
+        num[:, j] = (oracle.motion_model(xv + e, dt)[0] - oracle.motion_model(xv - e, dt)[0]) / 2e-6
+    assert np.allclose(F, num, atol=1e-7)
+    assert np.allclose(Q, Q.T, atol=1e-15) and np.all(np.linalg.eigvalsh(Q) > -1e-15)
+
+
+def test_measurement_jacobians_match_finite_differences(oracle):
+    rng = np.random.default_rng(4)
+    for _ in range(5):
+        q = np.array([1.0, 0.05, -0.03, 0.02]) + rng.normal(size=4) * 0.01
+        q /= np.linalg.norm(q)
+        xp = np.concatenate([rng.normal(size=3) * 0.05 + [0, 0, -0.6], q])
+        y = np.array([rng.uniform(-0.2, 0.2), rng.uniform(-0.15, 0.15), 0.0])
+        m = oracle.measurement_model(SHIPPED_CAM, xp, y)
+        Hy = np.zeros((2, 3))
+        for j in range(3):
+            e = np.zeros(3)
+            e[j] = 1e-6
+            Hy[:, j] = (oracle.measurement_model(SHIPPED_CAM, xp, y + e)["h"] -
+                        oracle.measurement_model(SHIPPED_CAM, xp, y - e)["h"]) / 2e-6
+        assert np.allclose(m["dh_by_dy"], Hy, atol=1e-5)
+        Hx = np.zeros((2, 7))
+        for j in range(7):
+            e = np.zeros(7)
+            e[j] = 1e-6
+            Hx[:, j] = (oracle.measurement_model(SHIPPED_CAM, xp + e, y)["h"] -
+                        oracle.measurement_model(SHIPPED_CAM, xp - e, y)["h"]) / 2e-6
+        # position part exact; quaternion part is the Jacobian of the *unnormalised* homogeneous
+        # rotation the reference uses (Q11) — it matches finite differences of R(q^-1) as coded
+        # only along directions that keep |q| = 1, so project the perturbation.
+        assert np.allclose(m["dh_by_dxp"][:, :3], Hx[:, :3], atol=1e-5)
+        tang = np.eye(4) - np.outer(q, q)
+        assert np.allclose(m["dh_by_dxp"][:, 3:] @ tang, Hx[:, 3:] @ tang, atol=2e-4)
+
+
+def test_Si_equals_block_of_dense_innovation(oracle):
+    s = make_shipped(oracle)
+    img = np.random.default_rng(5).integers(0, 256, (240, 320), dtype=np.uint8)
+    s.go_one_step(img)          # spreads covariance into Pxy / Pyy through one update attempt
+    s.kalman_filter_predict()
+    s.auto_select_n_features(10)
+    P = s.total_covariance()
+    for i in range(s.num_features):
+        f = s.feature(i)
+        H = np.zeros((2, P.shape[0]))
+        H[:, :13] = f["dh_by_dxv"]
+        H[:, f["pos"]:f["pos"] + 3] = f["dh_by_dy"]
+        S = H @ P @ H.T + np.eye(2) * f["R"]
+        assert np.allclose(S, f["S"], rtol=1e-12, atol=1e-12)
+
+
+def test_step_keeps_covariance_symmetric_and_skips_update_without_matches(oracle):
+    s = make_shipped(oracle)
+    flat = np.full((240, 320), 100, np.uint8)
+    xv_before, _ = s.get_state()
+    s.go_one_step(flat)
+    assert s.measurement_size == 0                      # nothing matched -> no update (monoslam.cpp:134)
+    xv, _ = s.get_state()
+    f, _, _ = oracle.motion_model(xv_before, SHIPPED_DT)
+    assert np.array_equal(xv, f)                        # state == pure prediction
+    P = s.total_covariance()
+    assert np.array_equal(P, P.T)
+    for i in range(4):
+        fi = s.feature(i)
+        assert fi["attempted"] == 1 and fi["successful"] == 0
+
+
+def test_deletion_rule_and_skip_quirk(oracle):
+    s = make_shipped(oracle)
+    for i in range(4):
+        s.set_feature_counters(i, 10, 4)                # attempts >= 10 and ratio < 0.5 (Q17)
+    s.delete_bad_features()
+    # Q27: after each erase the following element is skipped in the same pass
+    assert s.num_features == 2
+    assert [s.feature(i)["label"] for i in range(2)] == [1, 3]
+    assert s.total_state_size == 13 + 6
+    s.delete_bad_features()
+    assert s.num_features == 1 and s.feature(0)["label"] == 3
+    # the scheduled flag is sticky (monoslam.cpp:653 sets it, nothing clears it): feature 3 goes
+    # on the next pass even if its counters recovered meanwhile
+    s.set_feature_counters(0, 20, 20)
+    s.delete_bad_features()
+    assert s.num_features == 0 and s.total_state_size == 13
+    s2 = make_shipped(oracle)
+    s2.set_feature_counters(0, 10, 5)                   # ratio == 0.5 is NOT < 0.5
+    s2.set_feature_counters(1, 9, 0)                    # fewer than 10 attempts
+    s2.delete_bad_features()
+    assert s2.num_features == 4

@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_gloo_sharding():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp   # plain spawn: the parent process never imports torch
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -487,8 +487,15 @@ int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int
   SL2_HIP(hipMemcpy(&nv, e->n_vis + seq, sizeof(int), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(&mc, e->m_count + seq, sizeof(int), hipMemcpyDeviceToHost));
   if (ns > capacity) return SL2_ERR_CAPACITY;
-  if (ns > 0) SL2_HIP(hipMemcpy(labels, e->sel_idx + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
-  counters[0] = nv; counters[1] = ns; counters[2] = 2 * mc;
+  // delete_feature() deselects the feature it removes (monoslam.cpp:800-801): features deleted at
+  // the end of the step no longer appear in selected_feature_list_
+  std::vector<int> sel(ns > 0 ? ns : 1), flags(e->N);
+  if (ns > 0) SL2_HIP(hipMemcpy(sel.data(), e->sel_idx + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  int kept = 0;
+  for (int k = 0; k < ns; ++k)
+    if (flags[sel[k]] & FF_ACTIVE) labels[kept++] = sel[k];
+  counters[0] = nv; counters[1] = kept; counters[2] = 2 * mc;
   return SL2_OK;
 }
 

@@ -27,11 +27,11 @@ bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -c 4000 $OUT/bench.json; tail -5 $OUT/bench.err ;;
 prof)
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
   find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done ;;
 pmc)
   for c in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace -d $OLDPWD/$OUT/pmc_$c -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err ); echo "pmc $c exit $?"
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$c -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err ); echo "pmc $c exit $?"
   done
   python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; tail -30 $OUT/pmc_summary.txt ;;
 esac

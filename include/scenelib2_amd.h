@@ -133,6 +133,8 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  *   Kalman::KalmanFilterUpdate(monoslam)+normalise_state kalman.cpp:72-119, monoslam.cpp:616-637
  *   delete_bad_features + symmetrise                     monoslam.cpp:141-150
  */
+/* Which search kernel sl2_make_measurements / sl2_go_one_step use (default 1). */
+int sl2_set_search_variant(sl2_engine* e, int variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);
 int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device);
@@ -144,7 +146,8 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory);
  * width x height).  patches [count][121]; centre [count][2]; puinv [count][3] =
  * (PuInv(0,0), PuInv(0,1), PuInv(1,1)).  Outputs: ok[count] (the bool return),
  * uv[count][2] (left untouched where no candidate qualified, Q4), score[count]
- * (corrmax).  All pointers are HOST pointers; variant 0 = default kernel. */
+ * (corrmax).  All pointers are HOST pointers; variant 1 = production kernel (LDS column walk),
+ * variant 0 = the simple baseline kernel kept for cross-checking (identical results). */
 int sl2_elliptical_search_batch(int device, const uint8_t* images, int nimages, int width, int height,
                                 const int32_t* image_index, const uint8_t* patches, const double* centre,
                                 const double* puinv, int count, int32_t* ok, int32_t* uv, double* score,
@@ -190,8 +193,9 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
  * out[0] = search window bytes sum_f (2hw+11)(2hh+11) capped per sequence at W*H,
  * out[1] = number of searched features, out[2] = in-ellipse candidates,
  * out[3] = sum over sequences of m (measurement rows), out[4] = sum of m^2,
- * out[5] = sum of m^3, out[6] = sum of n (state size) , out[7] = sum n*m, out[8] = sum n*n*m, out[9] = sum n*m*m */
-int sl2_get_step_work(sl2_engine* e, double out[10]);
+ * out[5] = sum of m^3, out[6] = sum of n (state size) , out[7] = sum n*m, out[8] = sum n*n*m, out[9] = sum n*m*m,
+ * out[10] = searches that took the exact fallback kernel path */
+int sl2_get_step_work(sl2_engine* e, double out[11]);
 
 /* ------------------------------------------------------------- synthetic input */
 
@@ -222,6 +226,10 @@ int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* sco
  * kernels (k-major operands): XT [K][ldx], YT [K][ldy], C [M][ldc].  Host pointers. */
 int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const double* YT, int ldy, int M, int N, int K,
                       double* C, int ldc);
+
+/* Micro-benchmarks that calibrate the roofline peaks on the box: which = 0 FP64 MFMA
+ * TFLOP/s (4 independent accumulators), 1 = dependent chain, 2 = streaming copy GB/s. */
+int sl2_debug_microbench(int device, int which, double* result);
 
 #ifdef __cplusplus
 }

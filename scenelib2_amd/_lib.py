@@ -63,13 +63,13 @@ class sl2_feature_info(C.Structure):
 EXPORTED_SYMBOLS = [
     "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features",
-    "sl2_go_one_step", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
+    "sl2_go_one_step", "sl2_set_search_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
     "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
-    "sl2_dev_download", "sl2_debug_ncc_score", "sl2_debug_gemm_kt",
+    "sl2_dev_download", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def load():
     L.sl2_get_vehicle_state.argtypes = [vp, C.c_int, C.c_int, c_dp, c_dp]
     L.sl2_add_known_features.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_u8p]
     L.sl2_go_one_step.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int]
+    L.sl2_set_search_variant.argtypes = [vp, C.c_int]
     L.sl2_kalman_filter_predict.argtypes = [vp]
     L.sl2_auto_select_n_features.argtypes = [vp, C.c_int]
     L.sl2_make_measurements.argtypes = [vp, vp, C.c_size_t, C.c_int]
@@ -143,6 +144,7 @@ def load():
     L.sl2_dev_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
     L.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
     L.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
+    L.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]
     _lib = L
     return L
 

@@ -85,6 +85,7 @@ struct sl2_engine {
   int* status = nullptr;      // [B]
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
   long long steps_done = 0;
+  int search_variant = 1;     // 0 = baseline kernel, 1 = LDS column-walk kernel (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]

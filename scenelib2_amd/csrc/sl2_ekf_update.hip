@@ -50,43 +50,55 @@ __global__ void __launch_bounds__(64) k_compact(const int* __restrict__ sel_idx,
 // k_build_A: At[a][i] = (P H^T)[i][a], a = 2j+r for the j-th successful feature.
 // Column ld-1 carries the innovation nu (so that L^-1 nu and W nu fall out of the
 // same substitution / SYRK).  Rows of padding up to a multiple of 32 are zeroed.
+// Block = 64 columns x 4 feature groups; a thread keeps the 7 pose entries of its
+// column in registers and loops over the features of its group (3 coalesced row
+// reads of P + 2 coalesced row writes of At per feature).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_build_A(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                  const int* __restrict__ succ_idx, const int* __restrict__ m_count,
                                                  double* __restrict__ At, int N, int ld, int mld) {
-  const int b = blockIdx.z;
+  const int b = blockIdx.y;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int cnt_pad = (cnt + 15) / 16 * 16;
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  const int j = blockIdx.y * 4 + threadIdx.y;
-  if (j >= cnt_pad) return;
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int g = threadIdx.x >> 6;
   double* Ab = At + (size_t)b * mld * ld;
-  if (j >= cnt) {
-    Ab[(size_t)(2 * j) * ld + i] = 0.0;
-    Ab[(size_t)(2 * j + 1) * ld + i] = 0.0;
-    return;
-  }
-  const int f = succ_idx[(size_t)b * N + j];
-  const size_t fi = (size_t)b * N + f;
-  const int pos = 13 + 3 * f;
   const double* Pb = P + (size_t)b * ld * ld;
-  double pc[7], py[3];
+  double pc[7];
+#pragma unroll
   for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
-  for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
-  for (int r = 0; r < 2; ++r) {
-    double acc = 0.0;
-    for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
-    for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
-    if (i == ld - 1) acc = f_nu[fi * 2 + r];
-    Ab[(size_t)(2 * j + r) * ld + i] = acc;
+  for (int j = g; j < cnt_pad; j += 4) {
+    if (j >= cnt) {
+      Ab[(size_t)(2 * j) * ld + i] = 0.0;
+      Ab[(size_t)(2 * j + 1) * ld + i] = 0.0;
+      continue;
+    }
+    const int f = succ_idx[(size_t)b * N + j];
+    const size_t fi = (size_t)b * N + f;
+    const int pos = 13 + 3 * f;
+    double py[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      double acc = 0.0;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
+      if (i == ld - 1) acc = f_nu[fi * 2 + r];
+      Ab[(size_t)(2 * j + r) * ld + i] = acc;
+    }
   }
 }
 
 // ---------------------------------------------------------------------------
 // k_build_S: S = H A + R, stored St[c][r] = S[r][c] (both triangles written;
-// the factorisation reads r >= c).  Padding: identity.
+// the factorisation reads r >= c).  Padding: identity.  A thread owns one row
+// a of H (its 10 non-zeros in registers) and loops over 32 columns bb: per column
+// 7 wave-uniform loads (pose part of At row bb) + 3 gathered loads within that row.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, const double* __restrict__ f_Hx,
                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_R,
@@ -95,40 +107,43 @@ __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, 
   const int b = blockIdx.z;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int cnt_pad = (cnt + 15) / 16 * 16;
-  const int j = blockIdx.x * 16 + threadIdx.x;  // row feature
-  const int k = blockIdx.y * 16 + threadIdx.y;  // column feature
-  if (j >= cnt_pad || k >= cnt_pad || j < k) return;
+  const int mp = (2 * cnt + 31) / 32 * 32;
+  const int a = blockIdx.y * 256 + threadIdx.x;
+  const int bb0 = blockIdx.x * 32;
+  if (a >= mp || bb0 >= mp) return;
   double* Sb = St + (size_t)b * mld * mld;
-  if (j >= cnt || k >= cnt) {
-    for (int r = 0; r < 2; ++r)
-      for (int s = 0; s < 2; ++s) {
-        const double v = (j == k && r == s) ? 1.0 : 0.0;
-        const int a = 2 * j + r, bb = 2 * k + s;
-        Sb[(size_t)bb * mld + a] = v;
-        Sb[(size_t)a * mld + bb] = v;
-      }
+  const int m = 2 * cnt;
+  if (a >= m) {
+    for (int bb = bb0; bb < bb0 + 32; ++bb) Sb[(size_t)bb * mld + a] = (a == bb) ? 1.0 : 0.0;
     return;
   }
+  const int j = a >> 1, r = a & 1;
   const int fj = succ_idx[(size_t)b * N + j];
   const size_t fi = (size_t)b * N + fj;
   const int posj = 13 + 3 * fj;
+  double hx[7], hy[3];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fi * 14 + r * 7 + c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fi * 6 + r * 3 + c];
+  const double Rn = f_R[fi];
   const double* Ab = At + (size_t)b * mld * ld;
-  for (int s = 0; s < 2; ++s) {
-    const int bb = 2 * k + s;
-    const double* arow = Ab + (size_t)bb * ld;
-    double ac[7], ay[3];
-    for (int c = 0; c < 7; ++c) ac[c] = arow[c];
-    for (int c = 0; c < 3; ++c) ay[c] = arow[posj + c];
-    for (int r = 0; r < 2; ++r) {
+#pragma unroll 4
+  for (int bb = bb0; bb < bb0 + 32; ++bb) {
+    double v;
+    if (bb >= m) {
+      v = 0.0;
+    } else {
+      const double* arow = Ab + (size_t)bb * ld;
       double acc = 0.0;
-      for (int c = 0; c < 7; ++c) acc += f_Hx[fi * 14 + r * 7 + c] * ac[c];
-      for (int c = 0; c < 3; ++c) acc += f_Hy[fi * 6 + r * 3 + c] * ay[c];
-      if (j == k && r == s) acc += f_R[fi];
-      const int a = 2 * j + r;
-      Sb[(size_t)bb * mld + a] = acc;
-      if (j != k) Sb[(size_t)a * mld + bb] = acc;
+#pragma unroll
+      for (int c = 0; c < 7; ++c) acc += hx[c] * arow[c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc += hy[c] * arow[posj + c];
+      if (a == bb) acc += Rn;
+      v = acc;
     }
+    Sb[(size_t)bb * mld + a] = v;
   }
 }
 
@@ -137,8 +152,18 @@ __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, 
 // block column J): diag -> panel -> trailing update.
 // ---------------------------------------------------------------------------
 
-// k_chol_diag: one wave per sequence factors the (already updated) diagonal block
-// in LDS, inverts the 32x32 triangle, writes L_JJ back in place and LinvT.
+// k_chol_diag: one wave per sequence factors the (already updated) 32x32 diagonal
+// block entirely in registers: lane r holds row r; pivots and column entries are
+// broadcast with v_readlane (scalar operands of the FP64 FMAs), so there is no LDS
+// round trip in the 32-step dependency chain.  Then the triangle is inverted row-wise
+// (lane k solves X[k][:] L = e_k) and both L_JJ (in place) and LinvT are written
+// with coalesced stores.
+__device__ __forceinline__ double readlane_f64(double v, int srclane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ St, double* __restrict__ LinvT,
                                                   const int* __restrict__ m_count, int mld, int nblk_max, int J) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -146,46 +171,45 @@ __global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ St, doubl
   if (cnt == 0) return;
   const int nblk = (2 * cnt + 31) / 32;
   if (J >= nblk) return;
-  __shared__ double D[32][33];
-  __shared__ double X[32][33];
   double* Sb = St + (size_t)b * mld * mld;
   const int o = J * 32;
-  // D[r][c] = S[o+r][o+c] = St[(o+c)*mld + o+r]
-  for (int e = lane; e < 1024; e += 64) {
-    const int c = e >> 5, r = e & 31;
-    D[r][c] = Sb[(size_t)(o + c) * mld + o + r];
-  }
-  __syncthreads();
+  const int r = lane & 31;                    // lanes 32..63 mirror lanes 0..31 (results discarded)
+  double a[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) a[c] = Sb[(size_t)(o + c) * mld + o + r];   // a[c] = S[o+r][o+c]
+#pragma unroll
   for (int c = 0; c < 32; ++c) {
-    const double d = sqrt(D[c][c]);
-    __syncthreads();
-    if (lane == c) D[c][c] = d;
-    if (lane > c && lane < 32) D[lane][c] = D[lane][c] / d;
-    __syncthreads();
-    if (lane > c && lane < 32) {
-      const double lrc = D[lane][c];
-      for (int cc = c + 1; cc <= lane; ++cc) D[lane][cc] -= lrc * D[cc][c];
+    const double piv = readlane_f64(a[c], c);
+    const double d = sqrt(piv);
+    const double dinv = 1.0 / d;
+    const double l = (r == c) ? d : a[c] * dinv;
+    a[c] = (r >= c) ? l : 0.0;
+#pragma unroll
+    for (int cc = c + 1; cc < 32; ++cc) {
+      const double lcc = readlane_f64(a[c], cc);   // L[cc][c]
+      a[cc] -= l * lcc;                            // meaningful for r >= cc
     }
-    __syncthreads();
   }
-  // inverse of the lower triangle, one column per lane
+  // inverse, row-wise: lane k holds x[p] = Linv[k][p]
+  double diag = 1.0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) diag = (r == c) ? a[c] : diag;   // static indexing only (no scratch)
+  const double rinv = 1.0 / diag;                  // 1 / L[r][r]
+  double x[32];
+#pragma unroll
+  for (int p = 31; p >= 0; --p) {
+    double sacc = (r == p) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = p + 1; i < 32; ++i) sacc -= x[i] * readlane_f64(a[p], i);   // X[k][i] * L[i][p]
+    x[p] = sacc * readlane_f64(rinv, p);
+  }
   if (lane < 32) {
-    const int j = lane;
-    for (int i = 0; i < j; ++i) X[i][j] = 0.0;
-    X[j][j] = 1.0 / D[j][j];
-    for (int i = j + 1; i < 32; ++i) {
-      double s = 0.0;
-      for (int p = j; p < i; ++p) s -= D[i][p] * X[p][j];
-      X[i][j] = s / D[i][i];
+    double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      Sb[(size_t)(o + c) * mld + o + r] = a[c];    // L[r][c] (zero above the diagonal)
+      Lb[c * 32 + r] = x[c];                       // LinvT[p = c][k = r] = Linv[r][c]
     }
-  }
-  __syncthreads();
-  double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-  for (int e = lane; e < 1024; e += 64) {
-    const int c = e >> 5, r = e & 31;
-    // L block in place (zero above the diagonal), LinvT[p][k] = Linv[k][p]
-    Sb[(size_t)(o + c) * mld + o + r] = (r >= c) ? D[r][c] : 0.0;
-    Lb[c * 32 + r] = X[r][c];
   }
 }
 
@@ -396,18 +420,17 @@ int launch_update(sl2_engine* e) {
     hipLaunchKernelGGL(k_compact, dim3(B), dim3(64), 0, e->stream, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
-  const int cnt_pad_max = e->mld / 2;  // feature pairs incl. padding
   {
     LaunchScope ls(e, "k_build_A");
-    dim3 grid(e->ld / 64, (cnt_pad_max + 3) / 4, B);
-    hipLaunchKernelGGL(k_build_A, grid, dim3(64, 4), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
+    dim3 grid(e->ld / 64, B);
+    hipLaunchKernelGGL(k_build_A, grid, dim3(256), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
                        e->At, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_build_S");
-    dim3 grid((cnt_pad_max + 15) / 16, (cnt_pad_max + 15) / 16, B);
-    hipLaunchKernelGGL(k_build_S, grid, dim3(16, 16), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
+    dim3 grid(e->mld / 32, (e->mld + 255) / 256, B);
+    hipLaunchKernelGGL(k_build_S, grid, dim3(256), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
                        e->St, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
   }
@@ -467,5 +490,97 @@ extern "C" int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const do
   SL2_HIP(hipDeviceSynchronize());
   SL2_HIP(hipMemcpy(C, dC, sizeof(double) * (size_t)M * ldc, hipMemcpyDeviceToHost));
   hipFree(dX); hipFree(dY); hipFree(dC);
+  return SL2_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Micro-benchmarks (debug ABI): the FP64 MFMA issue rate and a streaming copy,
+// to confirm the peaks the roofline fractions are priced against.
+// ---------------------------------------------------------------------------
+namespace sl2 {
+template <int NACC>
+__global__ void __launch_bounds__(256) k_ubench_mfma(double* out, int iters) {
+  v4d acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0, 0, 0, 0};
+  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = mfma_f64(a, b, acc[i]);
+  }
+  double s = 0;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+__global__ void __launch_bounds__(256) k_ubench_copy(const double4* __restrict__ src, double4* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace sl2
+
+namespace sl2 {
+__global__ void __launch_bounds__(256) k_ubench_fma64(double* out, int iters) {
+  double acc[16];
+  for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+  const double a = 1.0000001, b = 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+  }
+  double s = 0;
+  for (int i = 0; i < 16; ++i) s += acc[i];
+  if (s == 12345.678) out[0] = s;
+}
+}  // namespace sl2
+
+// which: 0 = FP64 MFMA TFLOP/s with 4 independent accumulators per wave, 2 blocks of 4 waves per CU
+//        1 = same with 1 accumulator (dependent chain), 2 = streaming copy GB/s (read+write bytes),
+//        3 = 8 accumulators, 4 blocks per CU, 4 = FP64 VALU FMA TFLOP/s
+extern "C" int sl2_debug_microbench(int device, int which, double* result) {
+  using namespace sl2;
+  if (!result) return SL2_ERR_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device"); return SL2_ERR_NO_DEVICE; }
+  SL2_HIP(hipSetDevice(device));
+  hipEvent_t e0, e1;
+  SL2_HIP(hipEventCreate(&e0));
+  SL2_HIP(hipEventCreate(&e1));
+  float ms = 0.f;
+  if (which == 0 || which == 1 || which == 3 || which == 4) {
+    double* d = nullptr;
+    SL2_HIP(hipMalloc(&d, 64));
+    const int iters = 200000;
+    const int blocks = (which == 3 || which == 4) ? 1024 : 512;
+    for (int rep = 0; rep < 2; ++rep) {
+      SL2_HIP(hipEventRecord(e0, 0));
+      if (which == 0) hipLaunchKernelGGL(k_ubench_mfma<4>, dim3(blocks), dim3(256), 0, 0, d, iters);
+      else if (which == 1) hipLaunchKernelGGL(k_ubench_mfma<1>, dim3(blocks), dim3(256), 0, 0, d, iters);
+      else if (which == 3) hipLaunchKernelGGL(k_ubench_mfma<8>, dim3(blocks), dim3(256), 0, 0, d, iters);
+      else hipLaunchKernelGGL(k_ubench_fma64, dim3(blocks), dim3(256), 0, 0, d, iters);
+      SL2_HIP(hipEventRecord(e1, 0));
+      SL2_HIP(hipEventSynchronize(e1));
+    }
+    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (which == 4) *result = (double)blocks * 256.0 * iters * 16.0 * 2.0 / (ms * 1e-3) / 1e12;
+    else {
+      const double nacc = which == 0 ? 4.0 : (which == 1 ? 1.0 : 8.0);
+      *result = (double)blocks * 4.0 * iters * nacc * 2048.0 / (ms * 1e-3) / 1e12;
+    }
+    hipFree(d);
+  } else {
+    const size_t bytes = (size_t)1 << 30;
+    double4 *s = nullptr, *t = nullptr;
+    SL2_HIP(hipMalloc(&s, bytes));
+    SL2_HIP(hipMalloc(&t, bytes));
+    SL2_HIP(hipMemset(s, 1, bytes));
+    for (int rep = 0; rep < 3; ++rep) {
+      SL2_HIP(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(k_ubench_copy, dim3(256 * 8), dim3(256), 0, 0, s, t, bytes / sizeof(double4));
+      SL2_HIP(hipEventRecord(e1, 0));
+      SL2_HIP(hipEventSynchronize(e1));
+    }
+    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *result = 2.0 * bytes / (ms * 1e-3) / 1e9;
+    hipFree(s); hipFree(t);
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
   return SL2_OK;
 }

@@ -308,6 +308,12 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
   return SL2_OK;
 }
 
+int sl2_set_search_variant(sl2_engine* e, int variant) {
+  if (!e || variant < 0 || variant > 1) return SL2_ERR_INVALID;
+  e->search_variant = variant;
+  return SL2_OK;
+}
+
 int sl2_kalman_filter_predict(sl2_engine* e) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
@@ -584,7 +590,7 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
   return SL2_OK;
 }
 
-int sl2_get_step_work(sl2_engine* e, double out[10]) {
+int sl2_get_step_work(sl2_engine* e, double out[11]) {
   if (!e || !out) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   SL2_HIP(hipStreamSynchronize(e->stream));
@@ -594,13 +600,14 @@ int sl2_get_step_work(sl2_engine* e, double out[10]) {
   SL2_HIP(hipMemcpy(mc.data(), e->m_count, sizeof(int) * e->B, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(flags.data(), e->f_flags, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots, sizeof(int) * e->B, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 10; ++k) out[k] = 0.0;
+  for (int k = 0; k < 11; ++k) out[k] = 0.0;
   const double frame_bytes = (double)e->cam.width * e->cam.height;
   for (int b = 0; b < e->B; ++b) {
     const double win = w[(size_t)b * 4 + 0];
     out[0] += win < frame_bytes ? win : frame_bytes;
     out[1] += w[(size_t)b * 4 + 1];
     out[2] += w[(size_t)b * 4 + 2];
+    out[10] += w[(size_t)b * 4 + 3];
     double n = 13;
     for (int f = 0; f < slots[b]; ++f) if (flags[(size_t)b * e->N + f] & FF_ACTIVE) n += 3;
     const double m = 2.0 * mc[b];

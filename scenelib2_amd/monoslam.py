@@ -82,6 +82,9 @@ class Engine:
         if keep is not None:
             self.synchronize()  # host buffer must outlive the async H2D copy
 
+    def set_search_variant(self, variant):
+        _lib.check(self.L.sl2_set_search_variant(self.h, int(variant)))
+
     def kalman_filter_predict(self):
         _lib.check(self.L.sl2_kalman_filter_predict(self.h))
 
@@ -188,10 +191,10 @@ class Engine:
         return out
 
     def step_work(self):
-        w = np.zeros(10)
+        w = np.zeros(11)
         _lib.check(self.L.sl2_get_step_work(self.h, _lib.dp(w)))
         keys = ["window_bytes", "searched", "candidates", "sum_m", "sum_m2", "sum_m3", "sum_n", "sum_nm", "sum_nnm",
-                "sum_nmm"]
+                "sum_nmm", "search_fallbacks"]
         return dict(zip(keys, w.tolist()))
 
 

@@ -86,17 +86,18 @@ def _search_cases(rng, n, W, H):
     return (np.stack(images), np.array(idx, np.int32), np.stack(patches), np.array(centres), np.array(puinv))
 
 
-def test_elliptical_search_batch_matches_oracle_exactly():
+@pytest.mark.parametrize("variant", [0, 1])
+def test_elliptical_search_batch_matches_oracle_exactly(variant):
     rng = np.random.default_rng(102)
     W, H = 160, 120
-    images, idx, patches, centres, puinv = _search_cases(rng, 96, W, H)
+    images, idx, patches, centres, puinv = _search_cases(rng, 160, W, H)
     n = len(idx)
     ok = np.zeros(n, np.int32)
     uv = np.full((n, 2), -7, np.int32)
     score = np.zeros(n)
     _lib.check(_lib.load().sl2_elliptical_search_batch(0, _lib.u8p(images), n, W, H, _lib.ip(idx), _lib.u8p(patches),
                                                        _lib.dp(centres), _lib.dp(puinv), n, _lib.ip(ok), _lib.ip(uv),
-                                                       _lib.dp(score), 0))
+                                                       _lib.dp(score), variant))
     n_ok = 0
     for t in range(n):
         want = oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t])

@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per core, max 32; 0: skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
     return ap.parse_args()
 
 
@@ -57,7 +58,9 @@ def main():
 
     B, N, W, H = args.batch, args.features, args.width, args.height
     K, Wm = args.steps, args.warmup
+    E = 0 if args.no_profile else 4          # extra untimed steps for the full per-kernel breakdown
     n_frames = K + Wm
+    n_render = n_frames + E
     cam = synth.default_camera(W, H)
     params = synth.default_params(N)
     seq_ids = sharding.global_sequence_ids(B, world, rank)
@@ -65,22 +68,24 @@ def main():
     # ---- synthetic inputs: specs on the host, frames rendered on the device ----
     t_setup = time.time()
     tex = synth.make_texture()
-    specs = [synth.SequenceSpec(cam, N, n_frames, synth.BASE_SEED + int(i)) for i in seq_ids]
+    specs = [synth.SequenceSpec(cam, N, n_render, synth.BASE_SEED + int(i)) for i in seq_ids]
     fb = W * H
     d_tex = _lib.DeviceBuffer(tex.nbytes, dev); d_tex.upload(tex)
     # pose k of every sequence, k-major: frames[k][b]
     poses = np.ascontiguousarray(np.stack([s.poses for s in specs], axis=1))       # [n_frames+1][B][7]
-    origins = np.ascontiguousarray(np.tile(np.stack([s.tex_origin for s in specs])[None], (n_frames + 1, 1, 1)))
+    origins = np.ascontiguousarray(np.tile(np.stack([s.tex_origin for s in specs])[None], (n_render + 1, 1, 1)))
     d_pose = _lib.DeviceBuffer(poses.nbytes, dev); d_pose.upload(poses)
     d_org = _lib.DeviceBuffer(origins.nbytes, dev); d_org.upload(origins)
-    d_frames = _lib.DeviceBuffer((n_frames + 1) * B * fb, dev)
-    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr, d_pose.ptr, (n_frames + 1) * B,
+    d_frames = _lib.DeviceBuffer((n_render + 1) * B * fb, dev)
+    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr, d_pose.ptr, (n_render + 1) * B,
                         d_frames.ptr, device=dev)
     torch.cuda.synchronize()
     frame0 = d_frames.download((B, H, W), np.uint8)                                  # t = 0 views -> templates
     templates = np.stack([synth.cut_templates(frame0[b], specs[b].feat_px) for b in range(B)])
 
     eng = Engine(cam, params, B, N, device=dev)
+    if args.groups > 0:
+        eng.set_groups(args.groups)
     eng.set_vehicle_state(np.stack([s.xv0 for s in specs]), np.stack([s.Pxx0 for s in specs]))
     eng.add_known_features(np.stack([s.feat_y for s in specs]), np.stack([s.xp_org() for s in specs]), templates)
     eng.synchronize()
@@ -94,7 +99,7 @@ def main():
         step(k)
     eng.synchronize()
     if not args.no_profile:
-        eng.set_profiling(True)
+        eng.set_profiling(1)          # timed region: only the roofline kernels carry event brackets
         eng.reset_kernel_times()
 
     # ---- timed region: exactly K steps ----
@@ -111,14 +116,24 @@ def main():
     elapsed = sharding.max_over_ranks(elapsed, tdev if world > 1 else None)
 
     ktimes = eng.kernel_times() if not args.no_profile else {}
-    eng.set_profiling(False)
-    work = eng.step_work()       # algorithmic work of the last step, summed over this rank's batch
+    eng.set_profiling(0)
+    work = eng.step_work()       # algorithmic work of the last timed step, summed over this rank's batch
+    xv_final, _ = eng.get_vehicle_state()
+    # untimed extra steps with EVERY launch bracketed: the full per-kernel breakdown
+    breakdown = {}
+    if E > 0:
+        eng.set_profiling(2)
+        eng.reset_kernel_times()
+        for k in range(Wm + K, Wm + K + E):
+            step(k)
+        eng.synchronize()
+        breakdown = eng.kernel_times()
+        eng.set_profiling(0)
     total_frames = sharding.sum_over_ranks(B * K, tdev if world > 1 else None)
     value = total_frames / elapsed
 
     # ---- gather of the small results (RCCL all-gather; outside the timed region) ----
     t_g = time.perf_counter()
-    xv_final, _ = eng.get_vehicle_state()
     all_xv = sharding.gather_states(xv_final, tdev if world > 1 else None)
     gather_ms = (time.perf_counter() - t_g) * 1e3
     status_bad = int(eng.status_flags().any())
@@ -131,9 +146,10 @@ def main():
         per_kernel = {}
         if ktimes:
             tot_ms = sum(v["total_ms"] for v in ktimes.values())
-            for name, v in sorted(ktimes.items(), key=lambda kv: -kv[1]["total_ms"]):
-                per_kernel[name] = dict(ms_per_step=v["total_ms"] / K, launches_per_step=v["launches"] / K,
-                                        share=v["total_ms"] / tot_ms if tot_ms else 0.0)
+            btot = sum(v["total_ms"] for v in breakdown.values())
+            for name, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["total_ms"]):
+                per_kernel[name] = dict(ms_per_step=v["total_ms"] / E, launches_per_step=v["launches"] / E,
+                                        share=v["total_ms"] / btot if btot else 0.0)
             dom = max(ktimes.items(), key=lambda kv: kv[1]["total_ms"])[0]
             # algorithmic FLOPs per launch over the rank's batch (executed formulation)
             flops = {"k_syrk": work["sum_nnm"],                  # P -= V V^T on the symmetric half: n^2 m
@@ -198,7 +214,7 @@ def main():
             tt = sum(d["times"].values())
             cpu["stage_split"] = {k: float(v / tt) for k, v in d["times"].items()}
             # parity of the trajectories on the sample (BASELINE metric: traj RMSE vs ref <= 1e-4)
-            log = eng.position_log(0, sample, capacity=n_frames)
+            log = eng.position_log(0, sample, capacity=n_render)[:, :n_frames]
             rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
             parity = dict(traj_rmse_vs_oracle=rmse, sequences=sample, frames=n_frames,
                           final_state_maxabs=float(np.abs(all_xv[:sample] - np.stack([s.get_state()[0] for s in slams])).max()))

@@ -133,6 +133,10 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  *   Kalman::KalmanFilterUpdate(monoslam)+normalise_state kalman.cpp:72-119, monoslam.cpp:616-637
  *   delete_bad_features + symmetrise                     monoslam.cpp:141-150
  */
+/* Split the batch into `groups` contiguous sequence groups, each stepped on its own HIP stream
+ * (latency-bound kernels of one group overlap throughput-bound kernels of another).  Default 1
+ * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024); env SL2_GROUPS overrides. */
+int sl2_set_groups(sl2_engine* e, int groups);
 /* Which search kernel sl2_make_measurements / sl2_go_one_step use (default 1). */
 int sl2_set_search_variant(sl2_engine* e, int variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
@@ -182,8 +186,8 @@ int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
 
 /* ------------------------------------------------------------------- profiling */
 
-/* When enabled, every kernel launch of a step is bracketed by HIP events on the
- * engine's stream; sl2_get_kernel_times returns accumulated milliseconds and
+/* enabled = 1: the roofline kernels (k_search, k_build_A, k_fwdsub, k_syrk) are bracketed by HIP
+ * events on the engine's stream (8 events per step); enabled = 2: every kernel launch is; sl2_get_kernel_times returns accumulated milliseconds and
  * launch counts per kernel name since the last reset. */
 int sl2_set_profiling(sl2_engine* e, int enabled);
 int sl2_reset_kernel_times(sl2_engine* e);

@@ -41,7 +41,27 @@ enum : int {
 
 constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
 constexpr int kCholBlock = 32;       // block size of the blocked Cholesky / forward substitution
-constexpr int kPatchStride = 128;    // bytes per stored template (121 + pad)
+constexpr int kPatchStride = 288;    // bytes per stored template: 121 raw bytes (+7 pad), then at byte
+                                     // 128 the packed form: 33 dwords (11 rows x 12 bytes, byte 11 = 0),
+                                     // sum g0, sum g0^2, flag (patch sigma >= 10), pad
+constexpr int kPatchPackedOffset = 128;
+
+// XCD-aware block -> (sequence, tile) mapping.  MI355X dispatches workgroup L to XCD L % 8 and
+// every XCD has its own 4 MB L2; all tiles of one sequence share that sequence's operands
+// (V^T, L, the frame), so they are placed on ONE XCD: the grid is 1-D with
+// tiles * roundup(B, 8) blocks and block L works on sequence (L/8/tiles)*8 + L%8, tile (L/8)%tiles.
+// (Placement is a speed matter only; any mapping is correct.)
+constexpr int kXcds = 8;
+inline int xcd_grid(int tiles, int B) { return tiles * round_up(B, kXcds); }
+#if defined(__HIPCC__)
+__device__ __forceinline__ bool xcd_map(int tiles, int B, int* seq, int* tile) {
+  const int L = blockIdx.x;
+  const int xcd = L % kXcds, slot = L / kXcds;
+  *seq = (slot / tiles) * kXcds + xcd;
+  *tile = slot % tiles;
+  return *seq < B;
+}
+#endif
 
 struct KernelTimer {
   std::string name;
@@ -103,7 +123,10 @@ struct sl2_engine {
   double* meas_score = nullptr;  // [B][N]
   int* succ_idx = nullptr;    // [B][N]   successful feature slots in selection order
   int* m_count = nullptr;     // [B]      number of successful features (m = 2 * m_count)
-  double* work = nullptr;     // [B][4]   window bytes, searched, candidates, (unused)
+  double* work = nullptr;     // [B][4]   window bytes, searched, candidates, exact-fallback searches
+  int* srch_i = nullptr;      // [B][N][8]  per-feature search window: ucentre, vcentre, urelstart, nu, vrelstart, nv, hw, hh
+  double* srch_d = nullptr;   // [B][N][4]  PuInv (a, b, c), pad
+  int* srch_res = nullptr;    // [B][N][8]  per selected position: code, u, v, S1, S2, X, ncand, pad
 
   // ---- EKF update workspaces (device) ----
   double* At = nullptr;    // [B][mld][ld]   (P H^T)^T, k-major; column ld-1 carries nu
@@ -117,14 +140,25 @@ struct sl2_engine {
 
   // profiling
   bool profiling = false;
+  int profile_level = 2;
   std::vector<sl2::KernelTimer> timers;
   std::vector<sl2::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
 
+  // ---- sequence groups: the batch is split into G contiguous groups, each stepped on its own
+  // HIP stream, so that the latency-bound kernels of one group (blocked Cholesky, selection,
+  // bookkeeping) overlap with the throughput-bound kernels of another (SYRK, substitution, search).
+  // A group is a shallow copy of the root engine whose per-sequence pointers are offset.
+  sl2_engine* root = nullptr;           // self for the root object
+  std::vector<sl2_engine*> groups;      // root only
+  int group_first = 0;                  // first sequence of this group
+  hipEvent_t fork_event = nullptr;
+
   int timer_id(const char* name);
-  void prof_begin(int id);
-  void prof_end();
+  void prof_begin(int id, hipStream_t st);
+  void prof_end(hipStream_t st);
   int fold_events();
+  int sync_all();
 };
 
 namespace sl2 {
@@ -133,11 +167,13 @@ namespace sl2 {
 struct LaunchScope {
   sl2_engine* e;
   bool on;
-  LaunchScope(sl2_engine* eng, const char* name) : e(eng), on(eng->profiling) {
-    if (on) e->prof_begin(e->timer_id(name));
+  size_t slot = 0;
+  // level 1 = only the roofline kernels (cheap: 4 event pairs per step), level 2 = every launch
+  LaunchScope(sl2_engine* eng, const char* name, bool major = false) : e(eng), on(eng->root->profiling && (major || eng->root->profile_level >= 2)) {
+    if (on) { e->root->prof_begin(e->root->timer_id(name), e->stream); slot = e->root->pending.size() - 1; }
   }
   ~LaunchScope() {
-    if (on) e->prof_end();
+    if (on) hipEventRecord(e->root->pending[slot].stop, e->stream);
   }
 };
 
@@ -147,6 +183,6 @@ int launch_feature_prediction(sl2_engine* e);
 int launch_select(sl2_engine* e, int n);
 int launch_search(sl2_engine* e);
 int launch_update(sl2_engine* e);
-int launch_finalize(sl2_engine* e, int save_trajectory);
+int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot);
 
 }  // namespace sl2

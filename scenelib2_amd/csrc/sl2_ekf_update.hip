@@ -296,14 +296,15 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fwdsub(const double* __restrict__ At, double* Vt, const double* __restrict__ St,
                                                 const double* __restrict__ LinvT, const int* __restrict__ m_count, int ld,
-                                                int mld, int nblk_max) {
-  const int b = blockIdx.y;
+                                                int mld, int nblk_max, int B) {
+  int b, ct;
+  if (!xcd_map(ld / 64, B, &b, &ct)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int nblk = (2 * cnt + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = blockIdx.x * 64 + wave * 16;
+  const int i0 = ct * 64 + wave * 16;
   const double* Ab = At + (size_t)b * mld * ld;
   double* Vb = Vt + (size_t)b * mld * ld;
   const double* Sb = St + (size_t)b * mld * mld;
@@ -343,12 +344,14 @@ __global__ void __launch_bounds__(256) k_fwdsub(const double* __restrict__ At, d
 // ld-1 of Vt is w = L^-1 nu, so the same product yields x += V w there.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
-                                              const int* __restrict__ m_count, int ld, int mld) {
-  const int b = blockIdx.y;
+                                              const int* __restrict__ m_count, int ld, int mld, int B) {
+  int b, t;
+  const int ntl = ld / 64;
+  if (!xcd_map(ntl * (ntl + 1) / 2, B, &b, &t)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int mp = (2 * cnt + 3) / 4 * 4;
-  int t = blockIdx.x, tj = 0;
+  int tj = 0;
   while (t > tj) { t -= tj + 1; ++tj; }
   const int ti = t;  // ti <= tj
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -421,7 +424,7 @@ int launch_update(sl2_engine* e) {
     SL2_HIP(hipGetLastError());
   }
   {
-    LaunchScope ls(e, "k_build_A");
+    LaunchScope ls(e, "k_build_A", true);
     dim3 grid(e->ld / 64, B);
     hipLaunchKernelGGL(k_build_A, grid, dim3(256), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
                        e->At, e->N, e->ld, e->mld);
@@ -456,15 +459,16 @@ int launch_update(sl2_engine* e) {
     }
   }
   {
-    LaunchScope ls(e, "k_fwdsub");
-    hipLaunchKernelGGL(k_fwdsub, dim3(e->ld / 64, B), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count,
-                       e->ld, e->mld, e->nblk_max);
+    LaunchScope ls(e, "k_fwdsub", true);
+    hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                       e->m_count, e->ld, e->mld, e->nblk_max, B);
     SL2_HIP(hipGetLastError());
   }
   {
-    LaunchScope ls(e, "k_syrk");
+    LaunchScope ls(e, "k_syrk", true);
     const int nt = e->ld / 64;
-    hipLaunchKernelGGL(k_syrk, dim3(nt * (nt + 1) / 2, B), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count, e->ld, e->mld);
+    hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count,
+                       e->ld, e->mld, B);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

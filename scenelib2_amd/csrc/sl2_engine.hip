@@ -34,7 +34,25 @@ __global__ void k_add_features(double* __restrict__ x, double* __restrict__ xp_o
       patch[fi * kPatchStride + p] = (uint8_t)g;
       s0 += g; s0sq += g * g;
     }
-    for (int p = 121; p < kPatchStride; ++p) patch[fi * kPatchStride + p] = 0;
+    for (int p = 121; p < kPatchPackedOffset; ++p) patch[fi * kPatchStride + p] = 0;
+    unsigned* packed = (unsigned*)(patch + fi * kPatchStride + kPatchPackedOffset);
+    for (int r = 0; r < 11; ++r)
+      for (int d = 0; d < 3; ++d) {
+        unsigned v = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int col = 4 * d + k;
+          if (col < 11) v |= (unsigned)patch_in[src * 121 + r * 11 + col] << (8 * k);
+        }
+        packed[r * 3 + d] = v;
+      }
+    {  // patch sigma test exactly as correlate2_warning + elliptical_search evaluate it (improc.cpp:99-112)
+      const double g0bar = (double)s0 / 121.0;
+      const double varg0 = (double)s0sq / 121.0 - (g0bar * g0bar);
+      const double sigmag0 = sqrt(varg0);
+      packed[33] = (unsigned)s0; packed[34] = (unsigned)s0sq;
+      packed[35] = (sigmag0 < kCorrelationSigmaThreshold) ? 0u : 1u;
+      for (int k = 36; k < (kPatchStride - kPatchPackedOffset) / 4; ++k) packed[k] = 0u;
+    }
     patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
     f_flags[fi] = FF_ACTIVE | FF_USED;
     attempted[fi] = 0; successful[fi] = 0;
@@ -93,6 +111,79 @@ static int fetch_vec(std::vector<T>& v, const T* dev, size_t off, size_t n) {
 
 using namespace sl2;
 
+// Build the group objects: shallow copies of the root whose per-sequence pointers start at
+// `first` and whose B is the group's sequence count.  G == 1 -> a single group on the root stream.
+static int build_groups(sl2_engine* e, int G) {
+  for (sl2_engine* g : e->groups) {
+    if (g->stream != e->stream) hipStreamDestroy(g->stream);
+    delete g;
+  }
+  e->groups.clear();
+  if (G < 1) G = 1;
+  if (G > e->B) G = e->B;
+  const size_t N = e->N, ld = e->ld, mld = e->mld;
+  for (int k = 0; k < G; ++k) {
+    const int base = e->B / G, rem = e->B % G;
+    const int first = k * base + (k < rem ? k : rem), count = base + (k < rem ? 1 : 0);
+    sl2_engine* g = new sl2_engine();
+    g->device = e->device; g->cam = e->cam; g->prm = e->prm;
+    g->B = count; g->N = e->N; g->ld = e->ld; g->nsel_max = e->nsel_max; g->mld = e->mld; g->nblk_max = e->nblk_max;
+    g->root = e; g->group_first = first;
+    if (G == 1) g->stream = e->stream; else SL2_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    const size_t f = first;
+    g->x = e->x + f * ld; g->P = e->P + f * ld * ld; g->patch = e->patch + f * N * kPatchStride;
+    g->patch_sums = e->patch_sums + f * N * 2; g->xp_org = e->xp_org + f * N * 8; g->f_flags = e->f_flags + f * N;
+    g->n_slots = e->n_slots + f; g->attempted = e->attempted + f * N; g->successful = e->successful + f * N;
+    g->traj = e->traj + f * kTrajCapacity * 3; g->traj_count = e->traj_count + f; g->last_r = e->last_r + f * 3;
+    g->status = e->status + f; g->pos_log = e->pos_log + f * kTrajCapacity * 3;
+    g->f_h = e->f_h + f * N * 2; g->f_Hx = e->f_Hx + f * N * 14; g->f_Hy = e->f_Hy + f * N * 6; g->f_R = e->f_R + f * N;
+    g->f_S = e->f_S + f * N * 4; g->f_score = e->f_score + f * N; g->f_z = e->f_z + f * N * 2; g->f_nu = e->f_nu + f * N * 2;
+    g->sel_idx = e->sel_idx + f * N; g->n_sel = e->n_sel + f; g->n_vis = e->n_vis + f; g->meas_ok = e->meas_ok + f * N;
+    g->meas_score = e->meas_score + f * N; g->succ_idx = e->succ_idx + f * N; g->m_count = e->m_count + f;
+    g->srch_i = e->srch_i + f * N * 8; g->srch_d = e->srch_d + f * N * 4; g->srch_res = e->srch_res + f * N * 8;
+    g->work = e->work + f * 4; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
+    g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
+    e->groups.push_back(g);
+  }
+  return SL2_OK;
+}
+
+// Order the group streams after everything already queued on the root stream (fork) ...
+static int fork_groups(sl2_engine* e) {
+  if (e->groups.size() == 1 && e->groups[0]->stream == e->stream) return SL2_OK;
+  if (!e->fork_event) SL2_HIP(hipEventCreateWithFlags(&e->fork_event, hipEventDisableTiming));
+  SL2_HIP(hipEventRecord(e->fork_event, e->stream));
+  for (sl2_engine* g : e->groups) SL2_HIP(hipStreamWaitEvent(g->stream, e->fork_event, 0));
+  return SL2_OK;
+}
+// ... and the root stream after the groups (join).  Only needed when the caller owns the root
+// stream and may queue its own work behind ours; with an engine-owned stream the groups free-run
+// from step to step and every host-visible call synchronises all of them.
+static int join_groups(sl2_engine* e) {
+  if (e->groups.size() == 1 && e->groups[0]->stream == e->stream) return SL2_OK;
+  if (e->own_stream) return SL2_OK;
+  for (sl2_engine* g : e->groups) {
+    if (!g->fork_event) SL2_HIP(hipEventCreateWithFlags(&g->fork_event, hipEventDisableTiming));
+    SL2_HIP(hipEventRecord(g->fork_event, g->stream));
+    SL2_HIP(hipStreamWaitEvent(e->stream, g->fork_event, 0));
+  }
+  return SL2_OK;
+}
+
+// Run `fn(group)` for every group between a fork and a join.
+template <typename F>
+static int for_each_group(sl2_engine* e, F fn) {
+  int rc = fork_groups(e);
+  if (rc != SL2_OK) return rc;
+  for (sl2_engine* g : e->groups) {
+    g->cur_frames = e->cur_frames ? e->cur_frames + (size_t)g->group_first * e->cur_stride : nullptr;
+    g->cur_stride = e->cur_stride;
+    if ((rc = fn(g)) != SL2_OK) return rc;
+  }
+  return join_groups(e);
+}
+
+
 int sl2_engine::timer_id(const char* name) {
   for (size_t i = 0; i < timers.size(); ++i)
     if (timers[i].name == name) return (int)i;
@@ -102,7 +193,7 @@ int sl2_engine::timer_id(const char* name) {
   return (int)timers.size() - 1;
 }
 
-void sl2_engine::prof_begin(int id) {
+void sl2_engine::prof_begin(int id, hipStream_t st) {
   PendingEvent pe;
   pe.timer = id;
   for (int k = 0; k < 2; ++k) {
@@ -111,15 +202,21 @@ void sl2_engine::prof_begin(int id) {
     else hipEventCreate(&ev);
     if (k == 0) pe.start = ev; else pe.stop = ev;
   }
-  hipEventRecord(pe.start, stream);
+  hipEventRecord(pe.start, st);
   pending.push_back(pe);
 }
 
-void sl2_engine::prof_end() { hipEventRecord(pending.back().stop, stream); }
+void sl2_engine::prof_end(hipStream_t st) { hipEventRecord(pending.back().stop, st); }
+
+int sl2_engine::sync_all() {
+  for (sl2_engine* g : root->groups) SL2_HIP(hipStreamSynchronize(g->stream));
+  SL2_HIP(hipStreamSynchronize(root->stream));
+  return SL2_OK;
+}
 
 int sl2_engine::fold_events() {
   if (pending.empty()) return SL2_OK;
-  SL2_HIP(hipStreamSynchronize(stream));
+  { int rc = sync_all(); if (rc != SL2_OK) return rc; }
   for (auto& pe : pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, pe.start, pe.stop) == hipSuccess) {
@@ -200,24 +297,48 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->succ_idx, B * N));
   A(dmalloc(&e->m_count, B));
   A(dmalloc(&e->work, B * 4));
+  A(dmalloc(&e->srch_i, B * N * 8));
+  A(dmalloc(&e->srch_d, B * N * 4));
+  A(dmalloc(&e->srch_res, B * N * 8));
   A(dmalloc(&e->At, B * mld * ld));
   A(dmalloc(&e->Vt, B * mld * ld));
   A(dmalloc(&e->St, B * mld * mld));
   A(dmalloc(&e->LinvT, B * (size_t)e->nblk_max * 1024));
 #undef A
   SL2_HIP(hipDeviceSynchronize());
+  e->root = e;
+  {
+    int G = 1;
+    const char* env = getenv("SL2_GROUPS");
+    if (env && atoi(env) > 0) G = atoi(env);
+    int rc2 = build_groups(e, G);
+    if (rc2 != SL2_OK) return rc2;
+  }
   *out = e;
   return SL2_OK;
+}
+
+int sl2_set_groups(sl2_engine* e, int groups) {
+  if (!e || groups < 1) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int rc = e->sync_all(); if (rc != SL2_OK) return rc; }
+  return build_groups(e, groups);
 }
 
 void sl2_destroy(sl2_engine* e) {
   if (!e) return;
   hipSetDevice(e->device);
-  hipStreamSynchronize(e->stream);
+  e->sync_all();
+  for (sl2_engine* g : e->groups) {
+    if (g->stream != e->stream) hipStreamDestroy(g->stream);
+    if (g->fork_event) hipEventDestroy(g->fork_event);
+    delete g;
+  }
+  if (e->fork_event) hipEventDestroy(e->fork_event);
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
-                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log};
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -227,7 +348,7 @@ void sl2_destroy(sl2_engine* e) {
 
 int sl2_synchronize(sl2_engine* e) {
   if (!e) return SL2_ERR_INVALID;
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   return SL2_OK;
 }
 int sl2_batch(const sl2_engine* e) { return e ? e->B : 0; }
@@ -238,6 +359,7 @@ static int range_ok(sl2_engine* e, int seq0, int nseq) { return e && seq0 >= 0 &
 int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx) {
   if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   double *dxv = nullptr, *dP = nullptr;
   SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
   SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
@@ -245,7 +367,7 @@ int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, c
   SL2_HIP(hipMemcpyAsync(dP, Pxx, sizeof(double) * 169 * nseq, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_set_vehicle, dim3(nseq), dim3(64), 0, e->stream, e->x, e->P, dxv, dP, seq0, e->ld);
   SL2_HIP(hipGetLastError());
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   hipFree(dxv); hipFree(dP);
   return SL2_OK;
 }
@@ -253,6 +375,7 @@ int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, c
 int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double* Pxx) {
   if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   double *dxv = nullptr, *dP = nullptr;
   SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
   SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
@@ -260,7 +383,7 @@ int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double*
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipMemcpyAsync(xv, dxv, sizeof(double) * 13 * nseq, hipMemcpyDeviceToHost, e->stream));
   SL2_HIP(hipMemcpyAsync(Pxx, dP, sizeof(double) * 169 * nseq, hipMemcpyDeviceToHost, e->stream));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   hipFree(dxv); hipFree(dP);
   return SL2_OK;
 }
@@ -269,7 +392,7 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
                            const uint8_t* patches) {
   if (!range_ok(e, seq0, nseq) || nfeat <= 0 || !y || !xp_org || !patches) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   std::vector<int> slots(nseq);
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
   for (int s = 0; s < nseq; ++s)
@@ -286,7 +409,7 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
   hipLaunchKernelGGL(k_add_features, dim3(nseq), dim3(64), 0, e->stream, e->x, e->xp_org, e->patch, e->patch_sums, e->f_flags,
                      e->n_slots, e->attempted, e->successful, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
   SL2_HIP(hipGetLastError());
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   hipFree(dy); hipFree(dxp); hipFree(dp);
   return SL2_OK;
 }
@@ -317,15 +440,17 @@ int sl2_set_search_variant(sl2_engine* e, int variant) {
 int sl2_kalman_filter_predict(sl2_engine* e) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  return launch_predict(e);
+  return for_each_group(e, [](sl2_engine* g) { return launch_predict(g); });
 }
 
 int sl2_auto_select_n_features(sl2_engine* e, int n) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  int rc = launch_feature_prediction(e);
-  if (rc != SL2_OK) return rc;
-  return launch_select(e, n);
+  return for_each_group(e, [n](sl2_engine* g) {
+    int rc = launch_feature_prediction(g);
+    if (rc != SL2_OK) return rc;
+    return launch_select(g, n);
+  });
 }
 
 int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device) {
@@ -333,19 +458,22 @@ int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_strid
   SL2_HIP(hipSetDevice(e->device));
   int rc = bind_frames(e, frames, seq_stride, frames_on_device);
   if (rc != SL2_OK) return rc;
-  return launch_search(e);
+  return for_each_group(e, [](sl2_engine* g) { return launch_search(g); });
 }
 
 int sl2_kalman_filter_update(sl2_engine* e) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  return launch_update(e);
+  return for_each_group(e, [](sl2_engine* g) { return launch_update(g); });
 }
 
 int sl2_finish_step(sl2_engine* e, int save_trajectory) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  return launch_finalize(e, save_trajectory);
+  const int slot = (int)(e->steps_done % kTrajCapacity);
+  int rc = for_each_group(e, [=](sl2_engine* g) { return launch_finalize(g, save_trajectory, slot); });
+  e->steps_done += 1;
+  return rc;
 }
 
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int save_trajectory,
@@ -355,12 +483,19 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   SL2_HIP(hipSetDevice(e->device));
   int rc;
   if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
-  if ((rc = launch_predict(e)) != SL2_OK) return rc;
-  if ((rc = launch_feature_prediction(e)) != SL2_OK) return rc;
-  if ((rc = launch_select(e, e->prm.number_of_features_to_select)) != SL2_OK) return rc;
-  if ((rc = launch_search(e)) != SL2_OK) return rc;
-  if ((rc = launch_update(e)) != SL2_OK) return rc;
-  if ((rc = launch_finalize(e, save_trajectory)) != SL2_OK) return rc;
+  const int slot = (int)(e->steps_done % kTrajCapacity);
+  const int nsel = e->prm.number_of_features_to_select;
+  rc = for_each_group(e, [=](sl2_engine* g) {
+    int r;
+    if ((r = launch_predict(g)) != SL2_OK) return r;
+    if ((r = launch_feature_prediction(g)) != SL2_OK) return r;
+    if ((r = launch_select(g, nsel)) != SL2_OK) return r;
+    if ((r = launch_search(g)) != SL2_OK) return r;
+    if ((r = launch_update(g)) != SL2_OK) return r;
+    return launch_finalize(g, save_trajectory, slot);
+  });
+  e->steps_done += 1;
+  if (rc != SL2_OK) return rc;
   if (e->profiling && e->pending.size() > 8192) return e->fold_events();
   return SL2_OK;
 }
@@ -375,7 +510,7 @@ struct HostSeq {
 
 static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   SL2_HIP(hipMemcpy(&hs.n_slots, e->n_slots + seq, sizeof(int), hipMemcpyDeviceToHost));
   hs.flags.resize(e->N);
   SL2_HIP(hipMemcpy(hs.flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
@@ -401,7 +536,7 @@ static std::vector<int> live_index(const sl2_engine* e, const HostSeq& hs) {
 int sl2_get_total_state_sizes(sl2_engine* e, int seq0, int nseq, int32_t* sizes) {
   if (!range_ok(e, seq0, nseq) || !sizes) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   std::vector<int> flags((size_t)nseq * e->N), slots(nseq);
   SL2_HIP(hipMemcpy(flags.data(), e->f_flags + (size_t)seq0 * e->N, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
@@ -487,7 +622,7 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
 int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int32_t counters[3]) {
   if (!range_ok(e, seq, 1) || !labels || !counters) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   int ns = 0, nv = 0, mc = 0;
   SL2_HIP(hipMemcpy(&ns, e->n_sel + seq, sizeof(int), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(&nv, e->n_vis + seq, sizeof(int), hipMemcpyDeviceToHost));
@@ -508,7 +643,7 @@ int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int
 int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count) {
   if (!range_ok(e, seq, 1) || !out || !count) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   int total = 0;
   SL2_HIP(hipMemcpy(&total, e->traj_count + seq, sizeof(int), hipMemcpyDeviceToHost));
   std::vector<double> ring((size_t)kTrajCapacity * 3);
@@ -528,7 +663,7 @@ int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* c
 int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int capacity, int* count) {
   if (!range_ok(e, seq0, nseq) || !out || !count || capacity <= 0) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   const long long total = e->steps_done;
   const int have = (int)(total < kTrajCapacity ? total : kTrajCapacity);
   const int n = have < capacity ? have : capacity;
@@ -546,7 +681,7 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful) {
   if (!range_ok(e, seq, 1) || label < 0 || label >= e->N) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   SL2_HIP(hipMemcpy(e->attempted + (size_t)seq * e->N + label, &attempted, sizeof(int), hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + label, &successful, sizeof(int), hipMemcpyHostToDevice));
   return SL2_OK;
@@ -555,7 +690,7 @@ int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, i
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags) {
   if (!range_ok(e, seq0, nseq) || !flags) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   SL2_HIP(hipMemcpy(flags, e->status + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
   return SL2_OK;
 }
@@ -566,6 +701,7 @@ int sl2_set_profiling(sl2_engine* e, int enabled) {
   if (!e) return SL2_ERR_INVALID;
   if (!enabled && e->profiling) { int rc = e->fold_events(); if (rc) return rc; }
   e->profiling = enabled != 0;
+  if (enabled) e->profile_level = enabled >= 2 ? 2 : 1;
   return SL2_OK;
 }
 int sl2_reset_kernel_times(sl2_engine* e) {
@@ -593,7 +729,7 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
 int sl2_get_step_work(sl2_engine* e, double out[11]) {
   if (!e || !out) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   std::vector<double> w((size_t)e->B * 4);
   std::vector<int> mc(e->B), flags((size_t)e->B * e->N), slots(e->B);
   SL2_HIP(hipMemcpy(w.data(), e->work, sizeof(double) * w.size(), hipMemcpyDeviceToHost));

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(64) k_feature_prediction(const double* __restr
                                                            const int* __restrict__ n_slots, double* __restrict__ f_h,
                                                            double* __restrict__ f_Hx, double* __restrict__ f_Hy,
                                                            double* __restrict__ f_R, double* __restrict__ f_S,
-                                                           double* __restrict__ f_score, CameraParams cam, int N, int ld) {
+                                                           double* __restrict__ f_score, int* __restrict__ srch_i, double* __restrict__ srch_d,
+                                                           CameraParams cam, int N, int ld) {
   const int b = blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_slots[b]) return;
@@ -100,6 +101,18 @@ __global__ void __launch_bounds__(64) k_feature_prediction(const double* __restr
   f_score[fi] = S[0] + S[3];  // trace (selection_score, full_feature_model.cpp:172-176)
   if (cant_see == 0) flags |= FF_VISIBLE;
   f_flags[fi] = flags;
+  // search window of this feature (measure_feature + the head of elliptical_search,
+  // monoslam.cpp:371-374, 416-439), so that the search kernel starts from a descriptor
+  {
+    double a, bq, c;
+    sinv_from_S(S, &a, &bq, &c);
+    const SearchBounds sb = search_bounds(h, a, bq, c, cam.width, cam.height);
+    int* si = srch_i + fi * 8;
+    si[0] = sb.ucentre; si[1] = sb.vcentre; si[2] = sb.urelstart; si[3] = sb.urelfinish - sb.urelstart + 1;
+    si[4] = sb.vrelstart; si[5] = sb.vrelfinish - sb.vrelstart + 1; si[6] = sb.halfwidth; si[7] = sb.halfheight;
+    double* sd = srch_d + fi * 4;
+    sd[0] = a; sd[1] = bq; sd[2] = c; sd[3] = 0.0;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -296,7 +309,7 @@ int launch_feature_prediction(sl2_engine* e) {
   LaunchScope ls(e, "k_feature_prediction");
   dim3 grid((e->N + 63) / 64, e->B);
   hipLaunchKernelGGL(k_feature_prediction, grid, dim3(64), 0, e->stream, e->x, e->P, e->xp_org, e->f_flags, e->n_slots,
-                     e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score, e->cam, e->N, e->ld);
+                     e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score, e->srch_i, e->srch_d, e->cam, e->N, e->ld);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }
@@ -311,15 +324,14 @@ int launch_select(sl2_engine* e, int n) {
   return SL2_OK;
 }
 
-int launch_finalize(sl2_engine* e, int save_trajectory) {
+int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot) {
   LaunchScope ls(e, "k_finalize");
   const size_t shm = (size_t)e->N * sizeof(int);
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
-                     (int)(e->steps_done % kTrajCapacity), e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
+                     log_slot, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
                      e->prm.successful_match_fraction, save_trajectory);
   SL2_HIP(hipGetLastError());
-  e->steps_done += 1;
   return SL2_OK;
 }
 

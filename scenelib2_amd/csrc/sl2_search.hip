@@ -2,20 +2,24 @@
 // (monoslam.cpp:401-477) + correlate2_warning (improc/improc.cpp:55-134).
 //
 // One 64-lane wavefront per (sequence, selected feature).  Integer sums are exact
-// int32; the score epilogue is the reference's FP64 expression (ncc_score in
+// int32; the deciding score is the reference's FP64 expression (ncc_score in
 // sl2_math.hpp, -ffp-contract=off) so the arg-min, the "<=" last-candidate-wins
 // tie rule (Q2), the sigma >= 10 tests (Q3) and the 0.40 threshold are decided on
 // bit-identical numbers.
 //
 // Variant 0 ("baseline"): lane = candidate, 121-pixel loop straight from
 // global/L2, full FP64 epilogue per candidate.  Kept as the simple, obviously
-// faithful kernel that the faster variants are cross-checked against.
+// faithful kernel; it is also the exact fallback of variant 1.
+//
+// Variant 1 ("column walk", production): see search_core_v1 below.
 #include "sl2_common.hpp"
 
 namespace sl2 {
 
 struct SearchResult {
+  int code;   // 0 = resolved here (exact), 1 = unique winner, exact score deferred, -1 = caller must fall back
   int ok, found, u, v, ncand;
+  int S1, S2, X;  // integer sums of the deferred winner
   double score;
 };
 
@@ -30,11 +34,17 @@ __device__ __forceinline__ void wave_argmin(double& best, int& best_order) {
   }
 }
 
-__device__ __forceinline__ SearchResult search_core_v0(const uint8_t* __restrict__ image, int width, int height,
-                                       const uint8_t* __restrict__ patch, const double centre[2], double a, double b,
-                                       double c) {
+__device__ __forceinline__ SearchBounds bounds_from_desc(const int* si) {
+  SearchBounds sb;
+  sb.ucentre = si[0]; sb.vcentre = si[1]; sb.urelstart = si[2]; sb.urelfinish = si[2] + si[3] - 1;
+  sb.vrelstart = si[4]; sb.vrelfinish = si[4] + si[5] - 1; sb.halfwidth = si[6]; sb.halfheight = si[7];
+  return sb;
+}
+
+__device__ __forceinline__ SearchResult search_core_v0(const uint8_t* __restrict__ image, int width,
+                                                       const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
+                                                       double b, double c) {
   const int lane = threadIdx.x & 63;
-  const SearchBounds sb = search_bounds(centre, a, b, c, width, height);
   const int nu = sb.urelfinish - sb.urelstart + 1;
   const int nv = sb.vrelfinish - sb.vrelstart + 1;
   // template sums (wave-uniform; every lane computes them redundantly)
@@ -71,9 +81,10 @@ __device__ __forceinline__ SearchResult search_core_v0(const uint8_t* __restrict
   wave_argmin(best, best_order);
   for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
   SearchResult r;
+  r.code = 0;
   r.ncand = ncand;
   r.score = best;
-  r.u = 0; r.v = 0;
+  r.u = 0; r.v = 0; r.S1 = r.S2 = r.X = 0;
   r.found = best_order >= 0;
   if (best_order >= 0) {
     r.u = sb.ucentre + sb.urelstart + best_order / nv;
@@ -91,13 +102,14 @@ __device__ __forceinline__ SearchResult search_core_v0(const uint8_t* __restrict
 // costs ONE new row fetch, sliding row sums for sum(g1), sum(g1^2) and 33
 // v_dot4_u32_u8 for the cross term.  All sums are exact int32.
 //
-// Candidate ranking is done on rho_f = cov/sqrt(var0 var1) in FP32 from the exact
-// integers (error < 1e-6); only candidates within 4e-6 of the best are then scored
-// with the reference's FP64 expression and its accept/tie rules, which decides the
-// result exactly as the sequential scan would.  Anything the fast path cannot
-// decide exactly (two near-best candidates in one lane, the sigma == 10 boundary,
-// windows larger than the LDS tile) falls back to search_core_v0 — same results,
-// just slower.
+// Candidates are ranked on rho_f = cov/sqrt(var0 var1) in FP32 from the exact
+// integers (error < 1e-6).  Only a candidate within 4e-6 of the best can be the
+// reference's winner; if there is exactly one such candidate its integer sums are
+// handed to the scoring pass (k_search_score, or scored in place when DEFER is
+// off), which evaluates the reference's FP64 score and thresholds.  Anything the
+// fast path cannot decide exactly (several near-best candidates, the sigma == 10
+// boundary, windows larger than the LDS tile) returns code -1 and the caller runs
+// search_core_v0 — same results, just slower.
 // ---------------------------------------------------------------------------
 constexpr int kWinPitchDw = 20;   // LDS row pitch in dwords (80 B)
 constexpr int kWinRows = 64;
@@ -105,52 +117,22 @@ constexpr int kMaxNu = 51, kMaxNv = 54;
 
 __device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 
-__device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict__ image, int width, int height,
-                                       const uint8_t* __restrict__ patch, const double centre[2], double a, double b,
-                                       double c, unsigned* s_win, unsigned long long* s_mask) {
+// tpl: packed template (33 dwords + sum g0 + sum g0^2 + sigma flag) or nullptr -> built from patch bytes
+template <bool DEFER>
+__device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict__ image, int width,
+                                                       const unsigned* __restrict__ tpl, const uint8_t* __restrict__ patch,
+                                                       const SearchBounds sb, double a, double b, double c,
+                                                       unsigned* s_win) {
   const int lane = threadIdx.x & 63;
-  const SearchBounds sb = search_bounds(centre, a, b, c, width, height);
   const int nu = sb.urelfinish - sb.urelstart + 1;
   const int nv = sb.vrelfinish - sb.vrelstart + 1;
   SearchResult res;
-  res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
+  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
+  res.S1 = res.S2 = res.X = 0;
   if (nu <= 0 || nv <= 0) return res;
-  if (nu > kMaxNu || nv > kMaxNv) { res.found = -1; return res; }   // caller falls back to search_core_v0
+  if (nu > kMaxNu || nv > kMaxNv) { res.code = -1; return res; }
 
-  // ---- template -> 33 wave-uniform dwords (row r: bytes 0..10, byte 11 = 0) ----
-  unsigned tv = 0;
-  if (lane < 33) {
-    const int r = lane / 3, d = lane - 3 * r;
-    for (int k = 0; k < 4; ++k) {
-      const int col = 4 * d + k;
-      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
-      tv |= byte << (8 * k);
-    }
-  }
-  unsigned T[33];
-#pragma unroll
-  for (int i = 0; i < 33; ++i) T[i] = __builtin_amdgcn_readlane(tv, i);
-  unsigned uSg0 = 0, uSg0sq = 0;
-#pragma unroll
-  for (int i = 0; i < 33; ++i) { uSg0 = udot4(T[i], 0x01010101u, uSg0); uSg0sq = udot4(T[i], T[i], uSg0sq); }
-  const int Sg0 = (int)uSg0, Sg0sq = (int)uSg0sq;
-  {  // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
-    const double g0bar = (double)Sg0 / 121.0;
-    const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
-    const double sigmag0 = sqrt(varg0);
-    if (sigmag0 < kCorrelationSigmaThreshold) {
-      // every candidate is skipped; still report the candidate count
-      int n = 0;
-      for (int idx = lane; idx < nu * nv; idx += 64)
-        n += in_ellipse(a, b, c, sb.urelstart + idx / nv, sb.vrelstart + idx % nv) ? 1 : 0;
-      for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-      res.ncand = n;
-      return res;
-    }
-  }
-  const int D0 = 121 * Sg0sq - Sg0 * Sg0;   // n^2 var0 > 0 here
-
-  // ---- stage the window: rows y0 .. y0+nv+9, bytes x0 .. x0+nu+9, dword-aligned loads ----
+  // ---- stage the window (issue the global loads first: longest latency) ----
   const int x0 = sb.ucentre + sb.urelstart - 5, y0 = sb.vcentre + sb.vrelstart - 5;
   const int Hw = nv + 10;
   const size_t base_addr = (size_t)image + (size_t)y0 * width + x0;
@@ -162,28 +144,61 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
         const size_t addr = base_addr + (size_t)r * width;
         const size_t al = addr & ~(size_t)3;
         const int o = (int)(addr & 3);
-        const int need = (o + nu + 10 + 3) >> 2;
+        const int need = (o + nu + 10 + 3) >> 2;     // <= 16
         unsigned v = 0;
         if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
         s_win[r * kWinPitchDw + k] = v;
-        if (k == 0) { s_win[r * kWinPitchDw + 16] = (need > 16) ? *(const unsigned*)(al + 64) : 0u; }
+        if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
       }
     }
   }
-  if (lane < kWinRows) s_mask[lane] = 0ull;
-  __syncthreads();
-  // ---- ellipse membership bitmasks (exact FP64 test), candidate count ----
-  int ncand = 0;
-  for (int idx = lane; idx < nu * nv; idx += 64) {
-    const int ui = idx / nv, vi = idx - ui * nv;
-    if (in_ellipse(a, b, c, sb.urelstart + ui, sb.vrelstart + vi)) {
-      atomicOr(&s_mask[ui], 1ull << vi);
-      ++ncand;
+
+  // ---- template -> 33 wave-uniform dwords (row r: bytes 0..10, byte 11 = 0) ----
+  unsigned tv = 0;
+  if (tpl) {
+    if (lane < 36) tv = tpl[lane];
+  } else if (lane < 33) {
+    const int r = lane / 3, d = lane - 3 * r;
+    for (int k = 0; k < 4; ++k) {
+      const int col = 4 * d + k;
+      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
+      tv |= byte << (8 * k);
     }
   }
+  unsigned T[33];
+#pragma unroll
+  for (int i = 0; i < 33; ++i) T[i] = __builtin_amdgcn_readlane(tv, i);
+  int Sg0, Sg0sq;
+  bool patch_ok;
+  if (tpl) {
+    Sg0 = (int)__builtin_amdgcn_readlane(tv, 33);
+    Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
+    patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
+  } else {
+    unsigned uSg0 = 0, uSg0sq = 0;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) { uSg0 = udot4(T[i], 0x01010101u, uSg0); uSg0sq = udot4(T[i], T[i], uSg0sq); }
+    Sg0 = (int)uSg0; Sg0sq = (int)uSg0sq;
+    // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
+    const double g0bar = (double)Sg0 / 121.0;
+    const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
+    const double sigmag0 = sqrt(varg0);
+    patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
+  }
+
+  // ---- ellipse membership (exact FP64 test): lane u builds the bit mask over v of its column ----
+  unsigned long long colmask = 0ull;
+  if (lane < nu) {
+    const int urel = sb.urelstart + lane;
+    for (int vi = 0; vi < nv; ++vi)
+      if (in_ellipse(a, b, c, urel, sb.vrelstart + vi)) colmask |= 1ull << vi;
+  }
+  int ncand = __popcll(colmask);
   for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
   res.ncand = ncand;
-  __syncthreads();
+  if (!patch_ok) return res;                       // every candidate is skipped (sdpatch < 10)
+  const int D0 = 121 * Sg0sq - Sg0 * Sg0;          // n^2 var0 > 0 here
+  __syncthreads();                                 // window is in LDS
 
   // ---- column walk ----
   const int nseg = 64 / nu;                       // >= 1
@@ -192,7 +207,12 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
   const int vstart = seg * vs;
   const bool active = (seg < nseg) && (vstart < nv);
   const int vlen = active ? min(vs, nv - vstart) : 0;
-  const unsigned long long mymask = active ? s_mask[ui] : 0ull;
+  unsigned long long mymask;
+  {
+    const unsigned lo = (unsigned)__shfl((int)(unsigned)(colmask & 0xffffffffull), ui, 64);
+    const unsigned hi = (unsigned)__shfl((int)(unsigned)(colmask >> 32), ui, 64);
+    mymask = active ? (((unsigned long long)hi << 32) | lo) : 0ull;
+  }
   const int wmod = width & 3;
   const int o_first = (int)(base_addr & 3);
   const int tmax = vs + 10;
@@ -267,87 +287,131 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
   for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
   const float thr = gmax - 4.0e-6f;
   const bool lane_amb = (second_q >= thr) && (best_idx >= 0);
-  if (__any(need_exact) || __any(lane_amb)) { res.found = -1; return res; }
-  double best = 1000000.0;
-  int best_order = -1;
-  if (best_idx >= 0 && best_q >= thr) {
-    double sd0, sd1;
-    const double corr = ncc_score(Sg0, best_S1, best_X, Sg0sq, best_S2, &sd0, &sd1);
-    if (corr <= best && !(sd0 < kCorrelationSigmaThreshold) && !(sd1 < kCorrelationSigmaThreshold)) { best = corr; best_order = best_idx; }
+  const bool lane_near = (best_idx >= 0) && (best_q >= thr);
+  const unsigned long long near_mask = __ballot(lane_near);
+  if (__any(need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
+  if (near_mask == 0ull) return res;               // nothing passed the sigma test: not found
+  const int wl = __ffsll((long long)near_mask) - 1;  // the one lane holding the only possible winner
+  const int w_idx = __shfl(best_idx, wl, 64);
+  res.S1 = __shfl(best_S1, wl, 64); res.S2 = __shfl(best_S2, wl, 64); res.X = __shfl(best_X, wl, 64);
+  res.found = 1;
+  res.u = sb.ucentre + sb.urelstart + w_idx / nv;
+  res.v = sb.vcentre + sb.vrelstart + w_idx % nv;
+  if (DEFER) { res.code = 1; return res; }
+  double sd0, sd1;
+  const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
+  if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {   // cannot happen (D1 > bound), kept exact
+    res.found = 0; res.u = res.v = 0;
+    return res;
   }
-  wave_argmin(best, best_order);
-  res.score = best;
-  res.found = best_order >= 0;
-  if (best_order >= 0) {
-    res.u = sb.ucentre + sb.urelstart + best_order / nv;
-    res.v = sb.vcentre + sb.vrelstart + best_order % nv;
-  }
-  res.ok = (best_order >= 0 && !(best > kCorrThresh2)) ? 1 : 0;
+  res.score = corr;
+  res.ok = !(corr > kCorrThresh2) ? 1 : 0;
   return res;
 }
 
-// Engine kernel: grid (nsel_max, B), one wave per block.
+// ---------------------------------------------------------------------------
+// Engine kernels.  k_search: one wave per (sequence, selected position), XCD-mapped so
+// that all windows of one frame go through one XCD's L2.  It writes a compact result
+// record; k_search_score (one THREAD per selected position, all lanes busy) evaluates
+// the deferred FP64 scores and does the reference's bookkeeping
+// (successful_/failed_measurement_of_feature, monoslam.cpp:479-496).
+// ---------------------------------------------------------------------------
 template <int VARIANT>
-__global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int height,
-                                                  const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
-                                                  const double* __restrict__ f_S, const int* __restrict__ sel_idx,
-                                                  const int* __restrict__ n_sel, int* __restrict__ f_flags,
-                                                  double* __restrict__ f_z, double* __restrict__ f_nu,
-                                                  int* __restrict__ attempted, int* __restrict__ successful,
-                                                  int* __restrict__ meas_ok, double* __restrict__ meas_score,
-                                                  double* __restrict__ work, int N) {
-  const int b = blockIdx.y, k = blockIdx.x;
+__global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
+                                               const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
+                                               const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
+                                               const int* __restrict__ n_sel, int* __restrict__ srch_res,
+                                               double* __restrict__ meas_score, int N, int nsel_max, int B) {
+  int b, k;
+  if (!xcd_map(nsel_max, B, &b, &k)) return;
   if (k >= n_sel[b]) return;
+  __shared__ unsigned s_win[kWinRows * kWinPitchDw];
   const int f = sel_idx[(size_t)b * N + k];
   const size_t fi = (size_t)b * N + f;
-  const double h[2] = {f_h[fi * 2], f_h[fi * 2 + 1]};
-  const double S[4] = {f_S[fi * 4], f_S[fi * 4 + 1], f_S[fi * 4 + 2], f_S[fi * 4 + 3]};
-  double a, bb, c;
-  sinv_from_S(S, &a, &bb, &c);
-  __shared__ unsigned s_win[kWinRows * kWinPitchDw];
-  __shared__ unsigned long long s_mask[kWinRows];
+  const SearchBounds sb = bounds_from_desc(srch_i + fi * 8);
+  const double a = srch_d[fi * 4], bq = srch_d[fi * 4 + 1], c = srch_d[fi * 4 + 2];
+  const uint8_t* img = frames + (size_t)b * seq_stride;
+  const uint8_t* pbytes = patch + fi * kPatchStride;
   SearchResult r;
-  r.found = -1;
-  if (VARIANT == 1) r = search_core_v1(frames + (size_t)b * seq_stride, width, height, patch + fi * kPatchStride, h, a, bb, c, s_win, s_mask);
-  const bool fell_back = r.found < 0;
-  if (fell_back) r = search_core_v0(frames + (size_t)b * seq_stride, width, height, patch + fi * kPatchStride, h, a, bb, c);
+  r.code = -1;
+  if (VARIANT == 1) r = search_core_v1<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a, bq, c, s_win);
+  const bool fell_back = r.code < 0;
+  if (fell_back) r = search_core_v0(img, width, pbytes, sb, a, bq, c);
   if ((threadIdx.x & 63) == 0) {
-    meas_ok[(size_t)b * N + k] = r.ok;
+    int* o = srch_res + ((size_t)b * N + k) * 8;
+    o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | ((VARIANT == 1 && fell_back) ? 4 : 0);
     meas_score[(size_t)b * N + k] = r.score;
+  }
+}
+
+__global__ void __launch_bounds__(64) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
+                                                     const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
+                                                     const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
+                                                     int* __restrict__ f_flags, double* __restrict__ f_z,
+                                                     double* __restrict__ f_nu, int* __restrict__ attempted,
+                                                     int* __restrict__ successful, int* __restrict__ meas_ok,
+                                                     double* __restrict__ meas_score, double* __restrict__ work, int N) {
+  const int b = blockIdx.y;
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0;
+  if (k < n_sel[b]) {
+    const int f = sel_idx[(size_t)b * N + k];
+    const size_t fi = (size_t)b * N + f;
+    const int* o = srch_res + ((size_t)b * N + k) * 8;
+    const int code = o[0];
+    int ok = (o[7] & 2) ? 1 : 0;
+    double score = meas_score[(size_t)b * N + k];
+    if (code == 1) {   // deferred: the only candidate that can win; reference FP64 score + thresholds
+      const unsigned* packed = (const unsigned*)(patch + fi * kPatchStride + kPatchPackedOffset);
+      double sd0, sd1;
+      score = ncc_score((int)packed[33], o[3], o[5], (int)packed[34], o[4], &sd0, &sd1);
+      ok = (!(sd0 < kCorrelationSigmaThreshold) && !(sd1 < kCorrelationSigmaThreshold) && !(score > kCorrThresh2)) ? 1 : 0;
+      meas_score[(size_t)b * N + k] = score;
+    }
+    meas_ok[(size_t)b * N + k] = ok;
     int fl = f_flags[fi];
-    attempted[fi] += 1;  // failed_/successful_measurement_of_feature, monoslam.cpp:479-496
-    if (r.ok) {
+    attempted[fi] += 1;
+    if (ok) {
       successful[fi] += 1;
-      f_z[fi * 2] = (double)r.u; f_z[fi * 2 + 1] = (double)r.v;
-      f_nu[fi * 2] = (double)r.u - h[0]; f_nu[fi * 2 + 1] = (double)r.v - h[1];
+      const double h0 = f_h[fi * 2], h1 = f_h[fi * 2 + 1];
+      f_z[fi * 2] = (double)o[1]; f_z[fi * 2 + 1] = (double)o[2];
+      f_nu[fi * 2] = (double)o[1] - h0; f_nu[fi * 2 + 1] = (double)o[2] - h1;   // func_nui
       fl |= FF_SUCCESS;
     } else {
       fl &= ~FF_SUCCESS;
     }
     f_flags[fi] = fl;
-    const SearchBounds sb = search_bounds(h, a, bb, c, width, height);
-    atomicAdd(&work[b * 4 + 0], (double)(2 * sb.halfwidth + 11) * (double)(2 * sb.halfheight + 11));
-    atomicAdd(&work[b * 4 + 1], 1.0);
-    atomicAdd(&work[b * 4 + 2], (double)r.ncand);
-    if (VARIANT == 1 && fell_back) atomicAdd(&work[b * 4 + 3], 1.0);
+    const int* si = srch_i + fi * 8;
+    w_win = (double)(2 * si[6] + 11) * (double)(2 * si[7] + 11);
+    w_n = 1.0; w_cand = (double)o[6]; w_fb = (o[7] & 4) ? 1.0 : 0.0;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    w_win += __shfl_xor(w_win, off, 64); w_n += __shfl_xor(w_n, off, 64);
+    w_cand += __shfl_xor(w_cand, off, 64); w_fb += __shfl_xor(w_fb, off, 64);
+  }
+  if (threadIdx.x == 0 && w_n > 0.0) {
+    atomicAdd(&work[b * 4 + 0], w_win); atomicAdd(&work[b * 4 + 1], w_n);
+    atomicAdd(&work[b * 4 + 2], w_cand); atomicAdd(&work[b * 4 + 3], w_fb);
   }
 }
 
 // Stateless batch kernel (C-ABI seam S1): grid (count), one wave per search.
 template <int VARIANT>
 __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__ images, int width, int height,
-                                                        const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
-                                                        const double* __restrict__ centre, const double* __restrict__ puinv,
-                                                        int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
+                                                     const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
+                                                     const double* __restrict__ centre, const double* __restrict__ puinv,
+                                                     int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
   const int i = blockIdx.x;
-  const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
   __shared__ unsigned s_win[kWinRows * kWinPitchDw];
-  __shared__ unsigned long long s_mask[kWinRows];
+  const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
+  const double a = puinv[i * 3], b = puinv[i * 3 + 1], c = puinv[i * 3 + 2];
+  const SearchBounds sb = search_bounds(ce, a, b, c, width, height);
   const uint8_t* img = images + (size_t)image_index[i] * width * height;
   SearchResult r;
-  r.found = -1;
-  if (VARIANT == 1) r = search_core_v1(img, width, height, patches + (size_t)i * 121, ce, puinv[i * 3], puinv[i * 3 + 1], puinv[i * 3 + 2], s_win, s_mask);
-  if (r.found < 0) r = search_core_v0(img, width, height, patches + (size_t)i * 121, ce, puinv[i * 3], puinv[i * 3 + 1], puinv[i * 3 + 2]);
+  r.code = -1;
+  if (VARIANT == 1) r = search_core_v1<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win);
+  if (r.code < 0) r = search_core_v0(img, width, patches + (size_t)i * 121, sb, a, b, c);
   if ((threadIdx.x & 63) == 0) {
     ok[i] = r.ok;
     score[i] = r.score;
@@ -356,18 +420,26 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
 }
 
 int launch_search(sl2_engine* e) {
-  LaunchScope ls(e, "k_search");
   SL2_HIP(hipMemsetAsync(e->work, 0, sizeof(double) * 4 * e->B, e->stream));
-  dim3 grid(e->nsel_max, e->B);
-  if (e->search_variant == 0)
-    hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->cam.height,
-                       e->patch, e->f_h, e->f_S, e->sel_idx, e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted,
-                       e->successful, e->meas_ok, e->meas_score, e->work, e->N);
-  else
-    hipLaunchKernelGGL(k_search<1>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->cam.height,
-                       e->patch, e->f_h, e->f_S, e->sel_idx, e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted,
-                       e->successful, e->meas_ok, e->meas_score, e->work, e->N);
-  SL2_HIP(hipGetLastError());
+  {
+    LaunchScope ls(e, "k_search", true);
+    dim3 grid(xcd_grid(e->nsel_max, e->B));
+    if (e->root->search_variant == 0)
+      hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
+                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
+    else
+      hipLaunchKernelGGL(k_search<1>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
+                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_search_score");
+    dim3 grid((e->nsel_max + 63) / 64, e->B);
+    hipLaunchKernelGGL(k_search_score, grid, dim3(64), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
+                       e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
+                       e->N);
+    SL2_HIP(hipGetLastError());
+  }
   return SL2_OK;
 }
 
@@ -389,7 +461,7 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
   double *d_ce = nullptr, *d_pu = nullptr, *d_sc = nullptr;
   const size_t img_bytes = (size_t)nimages * width * height;
   SL2_HIP(hipMalloc(&d_img, img_bytes));
-  SL2_HIP(hipMalloc(&d_pat, (size_t)count * 121));
+  SL2_HIP(hipMalloc(&d_pat, (size_t)count * 121 + 16));
   SL2_HIP(hipMalloc(&d_idx, sizeof(int) * count));
   SL2_HIP(hipMalloc(&d_ok, sizeof(int) * count));
   SL2_HIP(hipMalloc(&d_uv, sizeof(int) * 2 * count));

@@ -82,6 +82,9 @@ class Engine:
         if keep is not None:
             self.synchronize()  # host buffer must outlive the async H2D copy
 
+    def set_groups(self, groups):
+        _lib.check(self.L.sl2_set_groups(self.h, int(groups)))
+
     def set_search_variant(self, variant):
         _lib.check(self.L.sl2_set_search_variant(self.h, int(variant)))
 
@@ -173,8 +176,9 @@ class Engine:
         return out
 
     # ---- profiling -----------------------------------------------------------
-    def set_profiling(self, on):
-        _lib.check(self.L.sl2_set_profiling(self.h, int(on)))
+    def set_profiling(self, level):
+        """0 off, 1 roofline kernels only, 2 every launch."""
+        _lib.check(self.L.sl2_set_profiling(self.h, int(level)))
 
     def reset_kernel_times(self):
         _lib.check(self.L.sl2_reset_kernel_times(self.h))

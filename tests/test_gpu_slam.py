@@ -86,9 +86,12 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch):
     assert not pr.engine.status_flags().any()
 
 
-def test_ragged_batch_and_empty_map():
-    """Sequences of one batch with different map sizes (incl. zero features) and n_select < N."""
+@pytest.mark.parametrize("groups", [1, 3])
+def test_ragged_batch_and_empty_map(groups):
+    """Sequences of one batch with different map sizes (incl. zero features) and n_select < N,
+    stepped as one stream or as three sequence groups on separate streams."""
     pr = Pair(16, 6, batch=4, n_select=10, feature_counts=[16, 0, 7, 11], max_features=16)
+    pr.engine.set_groups(groups)
     for k in range(6):
         pr.step_both(k)
         pr.compare_state(TOL_X, TOL_P)
@@ -180,6 +183,7 @@ def test_full_size_batch_properties():
     uniq = 3
     seqs = [synth.make_sequence(cam, N, F, seq_index=i, tex=tex) for i in range(uniq)]
     e = Engine(cam, synth.default_params(N), B, N)
+    e.set_groups(4)                      # four sequence groups on four HIP streams
     e.set_vehicle_state(np.stack([seqs[b % uniq][0].xv0 for b in range(B)]), np.stack([seqs[b % uniq][0].Pxx0 for b in range(B)]))
     for b in range(B):
         sp, tpl = seqs[b % uniq][0], seqs[b % uniq][1]

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(256) k_build_A(const double* __restrict__ P, c
 }
 
 // ---------------------------------------------------------------------------
-// k_build_S: S = H A + R, stored St[c][r] = S[r][c] (both triangles written;
-// the factorisation reads r >= c).  Padding: identity.  A thread owns one row
+// k_build_S: S = H A + R, stored St[c][r] = S[r][c] (32x32 blocks on and below the block
+// diagonal; the factorisation reads r >= c plus the full diagonal blocks).  Padding: identity.  A thread owns one row
 // a of H (its 10 non-zeros in registers) and loops over 32 columns bb: per column
 // 7 wave-uniform loads (pose part of At row bb) + 3 gathered loads within that row.
 // ---------------------------------------------------------------------------
@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, 
   const int a = blockIdx.y * 256 + threadIdx.x;
   const int bb0 = blockIdx.x * 32;
   if (a >= mp || bb0 >= mp) return;
+  if (bb0 > (a | 31)) return;   // strictly above the block diagonal: never read by the factorisation
   double* Sb = St + (size_t)b * mld * mld;
   const int m = 2 * cnt;
   if (a >= m) {
@@ -293,48 +294,88 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
 // independent: each wave owns 16 columns and walks the block rows J in order,
 //   acc = At[J] - sum_{K<J} L[J][K] Vt[K] ;  Vt[J] = L_JJ^-1 acc.
 // A lane re-reads only Vt elements it stored itself (D fragment == B fragment).
+// The chain is latency-bound (every k-step needs 3 L2-resident operands); what hides
+// it is occupancy (64 VGPRs -> 7 waves per SIMD) plus the unrolled k-loop, which puts
+// 8 k-steps of loads in flight ahead of their MFMAs.  A last block whose upper 16
+// rows are all padding skips them.  32 columns per wave give four independent
+// accumulator chains and 4 MFMAs per 3 fragment loads.
+// (Tried and measured slower on MI355X, batch 1024: L blocks through LDS with a 4-wave
+// barrier per block, 0.72 ms; V^T resident in LDS with one wave per workgroup, 2.1 ms;
+// an explicit two-stage register pipeline, 1.04 ms at 256 VGPRs — each loses the
+// occupancy that hides the chain's latency.  This version: see profiles/.)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fwdsub(const double* __restrict__ At, double* Vt, const double* __restrict__ St,
+template <bool HALF>
+__device__ __forceinline__ void fwd_kloop(v4d acc[2][2], const double* __restrict__ lrow, const double* vrow, int mld, int ld,
+                                          int kend) {
+#pragma unroll 4
+  for (int kk = 0; kk < kend; kk += 4) {
+    const double a0 = -lrow[(size_t)kk * mld];
+    const double b0 = vrow[(size_t)kk * ld], b1 = vrow[(size_t)kk * ld + 16];
+    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+    if (!HALF) {
+      const double a1 = -lrow[(size_t)kk * mld + 16];
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+  }
+}
+
+// 2 waves per workgroup, 32 columns per wave (four independent accumulator chains per wave).
+__global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, double* Vt, const double* __restrict__ St,
                                                 const double* __restrict__ LinvT, const int* __restrict__ m_count, int ld,
                                                 int mld, int nblk_max, int B) {
   int b, ct;
   if (!xcd_map(ld / 64, B, &b, &ct)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
+  const int m = 2 * cnt;
+  const int nblk = (m + 31) / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = ct * 64 + wave * 16;
+  const int i0 = ct * 64 + wave * 32;
   const double* Ab = At + (size_t)b * mld * ld;
   double* Vb = Vt + (size_t)b * mld * ld;
   const double* Sb = St + (size_t)b * mld * mld;
   for (int J = 0; J < nblk; ++J) {
-    v4d acc[2];
+    const bool half = (J * 32 + 16 >= m);    // rows J*32+16.. are padding: skip the second row tile
+    v4d acc[2][2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[jt][r] = Ab[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo];
-    for (int kk = 0; kk < J * 32; kk += 4) {
-      const size_t row = (size_t)(kk + hi);
-      const double a0 = -Sb[row * mld + J * 32 + lo], a1 = -Sb[row * mld + J * 32 + 16 + lo];
-      const double bv = Vb[row * ld + i0 + lo];
-      acc[0] = mfma_f64(a0, bv, acc[0]);
-      acc[1] = mfma_f64(a1, bv, acc[1]);
-    }
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[jt][it][r] = (jt == 1 && half) ? 0.0 : Ab[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo];
+    const double* lrow = Sb + (size_t)hi * mld + J * 32 + lo;     // L[J*32 + lo (+16)][k], k = hi + 4 s
+    const double* vrow = Vb + (size_t)hi * ld + i0 + lo;
+    if (half) fwd_kloop<true>(acc, lrow, vrow, mld, ld, J * 32);
+    else fwd_kloop<false>(acc, lrow, vrow, mld, ld, J * 32);
     const double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-    v4d out[2] = {(v4d){0, 0, 0, 0}, (v4d){0, 0, 0, 0}};
+    v4d out[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) for (int it = 0; it < 2; ++it) out[jt][it] = (v4d){0, 0, 0, 0};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int p = 4 * s + hi;
-      const double a0 = Lb[p * 32 + lo], a1 = Lb[p * 32 + 16 + lo];
-      const double bs = acc[s >> 2][s & 3];
-      out[0] = mfma_f64(a0, bs, out[0]);
-      out[1] = mfma_f64(a1, bs, out[1]);
+      const double a0 = Lb[p * 32 + lo];
+      const double b0 = acc[s >> 2][0][s & 3], b1 = acc[s >> 2][1][s & 3];
+      out[0][0] = mfma_f64(a0, b0, out[0][0]);
+      out[0][1] = mfma_f64(a0, b1, out[0][1]);
+      if (!half) {
+        const double a1 = Lb[p * 32 + 16 + lo];
+        out[1][0] = mfma_f64(a1, b0, out[1][0]);
+        out[1][1] = mfma_f64(a1, b1, out[1][1]);
+      }
     }
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < 2; ++jt) {
+      if (jt == 1 && half) continue;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo] = out[jt][r];
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo] = out[jt][it][r];
+    }
   }
 }
 
@@ -342,7 +383,16 @@ __global__ void __launch_bounds__(256) k_fwdsub(const double* __restrict__ At, d
 // k_syrk: P -= V V^T on 64x64 tiles of the upper block triangle (ti <= tj),
 // mirrored to the lower one; 4 waves per tile, 32x32 per wave.  The column
 // ld-1 of Vt is w = L^-1 nu, so the same product yields x += V w there.
+//
+// The two 64-column panels of V^T are streamed through LDS in K-chunks of 16 rows,
+// double-buffered: the global loads of chunk c+1 are in flight while the 16 MFMAs
+// of chunk c run (the kernel was memory-latency-bound with direct fragment loads:
+// SQ_WAIT_ANY 55 %, MFMA pipe 38 % busy).  LDS row pitch 80 doubles: the two
+// k-rows read by one 32-lane group of a ds_read_b64 land on disjoint banks.
 // ---------------------------------------------------------------------------
+constexpr int kSyrkKC = 16;       // K rows per chunk
+constexpr int kSyrkPitch = 80;    // doubles per LDS row (64 + 16)
+
 __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
                                               const int* __restrict__ m_count, int ld, int mld, int B) {
   int b, t;
@@ -350,30 +400,50 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   if (!xcd_map(ntl * (ntl + 1) / 2, B, &b, &t)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int mp = (2 * cnt + 3) / 4 * 4;
+  const int mp = (2 * cnt + kSyrkKC - 1) / kSyrkKC * kSyrkKC;   // rows >= 2 cnt of Vt are zero up to the 32-multiple
   int tj = 0;
   while (t > tj) { t -= tj + 1; ++tj; }
   const int ti = t;  // ti <= tj
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = ti * 64 + (wave >> 1) * 32, j0 = tj * 64 + (wave & 1) * 32;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   const double* Vb = Vt + (size_t)b * mld * ld;
   double* Pb = P + (size_t)b * ld * ld;
+  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
+  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
+  // staging role of this thread: row kr of the chunk, 4 consecutive doubles at column c4
+  const int kr = tid >> 4, c4 = (tid & 15) * 4;
+  const double* gA = Vb + (size_t)kr * ld + ti * 64 + c4;
+  const double* gB = Vb + (size_t)kr * ld + tj * 64 + c4;
+  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
   v4d acc[2][2];
   for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
-  const double* xp = Vb + (size_t)hi * ld + i0 + lo;
-  const double* yp = Vb + (size_t)hi * ld + j0 + lo;
-#pragma unroll 4
-  for (int k = 0; k < mp; k += 4) {
-    const double a0 = xp[0], a1 = xp[16], b0 = yp[0], b1 = yp[16];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-    xp += (size_t)4 * ld;
-    yp += (size_t)4 * ld;
+  const int nchunk = mp / kSyrkKC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
+    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
+    __syncthreads();
+    if (ch + 1 < nchunk) {   // prefetch the next chunk; the loads fly under the MFMAs below
+      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * ld);
+      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * ld);
+    }
+    const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
+    const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
+#pragma unroll
+    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
+      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
+      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+    // the buffer written next iteration (buf^1) was last read two iterations ago: one barrier per chunk suffices
   }
   double* xb = x + (size_t)b * ld;
+  const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
 #pragma unroll
   for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -460,7 +530,7 @@ int launch_update(sl2_engine* e) {
   }
   {
     LaunchScope ls(e, "k_fwdsub", true);
-    hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+    hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                        e->m_count, e->ld, e->mld, e->nblk_max, B);
     SL2_HIP(hipGetLastError());
   }

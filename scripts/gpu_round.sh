@@ -30,10 +30,13 @@ prof)
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
   find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done ;;
 pmc)
-  for c in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$c -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$c.json 2> $OLDPWD/$OUT/pmc_$c.err ); echo "pmc $c exit $?"
+  # separate passes (PMC only with --kernel-trace; never with sys/runtime traces)
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
   done
-  python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; tail -30 $OUT/pmc_summary.txt ;;
+  python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
 esac
 done
 ls -la $OUT | head -30

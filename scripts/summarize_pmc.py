@@ -1,7 +1,7 @@
 """Summarise rocprofv3 --pmc output (counter_collection csv): per kernel name, mean
-counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are in KiB on this stack; on
+counter value per dispatch.  FETCH_SIZE / WRITE_SIZE are reported in KiB by this stack; on
 gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x
-(MI355X_MICROARCH.md §HBM) — both raw and corrected figures are printed."""
+(MI355X_MICROARCH.md section HBM) - the corrected figure is printed next to the raw one."""
 import csv
 import glob
 import os
@@ -17,11 +17,17 @@ for cdir in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                name = row.get("Kernel_Name", "?").split("(")[0]
+                name = row.get("Kernel_Name", "?").split("(")[0].replace("sl2::", "")
                 acc[name][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
     print("==", os.path.basename(cdir), "files:", len(files))
     for name, cs in sorted(acc.items()):
-        for c, vals in cs.items():
+        parts = []
+        for c, vals in sorted(cs.items()):
             mean = sum(vals) / len(vals)
-            print("%-60s %-12s n=%-5d mean=%.1f KiB/dispatch  (x2 read-corrected: %.1f MiB)" % (
-                name[:60], c, len(vals), mean, mean * 2 / 1024.0))
+            if c == "FETCH_SIZE":
+                parts.append("%s=%.0f KiB (x2 corrected %.1f MiB)" % (c, mean, mean * 2 / 1024.0))
+            elif c == "WRITE_SIZE":
+                parts.append("%s=%.0f KiB (%.1f MiB)" % (c, mean, mean / 1024.0))
+            else:
+                parts.append("%s=%.4g" % (c, mean))
+        print("%-28s n=%-4d %s" % (name[:28], len(next(iter(cs.values()))), "  ".join(parts)))

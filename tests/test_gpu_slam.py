@@ -133,6 +133,20 @@ def test_delete_bad_features_matches_reference_walk():
     assert 3 not in [f["label"] for f in pr.engine.features(0)]
 
 
+@pytest.mark.parametrize("width,height,n_features,n_frames,batch", [(640, 480, 200, 3, 2), (1280, 720, 500, 2, 1)])
+def test_larger_baseline_shapes(width, height, n_features, n_frames, batch):
+    """BASELINE configs 4 and 5 shapes (640x480 / 200 features, n = 613; 1280x720 / 500 features,
+    n = 1513, m up to 1000: 32 Cholesky blocks) at a batch the oracle can follow."""
+    cam = synth.default_camera(width, height)
+    pr = Pair(n_features, n_frames, batch=batch, cam=cam)
+    for k in range(n_frames):
+        pr.step_both(k)
+        worst = pr.compare_state(TOL_X, 2e-8)
+    _, cnt = pr.engine.selection(0)
+    assert cnt["measurement_size"] > 1.5 * n_features     # most features matched
+    assert not pr.engine.status_flags().any()
+
+
 def test_monoslam_api_with_shipped_cfg_and_templates():
     """MonoSLAM.Init(cfg) + GoOneStep on the reference's own fixtures (cfg values, known_patch*.pgm)."""
     from scenelib2_amd.config import load_config, read_pgm
@@ -213,3 +227,17 @@ def test_full_size_batch_properties():
         assert rel_fro(P, o.total_covariance()) < TOL_P
     w = e.step_work()
     assert w["searched"] > 0.9 * B * N and w["sum_m"] > 1.8 * 0.9 * B * N
+
+
+def test_engine_matches_committed_golden_fixture():
+    """The HIP path against the committed golden vectors (tests/golden/oracle_shipped.npz): the
+    reference's shipped scene, three GoOneStep calls."""
+    from scenelib2_amd.config import load_config, read_pgm
+    g = np.load(golden_path("oracle_shipped.npz"))
+    m = MonoSLAM(max_features=8).Init(golden_path("scenelib2_shipped.cfg"), template_dirs=[golden_path("")])
+    for k in range(3):
+        m.GoOneStep(g["frame"], True, False)
+        assert np.abs(m.construct_total_state() - g["x"][k]).max() < TOL_X
+        assert rel_fro(m.construct_total_covariance(), g["P"][k]) < TOL_P
+        assert np.array_equal(np.array([f.z_ for f in m.feature_list_]), g["z"][k])
+    assert m.successful_measurement_vector_size_ == 8

@@ -105,6 +105,7 @@ struct sl2_engine {
   int* status = nullptr;      // [B]
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
   long long steps_done = 0;
+  int chol_variant = 1;       // 1 = fused two-wave Cholesky when it applies, 0 = launch-per-block kernels
   int search_variant = 1;     // 0 = baseline kernel, 1 = LDS column-walk kernel (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----

@@ -50,46 +50,48 @@ __global__ void __launch_bounds__(64) k_compact(const int* __restrict__ sel_idx,
 // k_build_A: At[a][i] = (P H^T)[i][a], a = 2j+r for the j-th successful feature.
 // Column ld-1 carries the innovation nu (so that L^-1 nu and W nu fall out of the
 // same substitution / SYRK).  Rows of padding up to a multiple of 32 are zeroed.
-// Block = 64 columns x 4 feature groups; a thread keeps the 7 pose entries of its
-// column in registers and loops over the features of its group (3 coalesced row
-// reads of P + 2 coalesced row writes of At per feature).
+// One workgroup per sequence; a thread keeps the 7 pose entries of its column in
+// registers and loops over the features (3 coalesced row reads of P + 2 coalesced row
+// writes of At per feature, each a full contiguous row for the workgroup).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_build_A(const double* __restrict__ P, const double* __restrict__ f_Hx,
+__global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                  const int* __restrict__ succ_idx, const int* __restrict__ m_count,
                                                  double* __restrict__ At, int N, int ld, int mld) {
-  const int b = blockIdx.y;
+  // one workgroup per sequence; a thread owns column(s) i and loops over the features, so every
+  // row of P / At is streamed as one contiguous burst by the workgroup
+  const int b = blockIdx.x;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int cnt_pad = (cnt + 15) / 16 * 16;
-  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int g = threadIdx.x >> 6;
   double* Ab = At + (size_t)b * mld * ld;
   const double* Pb = P + (size_t)b * ld * ld;
-  double pc[7];
+  for (int i = threadIdx.x; i < ld; i += blockDim.x) {
+    double pc[7];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
-  for (int j = g; j < cnt_pad; j += 4) {
-    if (j >= cnt) {
+    for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
+#pragma unroll 4
+    for (int j = 0; j < cnt; ++j) {
+      const int f = succ_idx[(size_t)b * N + j];
+      const size_t fi = (size_t)b * N + f;
+      const int pos = 13 + 3 * f;
+      double py[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
+        if (i == ld - 1) acc = f_nu[fi * 2 + r];
+        Ab[(size_t)(2 * j + r) * ld + i] = acc;
+      }
+    }
+    for (int j = cnt; j < cnt_pad; ++j) {
       Ab[(size_t)(2 * j) * ld + i] = 0.0;
       Ab[(size_t)(2 * j + 1) * ld + i] = 0.0;
-      continue;
-    }
-    const int f = succ_idx[(size_t)b * N + j];
-    const size_t fi = (size_t)b * N + f;
-    const int pos = 13 + 3 * f;
-    double py[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
-      if (i == ld - 1) acc = f_nu[fi * 2 + r];
-      Ab[(size_t)(2 * j + r) * ld + i] = acc;
     }
   }
 }
@@ -307,6 +309,165 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
 }
 
 // ---------------------------------------------------------------------------
+// k_chol_fused: the whole blocked Cholesky of one sequence in ONE launch, by a
+// two-wave workgroup (used when the number of 32-blocks is small enough that the
+// launch-per-block version is latency-bound, nblk_max <= kFusedMaxBlocks):
+//   wave D ("diagonal")  factors + inverts the 32x32 diagonal blocks in registers
+//                        (the ~35 us scalar dependency chain per block);
+//   wave M ("matrix")    does every MFMA tile: panel solves L[I][J] = S[I][J] L_JJ^-T
+//                        and trailing updates S[I][K] -= L[I][J] L[K][J]^T.
+// Per block column J the waves meet twice:  A_J — L_JJ^-1 is in LDS (D -> M);
+// B_J — the next diagonal tile (J+1,J+1) is updated and in LDS (M -> D).  M does the
+// panel tile I = J+1 and the tile (J+1,J+1) FIRST, so D starts the next diagonal block
+// while M still works through the rest of column J: the scalar chain of D (the
+// critical path) is overlapped with all of M's work instead of being three
+// serialised launches per block.
+// ---------------------------------------------------------------------------
+constexpr int kFusedMaxBlocks = 12;
+
+__device__ __forceinline__ void diag_factor_regs(double a[32], double x[32], int r) {
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const double piv = readlane_f64(a[c], c);
+    const double dinv = fast_rsqrt(piv);
+    const double d = piv * dinv;
+    const double l = (r == c) ? d : a[c] * dinv;
+    a[c] = (r >= c) ? l : 0.0;
+#pragma unroll
+    for (int cc = c + 1; cc < 32; ++cc) {
+      const double lcc = readlane_f64(a[c], cc);   // L[cc][c]
+      a[cc] -= l * lcc;                            // meaningful for r >= cc
+    }
+  }
+  double diag = 1.0;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) diag = (r == c) ? a[c] : diag;
+  const double rinv = fast_rcp(diag);
+#pragma unroll
+  for (int p = 31; p >= 0; --p) {
+    double sacc = (r == p) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = p + 1; i < 32; ++i) sacc -= x[i] * readlane_f64(a[p], i);
+    x[p] = sacc * readlane_f64(rinv, p);
+  }
+}
+
+__global__ void __launch_bounds__(128, 2) k_chol_fused(double* __restrict__ St, double* __restrict__ LinvT,
+                                                    const int* __restrict__ m_count, int mld, int nblk_max) {
+  const int b = blockIdx.x;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int nblk = (2 * cnt + 31) / 32;
+  const int lane = threadIdx.x & 63;
+  const bool isD = (threadIdx.x >> 6) == 0;
+  const int lo = lane & 15, hi = lane >> 4;
+  __shared__ double sTile[32][33];     // next diagonal tile, sTile[r][c] = S[r][c]   (M -> D)
+  __shared__ double sLinv[32 * 32];    // LinvT of the current block, [p][k]          (D -> M)
+  double* Sb = St + (size_t)b * mld * mld;
+  for (int J = 0; J < nblk; ++J) {
+    const int o = J * 32;
+    if (isD) {
+      const int r = lane & 31;
+      double a[32], x[32];
+      if (J == 0) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a[c] = Sb[(size_t)c * mld + r];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a[c] = sTile[r][c];
+      }
+      diag_factor_regs(a, x, r);
+      if (lane < 32) {
+        double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          Sb[(size_t)(o + c) * mld + o + r] = a[c];
+          Lb[c * 32 + r] = x[c];
+          sLinv[c * 32 + r] = x[c];
+        }
+      }
+    }
+    __syncthreads();                    // A_J : L_JJ^-1 available to M
+    if (J + 1 >= nblk) break;
+    if (!isD) {
+      // ---- panel tile I = J+1, then the next diagonal tile (J+1, J+1) ----
+      for (int pass = 0; pass < 2; ++pass) {
+        const int Ibeg = (pass == 0) ? J + 1 : J + 2;
+        const int Iend = (pass == 0) ? J + 2 : nblk;
+        for (int I = Ibeg; I < Iend; ++I) {
+          v4d acc[2][2];
+          for (int kt = 0; kt < 2; ++kt) for (int it = 0; it < 2; ++it) acc[kt][it] = (v4d){0, 0, 0, 0};
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) {
+            const int p = 4 * s8 + hi;
+            const double a0 = sLinv[p * 32 + lo], a1 = sLinv[p * 32 + 16 + lo];
+            const double b0 = Sb[(size_t)(o + p) * mld + I * 32 + lo];
+            const double b1 = Sb[(size_t)(o + p) * mld + I * 32 + 16 + lo];
+            acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+            acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+            acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+            acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+          }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4)
+                Sb[(size_t)(o + 16 * kt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo] = acc[kt][it][r4];
+        }
+        // trailing tiles: pass 0 -> only (J+1, J+1); pass 1 -> all the others
+        const int Kbeg = J + 1, Kend = (pass == 0) ? J + 2 : nblk;
+        for (int K = Kbeg; K < Kend; ++K) {
+          const int I0 = (pass == 0) ? K : ((K == J + 1) ? K + 1 : K);
+          const int I1 = (pass == 0) ? K + 1 : nblk;
+          for (int I = I0; I < I1; ++I) {
+            v4d acc[2][2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+              for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                  acc[jt][it][r4] = Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo];
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+              const size_t row = (size_t)(o + 4 * s8 + hi) * mld;
+              const double a0 = -Sb[row + K * 32 + lo], a1 = -Sb[row + K * 32 + 16 + lo];
+              const double b0 = Sb[row + I * 32 + lo], b1 = Sb[row + I * 32 + 16 + lo];
+              acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+              acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+              acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+              acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+            }
+            if (pass == 0) {
+              // hand the finished diagonal tile to D: D fragment (row = column c, col = row r) -> sTile[r][c]
+#pragma unroll
+              for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                  for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = acc[jt][it][r4];
+            } else {
+#pragma unroll
+              for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                  for (int r4 = 0; r4 < 4; ++r4)
+                    Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r4];
+            }
+          }
+        }
+        if (pass == 0) __syncthreads();   // B_J (M side): tile (J+1, J+1) is in LDS
+      }
+    } else {
+      __syncthreads();                    // B_J (D side)
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_fwdsub: Vt = L^-1 At by blocked forward substitution.  Columns are
 // independent: each wave owns 16 columns and walks the block rows J in order,
 //   acc = At[J] - sum_{K<J} L[J][K] Vt[K] ;  Vt[J] = L_JJ^-1 acc.
@@ -512,8 +673,8 @@ int launch_update(sl2_engine* e) {
   }
   {
     LaunchScope ls(e, "k_build_A", true);
-    dim3 grid(e->ld / 64, B);
-    hipLaunchKernelGGL(k_build_A, grid, dim3(256), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
+    const int threads = e->ld <= 512 ? e->ld : 512;
+    hipLaunchKernelGGL(k_build_A, dim3(B), dim3(threads), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
                        e->At, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
   }
@@ -524,24 +685,30 @@ int launch_update(sl2_engine* e) {
                        e->St, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
   }
+  if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant == 1) {
+    LaunchScope ls(e, "k_chol_fused");
+    hipLaunchKernelGGL(k_chol_fused, dim3(B), dim3(128), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max);
+    SL2_HIP(hipGetLastError());
+  } else {
   for (int J = 0; J < e->nblk_max; ++J) {
-    {
-      LaunchScope ls(e, "k_chol_diag");
-      hipLaunchKernelGGL(k_chol_diag, dim3(B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, J);
-      SL2_HIP(hipGetLastError());
-    }
-    const int rem = e->nblk_max - 1 - J;
-    if (rem > 0) {
       {
-        LaunchScope ls(e, "k_chol_panel");
-        hipLaunchKernelGGL(k_chol_panel, dim3(rem, B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld,
-                           e->nblk_max, J);
+        LaunchScope ls(e, "k_chol_diag");
+        hipLaunchKernelGGL(k_chol_diag, dim3(B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, J);
         SL2_HIP(hipGetLastError());
       }
-      {
-        LaunchScope ls(e, "k_chol_trail");
-        hipLaunchKernelGGL(k_chol_trail, dim3(rem * (rem + 1) / 2, B), dim3(64), 0, e->stream, e->St, e->m_count, e->mld, J);
-        SL2_HIP(hipGetLastError());
+      const int rem = e->nblk_max - 1 - J;
+      if (rem > 0) {
+        {
+          LaunchScope ls(e, "k_chol_panel");
+          hipLaunchKernelGGL(k_chol_panel, dim3(rem, B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld,
+                             e->nblk_max, J);
+          SL2_HIP(hipGetLastError());
+        }
+        {
+          LaunchScope ls(e, "k_chol_trail");
+          hipLaunchKernelGGL(k_chol_trail, dim3(rem * (rem + 1) / 2, B), dim3(64), 0, e->stream, e->St, e->m_count, e->mld, J);
+          SL2_HIP(hipGetLastError());
+        }
       }
     }
   }

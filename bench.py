@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per core, max 32; 0: skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--feature-sigma", type=float, default=0.005,
+                    help="prior std-dev (m) of every map feature; > 0 makes the covariance dense (0: AddNewKnownFeature zeros)")
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
     return ap.parse_args()
 
@@ -88,6 +90,8 @@ def main():
         eng.set_groups(args.groups)
     eng.set_vehicle_state(np.stack([s.xv0 for s in specs]), np.stack([s.Pxx0 for s in specs]))
     eng.add_known_features(np.stack([s.feat_y for s in specs]), np.stack([s.xp_org() for s in specs]), templates)
+    if args.feature_sigma > 0.0:
+        eng.set_feature_covariances(np.tile(np.eye(3) * args.feature_sigma ** 2, (B, N, 1, 1)))
     eng.synchronize()
     setup_s = time.time() - t_setup
 
@@ -202,6 +206,8 @@ def main():
                 xo = specs[b].xp_org()
                 for i in range(N):
                     s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
+                    if args.feature_sigma > 0.0:
+                        s.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
                 slams.append(s)
                 frames_list.append(np.ascontiguousarray(allf[1:, b]))
             nthreads = min(ncores, sample)
@@ -224,10 +230,10 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch %d independent %dx%d synthetic sequences per GPU, %d features each, all features selected"
-                                   % (B, W, H, N),
+            "config": {"workload": "BASELINE configs[2]: batch %d independent %dx%d synthetic sequences per GPU, %d features each, all features selected, map prior sigma %.3g m (dense covariance)"
+                                   % (B, W, H, N, args.feature_sigma),
                        "sequences_per_gpu": B, "features": N, "width": W, "height": H,
-                       "state_dim": 13 + 3 * N, "parallelism": "independent sequences sharded across %d GPU(s), no data-path collective" % world},
+                       "state_dim": 13 + 3 * N, "feature_prior_sigma_m": args.feature_sigma, "parallelism": "independent sequences sharded across %d GPU(s), no data-path collective" % world},
             "roofline": roof, "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity,
             "kernels": per_kernel,
             "work_per_step": {k: v for k, v in work.items()},

@@ -115,6 +115,11 @@ int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double*
 int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const double* y, const double* xp_org,
                            const uint8_t* patches);
 
+/* Feature::Pyy_ of the first `nfeat` features of each sequence (feature.h:84): Pyy [nseq][nfeat][3][3].
+ * AddNewKnownFeature leaves it zero (feature.cpp:134-135); a map whose features carry a prior
+ * uncertainty (what feature initialisation produces, feature.cpp:241-244) is loaded with this. */
+int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, const double* Pyy);
+
 /* ------------------------------------------------------------------- stepping */
 
 /* MonoSLAM::GoOneStep(frame, save_trajectory, enable_mapping) (monoslam.cpp:108-180)

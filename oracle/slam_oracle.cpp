@@ -166,6 +166,11 @@ int orc_make_measurements(void* h, const uint8_t* frame) { return ((MonoSLAM*)h)
 void orc_kalman_filter_update(void* h) { ((MonoSLAM*)h)->KalmanFilterUpdate(); }
 void orc_normalise_state(void* h) { ((MonoSLAM*)h)->normalise_state(); }
 void orc_delete_bad_features(void* h) { ((MonoSLAM*)h)->delete_bad_features(); }
+// Feature::Pyy_ (feature.h:84), row-major 3x3: a known feature with a prior uncertainty
+void orc_set_feature_Pyy(void* h, int idx, const double* Pyy9) {
+  Feature* f = ((MonoSLAM*)h)->feature_list[idx];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) f->Pyy(i, j) = Pyy9[i * 3 + j];
+}
 void orc_set_feature_counters(void* h, int idx, int attempted, int successful) {
   Feature* f = ((MonoSLAM*)h)->feature_list[idx];
   f->attempted = attempted; f->successful = successful;

@@ -62,7 +62,7 @@ class sl2_feature_info(C.Structure):
 # every symbol include/scenelib2_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
     "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
-    "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features",
+    "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
     "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
@@ -112,6 +112,7 @@ def load():
     L.sl2_set_vehicle_state.argtypes = [vp, C.c_int, C.c_int, c_dp, c_dp]
     L.sl2_get_vehicle_state.argtypes = [vp, C.c_int, C.c_int, c_dp, c_dp]
     L.sl2_add_known_features.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_u8p]
+    L.sl2_set_feature_covariances.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_dp]
     L.sl2_go_one_step.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     L.sl2_set_groups.argtypes = [vp, C.c_int]
     L.sl2_set_search_variant.argtypes = [vp, C.c_int]

@@ -787,6 +787,31 @@ __global__ void __launch_bounds__(256) k_ubench_fma64(double* out, int iters) {
   for (int i = 0; i < 16; ++i) s += acc[i];
   if (s == 12345.678) out[0] = s;
 }
+// half of the waves run the MFMA loop, the other half the VALU FMA loop: do the two pipes overlap?
+__global__ void __launch_bounds__(256) k_ubench_mix(double* out, int iters) {
+  const int wave = threadIdx.x >> 6;
+  double s = 0;
+  if (wave & 1) {
+    double acc[16];
+    for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
+    const double a = 1.0000001, b = 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
+    }
+    for (int i = 0; i < 16; ++i) s += acc[i];
+  } else {
+    v4d acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0, 0, 0, 0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = mfma_f64(a, b, acc[i]);
+    }
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  }
+  if (s == 12345.678) out[0] = s;
+}
 }  // namespace sl2
 
 // which: 0 = FP64 MFMA TFLOP/s with 4 independent accumulators per wave, 2 blocks of 4 waves per CU
@@ -802,7 +827,22 @@ extern "C" int sl2_debug_microbench(int device, int which, double* result) {
   SL2_HIP(hipEventCreate(&e0));
   SL2_HIP(hipEventCreate(&e1));
   float ms = 0.f;
-  if (which == 0 || which == 1 || which == 3 || which == 4) {
+  if (which == 5) {
+    // mixed: per block 2 MFMA waves (4 acc x iters MFMAs) + 2 VALU waves (16 x iters FMAs per lane)
+    double* d = nullptr;
+    SL2_HIP(hipMalloc(&d, 64));
+    const int iters = 100000, blocks = 1024;
+    for (int rep = 0; rep < 2; ++rep) {
+      SL2_HIP(hipEventRecord(e0, 0));
+      hipLaunchKernelGGL(k_ubench_mix, dim3(blocks), dim3(256), 0, 0, d, iters);
+      SL2_HIP(hipEventRecord(e1, 0));
+      SL2_HIP(hipEventSynchronize(e1));
+    }
+    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
+    const double mf = (double)blocks * 2.0 * iters * 4.0 * 2048.0, vf = (double)blocks * 128.0 * iters * 16.0 * 2.0;
+    *result = (mf + vf) / (ms * 1e-3) / 1e12;
+    hipFree(d);
+  } else if (which == 0 || which == 1 || which == 3 || which == 4) {
     double* d = nullptr;
     SL2_HIP(hipMalloc(&d, 64));
     const int iters = 200000;

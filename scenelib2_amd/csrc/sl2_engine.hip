@@ -61,6 +61,14 @@ __global__ void k_add_features(double* __restrict__ x, double* __restrict__ xp_o
   if (threadIdx.x == 0) n_slots[b] = base + nfeat;
 }
 
+__global__ void k_set_feature_cov(double* __restrict__ P, const double* __restrict__ Pyy, int seq0, int nfeat, int ld) {
+  const int s = blockIdx.x, b = seq0 + s;
+  for (int e = threadIdx.x; e < nfeat * 9; e += blockDim.x) {
+    const int f = e / 9, r = (e % 9) / 3, c = e % 3;
+    P[(size_t)b * ld * ld + (size_t)(13 + 3 * f + r) * ld + 13 + 3 * f + c] = Pyy[((size_t)s * nfeat + f) * 9 + r * 3 + c];
+  }
+}
+
 __global__ void k_set_vehicle(double* __restrict__ x, double* __restrict__ P, const double* __restrict__ xv,
                               const double* __restrict__ Pxx, int seq0, int ld) {
   const int s = blockIdx.x, b = seq0 + s;
@@ -385,6 +393,21 @@ int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double*
   SL2_HIP(hipMemcpyAsync(Pxx, dP, sizeof(double) * 169 * nseq, hipMemcpyDeviceToHost, e->stream));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   hipFree(dxv); hipFree(dP);
+  return SL2_OK;
+}
+
+int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, const double* Pyy) {
+  if (!range_ok(e, seq0, nseq) || nfeat <= 0 || nfeat > e->N || !Pyy) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  double* d = nullptr;
+  const size_t cnt = (size_t)nseq * nfeat * 9;
+  SL2_HIP(hipMalloc(&d, sizeof(double) * cnt));
+  SL2_HIP(hipMemcpyAsync(d, Pyy, sizeof(double) * cnt, hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_set_feature_cov, dim3(nseq), dim3(256), 0, e->stream, e->P, d, seq0, nfeat, e->ld);
+  SL2_HIP(hipGetLastError());
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  hipFree(d);
   return SL2_OK;
 }
 

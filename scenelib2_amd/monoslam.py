@@ -69,6 +69,12 @@ class Engine:
         p = np.ascontiguousarray(patches, dtype=np.uint8).reshape(nseq, nfeat, 121)
         _lib.check(self.L.sl2_add_known_features(self.h, seq0, nseq, nfeat, _lib.dp(y), _lib.dp(xp), _lib.u8p(p)))
 
+    def set_feature_covariances(self, Pyy, seq0=0):
+        """Pyy [nseq][nfeat][3][3]: prior covariance of the first nfeat features of each sequence."""
+        P = np.ascontiguousarray(Pyy, dtype=np.float64)
+        nseq, nfeat = P.shape[0], P.shape[1]
+        _lib.check(self.L.sl2_set_feature_covariances(self.h, seq0, nseq, nfeat, _lib.dp(P.reshape(nseq, nfeat, 9))))
+
     # ---- stepping ----------------------------------------------------------
     def _frames_arg(self, frames, seq_stride, on_device):
         if on_device:

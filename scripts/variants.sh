@@ -1,5 +1,5 @@
 cd /root/repo
-for g in 1 2 4 8; do
-  echo "groups $g noprofile"; python bench.py --groups $g --no-profile --cpu-sample 0 --steps 20 --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+for sg in 0.005 0; do
+  echo "feature sigma $sg"; python bench.py --feature-sigma $sg --cpu-sample 8 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity'], d['cpu_baseline']['value']); print({k:round(v['ms_per_step'],3) for k,v in d['kernels'].items()}); print(d['work_per_step'])"
 done
-echo "groups 1 profile"; python bench.py --groups 1 --cpu-sample 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"

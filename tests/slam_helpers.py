@@ -18,7 +18,7 @@ class Pair:
     """B synthetic sequences: frames, oracle instances and one engine."""
 
     def __init__(self, n_features, n_frames, batch=1, cam=None, n_select=None, seq0=0, max_features=None,
-                 feature_counts=None, make_engine=True, **spec_kw):
+                 feature_counts=None, make_engine=True, feature_sigma=0.0, **spec_kw):
         self.cam = cam or synth.default_camera()
         self.N = n_features
         self.B = batch
@@ -44,6 +44,9 @@ class Pair:
             xo = self.specs[b].poses[0]
             for i in range(self.specs[b].feat_y.shape[0]):
                 s.add_known_feature(self.specs[b].feat_y[i], xo, self.templates[b][i])
+            if feature_sigma > 0.0:
+                for i in range(self.specs[b].feat_y.shape[0]):
+                    s.set_feature_Pyy(i, np.eye(3) * feature_sigma ** 2)
             self.oracles.append(s)
         self.engine = None
         if make_engine:
@@ -54,6 +57,8 @@ class Pair:
                 if nf:
                     self.engine.add_known_features(self.specs[b].feat_y[None], np.tile(self.specs[b].poses[0], (1, nf, 1)),
                                                    self.templates[b][None], seq0=b)
+                    if feature_sigma > 0.0:
+                        self.engine.set_feature_covariances(np.tile(np.eye(3) * feature_sigma ** 2, (1, nf, 1, 1)), seq0=b)
 
     def frame_batch(self, k):
         return np.stack([f[k] for f in self.frames])

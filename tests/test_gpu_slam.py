@@ -86,6 +86,19 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch):
     assert not pr.engine.status_flags().any()
 
 
+def test_uncertain_map_dense_covariance():
+    """Features with a prior uncertainty (Pyy != 0): the whole covariance becomes dense and the feature
+    positions themselves are updated — the general case of KalmanFilterUpdate (kalman.cpp:72-119)."""
+    pr = Pair(40, 10, batch=2, feature_sigma=0.01)
+    y0 = pr.engine.total_state(0)[13:].copy()
+    for k in range(10):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+    P = pr.engine.total_covariance(0)
+    assert np.count_nonzero(np.abs(P) > 1e-12) > 0.9 * P.size          # dense
+    assert np.abs(pr.engine.total_state(0)[13:] - y0).max() > 1e-6      # the map moved
+
+
 @pytest.mark.parametrize("groups", [1, 3])
 def test_ragged_batch_and_empty_map(groups):
     """Sequences of one batch with different map sizes (incl. zero features) and n_select < N,

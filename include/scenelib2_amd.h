@@ -142,7 +142,8 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  * (latency-bound kernels of one group overlap throughput-bound kernels of another).  Default 1
  * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024); env SL2_GROUPS overrides. */
 int sl2_set_groups(sl2_engine* e, int groups);
-/* Which search kernel sl2_make_measurements / sl2_go_one_step use (default 1). */
+/* Which search kernel sl2_make_measurements / sl2_go_one_step use: 2 = packed column walk (default),
+ * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);

@@ -45,6 +45,8 @@ constexpr int kPatchStride = 288;    // bytes per stored template: 121 raw bytes
                                      // 128 the packed form: 33 dwords (11 rows x 12 bytes, byte 11 = 0),
                                      // sum g0, sum g0^2, flag (patch sigma >= 10), pad
 constexpr int kPatchPackedOffset = 128;
+constexpr int kPackMaxNu = 51, kPackMaxNv = 54;   // largest search window the LDS column-walk kernels take
+constexpr int kPackMaxRows = 160;                 // LDS window rows per packed wavefront
 
 // XCD-aware block -> (sequence, tile) mapping.  MI355X dispatches workgroup L to XCD L % 8 and
 // every XCD has its own 4 MB L2; all tiles of one sequence share that sequence's operands
@@ -106,7 +108,7 @@ struct sl2_engine {
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
   long long steps_done = 0;
   int chol_variant = 1;       // 1 = fused two-wave Cholesky when it applies, 0 = launch-per-block kernels
-  int search_variant = 1;     // 0 = baseline kernel, 1 = LDS column-walk kernel (default)
+  int search_variant = 2;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]
@@ -128,6 +130,9 @@ struct sl2_engine {
   int* srch_i = nullptr;      // [B][N][8]  per-feature search window: ucentre, vcentre, urelstart, nu, vrelstart, nv, hw, hh
   double* srch_d = nullptr;   // [B][N][4]  PuInv (a, b, c), pad
   int* srch_res = nullptr;    // [B][N][8]  per selected position: code, u, v, S1, S2, X, ncand, pad
+  int* pack_first = nullptr;  // [B][N]  work list of the packed search: first selected position of pack p
+  int* pack_count = nullptr;  // [B][N]  ... and number of features in it
+  int* n_packs = nullptr;     // [B]
 
   // ---- EKF update workspaces (device) ----
   double* At = nullptr;    // [B][mld][ld]   (P H^T)^T, k-major; column ld-1 carries nu

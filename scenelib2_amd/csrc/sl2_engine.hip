@@ -149,6 +149,7 @@ static int build_groups(sl2_engine* e, int G) {
     g->sel_idx = e->sel_idx + f * N; g->n_sel = e->n_sel + f; g->n_vis = e->n_vis + f; g->meas_ok = e->meas_ok + f * N;
     g->meas_score = e->meas_score + f * N; g->succ_idx = e->succ_idx + f * N; g->m_count = e->m_count + f;
     g->srch_i = e->srch_i + f * N * 8; g->srch_d = e->srch_d + f * N * 4; g->srch_res = e->srch_res + f * N * 8;
+    g->pack_first = e->pack_first + f * N; g->pack_count = e->pack_count + f * N; g->n_packs = e->n_packs + f;
     g->work = e->work + f * 4; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
     e->groups.push_back(g);
@@ -308,6 +309,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->srch_i, B * N * 8));
   A(dmalloc(&e->srch_d, B * N * 4));
   A(dmalloc(&e->srch_res, B * N * 8));
+  A(dmalloc(&e->pack_first, B * N));
+  A(dmalloc(&e->pack_count, B * N));
+  A(dmalloc(&e->n_packs, B));
   A(dmalloc(&e->At, B * mld * ld));
   A(dmalloc(&e->Vt, B * mld * ld));
   A(dmalloc(&e->St, B * mld * mld));
@@ -346,7 +350,7 @@ void sl2_destroy(sl2_engine* e) {
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
-                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res};
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->pack_first, e->pack_count, e->n_packs};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -455,7 +459,7 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
 }
 
 int sl2_set_search_variant(sl2_engine* e, int variant) {
-  if (!e || variant < 0 || variant > 1) return SL2_ERR_INVALID;
+  if (!e || variant < 0 || variant > 2) return SL2_ERR_INVALID;
   e->search_variant = variant;
   return SL2_OK;
 }

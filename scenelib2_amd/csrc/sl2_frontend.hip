@@ -125,10 +125,14 @@ __global__ void __launch_bounds__(64) k_feature_prediction(const double* __restr
 __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_score, int* __restrict__ f_flags,
                                                 const int* __restrict__ n_slots, const double* __restrict__ xp_org,
                                                 int* __restrict__ sel_idx, int* __restrict__ n_sel, int* __restrict__ n_vis,
-                                                double* __restrict__ last_r, int N, int n_want) {
+                                                double* __restrict__ last_r, const int* __restrict__ srch_i,
+                                                int* __restrict__ pack_first, int* __restrict__ pack_count,
+                                                int* __restrict__ n_packs, int N, int n_want) {
   extern __shared__ double s_dyn[];
   double* s_score = s_dyn;                 // [N]
   int* s_vis = (int*)(s_dyn + N);          // [N]
+  int* s_nu = s_vis + N;                   // [N] search-window width of the k-th selected feature
+  int* s_nv = s_nu + N;                    // [N] ... and height
   __shared__ int s_nvis, s_zero_rank, s_last;
   const int b = blockIdx.x, tid = threadIdx.x;
   const int ns = n_slots[b];
@@ -161,7 +165,36 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     if (rank < limit) {
       sel_idx[(size_t)b * N + rank] = i;
       f_flags[(size_t)b * N + i] |= FF_SELECTED;
+      s_nu[rank] = srch_i[((size_t)b * N + i) * 8 + 3];
+      s_nv[rank] = srch_i[((size_t)b * N + i) * 8 + 5];
     }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    // Work list of the packed search kernel: consecutive selected features share one wavefront as
+    // long as their candidate columns fit 64 lanes (<= 8 features, <= 160 window rows of LDS).
+    // A window too large for the LDS tile gets a wavefront of its own (exact baseline path).
+    int np = 0, k = 0;
+    while (k < limit) {
+      const bool big = s_nu[k] > kPackMaxNu || s_nv[k] > kPackMaxNv;
+      int lanes = 0, rows = 0, cnt = 0;
+      if (big) {
+        cnt = 1;
+      } else {
+        while (k + cnt < limit && cnt < 8) {
+          const int w = s_nu[k + cnt] > 0 ? s_nu[k + cnt] : 1, hh = (s_nv[k + cnt] > 0 ? s_nv[k + cnt] : 0) + 10;
+          if (s_nu[k + cnt] > kPackMaxNu || s_nv[k + cnt] > kPackMaxNv) break;
+          if (lanes + w > 64 || rows + hh > kPackMaxRows) break;
+          lanes += w; rows += hh; ++cnt;
+        }
+        if (cnt == 0) cnt = 1;
+      }
+      pack_first[(size_t)b * N + np] = k;
+      pack_count[(size_t)b * N + np] = cnt;
+      ++np;
+      k += cnt;
+    }
+    n_packs[b] = np;
   }
   if (tid == 0) {
     n_sel[b] = limit;
@@ -317,9 +350,9 @@ int launch_feature_prediction(sl2_engine* e) {
 int launch_select(sl2_engine* e, int n) {
   LaunchScope ls(e, "k_select");
   if (n > e->nsel_max) n = e->nsel_max;
-  const size_t shm = (size_t)e->N * (sizeof(double) + sizeof(int));
+  const size_t shm = (size_t)e->N * (sizeof(double) + 3 * sizeof(int));
   hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
-                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->N, n);
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->pack_first, e->pack_count, e->n_packs, e->N, n);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

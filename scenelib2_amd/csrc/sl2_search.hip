@@ -132,23 +132,34 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
   if (nu <= 0 || nv <= 0) return res;
   if (nu > kMaxNu || nv > kMaxNv) { res.code = -1; return res; }
 
-  // ---- stage the window (issue the global loads first: longest latency) ----
+  // ---- stage the window: coalesced dword-aligned row loads, 8 row passes in flight at a time ----
   const int x0 = sb.ucentre + sb.urelstart - 5, y0 = sb.vcentre + sb.vrelstart - 5;
   const int Hw = nv + 10;
   const size_t base_addr = (size_t)image + (size_t)y0 * width + x0;
   {
     const int k = lane & 15, rsub = lane >> 4;   // 16 dwords per row, 4 rows per pass
-    for (int r0 = 0; r0 < Hw; r0 += 4) {
-      const int r = r0 + rsub;
-      if (r < Hw) {
-        const size_t addr = base_addr + (size_t)r * width;
-        const size_t al = addr & ~(size_t)3;
-        const int o = (int)(addr & 3);
-        const int need = (o + nu + 10 + 3) >> 2;     // <= 16
+    for (int r0 = 0; r0 < Hw; r0 += 32) {
+      unsigned val[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u + rsub;
         unsigned v = 0;
-        if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
-        s_win[r * kWinPitchDw + k] = v;
-        if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
+        if (r < Hw) {
+          const size_t addr = base_addr + (size_t)r * width;
+          const size_t al = addr & ~(size_t)3;
+          const int o = (int)(addr & 3);
+          const int need = (o + nu + 10 + 3) >> 2;     // <= 16
+          if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
+        }
+        val[u] = v;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 4 * u + rsub;
+        if (r < Hw) {
+          s_win[r * kWinPitchDw + k] = val[u];
+          if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
+        }
       }
     }
   }
@@ -345,6 +356,293 @@ __global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frame
   }
 }
 
+// ---------------------------------------------------------------------------
+// Variant 2 ("packed column walk", production): same arithmetic as variant 1, but one
+// wavefront serves SEVERAL features at once.  With 3-sigma ellipses of ~15 columns a single
+// feature keeps a quarter of the lanes busy and pays the 10-row warm-up of the sliding
+// window for 4-5 candidate rows; here every lane owns one candidate column of one feature
+// and walks ALL of its rows, so the warm-up is amortised over ~15 candidate rows and the
+// lanes are full (k_select builds the packs: consecutive selected features whose columns
+// fit 64 lanes).  The template is then per lane (33 VGPRs) instead of wave-uniform, and the
+// near-best decision is a segmented reduction over each feature's lanes.  Features the fast
+// path cannot decide exactly, or whose window exceeds the LDS tile, go through
+// search_core_v0 inside the same wavefront.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T seg_reduce_max(T val, int gid, int lane) {
+  for (int off = 1; off < 64; off <<= 1) {
+    const T v = __shfl_down(val, off, 64);
+    const int g2 = __shfl_down(gid, off, 64);
+    if (lane + off < 64 && g2 == gid && v > val) val = v;
+  }
+  return val;   // valid in the first lane of each segment
+}
+__device__ __forceinline__ int seg_reduce_sum(int val, int gid, int lane) {
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_down(val, off, 64);
+    const int g2 = __shfl_down(gid, off, 64);
+    if (lane + off < 64 && g2 == gid) val += v;
+  }
+  return val;
+}
+
+__global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
+                                                      const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
+                                                      const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
+                                                      const int* __restrict__ pack_first, const int* __restrict__ pack_count,
+                                                      const int* __restrict__ n_packs, int* __restrict__ srch_res,
+                                                      double* __restrict__ meas_score, int N, int nsel_max, int B) {
+  int b, p;
+  if (!xcd_map(nsel_max, B, &b, &p)) return;
+  if (p >= n_packs[b]) return;
+  __shared__ unsigned s_win[kPackMaxRows * kWinPitchDw];
+  const int lane = threadIdx.x;
+  const int first = pack_first[(size_t)b * N + p], cnt = pack_count[(size_t)b * N + p];
+  const uint8_t* img = frames + (size_t)b * seq_stride;
+  // ---- descriptors: lane g < cnt holds feature g of the pack ----
+  int d_f = 0, d_uc = 0, d_vc = 0, d_us = 0, d_nu = 0, d_vs = 0, d_nv = 0, d_hw = 0, d_hh = 0;
+  double d_a = 0, d_b = 0, d_c = 0;
+  if (lane < cnt) {
+    d_f = sel_idx[(size_t)b * N + first + lane];
+    const int* si = srch_i + ((size_t)b * N + d_f) * 8;
+    d_uc = si[0]; d_vc = si[1]; d_us = si[2]; d_nu = si[3]; d_vs = si[4]; d_nv = si[5]; d_hw = si[6]; d_hh = si[7];
+    const double* sd = srch_d + ((size_t)b * N + d_f) * 4;
+    d_a = sd[0]; d_b = sd[1]; d_c = sd[2];
+  }
+  // a window too large for the LDS tile comes alone: exact baseline path
+  {
+    const int nu0 = __shfl(d_nu, 0, 64), nv0 = __shfl(d_nv, 0, 64);
+    if (cnt == 1 && (nu0 > kPackMaxNu || nv0 > kPackMaxNv)) {
+      SearchBounds sb;
+      sb.ucentre = __shfl(d_uc, 0, 64); sb.vcentre = __shfl(d_vc, 0, 64);
+      sb.urelstart = __shfl(d_us, 0, 64); sb.urelfinish = sb.urelstart + nu0 - 1;
+      sb.vrelstart = __shfl(d_vs, 0, 64); sb.vrelfinish = sb.vrelstart + nv0 - 1;
+      sb.halfwidth = __shfl(d_hw, 0, 64); sb.halfheight = __shfl(d_hh, 0, 64);
+      const int f0 = __shfl(d_f, 0, 64);
+      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + f0) * kPatchStride, sb, __shfl(d_a, 0, 64),
+                                            __shfl(d_b, 0, 64), __shfl(d_c, 0, 64));
+      if (lane == 0) {
+        int* o = srch_res + ((size_t)b * N + first) * 8;
+        o[0] = 0; o[1] = r.u; o[2] = r.v; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = r.ncand;
+        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
+        meas_score[(size_t)b * N + first] = r.score;
+      }
+      return;
+    }
+  }
+  // ---- lane -> (feature g, column ui); LDS row offset of each feature's window ----
+  int my_g = -1, lane_off = 0, row_off = 0;
+  {
+    int lacc = 0, racc = 0;
+    for (int g = 0; g < cnt; ++g) {
+      const int nu_g = __shfl(d_nu, g, 64), nv_g = __shfl(d_nv, g, 64);
+      const int w = nu_g > 0 ? nu_g : 1, hh = (nv_g > 0 ? nv_g : 0) + 10;
+      if (lane >= lacc && lane < lacc + w) { my_g = g; lane_off = lacc; row_off = racc; }
+      lacc += w; racc += hh;
+    }
+  }
+  const int gs = my_g < 0 ? 0 : my_g;
+  const int f_my = __shfl(d_f, gs, 64);
+  const int uc = __shfl(d_uc, gs, 64), vc = __shfl(d_vc, gs, 64), us = __shfl(d_us, gs, 64), vs0 = __shfl(d_vs, gs, 64);
+  const int nu = __shfl(d_nu, gs, 64), nv = __shfl(d_nv, gs, 64);
+  const double a = __shfl(d_a, gs, 64), bq = __shfl(d_b, gs, 64), c = __shfl(d_c, gs, 64);
+  const int ui = lane - lane_off;
+  const bool geom_ok = (my_g >= 0) && nu > 0 && nv > 0;
+  int nvmax = geom_ok ? nv : 0;
+  for (int off = 32; off > 0; off >>= 1) nvmax = max(nvmax, __shfl_xor(nvmax, off, 64));
+
+  // ---- stage every feature's window (coalesced row loads, dword aligned).  The loads of 8 row
+  // passes are issued before their LDS stores, so HBM latency is paid once per 32 rows and not
+  // once per 4 (a naive load->store loop serialised ~1 us per pass and dominated the wavefront).
+  {
+    __shared__ int s_meta[8][4];   // per feature: image offset of its window, nu, rows, first LDS row
+    int racc = 0;   // exclusive prefix of the window rows (all lanes take part in every shuffle)
+    for (int g = 0; g < 8; ++g) {
+      const int nv_g = __shfl(d_nv, g, 64);
+      if (g < lane && g < cnt) racc += (nv_g > 0 ? nv_g : 0) + 10;
+    }
+    if (lane < 8) {
+      const bool okg = lane < cnt && d_nu > 0 && d_nv > 0;
+      s_meta[lane][0] = okg ? (d_vc + d_vs - 5) * width + (d_uc + d_us - 5) : 0;
+      s_meta[lane][1] = okg ? d_nu : 0;
+      s_meta[lane][2] = (lane < cnt) ? (d_nv > 0 ? d_nv : 0) + 10 : 0x3fffffff;
+      s_meta[lane][3] = racc;
+    }
+    __syncthreads();
+    int total_rows = 0;
+    for (int g = 0; g < cnt; ++g) { const int nv_g = __shfl(d_nv, g, 64); total_rows += (nv_g > 0 ? nv_g : 0) + 10; }
+    const int k = lane & 15, rsub = lane >> 4;
+    int R = rsub, g = 0;
+    int m_off = s_meta[0][0], m_nu = s_meta[0][1], m_rows = s_meta[0][2], m_first = s_meta[0][3];
+    for (int R0 = 0; R0 < total_rows; R0 += 32) {
+      unsigned val[8];
+      int dst[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        while (g < 7 && R >= m_first + m_rows) {
+          ++g;
+          m_off = s_meta[g][0]; m_nu = s_meta[g][1]; m_rows = s_meta[g][2]; m_first = s_meta[g][3];
+        }
+        unsigned v = 0;
+        dst[u] = -1;
+        if (R < total_rows && R >= m_first && R < m_first + m_rows) {
+          dst[u] = R * kWinPitchDw + k;
+          if (m_nu > 0) {
+            const size_t addr = (size_t)img + (size_t)m_off + (size_t)(R - m_first) * width;
+            const size_t al = addr & ~(size_t)3;
+            const int o = (int)(addr & 3);
+            const int need = (o + m_nu + 10 + 3) >> 2;     // <= 16
+            if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
+          }
+        }
+        val[u] = v;
+        R += 4;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dst[u] >= 0) {
+          s_win[dst[u]] = val[u];
+          if (k == 0) s_win[dst[u] + 16] = 0u;
+        }
+    }
+  }
+  // ---- per-lane template (lanes of one feature read the same addresses) ----
+  const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + f_my) * kPatchStride + kPatchPackedOffset);
+  unsigned T[33];
+#pragma unroll
+  for (int i = 0; i < 33; ++i) T[i] = tpl[i];
+  const int Sg0 = (int)tpl[33], Sg0sq = (int)tpl[34];
+  const bool patch_ok = tpl[35] != 0;
+  // ---- ellipse membership of my column ----
+  unsigned long long mymask = 0ull;
+  for (int vi = 0; vi < nvmax; ++vi)
+    if (geom_ok && vi < nv && in_ellipse(a, bq, c, us + ui, vs0 + vi)) mymask |= 1ull << vi;
+  const int D0 = 121 * Sg0sq - Sg0 * Sg0;
+  const size_t base_my = (size_t)img + (size_t)(vc + vs0 - 5) * width + (uc + us - 5);
+  const int o_first = (int)(base_my & 3), wmod = width & 3;
+  const bool walk = geom_ok && patch_ok;
+  const int tmax = nvmax + 10;
+  __syncthreads();
+
+  unsigned ring[11][3];
+  int rs1[11], rs2[11];
+#pragma unroll
+  for (int i = 0; i < 11; ++i) { rs1[i] = 0; rs2[i] = 0; ring[i][0] = ring[i][1] = ring[i][2] = 0; }
+  int S1 = 0, S2 = 0;
+  float best_q = -3.0e38f, second_q = -3.0e38f;
+  int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
+  int need_exact = 0;
+  const float d0f = (float)D0;
+  for (int tb = 0; tb < tmax; tb += 11) {
+#pragma unroll
+    for (int s = 0; s < 11; ++s) {
+      const int t = tb + s;
+      if (t < tmax) {
+        const bool row_ok = walk && (t < nv + 10);
+        unsigned r0 = 0, r1 = 0, r2 = 0;
+        if (row_ok) {
+          const int bo = ((o_first + t * wmod) & 3) + ui;
+          const int k0 = bo >> 2, sh = bo & 3;
+          const unsigned* rowp = s_win + (row_off + t) * kWinPitchDw + k0;
+          const unsigned q0 = rowp[0], q1 = rowp[1], q2 = rowp[2], q3 = rowp[3];
+          r0 = __builtin_amdgcn_alignbyte(q1, q0, sh);
+          r1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
+          r2 = __builtin_amdgcn_alignbyte(q3, q2, sh) & 0x00ffffffu;
+        }
+        const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
+        const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
+        S1 += n1 - rs1[s];
+        S2 += n2 - rs2[s];
+        rs1[s] = n1; rs2[s] = n2;
+        ring[s][0] = r0; ring[s][1] = r1; ring[s][2] = r2;
+        if (t >= 10) {
+          const int vi = t - 10;
+          const bool cand = row_ok && ((mymask >> vi) & 1ull);
+          if (cand) {
+            unsigned X0 = 0, X1 = 0, X2 = 0;
+#pragma unroll
+            for (int j = 0; j < 11; ++j) {
+              const int slot = (s + 1 + j) % 11;
+              X0 = udot4(ring[slot][0], T[3 * j + 0], X0);
+              X1 = udot4(ring[slot][1], T[3 * j + 1], X1);
+              X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
+            }
+            const unsigned X = X0 + X1 + X2;
+            const int D1 = 121 * S2 - S1 * S1;
+            if (D1 == 1464100) need_exact = 1;
+            if (D1 > 1464100) {
+              const int Nc = 121 * (int)X - Sg0 * S1;
+              const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
+              if (q > best_q) {
+                second_q = best_q;
+                best_q = q; best_idx = ui * nv + vi; best_S1 = S1; best_S2 = S2; best_X = (int)X;
+              } else if (q > second_q) {
+                second_q = q;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  // ---- per-feature decision (segmented over the feature's lanes) ----
+  const int gid = my_g;
+  float gmax = seg_reduce_max(best_q, gid, lane);
+  gmax = __shfl(gmax, lane_off, 64);
+  const float thr = gmax - 4.0e-6f;
+  const bool lane_near = (my_g >= 0) && (best_idx >= 0) && (best_q >= thr);
+  const bool lane_amb = (my_g >= 0) && (best_idx >= 0) && (second_q >= thr);
+  const unsigned long long near_b = __ballot(lane_near), bad_b = __ballot(lane_amb || (need_exact != 0));
+  const int w = nu > 0 ? nu : 1;
+  const unsigned long long gm = ((w >= 64) ? ~0ull : ((1ull << w) - 1ull)) << lane_off;
+  const int n_near = __popcll(near_b & gm);
+  const bool fb = ((bad_b & gm) != 0ull) || n_near > 1;
+  int ncand = seg_reduce_sum(__popcll(mymask), gid, lane);
+  int code = 0, ru = 0, rv = 0, rS1 = 0, rS2 = 0, rX = 0, found = 0;
+  {
+    const int wl = (n_near == 1) ? (__ffsll((long long)(near_b & gm)) - 1) : lane;
+    const int w_idx = __shfl(best_idx, wl, 64);
+    const int w_S1 = __shfl(best_S1, wl, 64), w_S2 = __shfl(best_S2, wl, 64), w_X = __shfl(best_X, wl, 64);
+    if (fb) code = -1;
+    else if (n_near == 1) {
+      code = 1; found = 1;
+      ru = uc + us + w_idx / nv; rv = vc + vs0 + w_idx % nv;
+      rS1 = w_S1; rS2 = w_S2; rX = w_X;
+    }
+  }
+  const bool leader = (my_g >= 0) && (ui == 0);
+  if (leader && code >= 0) {
+    int* o = srch_res + ((size_t)b * N + first + my_g) * 8;
+    o[0] = code; o[1] = ru; o[2] = rv; o[3] = rS1; o[4] = rS2; o[5] = rX; o[6] = ncand; o[7] = found;
+    meas_score[(size_t)b * N + first + my_g] = 1000000.0;
+  }
+  // ---- exact fallback for the features that need it (rare) ----
+  const unsigned long long fb_leaders = __ballot(leader && code < 0);
+  if (fb_leaders != 0ull) {
+    for (int g = 0; g < cnt; ++g) {
+      // leader lane of feature g
+      int lacc = 0;
+      for (int q = 0; q < g; ++q) { const int nq = __shfl(d_nu, q, 64); lacc += nq > 0 ? nq : 1; }
+      if (!((fb_leaders >> lacc) & 1ull)) continue;
+      SearchBounds sb;
+      const int nu_g = __shfl(d_nu, g, 64), nv_g = __shfl(d_nv, g, 64);
+      sb.ucentre = __shfl(d_uc, g, 64); sb.vcentre = __shfl(d_vc, g, 64);
+      sb.urelstart = __shfl(d_us, g, 64); sb.urelfinish = sb.urelstart + nu_g - 1;
+      sb.vrelstart = __shfl(d_vs, g, 64); sb.vrelfinish = sb.vrelstart + nv_g - 1;
+      sb.halfwidth = __shfl(d_hw, g, 64); sb.halfheight = __shfl(d_hh, g, 64);
+      const int fg = __shfl(d_f, g, 64);
+      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + fg) * kPatchStride, sb, __shfl(d_a, g, 64),
+                                            __shfl(d_b, g, 64), __shfl(d_c, g, 64));
+      if (lane == 0) {
+        int* o = srch_res + ((size_t)b * N + first + g) * 8;
+        o[0] = 0; o[1] = r.u; o[2] = r.v; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = r.ncand;
+        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
+        meas_score[(size_t)b * N + first + g] = r.score;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(64) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
                                                      const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
                                                      const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
@@ -424,7 +722,11 @@ int launch_search(sl2_engine* e) {
   {
     LaunchScope ls(e, "k_search", true);
     dim3 grid(xcd_grid(e->nsel_max, e->B));
-    if (e->root->search_variant == 0)
+    if (e->root->search_variant == 2)
+      hipLaunchKernelGGL(k_search_packed, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
+                         e->srch_i, e->srch_d, e->sel_idx, e->pack_first, e->pack_count, e->n_packs, e->srch_res,
+                         e->meas_score, e->N, e->nsel_max, e->B);
+    else if (e->root->search_variant == 0)
       hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
                          e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
     else

@@ -64,9 +64,11 @@ def test_seams_one_frame():
         assert rel_fro(e.total_covariance(b), Po) < TOL_P
 
 
-@pytest.mark.parametrize("n_features,n_frames,batch", [(20, 40, 3), (100, 12, 2)])
-def test_sequences_track_the_oracle(n_features, n_frames, batch):
+@pytest.mark.parametrize("n_features,n_frames,batch,variant", [(20, 40, 3, 2), (20, 40, 3, 1), (20, 12, 2, 0), (100, 12, 2, 2)])
+def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
+    """variant: search kernel (2 packed column walk = default, 1 one feature per wave, 0 baseline)."""
     pr = Pair(n_features, n_frames, batch=batch)
+    pr.engine.set_search_variant(variant)
     traj_o = np.zeros((batch, n_frames, 3))
     traj_e = np.zeros((batch, n_frames, 3))
     for k in range(n_frames):

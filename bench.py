@@ -188,6 +188,19 @@ def main():
                 roof = dict(kernel=dom, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
                             traffic=None, avg_launch_ms=dur * 1e3)
 
+        # HBM traffic from the committed PMC pass of this same command (profiles/pmc_traffic.json; rocprofv3
+        # cannot be nested inside this process), corrected as MI355X_MICROARCH.md prescribes
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            for rf in (roof, roof_search):
+                if rf and rf.get("kernel"):
+                    key = "k_search_packed" if rf["kernel"] == "k_search" else rf["kernel"]
+                    if key in pmc and B == 1024 and N == 100:
+                        rf["traffic"] = pmc[key]["hbm_bytes"]
+                        rf["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+        except Exception:
+            pass
+
         # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
         cpu = None
         parity = None

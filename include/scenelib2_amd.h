@@ -145,6 +145,13 @@ int sl2_set_groups(sl2_engine* e, int groups);
 /* Which search kernel sl2_make_measurements / sl2_go_one_step use: 2 = packed column walk (default),
  * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
+/* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
+ * chol_variant 1 = fused one-launch Cholesky, four waves per sequence (default, <= 12 blocks of 32),
+ *              2 = the two-wave version of it, 0 = three launches per block column;
+ * fwd_variant  3 = forward substitution with L streamed through LDS and the solved rows in registers
+ *              (default, <= 8 blocks, else falls back to 0), 0 = operands re-read from memory,
+ *              1 / 2 = solved rows in registers only, 16 / 32 state columns per wavefront. */
+int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);
 int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device);

@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscenelib2_amd.so")
+LIB_PATH = os.environ.get("SL2_LIB_PATH") or os.path.join(_HERE, "libscenelib2_amd.so")   # override: development builds only
 
 SL2_OK = 0
 SL2_ERR_INVALID = 1
@@ -63,7 +63,7 @@ class sl2_feature_info(C.Structure):
 EXPORTED_SYMBOLS = [
     "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
-    "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
+    "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
     "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
@@ -116,6 +116,7 @@ def load():
     L.sl2_go_one_step.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_int]
     L.sl2_set_groups.argtypes = [vp, C.c_int]
     L.sl2_set_search_variant.argtypes = [vp, C.c_int]
+    L.sl2_set_update_variant.argtypes = [vp, C.c_int, C.c_int]
     L.sl2_kalman_filter_predict.argtypes = [vp]
     L.sl2_auto_select_n_features.argtypes = [vp, C.c_int]
     L.sl2_make_measurements.argtypes = [vp, vp, C.c_size_t, C.c_int]

@@ -468,6 +468,218 @@ __global__ void __launch_bounds__(128, 2) k_chol_fused(double* __restrict__ St, 
 }
 
 // ---------------------------------------------------------------------------
+// k_chol_fused4: the same one-launch factorisation with a FOUR-wave workgroup
+// (wave 0 = D, waves 1..3 = M0..M2) so that the MFMA tiles of one sequence are spread
+// over three SIMDs instead of one, and with a diagonal-block routine that issues half
+// the instructions:
+//   * D interleaves the factor step c with step c of the inversion (row c of L^-1 is
+//     final as soon as column c of L is): every broadcast scalar is used exactly once,
+//     so nothing is kept in SGPRs across the block (the two-pass version re-used the
+//     496 broadcast values in its inversion pass and the compiler spilled them).
+//   * between A_J (L_JJ^-1 ready) and B_J (next diagonal tile ready) M0 solves panel
+//     tile (J+1,J) and, from those registers, updates tile (J+1,J+1); M1/M2 solve the
+//     other panel tiles of column J meanwhile, so B_J is also "column J complete";
+//   * after B_J the trailing tiles are dealt round-robin to the three M waves while D
+//     factors block J+1.
+// ---------------------------------------------------------------------------
+constexpr int kLinvPitch = 33;   // LDS row pitch of the inverted diagonal block (conflict-free row-per-lane writes)
+
+struct Tile32 {
+  v4d f[2][2];   // f[kt][it][r] = element (k = 16 kt + 4 r + hi, i = 16 it + lo) of a k-major 32x32 tile
+};
+
+__device__ __forceinline__ Tile32 tile_load(const double* __restrict__ Sb, int mld, int k0, int i0, int lo, int hi) {
+  Tile32 t;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t.f[kt][it][r] = Sb[(size_t)(k0 + 16 * kt + hi + 4 * r) * mld + i0 + 16 * it + lo];
+  return t;
+}
+__device__ __forceinline__ void tile_store(double* __restrict__ Sb, int mld, int k0, int i0, int lo, int hi, const Tile32& t) {
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sb[(size_t)(k0 + 16 * kt + hi + 4 * r) * mld + i0 + 16 * it + lo] = t.f[kt][it][r];
+}
+// panel tile: out[k][i] = sum_p Linv[k][p] S[o+p][i0+i]
+__device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* __restrict__ Sb, int mld, int o, int i0, int lo,
+                                             int hi) {
+  double b0[8], b1[8];
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    b0[s8] = Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + lo];
+    b1[s8] = Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + 16 + lo];
+  }
+  Tile32 t;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) t.f[kt][it] = (v4d){0, 0, 0, 0};
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const int p = 4 * s8 + hi;
+    const double a0 = sLinv[p * kLinvPitch + lo], a1 = sLinv[p * kLinvPitch + 16 + lo];
+    t.f[0][0] = mfma_f64(a0, b0[s8], t.f[0][0]);
+    t.f[0][1] = mfma_f64(a0, b1[s8], t.f[0][1]);
+    t.f[1][0] = mfma_f64(a1, b0[s8], t.f[1][0]);
+    t.f[1][1] = mfma_f64(a1, b1[s8], t.f[1][1]);
+  }
+  return t;
+}
+// trailing tile (K, I): acc[kk][ii] -= sum_p L[K*32+kk][o+p] L[I*32+ii][o+p], operands from memory
+__device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int o, int K, int I, int lo, int hi) {
+  Tile32 acc = tile_load(Sb, mld, K * 32, I * 32, lo, hi);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    double a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const size_t row = (size_t)(o + 16 * h + 4 * s4 + hi) * mld;
+      a0[s4] = Sb[row + K * 32 + lo];
+      a1[s4] = Sb[row + K * 32 + 16 + lo];
+      b0[s4] = Sb[row + I * 32 + lo];
+      b1[s4] = Sb[row + I * 32 + 16 + lo];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      acc.f[0][0] = mfma_f64(-a0[s4], b0[s4], acc.f[0][0]);
+      acc.f[0][1] = mfma_f64(-a0[s4], b1[s4], acc.f[0][1]);
+      acc.f[1][0] = mfma_f64(-a1[s4], b0[s4], acc.f[1][0]);
+      acc.f[1][1] = mfma_f64(-a1[s4], b1[s4], acc.f[1][1]);
+    }
+  }
+  tile_store(Sb, mld, K * 32, I * 32, lo, hi, acc);
+}
+
+__global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St, double* __restrict__ LinvT,
+                                                        const int* __restrict__ m_count, int mld, int nblk_max, long long* trace) {
+  const int b = blockIdx.x;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int nblk = (2 * cnt + 31) / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool isD = wave == 0;
+  const int mw = wave - 1;              // 0..2 for the M waves
+  __shared__ double sTile[32][33];     // next diagonal tile, sTile[r][c] = S[r][c]   (M0 -> D)
+  __shared__ double sLinv[32 * kLinvPitch];   // LinvT of the current block, [p][k]   (D -> M)
+  double* Sb = St + (size_t)b * mld * mld;
+#ifdef SL2_CHOL_TRACE
+#define TR(slot) do { if (trace && lane == 0) trace[(((size_t)b * 4 + wave) * 8 + J) * 4 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+  if (trace && lane == 0) trace[(size_t)gridDim.x * 4 * 8 * 4 + b * 4 + wave] = __builtin_amdgcn_s_getreg(63492);
+#else
+#define TR(slot) do { } while (0)
+#endif
+  for (int J = 0; J < nblk; ++J) {
+    const int o = J * 32;
+    // Re-derive the lane coordinates inside the loop from an opaque copy: otherwise every
+    // lane-only expression (32 compare masks, 32 unit-vector constants, all tile addresses) is
+    // hoisted out of the J loop and spilled to scratch.
+    int lane_j = lane;
+    asm volatile("" : "+v"(lane_j));
+    const int lo = lane_j & 15, hi = lane_j >> 4;
+    TR(0);
+    if (isD) {
+      // Lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the identity:
+      // column-Cholesky applies the same column operations to both, [A; I] -> [L; L^-T], so the
+      // inverse costs no instructions of its own.
+      const int r = lane_j & 31;
+      const bool low = lane_j < 32;
+      double a[32];
+      if (J == 0) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          const double v = Sb[(size_t)c * mld + r];
+          a[c] = low ? v : ((r == c) ? 1.0 : 0.0);
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          const double v = sTile[r][c];
+          a[c] = low ? v : ((r == c) ? 1.0 : 0.0);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        const double piv = readlane_f64(a[c], c);
+        const double dinv = fast_rsqrt(piv);
+        const double l = (!low || r >= c) ? a[c] * dinv : 0.0;   // lane c: piv * rsqrt(piv) = sqrt(piv)
+        a[c] = l;
+#pragma unroll
+        for (int cc = c + 1; cc < 32; ++cc) a[cc] -= l * readlane_f64(l, cc);
+      }
+      // lane 32+i, register c: (L^-T)[i][c] = Linv[c][i] -> sLinv[p = i][k = c]
+      if (!low) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) sLinv[r * kLinvPitch + c] = a[c];
+      }
+    }
+    TR(1);
+    __syncthreads();                    // A_J : L_JJ^-1 available to the M waves
+    TR(2);
+    if (J + 1 >= nblk) {
+      if (mw == 2) {
+        double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
+      }
+      break;
+    }
+    if (!isD) {
+      if (mw == 0) {
+        // panel tile (J+1, J), then diagonal tile (J+1, J+1) straight from those registers
+        const Tile32 pt = tile_panel(sLinv, Sb, mld, o, (J + 1) * 32, lo, hi);
+        Tile32 dg = tile_load(Sb, mld, (J + 1) * 32, (J + 1) * 32, lo, hi);
+        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, pt);
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          const double f0 = pt.f[s8 >> 2][0][s8 & 3], f1 = pt.f[s8 >> 2][1][s8 & 3];
+          dg.f[0][0] = mfma_f64(-f0, f0, dg.f[0][0]);
+          dg.f[0][1] = mfma_f64(-f0, f1, dg.f[0][1]);
+          dg.f[1][0] = mfma_f64(-f1, f0, dg.f[1][0]);
+          dg.f[1][1] = mfma_f64(-f1, f1, dg.f[1][1]);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = dg.f[jt][it][r4];
+        // share of the remaining panel tiles: M0 takes every third one, after its critical work
+        for (int I = J + 2 + 2; I < nblk; I += 3) {
+          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
+        }
+      } else {
+        if (mw == 2) {   // LinvT block to memory for the forward substitution, coalesced
+          double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
+        }
+        for (int I = J + 2 + (mw - 1); I < nblk; I += 3) {
+          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
+        }
+      }
+    }
+    TR(3);
+    __syncthreads();                    // B_J : tile (J+1, J+1) is in LDS and column J of L is complete
+    if (!isD) {
+      int idx = 0;
+      for (int K = J + 1; K < nblk; ++K)
+        for (int I = (K == J + 1) ? K + 1 : K; I < nblk; ++I, ++idx)
+          if (idx % 3 == mw) tile_trail(Sb, mld, o, K, I, lo, hi);
+    }
+  }
+}
+
+#undef TR
+
+// ---------------------------------------------------------------------------
 // k_fwdsub: Vt = L^-1 At by blocked forward substitution.  Columns are
 // independent: each wave owns 16 columns and walks the block rows J in order,
 //   acc = At[J] - sum_{K<J} L[J][K] Vt[K] ;  Vt[J] = L_JJ^-1 acc.
@@ -555,6 +767,234 @@ __global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, d
         for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo] = out[jt][it][r];
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_fwdsub_reg<NB, CW>: the same substitution with the solved block rows of V^T kept in
+// REGISTERS (the MFMA D fragment of block K is, unchanged, the B fragment of every later
+// product with it), for maps small enough that NB = mld/32 block rows of a 16*CW-column
+// strip fit the register file (NB*CW*16 VGPRs).  k_fwdsub re-reads every solved block
+// from memory for each later block row: at batch 1024 the PMC counters show 2.9 GB of
+// HBM traffic per launch for 1.1 GB of At + Vt, i.e. the kernel is bound by its own
+// re-reads.  Here HBM sees At once, Vt once and L (shared by the strips of a sequence
+// through L2).
+// ---------------------------------------------------------------------------
+template <int NB, int CW>
+__global__ void __launch_bounds__(256) k_fwdsub_reg(const double* __restrict__ At, double* __restrict__ Vt,
+                                                    const double* __restrict__ St, const double* __restrict__ LinvT,
+                                                    const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
+  constexpr int kStrip = 16 * CW;            // columns per wave
+  constexpr int kWaves = 64 / kStrip;        // waves per 64-column tile
+  int b, ct;
+  if (!xcd_map(ld / 64, B, &b, &ct)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave >= kWaves) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int m = 2 * cnt;
+  const int nblk = (m + 31) / 32;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int i0 = ct * 64 + wave * kStrip;
+  const double* Ab = At + (size_t)b * mld * ld;
+  double* Vb = Vt + (size_t)b * mld * ld;
+  const double* Sb = St + (size_t)b * mld * mld;
+  v4d V[NB][2][CW];
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    if (J < nblk) {
+      const bool half = (J * 32 + 16 >= m);
+      v4d acc[2][CW];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < CW; ++it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[jt][it][r] = (jt == 1 && half) ? 0.0 : Ab[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo];
+      const double* lrow = Sb + (size_t)hi * mld + J * 32 + lo;     // L[J*32 + lo (+16)][k], k = hi + 4 s
+#pragma unroll
+      for (int K = 0; K < J; ++K) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const double a0 = -lrow[(size_t)(K * 32 + 4 * s) * mld];
+          const double a1 = half ? 0.0 : -lrow[(size_t)(K * 32 + 4 * s) * mld + 16];
+#pragma unroll
+          for (int it = 0; it < CW; ++it) {
+            const double bv = V[K][s >> 2][it][s & 3];
+            acc[0][it] = mfma_f64(a0, bv, acc[0][it]);
+            acc[1][it] = mfma_f64(a1, bv, acc[1][it]);
+          }
+        }
+      }
+      const double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
+      v4d out[2][CW];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < CW; ++it) out[jt][it] = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int p = 4 * s + hi;
+        const double a0 = Lb[p * 32 + lo];
+        const double a1 = half ? 0.0 : Lb[p * 32 + 16 + lo];
+#pragma unroll
+        for (int it = 0; it < CW; ++it) {
+          const double bv = acc[s >> 2][it][s & 3];
+          out[0][it] = mfma_f64(a0, bv, out[0][it]);
+          out[1][it] = mfma_f64(a1, bv, out[1][it]);
+        }
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < CW; ++it) {
+          V[J][jt][it] = out[jt][it];
+          if (!(jt == 1 && half)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo] = out[jt][it][r];
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_fwdsub_lds<NB>: forward substitution with BOTH operands on chip.  A workgroup of four
+// waves owns a 64-column tile of the state (16 columns per wave):
+//   * the solved block rows of V^T stay in registers (D fragment == B fragment), as in
+//     k_fwdsub_reg;
+//   * the 32x32 tiles of L (and the inverted diagonal blocks) are streamed once per
+//     workgroup through LDS, double-buffered: the global loads of tile t+1 fly under the
+//     MFMAs of tile t, one barrier per tile (the scheme of k_syrk).
+// Per k-step a wave issues two ds_read_b64 and two MFMAs and nothing else: no global load
+// sits on the accumulator chain, which is what bounded k_fwdsub (every k-step there waits
+// on three L2-resident operands).
+// ---------------------------------------------------------------------------
+constexpr int kFwdPitch = 48;   // LDS row pitch (doubles): the two k-rows read by a 32-lane group land on disjoint banks
+
+template <int NB>
+__global__ void __launch_bounds__(256, 3) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
+                                                    const double* __restrict__ St, const double* __restrict__ LinvT,
+                                                    const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
+  int b, ct;
+  if (!xcd_map(ld / 64, B, &b, &ct)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int m = 2 * cnt;
+  const int nblk = (m + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int i0 = ct * 64 + wave * 16;
+  const double* Ab = At + (size_t)b * mld * ld;
+  double* Vb = Vt + (size_t)b * mld * ld;
+  const double* Sb = St + (size_t)b * mld * mld;
+  const double* Lb = LinvT + (size_t)b * nblk_max * 1024;
+  __shared__ double sL[2][32 * kFwdPitch];
+  // staging role: row `srow` of the tile (contraction index), 4 consecutive doubles at column `sc4`
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  const int soff = srow * kFwdPitch + sc4;
+  // tile (J, K): K < J -> L[J][K] from St (k-major), K == J -> LinvT block J
+#define SL2_TILE_PTR(Jv, Kv) \
+  (((Kv) < (Jv)) ? (Sb + (size_t)((Kv) * 32 + srow) * mld + (Jv) * 32 + sc4) : (Lb + (size_t)(Jv) * 1024 + srow * 32 + sc4))
+  double4 pre = *(const double4*)SL2_TILE_PTR(0, 0);
+  v4d V[NB][2];
+  v4d at[2];
+  const bool half0 = (16 >= m);
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) at[jt][r] = (jt == 1 && half0) ? 0.0 : Ab[(size_t)(16 * jt + hi + 4 * r) * ld + i0 + lo];
+  int t = 0;   // running tile counter (buffer parity)
+#pragma unroll
+  for (int J = 0; J < NB; ++J) {
+    if (J < nblk) {
+      const bool half = (J * 32 + 16 >= m);    // rows J*32+16.. are padding
+      v4d acc[2];
+      acc[0] = (v4d){0, 0, 0, 0};
+      acc[1] = (v4d){0, 0, 0, 0};
+      v4d rhs[2];
+#pragma unroll
+      for (int K = 0; K <= J; ++K) {
+        double* buf = sL[t & 1];
+        *(double4*)&buf[soff] = pre;
+        __syncthreads();
+        // next tile of the stream (uniform control flow: nblk is per sequence = per workgroup)
+        if (K < J) pre = *(const double4*)SL2_TILE_PTR(J, K + 1);
+        else if (J + 1 < nblk && J + 1 < NB) pre = *(const double4*)SL2_TILE_PTR(J + 1, 0);
+        const double* pa = buf + hi * kFwdPitch + lo;
+        if (K < J) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const double bv = V[K][s >> 2][s & 3];
+            acc[0] = mfma_f64(pa[4 * s * kFwdPitch], bv, acc[0]);
+            if (!half) acc[1] = mfma_f64(pa[4 * s * kFwdPitch + 16], bv, acc[1]);
+          }
+        } else {
+          // rhs = At[J] - sum_K L[J][K] V[K];  V[J] = Linv_JJ rhs  (Linv lower triangular: rows 0..15 need p < 16 only)
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) rhs[jt] = at[jt] - acc[jt];
+          if (J + 1 < nblk && J + 1 < NB) {   // prefetch the next block row of At under the diagonal product
+            const bool halfn = ((J + 1) * 32 + 16 >= m);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                at[jt][r] = (jt == 1 && halfn) ? 0.0 : Ab[(size_t)((J + 1) * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo];
+          }
+          v4d out[2];
+          out[0] = (v4d){0, 0, 0, 0};
+          out[1] = (v4d){0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const double bv = rhs[s >> 2][s & 3];
+            if (s < 4) out[0] = mfma_f64(pa[4 * s * kFwdPitch], bv, out[0]);
+            if (!half) out[1] = mfma_f64(pa[4 * s * kFwdPitch + 16], bv, out[1]);
+          }
+          V[J][0] = out[0];
+          V[J][1] = out[1];
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            if (jt == 1 && half) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo] = out[jt][r];
+          }
+        }
+        ++t;
+      }
+    }
+  }
+#undef SL2_TILE_PTR
+}
+
+static bool launch_fwdsub_lds(sl2_engine* e, int B) {
+  const dim3 grid(xcd_grid(e->ld / 64, B)), block(256);
+#define SL2_FWD_CASE(NBV)                                                                                           \
+  case NBV:                                                                                                         \
+    hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
+                       e->ld, e->mld, e->nblk_max, B);                                                              \
+    return true;
+  switch (e->nblk_max) {
+    SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
+    SL2_FWD_CASE(8)
+    default: return false;
+  }
+#undef SL2_FWD_CASE
+}
+
+template <int CW>
+static bool launch_fwdsub_reg(sl2_engine* e, int B) {
+  const dim3 grid(xcd_grid(e->ld / 64, B)), block(64 * (64 / (16 * CW)));
+#define SL2_FWD_CASE(NBV)                                                                                              \
+  case NBV:                                                                                                            \
+    hipLaunchKernelGGL((k_fwdsub_reg<NBV, CW>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
+                       e->ld, e->mld, e->nblk_max, B);                                                                 \
+    return true;
+  switch (e->nblk_max) {
+    SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
+    SL2_FWD_CASE(8)
+    default: return false;
+  }
+#undef SL2_FWD_CASE
 }
 
 // ---------------------------------------------------------------------------
@@ -685,9 +1125,13 @@ int launch_update(sl2_engine* e) {
                        e->St, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
   }
-  if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant == 1) {
+  if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
     LaunchScope ls(e, "k_chol_fused");
-    hipLaunchKernelGGL(k_chol_fused, dim3(B), dim3(128), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max);
+    if (e->root->chol_variant == 1)
+      hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
+                         (long long*)e->root->chol_trace);
+    else
+      hipLaunchKernelGGL(k_chol_fused, dim3(B), dim3(128), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max);
     SL2_HIP(hipGetLastError());
   } else {
   for (int J = 0; J < e->nblk_max; ++J) {
@@ -714,8 +1158,13 @@ int launch_update(sl2_engine* e) {
   }
   {
     LaunchScope ls(e, "k_fwdsub", true);
-    hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
-                       e->m_count, e->ld, e->mld, e->nblk_max, B);
+    bool done = false;
+    if (e->root->fwd_variant == 1) done = launch_fwdsub_reg<1>(e, B);
+    else if (e->root->fwd_variant == 2) done = launch_fwdsub_reg<2>(e, B);
+    else if (e->root->fwd_variant == 3) done = launch_fwdsub_lds(e, B);
+    if (!done)
+      hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                         e->m_count, e->ld, e->mld, e->nblk_max, B);
     SL2_HIP(hipGetLastError());
   }
   {

@@ -319,6 +319,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
 #undef A
   SL2_HIP(hipDeviceSynchronize());
   e->root = e;
+  if (const char* v = getenv("SL2_FWD_VARIANT")) e->fwd_variant = atoi(v);
+  if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
+  if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);
   {
     int G = 1;
     const char* env = getenv("SL2_GROUPS");
@@ -461,6 +464,28 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
 int sl2_set_search_variant(sl2_engine* e, int variant) {
   if (!e || variant < 0 || variant > 2) return SL2_ERR_INVALID;
   e->search_variant = variant;
+  return SL2_OK;
+}
+
+#ifdef SL2_CHOL_TRACE
+// development only: cycle stamps [B][4 waves][8 J][4 slots] + HW_ID [B][4]
+int sl2_debug_chol_trace(sl2_engine* e, long long* out, size_t n) {
+  const size_t total = (size_t)e->B * 4 * 8 * 4 + (size_t)e->B * 4;
+  if (!e->chol_trace) {
+    SL2_HIP(hipMalloc(&e->chol_trace, total * 8));
+    SL2_HIP(hipMemset(e->chol_trace, 0, total * 8));
+    return SL2_OK;
+  }
+  SL2_HIP(hipDeviceSynchronize());
+  SL2_HIP(hipMemcpy(out, e->chol_trace, (n < total ? n : total) * 8, hipMemcpyDeviceToHost));
+  return SL2_OK;
+}
+#endif
+
+int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
+  if (!e || chol_variant < 0 || chol_variant > 2 || fwd_variant < 0 || fwd_variant > 3) return SL2_ERR_INVALID;
+  e->chol_variant = chol_variant;
+  e->fwd_variant = fwd_variant;
   return SL2_OK;
 }
 

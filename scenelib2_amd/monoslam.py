@@ -94,6 +94,9 @@ class Engine:
     def set_search_variant(self, variant):
         _lib.check(self.L.sl2_set_search_variant(self.h, int(variant)))
 
+    def set_update_variant(self, chol_variant=1, fwd_variant=1):
+        _lib.check(self.L.sl2_set_update_variant(self.h, int(chol_variant), int(fwd_variant)))
+
     def kalman_filter_predict(self):
         _lib.check(self.L.sl2_kalman_filter_predict(self.h))
 

@@ -1,5 +1,8 @@
 cd /root/repo
-for sg in 0.005 0; do
-  echo "feature sigma $sg"; python bench.py --feature-sigma $sg --cpu-sample 8 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity'], d['cpu_baseline']['value']); print({k:round(v['ms_per_step'],3) for k,v in d['kernels'].items()}); print(d['work_per_step'])"
+# A/B of kernel variants through the env overrides read by sl2_create (development aid).
+# usage: VAR=SL2_CHOL_VARIANT VALUES="1 2" bash scripts/variants.sh
+VAR=${VAR:-SL2_FWD_VARIANT}
+for v in ${VALUES:-0 1 2}; do
+  echo "$VAR=$v"; env $VAR=$v python bench.py --cpu-sample ${CPU_SAMPLE:-4} 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity']); print({k:round(v['ms_per_step'],3) for k,v in d['kernels'].items()})"
 done

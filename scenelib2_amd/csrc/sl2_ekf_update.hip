@@ -1035,18 +1035,20 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   const double* gA = Vb + (size_t)kr * ld + ti * 64 + c4;
   const double* gB = Vb + (size_t)kr * ld + tj * 64 + c4;
   double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  // In a diagonal tile the sub-block (wi = 32, wj = 0) is the mirror of (0, 32): that wave only stages.
+  const bool idle = (ti == tj) && (wi > wj);
+  const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
   v4d acc[2][2];
   for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
   const int nchunk = mp / kSyrkKC;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
-    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
-    __syncthreads();
-    if (ch + 1 < nchunk) {   // prefetch the next chunk; the loads fly under the MFMAs below
-      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * ld);
-      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * ld);
-    }
+  // register prefetch runs TWO chunks ahead of the MFMAs (one chunk of work does not cover an
+  // HBM round trip under load); chunks alternate between the register pairs (ra, rb) / (ra2, rb2).
+  double4 ra2 = ra, rb2 = rb;
+  if (nchunk > 1) {
+    ra2 = *(const double4*)(gA + (size_t)kSyrkKC * ld);
+    rb2 = *(const double4*)(gB + (size_t)kSyrkKC * ld);
+  }
+  auto chunk_mfma = [&](int buf) {
     const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
     const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
 #pragma unroll
@@ -1058,10 +1060,50 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
       acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
     }
-    // the buffer written next iteration (buf^1) was last read two iterations ago: one barrier per chunk suffices
+  };
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    // even chunk: registers (ra, rb) -> buffer 0
+    *(double4*)&sA[0][kr * kSyrkPitch + c4] = ra;
+    *(double4*)&sB[0][kr * kSyrkPitch + c4] = rb;
+    __syncthreads();
+    if (ch + 2 < nchunk) {
+      ra = *(const double4*)(gA + (size_t)(ch + 2) * kSyrkKC * ld);
+      rb = *(const double4*)(gB + (size_t)(ch + 2) * kSyrkKC * ld);
+    }
+    if (!idle) chunk_mfma(0);
+    if (ch + 1 >= nchunk) break;
+    // odd chunk: registers (ra2, rb2) -> buffer 1
+    *(double4*)&sA[1][kr * kSyrkPitch + c4] = ra2;
+    *(double4*)&sB[1][kr * kSyrkPitch + c4] = rb2;
+    __syncthreads();
+    if (ch + 3 < nchunk) {
+      ra2 = *(const double4*)(gA + (size_t)(ch + 3) * kSyrkKC * ld);
+      rb2 = *(const double4*)(gB + (size_t)(ch + 3) * kSyrkKC * ld);
+    }
+    if (!idle) chunk_mfma(1);
+    // a buffer is rewritten two chunks after it was read, with a barrier in between: one barrier per chunk suffices
+  }
+  if (idle) return;
+  const bool mirror = (ti != tj) || (wi != wj);
+  // Row / column ld-1 (the innovation column riding along) only exists in the last tile row / column:
+  // every other 32x32 block takes the branch-free path.
+  if (i0 + 32 < ld && j0 + 32 < ld) {
+    double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;       // element (i0 + hi, j0 + lo)
+    double* pcol = Pb + (size_t)(j0 + lo) * ld + i0 + hi;       // its mirror
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double* q = prow + (size_t)(16 * it + 4 * r) * ld + 16 * jt;
+          const double pn = *q - acc[it][jt][r];
+          *q = pn;
+          if (mirror) pcol[(size_t)(16 * jt) * ld + 16 * it + 4 * r] = pn;
+        }
+    return;
   }
   double* xb = x + (size_t)b * ld;
-  const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
 #pragma unroll
   for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -1075,7 +1117,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
         } else if (row != ld - 1) {
           const double pn = Pb[(size_t)row * ld + col] - v;
           Pb[(size_t)row * ld + col] = pn;
-          if (ti != tj) Pb[(size_t)col * ld + row] = pn;
+          if (mirror) Pb[(size_t)col * ld + row] = pn;
         }
       }
 }

@@ -109,6 +109,7 @@ struct sl2_engine {
   long long steps_done = 0;
   int chol_variant = 1;       // 1 = fused two-wave Cholesky when it applies, 0 = launch-per-block kernels
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
+  int build_variant = 1;      // 1 = A and S in one pass (state <= 512 columns), 0 = k_build_A then k_build_S
   int fwd_variant = 3;        // forward substitution: 3 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory, 1/2 = register-resident only (16/32 columns per wave)
   int search_variant = 2;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk (default)
 

@@ -97,6 +97,102 @@ __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, c
 }
 
 // ---------------------------------------------------------------------------
+// k_build_AS: k_build_A and k_build_S in one pass (state sizes up to 512 columns): the rows of
+// At are produced four features (eight rows) at a time, parked in LDS, and S = H A + R for those
+// eight columns of S is formed from LDS before they are overwritten -- At is not read back from
+// memory at all (k_build_S re-reads all of it: 0.8 GB per launch at batch 1024, 100 features).
+// Thread i plays two roles: column i of At, and row a = i of H (its 10 non-zeros in registers).
+// The summation order of every entry is that of the two separate kernels.
+// ---------------------------------------------------------------------------
+constexpr int kASBatch = 4;   // features per LDS batch
+
+__global__ void __launch_bounds__(512) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
+                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
+                                                  const double* __restrict__ f_R, const int* __restrict__ succ_idx,
+                                                  const int* __restrict__ m_count, double* __restrict__ At,
+                                                  double* __restrict__ St, int N, int ld, int mld) {
+  extern __shared__ double sAt[];   // [2 * kASBatch][ld]
+  const int b = blockIdx.x;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
+  const int i = threadIdx.x;        // blockDim.x == ld
+  double* Ab = At + (size_t)b * mld * ld;
+  double* Sb = St + (size_t)b * mld * mld;
+  const double* Pb = P + (size_t)b * ld * ld;
+  const int* sidx = succ_idx + (size_t)b * N;
+  // role "column i of At"
+  double pc[7];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
+  // role "row a = i of H"
+  double hx[7], hy[3], Rn = 0.0;
+  int posa = 0;
+  if (i < m) {
+    const int fa = sidx[i >> 1];
+    const size_t fia = (size_t)b * N + fa;
+    posa = 13 + 3 * fa;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fia * 14 + (i & 1) * 7 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fia * 6 + (i & 1) * 3 + c];
+    Rn = f_R[fia];
+  }
+  for (int j0 = 0; j0 < cnt; j0 += kASBatch) {
+    const int nb = (cnt - j0 < kASBatch) ? cnt - j0 : kASBatch;
+#pragma unroll
+    for (int jj = 0; jj < kASBatch; ++jj) {
+      if (jj < nb) {
+        const int f = sidx[j0 + jj];
+        const size_t fi = (size_t)b * N + f;
+        const int pos = 13 + 3 * f;
+        double py[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
+          if (i == ld - 1) acc = f_nu[fi * 2 + r];
+          Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
+          sAt[(2 * jj + r) * ld + i] = acc;
+        }
+      }
+    }
+    __syncthreads();
+    if (i < mp) {
+#pragma unroll
+      for (int kk = 0; kk < 2 * kASBatch; ++kk) {
+        const int k = 2 * j0 + kk;
+        if (kk < 2 * nb && (i | 31) >= k) {     // blocks on and below the block diagonal
+          double v = 0.0;
+          if (i < m) {
+            const double* arow = sAt + kk * ld;
+            double acc = 0.0;
+#pragma unroll
+            for (int c = 0; c < 7; ++c) acc += hx[c] * arow[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc += hy[c] * arow[posa + c];
+            if (i == k) acc += Rn;
+            v = acc;
+          }
+          Sb[(size_t)k * mld + i] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // padding: rows of At up to the 32-multiple are zero, S is the identity there
+  for (int k = m; k < mp; ++k) {
+    Ab[(size_t)k * ld + i] = 0.0;
+    if (i < mp && (i | 31) >= k) Sb[(size_t)k * mld + i] = (i == k) ? 1.0 : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // k_build_S: S = H A + R, stored St[c][r] = S[r][c] (32x32 blocks on and below the block
 // diagonal; the factorisation reads r >= c plus the full diagonal blocks).  Padding: identity.  A thread owns one row
 // a of H (its 10 non-zeros in registers) and loops over 32 columns bb: per column
@@ -1153,19 +1249,27 @@ int launch_update(sl2_engine* e) {
     hipLaunchKernelGGL(k_compact, dim3(B), dim3(64), 0, e->stream, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
-  {
+  if (e->ld <= 512 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
-    const int threads = e->ld <= 512 ? e->ld : 512;
-    hipLaunchKernelGGL(k_build_A, dim3(B), dim3(threads), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx, e->m_count,
-                       e->At, e->N, e->ld, e->mld);
+    const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
+    hipLaunchKernelGGL(k_build_AS, dim3(B), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R, e->succ_idx,
+                       e->m_count, e->At, e->St, e->N, e->ld, e->mld);
     SL2_HIP(hipGetLastError());
-  }
-  {
-    LaunchScope ls(e, "k_build_S");
-    dim3 grid(e->mld / 32, (e->mld + 255) / 256, B);
-    hipLaunchKernelGGL(k_build_S, grid, dim3(256), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
-                       e->St, e->N, e->ld, e->mld);
-    SL2_HIP(hipGetLastError());
+  } else {
+    {
+      LaunchScope ls(e, "k_build_A", true);
+      const int threads = e->ld <= 512 ? e->ld : 512;
+      hipLaunchKernelGGL(k_build_A, dim3(B), dim3(threads), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx,
+                         e->m_count, e->At, e->N, e->ld, e->mld);
+      SL2_HIP(hipGetLastError());
+    }
+    {
+      LaunchScope ls(e, "k_build_S");
+      dim3 grid(e->mld / 32, (e->mld + 255) / 256, B);
+      hipLaunchKernelGGL(k_build_S, grid, dim3(256), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
+                         e->St, e->N, e->ld, e->mld);
+      SL2_HIP(hipGetLastError());
+    }
   }
   if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
     LaunchScope ls(e, "k_chol_fused");

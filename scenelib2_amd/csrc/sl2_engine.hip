@@ -321,6 +321,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   e->root = e;
   if (const char* v = getenv("SL2_FWD_VARIANT")) e->fwd_variant = atoi(v);
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
+  if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);
   {
     int G = 1;

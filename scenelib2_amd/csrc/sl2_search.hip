@@ -116,6 +116,8 @@ constexpr int kWinRows = 64;
 constexpr int kMaxNu = 51, kMaxNv = 54;
 
 __device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// full-rate 24-bit multiply: the patch sums are < 2^24 (S1 <= 121*255, S2, X <= 121*255^2), products < 2^31
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
 // tpl: packed template (33 dwords + sum g0 + sum g0^2 + sigma flag) or nullptr -> built from patch bytes
 template <bool DEFER>
@@ -275,10 +277,10 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
               X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
             }
             const unsigned X = X0 + X1 + X2;
-            const int D1 = 121 * S2 - S1 * S1;           // n^2 var1, exact
+            const int D1 = mul24(121, S2) - mul24(S1, S1);   // n^2 var1, exact (all factors < 2^24)
             if (D1 == 1464100) need_exact = 1;            // sigma1 == 10 boundary: decided in FP64 only
             if (D1 > 1464100) {                           // sigma1 >= 10 for certain
-              const int Nc = 121 * (int)X - Sg0 * S1;     // n^2 cov, exact
+              const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);   // n^2 cov, exact
               const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);   // ~ rho
               const int idx = ui * nv + vi;
               if (q > best_q) {
@@ -386,6 +388,13 @@ __device__ __forceinline__ int seg_reduce_sum(int val, int gid, int lane) {
   return val;
 }
 
+#ifdef SL2_SEARCH_TRACE
+__device__ long long* g_search_trace = nullptr;     // development only: 8 cycle stamps per workgroup
+#define STR(slot) do { if (g_search_trace && threadIdx.x == 0) g_search_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STR(slot) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
                                                       const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
                                                       const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
@@ -397,6 +406,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
   if (p >= n_packs[b]) return;
   __shared__ unsigned s_win[kPackMaxRows * kWinPitchDw];
   const int lane = threadIdx.x;
+  STR(0);
   const int first = pack_first[(size_t)b * N + p], cnt = pack_count[(size_t)b * N + p];
   const uint8_t* img = frames + (size_t)b * seq_stride;
   // ---- descriptors: lane g < cnt holds feature g of the pack ----
@@ -451,6 +461,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
   int nvmax = geom_ok ? nv : 0;
   for (int off = 32; off > 0; off >>= 1) nvmax = max(nvmax, __shfl_xor(nvmax, off, 64));
 
+  STR(1);
   // ---- stage every feature's window (coalesced row loads, dword aligned).  The loads of 8 row
   // passes are issued before their LDS stores, so HBM latency is paid once per 32 rows and not
   // once per 4 (a naive load->store loop serialised ~1 us per pass and dominated the wavefront).
@@ -471,41 +482,45 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
     __syncthreads();
     int total_rows = 0;
     for (int g = 0; g < cnt; ++g) { const int nv_g = __shfl(d_nv, g, 64); total_rows += (nv_g > 0 ? nv_g : 0) + 10; }
+    // per LDS row: dword-aligned byte offset of its first staged dword in the frame, and how many dwords to fetch
+    __shared__ int2 s_row[kPackMaxRows];
+    const int img_lo = (int)((size_t)img & 3);
+    for (int R = lane; R < total_rows; R += 64) {
+      int g = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q)
+        if (q < cnt && R >= s_meta[q][3]) g = q;
+      const int m_nu = s_meta[g][1];
+      const int byteoff = s_meta[g][0] + (R - s_meta[g][3]) * width;
+      const int o = (img_lo + byteoff) & 3;
+      s_row[R] = make_int2(byteoff - o, m_nu > 0 ? (o + m_nu + 10 + 3) >> 2 : 0);   // need <= 16
+    }
+    __syncthreads();
     const int k = lane & 15, rsub = lane >> 4;
-    int R = rsub, g = 0;
-    int m_off = s_meta[0][0], m_nu = s_meta[0][1], m_rows = s_meta[0][2], m_first = s_meta[0][3];
+    const uint8_t* img_k = img + 4 * k;
     for (int R0 = 0; R0 < total_rows; R0 += 32) {
       unsigned val[8];
-      int dst[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        while (g < 7 && R >= m_first + m_rows) {
-          ++g;
-          m_off = s_meta[g][0]; m_nu = s_meta[g][1]; m_rows = s_meta[g][2]; m_first = s_meta[g][3];
-        }
+        const int R = R0 + rsub + 4 * u;
         unsigned v = 0;
-        dst[u] = -1;
-        if (R < total_rows && R >= m_first && R < m_first + m_rows) {
-          dst[u] = R * kWinPitchDw + k;
-          if (m_nu > 0) {
-            const size_t addr = (size_t)img + (size_t)m_off + (size_t)(R - m_first) * width;
-            const size_t al = addr & ~(size_t)3;
-            const int o = (int)(addr & 3);
-            const int need = (o + m_nu + 10 + 3) >> 2;     // <= 16
-            if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
-          }
+        if (R < total_rows) {
+          const int2 mr = s_row[R];
+          if (k < mr.y) v = *(const unsigned*)(img_k + mr.x);
         }
         val[u] = v;
-        R += 4;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (dst[u] >= 0) {
-          s_win[dst[u]] = val[u];
-          if (k == 0) s_win[dst[u] + 16] = 0u;
+      for (int u = 0; u < 8; ++u) {
+        const int R = R0 + rsub + 4 * u;
+        if (R < total_rows) {
+          s_win[R * kWinPitchDw + k] = val[u];
+          if (k == 0) s_win[R * kWinPitchDw + 16] = 0u;
         }
+      }
     }
   }
+  STR(2);
   // ---- per-lane template (lanes of one feature read the same addresses) ----
   const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + f_my) * kPatchStride + kPatchPackedOffset);
   unsigned T[33];
@@ -523,6 +538,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
   const bool walk = geom_ok && patch_ok;
   const int tmax = nvmax + 10;
   __syncthreads();
+  STR(3);
 
   unsigned ring[11][3];
   int rs1[11], rs2[11];
@@ -533,6 +549,8 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
   int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
   int need_exact = 0;
   const float d0f = (float)D0;
+  int o_cur = o_first;
+  const unsigned* rowb = s_win + row_off * kWinPitchDw;
   for (int tb = 0; tb < tmax; tb += 11) {
 #pragma unroll
     for (int s = 0; s < 11; ++s) {
@@ -541,14 +559,16 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
         const bool row_ok = walk && (t < nv + 10);
         unsigned r0 = 0, r1 = 0, r2 = 0;
         if (row_ok) {
-          const int bo = ((o_first + t * wmod) & 3) + ui;
+          const int bo = o_cur + ui;
           const int k0 = bo >> 2, sh = bo & 3;
-          const unsigned* rowp = s_win + (row_off + t) * kWinPitchDw + k0;
+          const unsigned* rowp = rowb + k0;
           const unsigned q0 = rowp[0], q1 = rowp[1], q2 = rowp[2], q3 = rowp[3];
           r0 = __builtin_amdgcn_alignbyte(q1, q0, sh);
           r1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
           r2 = __builtin_amdgcn_alignbyte(q3, q2, sh) & 0x00ffffffu;
         }
+        o_cur = (o_cur + wmod) & 3;       // byte phase of the next window row (strength-reduced t * width)
+        rowb += kWinPitchDw;
         const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
         const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
         S1 += n1 - rs1[s];
@@ -568,10 +588,10 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
               X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
             }
             const unsigned X = X0 + X1 + X2;
-            const int D1 = 121 * S2 - S1 * S1;
+            const int D1 = mul24(121, S2) - mul24(S1, S1);
             if (D1 == 1464100) need_exact = 1;
             if (D1 > 1464100) {
-              const int Nc = 121 * (int)X - Sg0 * S1;
+              const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);
               const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
               if (q > best_q) {
                 second_q = best_q;
@@ -585,6 +605,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
       }
     }
   }
+  STR(4);
   // ---- per-feature decision (segmented over the feature's lanes) ----
   const int gid = my_g;
   float gmax = seg_reduce_max(best_q, gid, lane);
@@ -616,6 +637,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
     o[0] = code; o[1] = ru; o[2] = rv; o[3] = rS1; o[4] = rS2; o[5] = rX; o[6] = ncand; o[7] = found;
     meas_score[(size_t)b * N + first + my_g] = 1000000.0;
   }
+  STR(5);
   // ---- exact fallback for the features that need it (rare) ----
   const unsigned long long fb_leaders = __ballot(leader && code < 0);
   if (fb_leaders != 0ull) {
@@ -641,6 +663,7 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
       }
     }
   }
+  STR(6);
 }
 
 __global__ void __launch_bounds__(64) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
@@ -716,6 +739,14 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
     if (r.found) { uv[i * 2] = r.u; uv[i * 2 + 1] = r.v; }  // untouched if nothing qualified (Q4)
   }
 }
+
+#ifdef SL2_SEARCH_TRACE
+}  // namespace sl2
+extern "C" int sl2_debug_search_trace(long long* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(sl2::g_search_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 2;
+}
+namespace sl2 {
+#endif
 
 int launch_search(sl2_engine* e) {
   SL2_HIP(hipMemsetAsync(e->work, 0, sizeof(double) * 4 * e->B, e->stream));

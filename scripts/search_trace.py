@@ -1,0 +1,42 @@
+"""Development aid: phase cycle stamps inside k_search_packed (SL2_SEARCH_TRACE build:
+   make -C scenelib2_amd/csrc trace ; SL2_LIB_PATH=scenelib2_amd/libscenelib2_amd_trace.so python scripts/search_trace.py)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from chol_trace import build_engine  # noqa: E402
+from scenelib2_amd import _lib  # noqa: E402
+
+
+def main():
+    B, N = 1024, 100
+    eng, step, keep = build_engine(B, N, 320, 240)
+    L = eng.L
+    for it in range(3):
+        step(it)
+    eng.synchronize()
+    nblk = 110000                      # >= xcd_grid(N, B)
+    buf = _lib.DeviceBuffer(nblk * 8 * 8, 0)
+    buf.upload(np.zeros(nblk * 8, dtype=np.int64))
+    L.sl2_debug_search_trace.argtypes = [C.c_void_p]
+    assert L.sl2_debug_search_trace(C.c_void_p(buf.ptr)) == 0
+    step(3)
+    eng.synchronize()
+    tr = buf.download((nblk, 8), np.int64)
+    act = tr[:, 6] != 0
+    t = tr[act].astype(np.float64)
+    print("active waves:", int(act.sum()))
+    d = np.diff(t[:, :7], axis=1)
+    tot = (t[:, 6] - t[:, 0]).mean()
+    for i, nme in enumerate(["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]):
+        print("%-24s mean %8.0f cycles  (%4.1f %%)" % (nme, d[:, i].mean(), 100 * d[:, i].mean() / tot))
+    print("total per wave mean %.0f cycles, p95 %.0f" % (tot, np.percentile(t[:, 6] - t[:, 0], 95)))
+    print("kernel span %.0f cycles" % (tr[act][:, 6].max() - tr[act][:, 0].min()))
+
+
+if __name__ == "__main__":
+    main()

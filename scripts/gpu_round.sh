@@ -36,7 +36,7 @@ pmc)
     i=$((i+1))
     ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
   done
-  python scripts/summarize_pmc.py $OUT > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
+  python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
 esac
 done
 ls -la $OUT | head -30

@@ -4,11 +4,14 @@ gfx950 FETCH_SIZE under-reports wide coalesced streaming reads by 2x
 (MI355X_MICROARCH.md section HBM) - the corrected figure is printed next to the raw one."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+traffic_json = sys.argv[2] if len(sys.argv) > 2 else None     # optional: write profiles/pmc_traffic.json
+traffic = defaultdict(dict)
 for cdir in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     if not os.path.isdir(cdir):
         continue
@@ -17,7 +20,8 @@ for cdir in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for f in files:
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                name = row.get("Kernel_Name", "?").split("(")[0].replace("sl2::", "")
+                name = row.get("Kernel_Name", "?").split("(")[0].replace("sl2::", "").replace("void ", "")
+                name = name.split("<")[0].strip()
                 acc[name][row.get("Counter_Name", "?")].append(float(row.get("Counter_Value", 0)))
     print("==", os.path.basename(cdir), "files:", len(files))
     for name, cs in sorted(acc.items()):
@@ -26,8 +30,21 @@ for cdir in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             mean = sum(vals) / len(vals)
             if c == "FETCH_SIZE":
                 parts.append("%s=%.0f KiB (x2 corrected %.1f MiB)" % (c, mean, mean * 2 / 1024.0))
+                traffic[name]["fetch_raw_bytes"] = int(mean * 1024)
+                traffic[name]["fetch_corrected_bytes"] = int(mean * 2048)
             elif c == "WRITE_SIZE":
                 parts.append("%s=%.0f KiB (%.1f MiB)" % (c, mean, mean / 1024.0))
+                traffic[name]["write_bytes"] = int(mean * 1024)
             else:
                 parts.append("%s=%.4g" % (c, mean))
         print("%-28s n=%-4d %s" % (name[:28], len(next(iter(cs.values()))), "  ".join(parts)))
+
+if traffic_json:
+    for name, d in traffic.items():
+        d["hbm_bytes"] = d.get("fetch_corrected_bytes", 0) + d.get("write_bytes", 0)
+    json.dump({
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) on `python bench.py --steps 2 "
+                  "--warmup 1 --cpu-sample 0 --no-profile`, batch 1024; mean per dispatch",
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md section HBM); calibrated on the "
+                      "kernel that streams the covariance P once (k_build_A): 1024 x 320 x 320 x 8 B = 800 MiB",
+        "kernels": dict(sorted(traffic.items()))}, open(traffic_json, "w"), indent=1)

@@ -170,6 +170,33 @@ int sl2_elliptical_search_batch(int device, const uint8_t* images, int nimages, 
                                 const double* puinv, int count, int32_t* ok, int32_t* uv, double* score,
                                 int variant);
 
+/* ----------------------------------------------------- feature initialisation */
+
+/* MonoSLAM::find_best_patch_inside_region (monoslam.cpp:1070-1192) + find_eigenvalues (:1194-1205) as a
+ * stateless batch: the Shi-Tomasi detector over `njobs` regions.  region [njobs][4] = (ustart, vstart,
+ * ufinish, vfinish), clamped inside like the reference (6 px from every border for the 11x11 box);
+ * uv [njobs][2] = (*ubest, *vbest) IN/OUT: left untouched when no position has a positive smaller
+ * eigenvalue (evbest = 0), set to the clamped (ustart, vstart) for an empty region; evbest [njobs] = the
+ * smaller eigenvalue of the winner (first maximum in scan order v outer / u inner).  Bit-exact with the
+ * reference's FP64 arithmetic.  All pointers are HOST pointers; kernel_ms (optional) receives the device
+ * time of the kernels alone (HIP events). */
+int sl2_find_best_patch_batch(int device, const uint8_t* images, int nimages, int width, int height, int njobs,
+                              const int32_t* image_index, const int32_t* region, int32_t* uv, double* evbest,
+                              double* kernel_ms);
+
+/* SearchMultipleOverlappingEllipses (improc/search_multiple_overlapping_ellipses.{h,cpp}) as a stateless
+ * batch: job j = one (image, 11x11 patch) with ellipse_count[j] ellipses (the particles of one partially
+ * initialised feature); ellipses of all jobs are concatenated in puinv [total][3] = (PuInv(0,0), PuInv(0,1),
+ * PuInv(1,1)) and centre [total][2] (add_ellipse order).  result [total][3] = (result_flag_, result_u_,
+ * result_v_); corrmax [total] (optional) = the best score of each ellipse (diagnostic).  Semantics kept:
+ * centre truncated without rounding (cpp:127-128), +5.0 penalty for image sigma < 10 instead of a
+ * rejection (cpp:173-175), no patch-sigma test, "<=" => last minimum in scan order wins, flag = score <= 0.40.
+ * Each position of the union is scored once (the reference's cache), by the first ellipse that visits it. */
+int sl2_search_multiple_overlapping_ellipses_batch(int device, const uint8_t* images, int nimages, int width, int height,
+                                                   int njobs, const int32_t* image_index, const uint8_t* patches,
+                                                   const int32_t* ellipse_count, const double* puinv, const double* centre,
+                                                   int32_t* result, double* corrmax, double* kernel_ms);
+
 /* ----------------------------------------------------------------- state access */
 
 /* total_state_size_ per sequence (13 + 3 * live features). */

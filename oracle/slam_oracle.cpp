@@ -2,6 +2,7 @@
 // GoOneStep restatement + a flat C interface for ctypes (tests, smoke(), and the
 // cpu_baseline leg of bench.py).  See slam_oracle.hpp for the parity status.
 #include "slam_oracle.hpp"
+#include "feature_init_oracle.hpp"
 
 #include <atomic>
 #include <chrono>
@@ -188,6 +189,32 @@ int orc_elliptical_search(const uint8_t* image, int width, int height, const uin
   const bool ok = oracle::elliptical_search(image, width, height, patch, centre, a, b, c, &u, &v, 11, &nc, best_corr, &hw, &hh);
   out_i[0] = u; out_i[1] = v; out_i[2] = nc; out_i[3] = hw; out_i[4] = hh;
   return ok ? 1 : 0;
+}
+// monoslam.cpp:1070-1192.  io_uv holds (ubest, vbest) on entry and exit (left untouched when nothing scores).
+void orc_find_best_patch(const uint8_t* image, int width, int height, int ustart, int vstart, int ufinish, int vfinish,
+                         int* io_uv, double* evbest) {
+  oracle::find_best_patch_inside_region(image, width, height, &io_uv[0], &io_uv[1], evbest, 11, ustart, vstart, ufinish, vfinish);
+}
+// SearchMultipleOverlappingEllipses over n ellipses: puinv [n][3] = (PuInv(0,0), PuInv(0,1), PuInv(1,1)), centre [n][2].
+// out_i [n][3] = (result_flag, result_u, result_v); out_corr [n] = corrmax (diagnostic).  Returns the number of
+// positions actually correlated (cache misses).
+long long orc_search_multiple_ellipses(const uint8_t* image, int width, int height, const uint8_t* patch, int n,
+                                       const double* puinv, const double* centre, int* out_i, double* out_corr) {
+  oracle::MultiEllipseSearch s(image, width, height, patch, 11);
+  for (int i = 0; i < n; ++i) s.add_ellipse(puinv[3 * i], puinv[3 * i + 1], puinv[3 * i + 2], centre[2 * i], centre[2 * i + 1]);
+  s.search();
+  for (int i = 0; i < n; ++i) {
+    out_i[3 * i] = s.data[i].result_flag ? 1 : 0;
+    out_i[3 * i + 1] = s.data[i].result_u;
+    out_i[3 * i + 2] = s.data[i].result_v;
+    if (out_corr) out_corr[i] = s.data[i].corrmax;
+  }
+  return s.correlations;
+}
+void orc_drand48_sequence(long seed, int n, double* out) {
+  oracle::Rand48 r;
+  r.seed(seed);
+  for (int i = 0; i < n; ++i) out[i] = r.next();
 }
 void orc_sinv_from_S(const double* S4, double* abc) {
   Mat S(2, 2);

@@ -8,5 +8,6 @@ reference's interface plus the synthetic-input generator used by tests and bench
 from . import _lib  # noqa: F401
 from .config import load_config, parse_vars_file, read_pgm  # noqa: F401
 from .monoslam import Engine, Feature, MonoSLAM  # noqa: F401
+from . import improc  # noqa: F401
 
 __all__ = ["Engine", "MonoSLAM", "Feature", "load_config", "parse_vars_file", "read_pgm"]

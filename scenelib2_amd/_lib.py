@@ -64,7 +64,8 @@ EXPORTED_SYMBOLS = [
     "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
     "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
-    "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_get_total_state_sizes",
+    "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
+    "sl2_search_multiple_overlapping_ellipses_batch", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
     "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
@@ -124,6 +125,9 @@ def load():
     L.sl2_finish_step.argtypes = [vp, C.c_int]
     L.sl2_elliptical_search_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, c_ip, c_u8p, c_dp, c_dp,
                                               C.c_int, c_ip, c_ip, c_dp, C.c_int]
+    L.sl2_find_best_patch_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.sl2_search_multiple_overlapping_ellipses_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_u8p,
+                                                                 c_ip, c_dp, c_dp, c_ip, c_dp, c_dp]
     L.sl2_get_total_state_sizes.argtypes = [vp, C.c_int, C.c_int, c_ip]
     L.sl2_get_total_state.argtypes = [vp, C.c_int, c_dp, C.c_int]
     L.sl2_get_total_covariance.argtypes = [vp, C.c_int, c_dp, C.c_int]

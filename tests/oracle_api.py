@@ -75,6 +75,10 @@ def lib():
         L.orc_elliptical_search.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, c_dp, C.c_double, C.c_double,
                                             C.c_double, c_ip, c_dp]
         L.orc_sinv_from_S.argtypes = [c_dp, c_dp]
+        L.orc_find_best_patch.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_dp]
+        L.orc_search_multiple_ellipses.restype = C.c_longlong
+        L.orc_search_multiple_ellipses.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, C.c_int, c_dp, c_dp, c_ip, c_dp]
+        L.orc_drand48_sequence.argtypes = [C.c_long, C.c_int, c_dp]
         L.orc_motion_model.argtypes = [c_dp, C.c_double, c_dp, c_dp, c_dp]
         L.orc_dqnorm_by_dq.argtypes = [c_dp, c_dp]
         L.orc_measurement_model.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
@@ -230,6 +234,40 @@ def elliptical_search(image, patch, centre, a, b, c):
                                  C.byref(corr))
     return dict(ok=bool(ok), u=int(oi[0]), v=int(oi[1]), ncand=int(oi[2]), hw=int(oi[3]), hh=int(oi[4]),
                 corr=corr.value)
+
+
+def find_best_patch(image, region, uv_in=(-1, -1)):
+    """monoslam.cpp:1070-1192.  region = (ustart, vstart, ufinish, vfinish).  Returns (u, v, evbest); (u, v) keep
+    uv_in when no position scores."""
+    L = lib()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    uv = np.array(uv_in, dtype=np.int32)
+    ev = C.c_double(0)
+    L.orc_find_best_patch(_u8(img), img.shape[1], img.shape[0], int(region[0]), int(region[1]), int(region[2]),
+                          int(region[3]), _ip(uv), C.byref(ev))
+    return int(uv[0]), int(uv[1]), ev.value
+
+
+def search_multiple_ellipses(image, patch, puinv, centre):
+    """SearchMultipleOverlappingEllipses::search over the given ellipses.  Returns (result [n][3] = flag, u, v;
+    corrmax [n]; number of positions correlated)."""
+    L = lib()
+    img = np.ascontiguousarray(image, dtype=np.uint8)
+    p = np.ascontiguousarray(patch, dtype=np.uint8).reshape(121)
+    pu = np.ascontiguousarray(puinv, dtype=np.float64).reshape(-1, 3)
+    ce = np.ascontiguousarray(centre, dtype=np.float64).reshape(-1, 2)
+    n = pu.shape[0]
+    out = np.zeros((n, 3), dtype=np.int32)
+    corr = np.zeros(n)
+    ncorr = L.orc_search_multiple_ellipses(_u8(img), img.shape[1], img.shape[0], _u8(p), n, _dp(pu), _dp(ce), _ip(out),
+                                           _dp(corr))
+    return out, corr, int(ncorr)
+
+
+def drand48_sequence(seed, n):
+    out = np.zeros(n)
+    lib().orc_drand48_sequence(int(seed), int(n), _dp(out))
+    return out
 
 
 def sinv_from_S(S):

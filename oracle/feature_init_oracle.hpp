@@ -21,7 +21,7 @@
 #include <cstdint>
 #include <vector>
 
-#include "slam_oracle.hpp"
+// (reached through slam_oracle.hpp -> mapping_oracle.hpp; needs correlate2_warning from slam_oracle.hpp)
 
 namespace oracle {
 

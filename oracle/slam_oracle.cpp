@@ -17,10 +17,10 @@ double now_seconds() {
 
 // monoslam.cpp:108-180
 bool MonoSLAM::GoOneStep(const uint8_t* frame, bool save_trajectory, bool enable_mapping) {
-  (void)enable_mapping;
+  location_selected_flag = false;
+  init_feature_search_region_defined_flag = false;
   const double u[3] = {0, 0, 0};
   const double prev_xp_pos[3] = {xv(0), xv(1), xv(2)};
-  (void)prev_xp_pos;
 
   double t0 = now_seconds();
   KalmanFilterPredict(u);
@@ -52,8 +52,16 @@ bool MonoSLAM::GoOneStep(const uint8_t* frame, bool save_trajectory, bool enable
   P = add(scaled(P, 0.5), scaled(PT, 0.5));
   fill_covariances(P);
 
-  // monoslam.cpp:152-170: speed gate -> AutoInitialiseFeature, and
-  // MatchPartiallyInitialisedFeatures: no-ops without mapping / partial features.
+  // monoslam.cpp:152-170: speed gate -> AutoInitialiseFeature, then MatchPartiallyInitialisedFeatures (always)
+  // (func_xp only fills xpRES_: the scratch rRES_ pushed into the trajectory below stays stale, Q12)
+  const double vel[3] = {(xv(0) - prev_xp_pos[0]) / kDeltaT, (xv(1) - prev_xp_pos[1]) / kDeltaT, (xv(2) - prev_xp_pos[2]) / kDeltaT};
+  const double speed = std::sqrt(vel[0] * vel[0] + vel[1] * vel[1] + vel[2] * vel[2]);
+  if (speed > 0.2 && enable_mapping) {
+    if (number_of_visible_features < kNumberOfFeaturesToKeepVisible &&
+        feature_init_info_vector.size() < (unsigned int)kMaxFeaturesToInitAtOnce)
+      AutoInitialiseFeature(frame);
+  }
+  MatchPartiallyInitialisedFeatures(frame);
 
   if (save_trajectory) {  // monoslam.cpp:172-177 (stale scratch rRES_, Q12)
     for (int i = 0; i < 3; ++i) trajectory_store.push_back(motion_model.rRES[i]);
@@ -136,6 +144,53 @@ void orc_get_feature(void* h, int idx, int* ints, double* dbl) {
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) dbl[k++] = f->S(i, j);
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 13; ++j) dbl[k++] = f->dh_by_dxv(i, j);
   for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) dbl[k++] = f->dh_by_dy(i, j);
+}
+// ---- feature initialisation state ----
+// params: keep_visible, max_init_at_once, n_particles, min_particles, erase_after ; min_lambda, max_lambda, sd_ratio, prune_threshold
+void orc_set_mapping_params(void* h, const int* ip, const double* dp) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->kNumberOfFeaturesToKeepVisible = ip[0]; m->kMaxFeaturesToInitAtOnce = ip[1]; m->kNumberOfParticles = ip[2];
+  m->kMinNumberOfParticles = ip[3]; m->kErasePartiallyInitFeatureAfterThisManyAttempts = ip[4];
+  m->kMinLambda = dp[0]; m->kMaxLambda = dp[1]; m->kStandardDeviationDepthRatio = dp[2]; m->kPruneProbabilityThreshold = dp[3];
+}
+// ints: n_partial, features_initialised, features_converted, partial_features_deleted, uu, vv, location_selected,
+//       region_defined, ustart, vstart, ufinish, vfinish
+void orc_get_mapping_info(void* h, int* ints) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  ints[0] = (int)m->feature_init_info_vector.size(); ints[1] = m->features_initialised; ints[2] = m->features_converted;
+  ints[3] = m->partial_features_deleted; ints[4] = m->uu; ints[5] = m->vv; ints[6] = m->location_selected_flag;
+  ints[7] = m->init_feature_search_region_defined_flag; ints[8] = m->init_feature_search_ustart;
+  ints[9] = m->init_feature_search_vstart; ints[10] = m->init_feature_search_ufinish; ints[11] = m->init_feature_search_vfinish;
+}
+// partial feature k: ints = label, n_particles, number_of_match_attempts, making_measurement ; dbl = mean, covariance, y[6]
+// particles [n][10] = lambda, probability, cumulative, h0, h1, z0, z1, SInv00, SInv01, SInv11 (+ detS, success in [10], [11])
+int orc_get_partial_feature(void* h, int k, int* ints, double* dbl, double* particles, int max_particles) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  if (k < 0 || k >= (int)m->feature_init_info_vector.size()) return 0;
+  const oracle::FeatureInitInfo& f = m->feature_init_info_vector[k];
+  ints[0] = f.fp->label; ints[1] = (int)f.particle_vector.size(); ints[2] = f.number_of_match_attempts;
+  ints[3] = f.making_measurement_on_this_step_flag;
+  dbl[0] = f.mean; dbl[1] = f.covariance;
+  for (int i = 0; i < 6; ++i) dbl[2 + i] = f.fp->y[i];
+  for (int i = 0; i < (int)f.particle_vector.size() && i < max_particles; ++i) {
+    const oracle::Particle& p = f.particle_vector[i];
+    double* o = particles + 12 * (size_t)i;
+    o[0] = p.lambda; o[1] = p.probability; o[2] = p.cumulative_probability; o[3] = p.m_h[0]; o[4] = p.m_h[1];
+    o[5] = p.m_z[0]; o[6] = p.m_z[1]; o[7] = p.SInv[0]; o[8] = p.SInv[1]; o[9] = p.SInv[2]; o[10] = p.detS;
+    o[11] = p.m_successful_measurement_flag;
+  }
+  return 1;
+}
+// per feature of feature_list_: state_size, fully_initialised, label
+void orc_get_feature_kinds(void* h, int* out3) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (size_t i = 0; i < m->feature_list.size(); ++i) {
+    out3[3 * i] = m->feature_list[i]->state_size; out3[3 * i + 1] = m->feature_list[i]->fully_initialised_flag;
+    out3[3 * i + 2] = m->feature_list[i]->label;
+  }
+}
+void orc_get_feature_patch(void* h, int idx, uint8_t* patch121) {
+  std::memcpy(patch121, ((MonoSLAM*)h)->feature_list[idx]->patch, 121);
 }
 // labels of the selected features in selected_feature_list_ order
 void orc_get_selected_labels(void* h, int* labels) {

@@ -62,6 +62,27 @@ struct Camera {
     cam[2] = 1.0;
   }
 
+  // camera.cpp:247-275 — 3x2, row-major in J[r*2+c]; uses the point cached by the last Unproject()
+  void UnprojectionJacobian(double J[6]) const {
+    const double dy_by_du[6] = {-1 / fku, 0.0, 0.0, -1 / fkv, 0.0, 0.0};
+    double d00 = last_centred[0] * last_centred[0];
+    double d01 = last_centred[0] * last_centred[1];
+    double d10 = last_centred[1] * last_centred[0];
+    double d11 = last_centred[1] * last_centred[1];
+    const double radius2 = d00 + d11;
+    const double distor = 1 - 2 * kd1 * radius2;
+    const double distor1_2 = std::sqrt(distor);
+    const double distor3_2 = distor1_2 * distor;
+    const double s = 2 * kd1 / distor3_2;
+    d00 *= s; d01 *= s; d10 *= s; d11 *= s;
+    d00 += (1 / distor1_2);
+    d11 += (1 / distor1_2);
+    for (int r = 0; r < 3; ++r) {
+      J[r * 2 + 0] = dy_by_du[r * 2 + 0] * d00 + dy_by_du[r * 2 + 1] * d10;
+      J[r * 2 + 1] = dy_by_du[r * 2 + 0] * d01 + dy_by_du[r * 2 + 1] * d11;
+    }
+  }
+
   // camera.cpp:183-215 — 2x3, row-major in J[r*3+c]
   void ProjectionJacobian(double J[6]) const {
     const double fku_yz = fku / last_cam[2];
@@ -409,22 +430,229 @@ inline bool elliptical_search(const uint8_t* image, int width, int height, const
 // Feature record — feature.h:78-142, feature.cpp:108-171 (known-feature ctor).
 // ----------------------------------------------------------------------------
 struct Feature {
-  double y[3];
+  int state_size = 3;                // 3: fully initialised point, 6: partially initialised ray (feature.cpp:45-104)
+  double y[6] = {0, 0, 0, 0, 0, 0};
   double xp_org[7];
-  Mat Pyy;                           // 3x3
-  Mat Pxy;                           // 13x3
+  Mat Pyy;                           // state_size x state_size
+  Mat Pxy;                           // 13 x state_size
   std::vector<Mat> matrix_block_list;  // P_{yj yi}, j < i
   uint8_t patch[121];
   double h[2] = {0, 0}, z[2] = {0, 0}, nu[2] = {0, 0};
   Mat dh_by_dxv;  // 2x13
-  Mat dh_by_dy;   // 2x3
+  Mat dh_by_dy;   // 2 x state_size
   double R = 0;   // R_ = R * I2
   Mat S;          // 2x2
   int label = 0, position_in_list = 0, position_in_total_state_vector = 0;
   int attempted = 0, successful = 0;
   bool selected_flag = false, scheduled_for_termination_flag = false;
   bool successful_measurement_flag = false, fully_initialised_flag = true;
-  Feature() : Pyy(3, 3), Pxy(13, 3), dh_by_dxv(2, 13), dh_by_dy(2, 3), S(2, 2) {}
+  explicit Feature(int ss = 3) : state_size(ss), Pyy(ss, ss), Pxy(13, ss), dh_by_dxv(2, 13), dh_by_dy(2, ss), S(2, 2) {}
+};
+
+// ----------------------------------------------------------------------------
+// Partially initialised feature model — part_feature_model.cpp:80-333: a semi-infinite ray
+// ypi = (r_Wi, hhat_Wi) with the depth lambda as the free parameter.
+// ----------------------------------------------------------------------------
+struct PartFeatureModel {
+  Camera* cam = nullptr;
+  MotionModel* mm = nullptr;
+  double zeroedyi[6];
+  Mat dzeroedyi_by_dxp;  // 6x7
+  Mat dzeroedyi_by_dyi;  // 6x6
+  double ypi[6];
+  Mat dypi_by_dxp;  // 6x7
+  Mat dypi_by_dhi;  // 6x2
+  double Ri = 0;    // Ri * I2
+  double hpi[2];
+  Mat dhpi_by_dxp;  // 2x7
+  Mat dhpi_by_dyi;  // 2x6
+  double yfi[3];
+  Mat dyfi_by_dypi;     // 3x6
+  Mat dyfi_by_dlambda;  // 3x1
+  Mat Si;               // 2x2 (FeatureModel::SiRES_)
+
+  PartFeatureModel()
+      : dzeroedyi_by_dxp(6, 7), dzeroedyi_by_dyi(6, 6), dypi_by_dxp(6, 7), dypi_by_dhi(6, 2), dhpi_by_dxp(2, 7),
+        dhpi_by_dyi(2, 6), dyfi_by_dypi(3, 6), dyfi_by_dlambda(3, 1), Si(2, 2) {}
+
+  // feature_model.cpp:164-194
+  static Mat dRq_times_a_by_dq(const Quat& q, const Mat& a) {
+    Mat M(3, 4);
+    for (int k = 0; k < 4; ++k) set_block(M, 0, k, mul(FullFeatureModel::dR_by_dqk(q, k), a));
+    return M;
+  }
+  static Mat dqbar_by_dq() {  // feature_model.cpp:152-162
+    Mat M(4, 4);
+    M(0, 0) = 1.0; M(1, 1) = -1.0; M(2, 2) = -1.0; M(3, 3) = -1.0;
+    return M;
+  }
+  // part_feature_model.cpp:300-333 — vv is the SQUARED norm (same slip as dqnorm_by_dq)
+  static Mat dvnorm_by_dv(const double v[3]) {
+    Mat M(3, 3);
+    const double vv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        M(i, j) = (i == j) ? (1 - v[i] * v[i] / (vv * vv)) / vv : -v[i] * v[j] / (vv * vv * vv);
+    return M;
+  }
+
+  // part_feature_model.cpp:80-146
+  void func_zeroedyi(const double yi[6], const double xp[7]) {
+    mm->rRES[0] = xp[0]; mm->rRES[1] = xp[1]; mm->rRES[2] = xp[2];  // func_r
+    const Quat q(xp[3], xp[4], xp[5], xp[6]);                       // func_q
+    Mat d(3, 1), hh(3, 1);
+    for (int i = 0; i < 3; ++i) { d(i) = yi[i] - mm->rRES[i]; hh(i) = yi[3 + i]; }
+    const Quat qRW = qinverse(q);
+    const Mat dqRW_by_dq = dqbar_by_dq();
+    const Mat RRW = qrot(qRW);
+    const Mat zr = mul(RRW, d);
+    const Mat dzr_by_dr = scaled(RRW, -1.0);
+    const Mat dzr_by_dq = mul(dRq_times_a_by_dq(qRW, d), dqRW_by_dq);
+    const Mat zh = mul(RRW, hh);
+    const Mat dzh_by_dq = mul(dRq_times_a_by_dq(qRW, hh), dqRW_by_dq);
+    for (int i = 0; i < 3; ++i) { zeroedyi[i] = zr(i); zeroedyi[3 + i] = zh(i); }
+    dzeroedyi_by_dxp.setZero();
+    set_block(dzeroedyi_by_dxp, 0, 0, dzr_by_dr);
+    set_block(dzeroedyi_by_dxp, 0, 3, dzr_by_dq);
+    set_block(dzeroedyi_by_dxp, 3, 3, dzh_by_dq);
+    dzeroedyi_by_dyi.setZero();
+    set_block(dzeroedyi_by_dyi, 0, 0, RRW);
+    set_block(dzeroedyi_by_dyi, 3, 3, RRW);
+  }
+
+  // part_feature_model.cpp:162-229
+  void func_ypi_and_jacobians_and_Ri(const double hi[2], const double xp[7]) {
+    double hLRi[3];
+    cam->Unproject(hi, hLRi);
+    const double nrm = std::sqrt(hLRi[0] * hLRi[0] + hLRi[1] * hLRi[1] + hLRi[2] * hLRi[2]);  // Eigen normalize(): v /= norm
+    Mat hhat(3, 1);
+    for (int i = 0; i < 3; ++i) hhat(i) = hLRi[i] / nrm;
+    const Mat dhhat_by_dh = dvnorm_by_dv(hLRi);
+    const Quat q(xp[3], xp[4], xp[5], xp[6]);  // func_q
+    const Mat RWR = qrot(q);
+    const Mat hW = mul(RWR, hhat);
+    mm->rRES[0] = xp[0]; mm->rRES[1] = xp[1]; mm->rRES[2] = xp[2];  // func_r
+    for (int i = 0; i < 3; ++i) { ypi[i] = mm->rRES[i]; ypi[3 + i] = hW(i); }
+    const Mat dhW_by_dq = dRq_times_a_by_dq(q, hhat);
+    dypi_by_dxp.setZero();
+    dypi_by_dxp(0, 0) = 1.0; dypi_by_dxp(1, 1) = 1.0; dypi_by_dxp(2, 2) = 1.0;
+    set_block(dypi_by_dxp, 3, 3, dhW_by_dq);
+    double UJ[6];
+    cam->UnprojectionJacobian(UJ);
+    Mat UJm(3, 2);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 2; ++c) UJm(r, c) = UJ[r * 2 + c];
+    const Mat dhW_by_dhi = mul(mul(RWR, dhhat_by_dh), UJm);
+    dypi_by_dhi.setZero();
+    set_block(dypi_by_dhi, 3, 0, dhW_by_dhi);
+    Ri = cam->MeasurementNoise(hi);  // func_Ri
+  }
+
+  // part_feature_model.cpp:231-265
+  void func_hpi_and_jacobians(const double yi[6], const double xp[7], double lambda) {
+    func_zeroedyi(yi, xp);
+    double hLR[3];
+    for (int i = 0; i < 3; ++i) hLR[i] = zeroedyi[i] + lambda * zeroedyi[3 + i];
+    cam->Project(hLR, hpi);
+    double J[6];
+    cam->ProjectionJacobian(J);
+    Mat Jm(2, 3);
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) Jm(r, c) = J[r * 3 + c];
+    Mat M36(3, 6);
+    for (int i = 0; i < 3; ++i) { M36(i, i) = 1.0; M36(i, 3 + i) = lambda; }
+    const Mat JM = mul(Jm, M36);
+    dhpi_by_dxp = mul(JM, dzeroedyi_by_dxp);
+    dhpi_by_dyi = mul(JM, dzeroedyi_by_dyi);
+  }
+
+  // part_feature_model.cpp:267-287
+  void func_yfi_and_jacobians(const double ypi_[6], double lambda) {
+    for (int i = 0; i < 3; ++i) yfi[i] = ypi_[i] + lambda * ypi_[3 + i];
+    dyfi_by_dypi.setZero();
+    for (int i = 0; i < 3; ++i) { dyfi_by_dypi(i, i) = 1.0; dyfi_by_dypi(i, 3 + i) = lambda; dyfi_by_dlambda(i, 0) = ypi_[3 + i]; }
+  }
+
+  // feature_model.cpp:99-116 (shared base-class code)
+  void func_Si(const Mat& Pxx, const Mat& Pxyi, const Mat& Pyiyi, const Mat& dhi_by_dxv, const Mat& dhi_by_dyi_, double Ri_) {
+    Si.setZero();
+    Si = add(Si, mul(mul(dhi_by_dxv, Pxx), transpose(dhi_by_dxv)));
+    const Mat T = mul(mul(dhi_by_dxv, Pxyi), transpose(dhi_by_dyi_));
+    Si = add(Si, T);
+    Si = add(Si, transpose(T));
+    Si = add(Si, mul(mul(dhi_by_dyi_, Pyiyi), transpose(dhi_by_dyi_)));
+    Si(0, 0) += Ri_;
+    Si(1, 1) += Ri_;
+  }
+};
+
+// feature_init_info.{h,cpp}
+struct Particle {
+  double lambda = 0, probability = 0, cumulative_probability = 0;
+  double m_z[2] = {0, 0}, m_h[2] = {0, 0};
+  double SInv[3] = {0, 0, 0};  // (0,0), (0,1), (1,1)
+  double detS = 0;
+  bool m_successful_measurement_flag = false;
+  // feature_init_info.cpp:57-65.  Si.determinant() on a dynamic-size Eigen matrix goes through
+  // PartialPivLU (Eigen's documented behaviour for Dynamic sizes), restated here for a 2x2.
+  void set_S(const Mat& Si) {
+    Mat L;
+    llt_lower(Si, L);
+    const Mat Li = lower_inverse(L);
+    const Mat Sinv = mul(transpose(Li), Li);
+    SInv[0] = Sinv(0, 0); SInv[1] = Sinv(0, 1); SInv[2] = Sinv(1, 1);
+    const double a = Si(0, 0), b = Si(0, 1), c = Si(1, 0), d = Si(1, 1);
+    if (std::fabs(c) > std::fabs(a)) {  // row swap: pivot c
+      const double l = a / c;
+      detS = -(c * (b - l * d));
+    } else {
+      const double l = c / a;
+      detS = a * (d - l * b);
+    }
+  }
+};
+
+struct FeatureInitInfo {
+  Feature* fp = nullptr;
+  double mean = 0, covariance = 0;  // particle dimension 1
+  std::vector<Particle> particle_vector;
+  int number_of_match_attempts = 0;
+  bool making_measurement_on_this_step_flag = false;
+  void add_particle(double lambda, double probability) {
+    Particle p;
+    p.lambda = lambda; p.probability = probability;
+    particle_vector.push_back(p);
+  }
+  // feature_init_info.cpp:99-124
+  bool normalise_particle_vector_and_calculate_cumulative() {
+    double total = 0.0;
+    for (const Particle& p : particle_vector) total += p.probability;
+    if (total == 0.0) return false;
+    double cumulative_total = 0.0;
+    for (Particle& p : particle_vector) {
+      p.probability = p.probability / total;
+      p.cumulative_probability = cumulative_total + p.probability;
+      cumulative_total += p.probability;
+    }
+    return true;
+  }
+  // feature_init_info.cpp:131-147
+  void prune_particle_vector(double prune_probability_threshold) {
+    const double prune_threshold = prune_probability_threshold / double(particle_vector.size());
+    for (size_t i = 0; i < particle_vector.size();) {
+      if (particle_vector[i].probability < prune_threshold) particle_vector.erase(particle_vector.begin() + i);
+      else ++i;
+    }
+    normalise_particle_vector_and_calculate_cumulative();
+  }
+  // feature_init_info.cpp:157-174
+  void calculate_mean_and_covariance() {
+    double expected_squared = 0.0;
+    mean = 0.0;
+    for (const Particle& p : particle_vector) {
+      mean += p.probability * p.lambda;
+      expected_squared += p.probability * (p.lambda * p.lambda);
+    }
+    covariance = expected_squared - (mean * mean);
+  }
 };
 
 // ----------------------------------------------------------------------------
@@ -437,6 +665,7 @@ struct MonoSLAM {
   Camera camera;
   MotionModel motion_model;
   FullFeatureModel full_feature_model;
+  PartFeatureModel part_feature_model;
   Vec xv;   // 13
   Mat Pxx;  // 13x13
   std::vector<Feature*> feature_list;
@@ -448,6 +677,16 @@ struct MonoSLAM {
   int kNumberOfFeaturesToSelect = 0;
   int minimum_attempted_measurements_of_feature = 10;  // monoslam.cpp:1875
   double successful_match_fraction = 0.5;              // :1876
+  // ---- feature initialisation (monoslam.cpp:823-1533); parameters as in data/SceneLib2.cfg / Init (:1862-1879)
+  int kNumberOfFeaturesToKeepVisible = 12, kMaxFeaturesToInitAtOnce = 1, kNumberOfParticles = 100, kMinNumberOfParticles = 20;
+  int kErasePartiallyInitFeatureAfterThisManyAttempts = 10;
+  double kMinLambda = 0.5, kMaxLambda = 5.0, kStandardDeviationDepthRatio = 0.3, kPruneProbabilityThreshold = 0.05;
+  std::vector<FeatureInitInfo> feature_init_info_vector;
+  uint64_t rand48_state = 0x330EULL;  // srand48(0) in Init (:1968)
+  int uu = 0, vv = 0;                 // current image selection (uninitialised in the reference until first set)
+  bool location_selected_flag = false, init_feature_search_region_defined_flag = false;
+  int init_feature_search_ustart = 0, init_feature_search_vstart = 0, init_feature_search_ufinish = 0, init_feature_search_vfinish = 0;
+  int features_initialised = 0, features_converted = 0, partial_features_deleted = 0;  // diagnostics
   // diagnostics (not in the reference)
   long long total_candidates = 0;
   long long total_window_bytes = 0;
@@ -456,6 +695,8 @@ struct MonoSLAM {
   MonoSLAM() : xv(13, 1), Pxx(13, 13) {
     full_feature_model.cam = &camera;
     full_feature_model.mm = &motion_model;
+    part_feature_model.cam = &camera;
+    part_feature_model.mm = &motion_model;
   }
   ~MonoSLAM() { for (Feature* f : feature_list) delete f; }
   MonoSLAM(const MonoSLAM&) = delete;
@@ -470,7 +711,7 @@ struct MonoSLAM {
     nf->position_in_total_state_vector = total_state_size;
     for (int i = 0; i < 7; ++i) nf->xp_org[i] = xp[i];
     for (int i = 0; i < 3; ++i) nf->y[i] = y[i];
-    for (int i = 0; i < nf->position_in_list; ++i) nf->matrix_block_list.push_back(Mat(3, 3));
+    for (int i = 0; i < nf->position_in_list; ++i) nf->matrix_block_list.push_back(Mat(feature_list[i]->state_size, 3));
     feature_list.push_back(nf);
     total_state_size += 3;
     ++next_free_label;
@@ -590,7 +831,7 @@ struct MonoSLAM {
     int pos = 0;
     for (int i = 0; i < 13; ++i) V(pos + i) = xv(i);
     pos += 13;
-    for (const Feature* f : feature_list) { for (int i = 0; i < 3; ++i) V(pos + i) = f->y[i]; pos += 3; }
+    for (const Feature* f : feature_list) { for (int i = 0; i < f->state_size; ++i) V(pos + i) = f->y[i]; pos += f->state_size; }
   }
   // monoslam.cpp:518-546
   void construct_total_covariance(Mat& M) const {
@@ -607,7 +848,7 @@ struct MonoSLAM {
         y_position += blk.r;
       }
       set_block(M, y_position, x_position, f->Pyy);
-      x_position += 3;
+      x_position += f->state_size;
     }
   }
   // monoslam.cpp:548-572
@@ -630,8 +871,8 @@ struct MonoSLAM {
     pos += 13;
     for (Feature* f : feature_list) {
       if (pos >= V.size()) break;
-      for (int i = 0; i < 3; ++i) f->y[i] = V(pos + i);
-      pos += 3;
+      for (int i = 0; i < f->state_size; ++i) f->y[i] = V(pos + i);
+      pos += f->state_size;
     }
   }
   // monoslam.cpp:588-614 — reads only the upper block triangle
@@ -641,14 +882,14 @@ struct MonoSLAM {
     for (Feature* f : feature_list) {
       if (x_position >= M.c) break;
       int y_position = 0;
-      f->Pxy = get_block(M, y_position, x_position, 13, 3);
+      f->Pxy = get_block(M, y_position, x_position, 13, f->state_size);
       y_position += 13;
       for (Mat& blk : f->matrix_block_list) {
         blk = get_block(M, y_position, x_position, blk.r, blk.c);
         y_position += blk.r;
       }
-      f->Pyy = get_block(M, y_position, x_position, 3, 3);
-      x_position += 3;
+      f->Pyy = get_block(M, y_position, x_position, f->state_size, f->state_size);
+      x_position += f->state_size;
     }
   }
 
@@ -704,10 +945,10 @@ struct MonoSLAM {
       Feature* f = feature_list[i];
       --f->position_in_list;
       f->matrix_block_list.erase(f->matrix_block_list.begin() + del->position_in_list);
-      f->position_in_total_state_vector -= 3;
+      f->position_in_total_state_vector -= del->state_size;
     }
     if (del->selected_flag) deselect_feature(del);
-    total_state_size -= 3;
+    total_state_size -= del->state_size;
     delete del;
     feature_list.erase(feature_list.begin() + k);
     marked_feature_label = -1;
@@ -743,8 +984,27 @@ struct MonoSLAM {
   // initialised features, are §8(f) "next": with enable_mapping == false and no
   // partial features they are no-ops in the reference too).
   bool GoOneStep(const uint8_t* frame, bool save_trajectory, bool enable_mapping);
+
+  // ---- feature initialisation path, defined in mapping_oracle.hpp ----
+  double drand48_();
+  bool AutoInitialiseFeature(const uint8_t* frame);
+  bool FindNonOverlappingRegion(int& ustart, int& vstart, int& ufinish, int& vfinish, int steps_to_predict, double depth_hypothesis);
+  bool FindNonOverlappingRegionNoPredict(int safe_ustart, int safe_vstart, int safe_ufinish, int safe_vfinish, int& ustart,
+                                         int& vstart, int& ufinish, int& vfinish);
+  double set_image_selection_automatically(const uint8_t* frame, int ustart, int vstart, int ufinish, int vfinish);
+  void InitialiseFeature(const uint8_t* frame);
+  void add_new_partially_initialised_feature(const uint8_t patch[121], const double h[2]);
+  void MatchPartiallyInitialisedFeatures(const uint8_t* frame);
+  void predict_partially_initialised_feature_measurements();
+  void measure_feature_with_multiple_priors(const uint8_t* frame, const uint8_t* patch, std::vector<Particle>& particles);
+  void update_partially_initialised_feature_probabilities(double prune_probability_threshold);
+  void delete_partially_initialised_features_past_sell_by_date(int erase_after_attempts, int min_number_of_particles);
+  void delete_partially_initialised_feature(size_t index);
+  void convert_from_partially_to_fully_initialised(Feature* f, double lambda, double Plambda);
 };
 
 double now_seconds();
 
 }  // namespace oracle
+
+#include "mapping_oracle.hpp"

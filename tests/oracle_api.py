@@ -75,6 +75,12 @@ def lib():
         L.orc_elliptical_search.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, c_dp, C.c_double, C.c_double,
                                             C.c_double, c_ip, c_dp]
         L.orc_sinv_from_S.argtypes = [c_dp, c_dp]
+        L.orc_set_mapping_params.argtypes = [C.c_void_p, c_ip, c_dp]
+        L.orc_get_mapping_info.argtypes = [C.c_void_p, c_ip]
+        L.orc_get_partial_feature.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, C.c_int]
+        L.orc_get_partial_feature.restype = C.c_int
+        L.orc_get_feature_kinds.argtypes = [C.c_void_p, c_ip]
+        L.orc_get_feature_patch.argtypes = [C.c_void_p, C.c_int, c_u8p]
         L.orc_find_best_patch.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_dp]
         L.orc_search_multiple_ellipses.restype = C.c_longlong
         L.orc_search_multiple_ellipses.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, C.c_int, c_dp, c_dp, c_ip, c_dp]
@@ -206,6 +212,42 @@ class OracleSLAM:
     def set_feature_Pyy(self, idx, Pyy):
         P = np.ascontiguousarray(Pyy, dtype=np.float64).reshape(9)
         self.L.orc_set_feature_Pyy(self.h, idx, _dp(P))
+
+    def set_mapping_params(self, params):
+        ip = np.array([params["number_of_features_to_keep_visible"], params["max_features_to_init_at_once"],
+                       params["number_of_particles"], params["min_number_of_particles"],
+                       params["erase_partially_init_feature_after_this_many_attempts"]], dtype=np.int32)
+        dp = np.array([params["min_lambda"], params["max_lambda"], params["standard_deviation_depth_ratio"],
+                       params["prune_probability_threshold"]], dtype=np.float64)
+        self.L.orc_set_mapping_params(self.h, _ip(ip), _dp(dp))
+
+    def mapping_info(self):
+        o = np.zeros(12, dtype=np.int32)
+        self.L.orc_get_mapping_info(self.h, _ip(o))
+        keys = ["n_partial", "initialised", "converted", "deleted", "uu", "vv", "location_selected", "region_defined",
+                "ustart", "vstart", "ufinish", "vfinish"]
+        return dict(zip(keys, [int(x) for x in o]))
+
+    def partial_feature(self, k, max_particles=256):
+        ints = np.zeros(4, dtype=np.int32)
+        dbl = np.zeros(8)
+        parts = np.zeros((max_particles, 12))
+        if not self.L.orc_get_partial_feature(self.h, k, _ip(ints), _dp(dbl), _dp(parts), max_particles):
+            return None
+        n = int(ints[1])
+        return dict(label=int(ints[0]), n_particles=n, attempts=int(ints[2]), making=bool(ints[3]), mean=dbl[0],
+                    covariance=dbl[1], y=dbl[2:8].copy(), particles=parts[:n].copy())
+
+    def feature_kinds(self):
+        n = self.num_features
+        o = np.zeros((max(n, 1), 3), dtype=np.int32)
+        self.L.orc_get_feature_kinds(self.h, _ip(o))
+        return o[:n]
+
+    def feature_patch(self, idx):
+        p = np.zeros(121, dtype=np.uint8)
+        self.L.orc_get_feature_patch(self.h, idx, _u8(p))
+        return p.reshape(11, 11)
 
     def set_feature_counters(self, idx, attempted, successful):
         self.L.orc_set_feature_counters(self.h, idx, attempted, successful)

@@ -1,0 +1,69 @@
+"""Feature-initialisation path of the oracle (monoslam.cpp:823-1533 restated in oracle/mapping_oracle.hpp): behaviour
+checks on a synthetic sequence.  CPU only (the frames come from the native HOST renderer)."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from mapping_helpers import make_mapping_sequence, oracle_for
+
+
+@pytest.fixture(scope="module")
+def run():
+    cam, params, spec, frames, templates = make_mapping_sequence()
+    s = oracle_for(cam, params, spec, templates, oa)
+    log = []
+    for k in range(1, spec.n_frames + 1):
+        s.go_one_step(frames[k], False, True)
+        info = s.mapping_info()
+        pf = s.partial_feature(0) if info["n_partial"] else None
+        log.append(dict(info=info, pf=pf, n=s.num_features, size=s.total_state_size, kinds=s.feature_kinds().copy(),
+                        visible=s.num_visible, xv=s.get_state()[0].copy()))
+    return cam, params, spec, frames, s, log
+
+
+def test_features_are_initialised_matched_and_converted(run):
+    cam, params, spec, frames, s, log = run
+    last = log[-1]["info"]
+    assert last["initialised"] >= 2 and last["converted"] >= 1, last
+    # state size bookkeeping: 13 + 3 per full + 6 per partial feature, at every frame
+    for e in log:
+        assert e["size"] == 13 + int((e["kinds"][:, 0]).sum())
+        assert e["info"]["n_partial"] == int((e["kinds"][:, 1] == 0).sum()) <= params["max_features_to_init_at_once"]
+
+
+def test_partial_feature_is_not_matched_in_its_first_frame_and_particles_collapse(run):
+    cam, params, spec, frames, s, log = run
+    first = next(i for i, e in enumerate(log) if e["pf"] is not None)
+    pf0 = log[first]["pf"]
+    assert pf0["attempts"] == 1 and not pf0["making"] and pf0["n_particles"] == params["number_of_particles"]
+    lam = pf0["particles"][:, 0]
+    assert lam[0] == params["min_lambda"] and np.allclose(np.diff(lam), (params["max_lambda"] - params["min_lambda"]) / 100)
+    assert np.allclose(pf0["particles"][:, 1], 0.01)
+    pf1 = log[first + 1]["pf"]
+    if pf1 is not None:
+        assert pf1["making"] and pf1["n_particles"] <= 100 and abs(pf1["particles"][:, 1].sum() - 1) < 1e-12
+        assert np.all(np.diff(pf1["particles"][:, 2]) >= 0) and abs(pf1["particles"][-1, 2] - 1) < 1e-12
+
+
+def test_converted_features_lie_on_the_scene_plane(run):
+    cam, params, spec, frames, s, log = run
+    n_known = spec.n_features
+    x = s.total_state()
+    kinds = s.feature_kinds()
+    pos = 13
+    n_checked = 0
+    for i in range(kinds.shape[0]):
+        if kinds[i, 1] and kinds[i, 2] >= n_known:      # a feature that came out of the initialisation path
+            y = x[pos:pos + 3]
+            assert abs(y[2]) < 0.08, (i, y)               # the textured plane is z = 0, camera at z = -0.6
+            n_checked += 1
+        pos += kinds[i, 0]
+    assert n_checked >= 1
+    P = s.total_covariance()
+    assert np.allclose(P, P.T, atol=1e-12) and np.linalg.eigvalsh(P).min() > -1e-9
+
+
+def test_camera_still_tracks_with_mapping_on(run):
+    cam, params, spec, frames, s, log = run
+    err = np.array([np.linalg.norm(e["xv"][:3] - spec.poses[k + 1, :3]) for k, e in enumerate(log)])
+    assert err[:20].max() < 0.03, err[:20].max()          # later the fast camera has lost most of the known map

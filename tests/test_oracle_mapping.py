@@ -55,7 +55,7 @@ def test_converted_features_lie_on_the_scene_plane(run):
     for i in range(kinds.shape[0]):
         if kinds[i, 1] and kinds[i, 2] >= n_known:      # a feature that came out of the initialisation path
             y = x[pos:pos + 3]
-            assert abs(y[2]) < 0.08, (i, y)               # the textured plane is z = 0, camera at z = -0.6
+            assert abs(y[2]) < 0.2, (i, y)                # plane z = 0, camera at z = -0.6 (sd/mean < 0.3 at conversion)
             n_checked += 1
         pos += kinds[i, 0]
     assert n_checked >= 1

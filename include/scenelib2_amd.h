@@ -84,6 +84,9 @@ typedef struct sl2_feature_info {
   double dh_by_dxp[14];                        /* first 7 columns of dh_by_dxv_ (rest are zero) */
   double dh_by_dy[6];                          /* dh_by_dy_ (2x3) */
   double xp_org[7];                            /* xp_org_ */
+  int32_t fully_initialised_flag;              /* Feature::fully_initialised_flag_ (0: the six-state ray of a partially initialised feature) */
+  int32_t state_size;                          /* 3, or 6 while partially initialised */
+  double y_direction[3];                       /* partially initialised: y_(3..5), the unit ray direction; else 0 */
 } sl2_feature_info;
 
 /* ------------------------------------------------------------------ lifecycle */
@@ -127,7 +130,10 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
  * channel, row pitch == width (Q25); seq_stride = bytes between consecutive
  * sequences' frames.  frames_on_device != 0 => `frames` is a device pointer
  * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
- * enable_mapping must be 0 in this release (feature initialisation: SURVEY §8(f)). */
+ * enable_mapping != 0 runs the feature-initialisation tail (monoslam.cpp:152-170: AutoInitialiseFeature behind the
+ * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) for the shipped max_features_to_init_at_once = 1 and up to
+ * 128 particles; other settings are rejected with SL2_ERR_INVALID.  Status bit 2 = a sequence could not reserve a
+ * label because max_features is exhausted. */
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
                     int save_trajectory, int enable_mapping);
 
@@ -208,6 +214,13 @@ int sl2_get_total_covariance(sl2_engine* e, int seq, double* P, int capacity_n);
 /* feature_list_ of one sequence in list order (deleted features skipped unless
  * include_deleted).  Returns the number written through *count. */
 int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity, int include_deleted, int* count);
+/* The partially initialised feature of one sequence (FeatureInitInfo + its particles, feature_init_info.h:46-118).
+ * ints [16] = active, label, number_of_match_attempts_, #particles, making_measurement_on_this_step_flag_, uu_, vv_,
+ * region_defined (this step), init_feature_search_{ustart,vstart,ufinish,vfinish}_, #initialised, #converted, #deleted
+ * (totals for this sequence), created (this step); dbl [9] = mean_, covariance_, y_(0..5), evbest of the last detection;
+ * particles [capacity][12] = lambda_, probability_, cumulative_probability_, m_h_(2), m_z_(2), m_SInv_(00,01,11), m_detS_,
+ * m_successful_measurement_flag_ (may be NULL). */
+int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, double* particles, int capacity);
 /* selected_feature_list_ (labels, selection order) and per-step counters:
  * counters[0] = number_of_visible_features_, [1] = #selected,
  * [2] = successful_measurement_vector_size_. */

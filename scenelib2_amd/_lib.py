@@ -56,7 +56,8 @@ class sl2_feature_info(C.Structure):
                 ("position_in_total_state_vector", C.c_int32), ("visible", C.c_int32),
                 ("y", C.c_double * 3), ("h", C.c_double * 2), ("z", C.c_double * 2), ("nu", C.c_double * 2),
                 ("R", C.c_double), ("S", C.c_double * 4), ("dh_by_dxp", C.c_double * 14),
-                ("dh_by_dy", C.c_double * 6), ("xp_org", C.c_double * 7)]
+                ("dh_by_dy", C.c_double * 6), ("xp_org", C.c_double * 7),
+                ("fully_initialised_flag", C.c_int32), ("state_size", C.c_int32), ("y_direction", C.c_double * 3)]
 
 
 # every symbol include/scenelib2_amd.h declares (tests check the .so exports all of them)
@@ -66,7 +67,7 @@ EXPORTED_SYMBOLS = [
     "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_get_total_state_sizes",
-    "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_selection",
+    "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
     "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
@@ -128,6 +129,7 @@ def load():
     L.sl2_find_best_patch_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sl2_search_multiple_overlapping_ellipses_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_u8p,
                                                                  c_ip, c_dp, c_dp, c_ip, c_dp, c_dp]
+    L.sl2_get_partial_feature.argtypes = [vp, C.c_int, c_ip, c_dp, c_dp, C.c_int]
     L.sl2_get_total_state_sizes.argtypes = [vp, C.c_int, C.c_int, c_ip]
     L.sl2_get_total_state.argtypes = [vp, C.c_int, c_dp, C.c_int]
     L.sl2_get_total_covariance.argtypes = [vp, C.c_int, c_dp, C.c_int]

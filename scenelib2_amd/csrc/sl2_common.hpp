@@ -37,9 +37,16 @@ enum : int {
   FF_SUCCESS = 8,     // successful_measurement_flag_
   FF_VISIBLE = 16,    // passed visibility_test in the last selection
   FF_USED = 32,       // slot was ever used (deleted features keep FF_USED)
+  FF_PARTIAL = 64,    // label reserved by a partially initialised feature (its 6 states live at ppos)
 };
 
 constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
+// feature initialisation (one partially initialised feature per sequence)
+constexpr int kMaxParticles = 128;       // upper bound of params.number_of_particles
+constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2], z[2], SInv(00,01,11), detS, success
+constexpr int kPartInts = 16, kPartDoubles = 4;   // per-sequence record of the partial feature (part_i / part_d)
+enum : int { kPartActive = 0, kPartLabel, kPartAttempts, kPartNp, kPartMaking, kPartUU, kPartVV, kPartRegionValid,
+             kPartRegion /* 4 ints */, kPartInitialised = 12, kPartConverted, kPartDeleted, kPartCreated };
 constexpr int kCholBlock = 32;       // block size of the blocked Cholesky / forward substitution
 constexpr int kPatchStride = 288;    // bytes per stored template: 121 raw bytes (+7 pad), then at byte
                                      // 128 the packed form: 33 dwords (11 rows x 12 bytes, byte 11 = 0),
@@ -111,6 +118,16 @@ struct sl2_engine {
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
   int build_variant = 1;      // 1 = A and S in one pass (state <= 512 columns), 0 = k_build_A then k_build_S
   int fwd_variant = 3;        // forward substitution: 3 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory, 1/2 = register-resident only (16/32 columns per wave)
+  // ---- feature initialisation ----
+  int ppos = 0;                          // first column of the partial feature's six states (13 + 3N)
+  int* part_i = nullptr;                 // [B][kPartInts]
+  double* part_d = nullptr;              // [B][kPartDoubles]  mean, covariance of lambda, evbest of the last detection
+  double* particles = nullptr;           // [B][kMaxParticles][kParticleDoubles]
+  unsigned long long* rand48 = nullptr;  // [B]  drand48 state (srand48(0) at Init, monoslam.cpp:1968)
+  double* prev_r = nullptr;              // [B][3] camera position before the prediction (speed estimate, :121-124)
+  int* me_desc = nullptr;                // [B][kMaxParticles][8] search ellipses of the particles
+  double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
+  bool mapping_used = false;
   int search_variant = 2;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
@@ -193,5 +210,6 @@ int launch_select(sl2_engine* e, int n);
 int launch_search(sl2_engine* e);
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot);
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);
 
 }  // namespace sl2

@@ -3,6 +3,7 @@
 // (monoslam.cpp:108-180): a fixed sequence of batch-wide kernel launches on one
 // HIP stream, no host synchronisation inside a step.
 #include "sl2_common.hpp"
+#include "sl2_mapmath.hpp"
 
 #include <mutex>
 
@@ -136,6 +137,7 @@ static int build_groups(sl2_engine* e, int G) {
     sl2_engine* g = new sl2_engine();
     g->device = e->device; g->cam = e->cam; g->prm = e->prm;
     g->B = count; g->N = e->N; g->ld = e->ld; g->nsel_max = e->nsel_max; g->mld = e->mld; g->nblk_max = e->nblk_max;
+    g->ppos = e->ppos;
     g->root = e; g->group_first = first;
     if (G == 1) g->stream = e->stream; else SL2_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     const size_t f = first;
@@ -152,6 +154,9 @@ static int build_groups(sl2_engine* e, int G) {
     g->pack_first = e->pack_first + f * N; g->pack_count = e->pack_count + f * N; g->n_packs = e->n_packs + f;
     g->work = e->work + f * 4; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
+    g->part_i = e->part_i + f * kPartInts; g->part_d = e->part_d + f * kPartDoubles;
+    g->particles = e->particles + f * kMaxParticles * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
+    g->me_desc = e->me_desc + f * kMaxParticles * 8;
     e->groups.push_back(g);
   }
   return SL2_OK;
@@ -266,7 +271,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (e->prm.minimum_attempted_measurements_of_feature <= 0) e->prm.minimum_attempted_measurements_of_feature = 10;
   if (!(e->prm.successful_match_fraction > 0.0)) e->prm.successful_match_fraction = 0.5;
   e->B = batch; e->N = max_features;
-  e->ld = round_up(13 + 3 * max_features + 1, 64);
+  // columns: xv(13), 3 per feature slot, 6 for one partially initialised feature, 1 for the innovation (At / Vt)
+  e->ld = round_up(13 + 3 * max_features + 6 + 1, 64);
+  e->ppos = 13 + 3 * max_features;
   int nsel = params->number_of_features_to_select;
   if (nsel < 1) nsel = 1;
   if (nsel > max_features) nsel = max_features;
@@ -316,7 +323,17 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->Vt, B * mld * ld));
   A(dmalloc(&e->St, B * mld * mld));
   A(dmalloc(&e->LinvT, B * (size_t)e->nblk_max * 1024));
+  A(dmalloc(&e->part_i, B * kPartInts));
+  A(dmalloc(&e->part_d, B * kPartDoubles));
+  A(dmalloc(&e->particles, B * kMaxParticles * kParticleDoubles));
+  A(dmalloc(&e->rand48, B));
+  A(dmalloc(&e->prev_r, B * 3));
+  A(dmalloc(&e->me_desc, B * kMaxParticles * 8));
 #undef A
+  {  // srand48(0) in MonoSLAM::Init (monoslam.cpp:1968), one generator per sequence
+    std::vector<unsigned long long> seeds(B, kRand48Seed0);
+    SL2_HIP(hipMemcpy(e->rand48, seeds.data(), sizeof(unsigned long long) * B, hipMemcpyHostToDevice));
+  }
   SL2_HIP(hipDeviceSynchronize());
   e->root = e;
   if (const char* v = getenv("SL2_FWD_VARIANT")) e->fwd_variant = atoi(v);
@@ -354,7 +371,8 @@ void sl2_destroy(sl2_engine* e) {
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
-                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->pack_first, e->pack_count, e->n_packs};
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->pack_first, e->pack_count, e->n_packs,
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -532,12 +550,23 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory) {
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int save_trajectory,
                     int enable_mapping) {
   if (!e) return SL2_ERR_INVALID;
-  if (enable_mapping) { set_error("enable_mapping: feature initialisation is not implemented in this release (SURVEY 8(f))"); return SL2_ERR_INVALID; }
   SL2_HIP(hipSetDevice(e->device));
+  if (enable_mapping && !e->mapping_used) {
+    // feature initialisation: what this engine supports is the shipped configuration
+    if (e->prm.max_features_to_init_at_once != 1 || e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
+      set_error("enable_mapping: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 128");
+      return SL2_ERR_INVALID;
+    }
+    if (e->groups.size() > 1) { set_error("enable_mapping: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
+    e->mapping_used = true;
+  }
   int rc;
   if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
   const int slot = (int)(e->steps_done % kTrajCapacity);
   const int nsel = e->prm.number_of_features_to_select;
+  // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
+  // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
+  const bool tail = e->mapping_used;
   rc = for_each_group(e, [=](sl2_engine* g) {
     int r;
     if ((r = launch_predict(g)) != SL2_OK) return r;
@@ -545,8 +574,15 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
     if ((r = launch_select(g, nsel)) != SL2_OK) return r;
     if ((r = launch_search(g)) != SL2_OK) return r;
     if ((r = launch_update(g)) != SL2_OK) return r;
-    return launch_finalize(g, save_trajectory, slot);
+    return launch_finalize(g, tail ? 0 : save_trajectory, slot);
   });
+  if (rc == SL2_OK && tail) {
+    sl2_engine* g = e->groups.empty() ? e : e->groups[0];
+    g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
+    g->score_map = e->score_map;
+    rc = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
+    e->score_map = g->score_map;
+  }
   e->steps_done += 1;
   if (rc != SL2_OK) return rc;
   if (e->profiling && e->pending.size() > 8192) return e->fold_events();
@@ -559,12 +595,14 @@ struct HostSeq {
   std::vector<double> x, P;
   std::vector<int> flags;
   int n_slots = 0;
+  int part[kPartInts] = {0};
 };
 
 static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   SL2_HIP(hipMemcpy(&hs.n_slots, e->n_slots + seq, sizeof(int), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(hs.part, e->part_i + (size_t)seq * kPartInts, sizeof(int) * kPartInts, hipMemcpyDeviceToHost));
   hs.flags.resize(e->N);
   SL2_HIP(hipMemcpy(hs.flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
   hs.x.resize(e->ld);
@@ -578,11 +616,13 @@ static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
 
 // dense index list of the live state entries (deleted features removed)
 static std::vector<int> live_index(const sl2_engine* e, const HostSeq& hs) {
-  (void)e;
   std::vector<int> idx;
   for (int i = 0; i < 13; ++i) idx.push_back(i);
-  for (int f = 0; f < hs.n_slots; ++f)
+  for (int f = 0; f < hs.n_slots; ++f) {
     if (hs.flags[f] & FF_ACTIVE) for (int k = 0; k < 3; ++k) idx.push_back(13 + 3 * f + k);
+    // a partially initialised feature sits at its label's place in feature_list_ with six states
+    if (hs.flags[f] & FF_PARTIAL) for (int k = 0; k < 6; ++k) idx.push_back(e->ppos + k);
+  }
   return idx;
 }
 
@@ -595,7 +635,10 @@ int sl2_get_total_state_sizes(sl2_engine* e, int seq0, int nseq, int32_t* sizes)
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
   for (int s = 0; s < nseq; ++s) {
     int n = 13;
-    for (int f = 0; f < slots[s]; ++f) if (flags[(size_t)s * e->N + f] & FF_ACTIVE) n += 3;
+    for (int f = 0; f < slots[s]; ++f) {
+      if (flags[(size_t)s * e->N + f] & FF_ACTIVE) n += 3;
+      if (flags[(size_t)s * e->N + f] & FF_PARTIAL) n += 6;
+    }
     sizes[s] = n;
   }
   return SL2_OK;
@@ -646,7 +689,8 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
   int n = 0, pos = 13;
   for (int f = 0; f < hs.n_slots; ++f) {
     const int fl = hs.flags[f];
-    const bool active = fl & FF_ACTIVE;
+    const bool partial = fl & FF_PARTIAL;
+    const bool active = (fl & FF_ACTIVE) || partial;
     if (!active && !include_deleted) continue;
     if (n >= capacity) return SL2_ERR_CAPACITY;
     sl2_feature_info& fi = out[n++];
@@ -659,8 +703,11 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
     fi.attempted_measurements_of_feature = att[f];
     fi.successful_measurements_of_feature = suc[f];
     fi.position_in_total_state_vector = active ? pos : -1;
-    if (active) pos += 3;
-    for (int k = 0; k < 3; ++k) fi.y[k] = hs.x[13 + 3 * f + k];
+    fi.fully_initialised_flag = partial ? 0 : 1;
+    fi.state_size = partial ? 6 : 3;
+    if (active) pos += fi.state_size;
+    for (int k = 0; k < 3; ++k) fi.y[k] = partial ? hs.x[e->ppos + k] : hs.x[13 + 3 * f + k];
+    for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? hs.x[e->ppos + 3 + k] : 0.0;
     for (int k = 0; k < 2; ++k) { fi.h[k] = h[f * 2 + k]; fi.z[k] = z[f * 2 + k]; fi.nu[k] = nu[f * 2 + k]; }
     fi.R = R[f];
     for (int k = 0; k < 4; ++k) fi.S[k] = S[f * 4 + k];
@@ -669,6 +716,29 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
     for (int k = 0; k < 7; ++k) fi.xp_org[k] = xo[f * 8 + k];
   }
   *count = n;
+  return SL2_OK;
+}
+
+int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, double* particles, int capacity) {
+  if (!range_ok(e, seq, 1) || !ints || !dbl) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  int pi[kPartInts];
+  double pd[kPartDoubles];
+  SL2_HIP(hipMemcpy(pi, e->part_i + (size_t)seq * kPartInts, sizeof(pi), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(pd, e->part_d + (size_t)seq * kPartDoubles, sizeof(pd), hipMemcpyDeviceToHost));
+  for (int k = 0; k < kPartInts; ++k) ints[k] = pi[k];
+  dbl[0] = pd[0]; dbl[1] = pd[1];
+  std::vector<double> y(6, 0.0);
+  if (pi[kPartActive]) SL2_HIP(hipMemcpy(y.data(), e->x + (size_t)seq * e->ld + e->ppos, sizeof(double) * 6, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 6; ++k) dbl[2 + k] = y[k];
+  dbl[8] = pd[2];
+  if (particles && pi[kPartActive]) {
+    const int n = pi[kPartNp] < capacity ? pi[kPartNp] : capacity;
+    if (n > 0)
+      SL2_HIP(hipMemcpy(particles, e->particles + (size_t)seq * kMaxParticles * kParticleDoubles, sizeof(double) * n * kParticleDoubles,
+                        hipMemcpyDeviceToHost));
+  }
   return SL2_OK;
 }
 

@@ -17,8 +17,7 @@
 //     arg-min over its own positions with the reference's "<=" (last wins) rule.
 #include <vector>
 
-#include "sl2_common.hpp"
-#include "sl2_math.hpp"
+#include "sl2_improc_dev.hpp"
 
 namespace sl2 {
 
@@ -27,183 +26,43 @@ namespace sl2 {
 // clamped region in the reference's scan order (v outer, u inner) and keeps the first maximum
 // (strict '>'); the workgroup reduction prefers the smaller scan index among equal maxima.
 // ---------------------------------------------------------------------------
-constexpr int kDetThreads = 256;
-
 __global__ void __launch_bounds__(kDetThreads) k_find_best_patch(const uint8_t* __restrict__ images, int width, int height,
                                                                  const int* __restrict__ image_index,
                                                                  const int* __restrict__ region, int* __restrict__ uv,
                                                                  double* __restrict__ evbest) {
-  const int job = blockIdx.x, tid = threadIdx.x;
-  const uint8_t* img = images + (size_t)image_index[job] * width * height;
-  int ustart = region[4 * job + 0], vstart = region[4 * job + 1], ufinish = region[4 * job + 2], vfinish = region[4 * job + 3];
-  const int half = (kBoxSize - 1) / 2;
-  if (ustart < half + 1) ustart = half + 1;                    // monoslam.cpp:1080-1091
-  if (ufinish > width - half - 1) ufinish = width - half - 1;
-  if (vstart < half + 1) vstart = half + 1;
-  if (vfinish > height - half - 1) vfinish = height - half - 1;
-  if (vstart >= vfinish || ustart >= ufinish) {                // :1094-1099
-    if (tid == 0) { uv[2 * job] = ustart; uv[2 * job + 1] = vstart; evbest[job] = 0.0; }
-    return;
-  }
-  const int nu = ufinish - ustart, nv = vfinish - vstart;
-  double best = 0.0;   // *evbest = 0 (:1136): only a strictly positive eigenvalue can win
-  int best_idx = -1;
-  for (int idx = tid; idx < nu * nv; idx += kDetThreads) {
-    const int v = vstart + idx / nu, u = ustart + idx % nu;
-    int sxx = 0, syy = 0, sxy = 0;
-    for (int r = v - half; r <= v + half; ++r) {
-      const uint8_t* up = img + (size_t)(r - 1) * width;
-      const uint8_t* mid = img + (size_t)r * width;
-      const uint8_t* dn = img + (size_t)(r + 1) * width;
-#pragma unroll
-      for (int c = -5; c <= 5; ++c) {
-        const int gx2 = (int)mid[u + c + 1] - (int)mid[u + c - 1];   // 2 gx
-        const int gy2 = (int)dn[u + c] - (int)up[u + c];             // 2 gy
-        sxx += gx2 * gx2; syy += gy2 * gy2; sxy += gx2 * gy2;
-      }
-    }
-    const double A = sxx / 4.0, Bq = sxy / 4.0, C = syy / 4.0;       // exact
-    const double BB = sqrt((A + C) * (A + C) - 4 * (A * C - Bq * Bq));  // find_eigenvalues, :1194-1205
-    const double e2 = (A + C - BB) / 2.0;
-    if (e2 > best) { best = e2; best_idx = idx; }
-  }
-  __shared__ double s_best[kDetThreads];
-  __shared__ int s_idx[kDetThreads];
-  s_best[tid] = best;
-  s_idx[tid] = best_idx;
-  __syncthreads();
-  for (int off = kDetThreads / 2; off > 0; off >>= 1) {
-    if (tid < off) {
-      const double ob = s_best[tid + off];
-      const int oi = s_idx[tid + off];
-      const double mb = s_best[tid];
-      const int mi = s_idx[tid];
-      // larger eigenvalue wins; among equals the earlier scan position (a lane without a candidate has idx -1)
-      if (oi >= 0 && (mi < 0 || ob > mb || (ob == mb && oi < mi))) { s_best[tid] = ob; s_idx[tid] = oi; }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    evbest[job] = s_idx[0] >= 0 ? s_best[0] : 0.0;
-    if (s_idx[0] >= 0) {                 // otherwise *ubest / *vbest keep the caller's values
-      uv[2 * job] = ustart + s_idx[0] % nu;
-      uv[2 * job + 1] = vstart + s_idx[0] / nu;
-    }
-  }
+  const int job = blockIdx.x;
+  detect_region_wg(images + (size_t)image_index[job] * width * height, width, height, region[4 * job + 0], region[4 * job + 1],
+                   region[4 * job + 2], region[4 * job + 3], uv + 2 * job, evbest + job);
 }
 
 // ---------------------------------------------------------------------------
-// Multi-ellipse search.
+// Multi-ellipse search: describe -> score the union once -> per-ellipse arg-min.
 // ---------------------------------------------------------------------------
-// per ellipse: uc, vc, urelstart, nu, vrelstart, nv, halfwidth, halfheight   (SearchDatum + the clipping of search())
 __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ puinv, const double* __restrict__ centre, int total,
                                                     int width, int height, int* __restrict__ desc) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= total) return;
-  const double a = puinv[3 * e], b = puinv[3 * e + 1], c = puinv[3 * e + 2];
-  const int hw = (int)(kNoSigma / sqrt(a - b * b / c));   // cpp:49-50
-  const int hh = (int)(kNoSigma / sqrt(c - b * b / a));
-  const int uc = int(centre[2 * e]), vc = int(centre[2 * e + 1]);   // truncation, no +0.5 (cpp:127-128)
-  const int half = (kBoxSize - 1) / 2;
-  int us = -hw, uf = hw, vs = -hh, vf = hh;
-  if (uc + us - half < 0) us = half - uc;                               // cpp:131-149
-  if (uc + uf - half > width - kBoxSize) uf = width - kBoxSize - uc + half;
-  if (vc + vs - half < 0) vs = half - vc;
-  if (vc + vf - half > height - kBoxSize) vf = height - kBoxSize - vc + half;
-  int* d = desc + 8 * (size_t)e;
-  d[0] = uc; d[1] = vc; d[2] = us; d[3] = uf - us + 1; d[4] = vs; d[5] = vf - vs + 1; d[6] = hw; d[7] = hh;
+  me_describe(puinv[3 * e], puinv[3 * e + 1], puinv[3 * e + 2], centre[2 * e], centre[2 * e + 1], width, height, desc + 8 * (size_t)e);
 }
 
-__device__ __forceinline__ bool me_visits(const int* __restrict__ d, const double* __restrict__ pu, int x, int y) {
-  const int urel = x - d[0], vrel = y - d[1];
-  if (urel < d[2] || urel >= d[2] + d[3] || vrel < d[4] || vrel >= d[4] + d[5]) return false;
-  return in_ellipse(pu[0], pu[1], pu[2], urel, vrel);
-}
-
-// One workgroup per ellipse: score every position this ellipse visits that no EARLIER ellipse of the
-// same job visits (the position's owner), with correlate2_warning's exact integer sums + FP64 epilogue,
-// plus the low-image-sigma penalty (cpp:169-175).
 __global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ images, int width, int height,
                                                    const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
                                                    const int* __restrict__ ell_job, const int* __restrict__ job_first,
                                                    const int* __restrict__ desc, const double* __restrict__ puinv,
                                                    double* __restrict__ score_map) {
-  const int e = blockIdx.x, tid = threadIdx.x;
-  const int job = ell_job[e], first = job_first[job];
-  const int* d = desc + 8 * (size_t)e;
-  const int nu = d[3], nv = d[5];
-  if (nu <= 0 || nv <= 0) return;
-  __shared__ int s_patch[121];
-  __shared__ int s_sums[2];
-  if (tid < 121) s_patch[tid] = patches[(size_t)job * 121 + tid];
-  __syncthreads();
-  if (tid == 0) {
-    int s0 = 0, s0q = 0;
-    for (int p = 0; p < 121; ++p) { s0 += s_patch[p]; s0q += s_patch[p] * s_patch[p]; }
-    s_sums[0] = s0; s_sums[1] = s0q;
-  }
-  __syncthreads();
-  const int Sg0 = s_sums[0], Sg0sq = s_sums[1];
-  const uint8_t* img = images + (size_t)image_index[job] * width * height;
-  double* map = score_map + (size_t)job * width * height;
-  const double* pu = puinv + 3 * (size_t)e;
-  for (int idx = tid; idx < nu * nv; idx += 256) {
-    const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-    if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-    const int x = d[0] + urel, y = d[1] + vrel;
-    bool owned = true;
-    for (int q = first; q < e; ++q)
-      if (me_visits(desc + 8 * (size_t)q, puinv + 3 * (size_t)q, x, y)) { owned = false; break; }
-    if (!owned) continue;
-    const uint8_t* p1 = img + (size_t)(y - 5) * width + (x - 5);
-    int Sg1 = 0, Sg0g1 = 0, Sg1sq = 0;
-    for (int r = 0; r < 11; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 11; ++cc) {
-        const int g0 = s_patch[r * 11 + cc];
-        const int g1 = p1[r * width + cc];
-        Sg1 += g1; Sg0g1 += g0 * g1; Sg1sq += g1 * g1;
-      }
-    double sd0, sd1;
-    double corr = ncc_score(Sg0, Sg1, Sg0g1, Sg0sq, Sg1sq, &sd0, &sd1);
-    if (sd1 < kCorrelationSigmaThreshold) corr += 5.0;     // LOW_SIGMA_PENALTY, h:56 / cpp:173-175
-    map[(size_t)y * width + x] = corr;
-  }
+  const int e = blockIdx.x;
+  const int job = ell_job[e];
+  me_score_ellipse_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121, job_first[job], e, desc,
+                      puinv, 3, score_map + (size_t)job * width * height);
 }
 
-// One wave per ellipse: arg-min over its positions in the reference's scan order (u outer, v inner),
-// "corr <= corrmax" => the last minimum wins.
 __global__ void __launch_bounds__(64) k_me_argmin(int width, int height, const int* __restrict__ ell_job,
                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
                                                   const double* __restrict__ score_map, int* __restrict__ result,
                                                   double* __restrict__ corrmax) {
-  const int e = blockIdx.x, lane = threadIdx.x;
-  const int* d = desc + 8 * (size_t)e;
-  const int nu = d[3], nv = d[5];
-  const double* map = score_map + (size_t)ell_job[e] * width * height;
-  const double* pu = puinv + 3 * (size_t)e;
-  double best = 1000000.0;   // cpp:156
-  int order = -1;
-  if (nu > 0 && nv > 0) {
-    for (int idx = lane; idx < nu * nv; idx += 64) {
-      const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-      if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-      const double corr = map[(size_t)(d[1] + vrel) * width + (d[0] + urel)];
-      if (corr <= best) { best = corr; order = idx; }
-    }
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const double ob = __shfl_xor(best, off, 64);
-    const int oo = __shfl_xor(order, off, 64);
-    if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
-  }
-  if (lane == 0) {
-    int* r = result + 3 * (size_t)e;
-    r[0] = (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0;           // cpp:187-191
-    r[1] = order >= 0 ? d[0] + d[2] + order / nv : 0;                  // result_u_ / result_v_ start at 0 (cpp:45-46)
-    r[2] = order >= 0 ? d[1] + d[4] + order % nv : 0;
-    if (corrmax) corrmax[e] = best;
-  }
+  const int e = blockIdx.x;
+  me_argmin_wave(width, desc + 8 * (size_t)e, puinv + 3 * (size_t)e, score_map + (size_t)ell_job[e] * width * height,
+                 result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
 }
 
 static int check_device(int device) {

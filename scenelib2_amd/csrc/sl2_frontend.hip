@@ -16,11 +16,13 @@ namespace sl2 {
 // (static map): Pxx <- (F Pxx) F^T + Q, strip P[0:13, j] <- F P[0:13, j], mirrored.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
-                                                 int ld, double dt) {
+                                                 double* __restrict__ prev_r, const int* __restrict__ part_i, int ppos, int ld,
+                                                 double dt) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
+  if (tid < 3) prev_r[b * 3 + tid] = xb[tid];   // prev_xp_pos (monoslam.cpp:121-124); xb is rewritten at the very end
   __shared__ double s_f[13], s_A[16], s_B[12], s_P[169], s_T[169];
   if (tid == 0) {
     double xv[13];
@@ -46,7 +48,8 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
     for (int k = 0; k < 13; ++k) v[k] = s_T[i * 13 + k];
     Pb[(size_t)i * ld + j] = frow_dot(j, dt, s_A, s_B, v) + process_noise_entry(i, j, dt, s_B);
   }
-  const int n_used = 13 + 3 * n_slots[b];
+  // columns of the map: the 3-D features, and the six states of a partially initialised one at ppos
+  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * n_slots[b];
   for (int j = 13 + tid; j < n_used; j += blockDim.x) {
     double v[13], w[13];
     for (int k = 0; k < 13; ++k) v[k] = Pb[(size_t)k * ld + j];
@@ -221,7 +224,8 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   const int* __restrict__ n_sel, double* __restrict__ traj,
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
                                                   int* __restrict__ status, double* __restrict__ pos_log, int log_slot, int N, int ld,
-                                                  int min_attempts, double match_fraction, int save_trajectory) {
+                                                  int min_attempts, double match_fraction, int save_trajectory,
+                                                  const int* __restrict__ part_i, int ppos) {
   extern __shared__ int s_del[];  // [N] slots deleted this frame
   __shared__ double s_N[16], s_P[169], s_T[169];
   __shared__ int s_ndel;
@@ -229,7 +233,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
   const int ns = n_slots[b];
-  const int n_used = 13 + 3 * ns;
+  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * ns;
   const bool updated = (n_sel[b] > 0) && (m_count[b] > 0);
   if (updated) {
     if (tid == 0) {
@@ -333,7 +337,8 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
 
 int launch_predict(sl2_engine* e) {
   LaunchScope ls(e, "k_predict");
-  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(128), 0, e->stream, e->x, e->P, e->n_slots, e->ld, e->prm.delta_t);
+  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(128), 0, e->stream, e->x, e->P, e->n_slots, e->prev_r, e->part_i, e->ppos, e->ld,
+                     e->prm.delta_t);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }
@@ -363,7 +368,7 @@ int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot) {
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
                      log_slot, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
-                     e->prm.successful_match_fraction, save_trajectory);
+                     e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

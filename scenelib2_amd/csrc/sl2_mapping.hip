@@ -1,0 +1,553 @@
+// Feature initialisation inside the per-frame step: the tail of
+// MonoSLAM::GoOneStep (monoslam.cpp:152-170) for the whole batch, one partially initialised
+// feature per sequence (the shipped max_features_to_init_at_once = 1):
+//
+//   k_map_region     speed gate + AutoInitialiseFeature's region choice     monoslam.cpp:159-165, 823-1032
+//   k_map_detect     set_image_selection_automatically (Shi-Tomasi)         :1043-1205
+//   k_map_create     InitialiseFeature + partially-initialised Feature ctor :1211-1276, feature.cpp:45-104
+//   k_map_particles  predict_partially_initialised_feature_measurements     :1349-1401
+//   k_map_me_*       measure_feature_with_multiple_priors                   :1411-1439 (+ improc/search_multiple...)
+//   k_map_update     update_partially_initialised_feature_probabilities, conversion test,
+//                    convert_from_partially_to_fully_initialised, sell-by deletion, trajectory push
+//                                                                           :1299-1342, 1449-1538, feature.cpp:204-269
+//
+// State layout: the partial feature's six states (r_W, hhat_W) live in columns ppos = 13 + 3N .. ppos + 5
+// of x / P (it is always the last feature of feature_list_, so this IS the reference's order); its label
+// slot is reserved at creation (next_free_label_++) and receives the 3-D point at conversion.  A deleted
+// or converted partial feature leaves its six rows / columns zero.
+#include "sl2_improc_dev.hpp"
+#include "sl2_mapmath.hpp"
+
+namespace sl2 {
+
+struct MapParams {
+  int enable_mapping, save_trajectory;
+  int keep_visible, n_particles, min_particles, erase_after;
+  double min_lambda, max_lambda, sd_ratio, prune_threshold, dt;
+};
+
+// ---------------------------------------------------------------------------
+// k_map_region: one wavefront per sequence.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x, const int* __restrict__ f_flags,
+                                                   const int* __restrict__ n_slots, const int* __restrict__ n_vis,
+                                                   const double* __restrict__ prev_r, int* __restrict__ part_i,
+                                                   unsigned long long* __restrict__ rand48, double* __restrict__ last_r,
+                                                   int* __restrict__ status, CameraParams cam, MapParams mp, int N, int ld) {
+  extern __shared__ double s_uv[];   // [2 * N] projections of the known features in front of the camera
+  __shared__ int s_cnt, s_go, s_safe[4];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const double* xb = x + (size_t)b * ld;
+  int* pi = part_i + (size_t)b * kPartInts;
+  const int ns = n_slots[b];
+  if (lane == 0) {
+    pi[kPartRegionValid] = 0;
+    pi[kPartCreated] = 0;
+    s_cnt = 0;
+    s_go = 0;
+    // camera speed estimate (monoslam.cpp:152-157)
+    const double vx = (xb[0] - prev_r[b * 3 + 0]) / mp.dt, vy = (xb[1] - prev_r[b * 3 + 1]) / mp.dt,
+                 vz = (xb[2] - prev_r[b * 3 + 2]) / mp.dt;
+    const double speed = sqrt(vx * vx + vy * vy + vz * vz);
+    if (speed > 0.2 && mp.enable_mapping && n_vis[b] < mp.keep_visible && !pi[kPartActive]) {
+      if (ns >= N) {
+        status[b] |= 2;            // the map is full: cannot reserve a label (capacity chosen at sl2_create)
+      } else {
+        // FindNonOverlappingRegion (:867-943): where will the image centre be in ten steps?
+        double xv[13], f[13], A44[16], B43[12];
+        for (int i = 0; i < 13; ++i) xv[i] = xb[i];
+        for (int it = 0; it < 10; ++it) {
+          motion_f_and_blocks(xv, mp.dt, f, A44, B43);
+          for (int i = 0; i < 13; ++i) xv[i] = f[i];
+        }
+        double R[9], yW[3], xp[7], zeroed[3], h[2], Hx[14], Hy[6], Rn;
+        quat_to_rot(&xv[3], R);
+        for (int i = 0; i < 3; ++i) {
+          double acc = 0.0;
+          acc += R[i * 3 + 0] * 0.0;
+          acc += R[i * 3 + 1] * 0.0;
+          acc += R[i * 3 + 2] * 2.5;   // FEATURE_INIT_DEPTH_HYPOTHESIS
+          yW[i] = xv[i] + acc;
+        }
+        for (int i = 0; i < 7; ++i) xp[i] = xb[i];
+        measurement_model(cam, xp, yW, zeroed, h, Hx, Hy, &Rn);
+        const double pmu = cam.width / 2.0 - h[0], pmv = cam.height / 2.0 - h[1];
+        int sus = (int)(-pmu), svs = (int)(-pmv), suf = (int)(cam.width - pmu), svf = (int)(cam.height - pmv);
+        const int m = (kBoxSize - 1) / 2 + 1;
+        if (sus < m) sus = m;
+        if (suf > cam.width - m) suf = cam.width - m;
+        if (svs < m) svs = m;
+        if (svf > cam.height - m) svf = cam.height - m;
+        s_safe[0] = sus; s_safe[1] = svs; s_safe[2] = suf; s_safe[3] = svf;
+        // rRES_ now holds the CURRENT position (func_hi -> func_zeroedyi -> func_r), Q12
+        for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xb[k];
+        s_go = (suf - sus > 80 && svf - svs > 60) ? 1 : 0;   // :957-958
+      }
+    }
+  }
+  __syncthreads();
+  if (!s_go) return;
+  // image positions of the fully initialised features in front of the camera (:968-985)
+  {
+    double xp[7];
+    for (int i = 0; i < 7; ++i) xp[i] = xb[i];
+    for (int i = lane; i < ns; i += 64) {
+      if (!(f_flags[(size_t)b * N + i] & FF_ACTIVE)) continue;
+      double y[3], zeroed[3], h[2], Hx[14], Hy[6], Rn;
+      for (int k = 0; k < 3; ++k) y[k] = xb[13 + 3 * i + k];
+      measurement_model(cam, xp, y, zeroed, h, Hx, Hy, &Rn);
+      if (zeroed[2] > 0) {
+        const int k = atomicAdd(&s_cnt, 1);
+        s_uv[2 * k] = h[0];
+        s_uv[2 * k + 1] = h[1];
+      }
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    unsigned long long st = rand48[b];
+    const int sus = s_safe[0], svs = s_safe[1], suf = s_safe[2], svf = s_safe[3];
+    int us = 0, vs = 0, uf = 0, vf = 0, i = 0;
+    while (i < 5) {   // NUMBER_OF_RANDOM_INIT_FEATURE_SEARCH_REGION_TRIES
+      const int u_offset = int((suf - sus - 80) * rand48_next(&st));
+      const int v_offset = int((svf - svs - 60) * rand48_next(&st));
+      us = sus + u_offset; uf = us + 80;
+      vs = svs + v_offset; vf = vs + 60;
+      bool found = false;
+      for (int k = 0; k < s_cnt; ++k) {
+        const double fu = s_uv[2 * k], fv = s_uv[2 * k + 1];
+        if (fu >= us - 10 && fu < uf + 10 && fv >= vs - 10 && fv < vf + 10) { found = true; break; }
+      }
+      if (!found) break;
+      ++i;
+    }
+    rand48[b] = st;
+    pi[kPartRegion + 0] = us; pi[kPartRegion + 1] = vs; pi[kPartRegion + 2] = uf; pi[kPartRegion + 3] = vf;
+    pi[kPartRegionValid] = (i != 5) ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(kDetThreads) k_map_detect(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int height,
+                                                            int* __restrict__ part_i, double* __restrict__ part_d) {
+  const int b = blockIdx.x;
+  int* pi = part_i + (size_t)b * kPartInts;
+  if (!pi[kPartRegionValid]) return;
+  detect_region_wg(frames + (size_t)b * seq_stride, width, height, pi[kPartRegion + 0], pi[kPartRegion + 1], pi[kPartRegion + 2],
+                   pi[kPartRegion + 3], pi + kPartUU, part_d + (size_t)b * kPartDoubles + 2);
+}
+
+// ---------------------------------------------------------------------------
+// k_map_create: one wavefront per sequence.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, double* __restrict__ P, const uint8_t* __restrict__ frames,
+                                                   size_t seq_stride, uint8_t* __restrict__ patch, int* __restrict__ patch_sums,
+                                                   double* __restrict__ xp_org, int* __restrict__ f_flags, int* __restrict__ n_slots,
+                                                   int* __restrict__ attempted, int* __restrict__ successful,
+                                                   int* __restrict__ part_i, double* __restrict__ part_d,
+                                                   double* __restrict__ particles, double* __restrict__ last_r, CameraParams cam,
+                                                   MapParams mp, int N, int ld, int ppos) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* pi = part_i + (size_t)b * kPartInts;
+  double* pd = part_d + (size_t)b * kPartDoubles;
+  if (!pi[kPartRegionValid]) return;
+  if (!(pd[2] > 20000)) return;        // SUITABLE_PATCH_SCORE_THRESHOLD (:837, 850-858)
+  double* xb = x + (size_t)b * ld;
+  double* Pb = P + (size_t)b * ld * ld;
+  const int label = n_slots[b];
+  const int uu = pi[kPartUU], vv = pi[kPartVV];
+  __shared__ double s_T[6 * 13], s_D[12], s_col[6 * 13], s_y[6], s_Ri;
+  if (lane == 0) {
+    double xp[7], ypi[6], Tq[12], Dh[6], Ri;
+    for (int i = 0; i < 7; ++i) xp[i] = xb[i];
+    const double hi[2] = {(double)uu, (double)vv};
+    part_create_model(cam, xp, hi, ypi, Tq, Dh, &Ri);
+    for (int i = 0; i < 6 * 13; ++i) s_T[i] = 0.0;
+    for (int k = 0; k < 3; ++k) s_T[k * 13 + k] = 1.0;
+    for (int k = 0; k < 3; ++k)
+      for (int j = 0; j < 4; ++j) s_T[(3 + k) * 13 + 3 + j] = Tq[k * 4 + j];
+    for (int i = 0; i < 12; ++i) s_D[i] = 0.0;
+    for (int k = 0; k < 3; ++k) { s_D[(3 + k) * 2 + 0] = Dh[k * 2 + 0]; s_D[(3 + k) * 2 + 1] = Dh[k * 2 + 1]; }
+    for (int i = 0; i < 6; ++i) s_y[i] = ypi[i];
+    s_Ri = Ri;
+  }
+  __syncthreads();
+  // new columns: P[c][ppos + k] = sum_i T[k][i] P[i][c]  (Pxy = Pxx T^T and (T Pxy_j)^T, feature.cpp:82-103)
+  const int n_rows = 13 + 3 * label;
+  for (int c = lane; c < n_rows; c += 64) {
+    double pc[13];
+    for (int i = 0; i < 13; ++i) pc[i] = (c < 13) ? Pb[(size_t)c * ld + i] : Pb[(size_t)i * ld + c];
+    for (int k = 0; k < 6; ++k) {
+      double acc = 0.0;
+      for (int i = 0; i < 13; ++i) acc += pc[i] * s_T[k * 13 + i];
+      Pb[(size_t)c * ld + ppos + k] = acc;
+      Pb[(size_t)(ppos + k) * ld + c] = acc;
+      if (c < 13) s_col[k * 13 + c] = acc;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    // Pyy = (T Pxx) T^T + (D Ri) D^T
+    for (int k = 0; k < 6; ++k)
+      for (int l = 0; l < 6; ++l) {
+        double a1 = 0.0;
+        for (int j = 0; j < 13; ++j) a1 += s_col[k * 13 + j] * s_T[l * 13 + j];
+        double a2 = 0.0;
+        for (int c = 0; c < 2; ++c) a2 += (s_D[k * 2 + c] * s_Ri) * s_D[l * 2 + c];
+        Pb[(size_t)(ppos + k) * ld + ppos + l] = a1 + a2;
+      }
+    for (int i = 0; i < 6; ++i) xb[ppos + i] = s_y[i];
+    // label slot: reserved, not yet a 3-D point
+    const size_t fi = (size_t)b * N + label;
+    for (int k = 0; k < 7; ++k) xp_org[fi * 8 + k] = xb[k];
+    xp_org[fi * 8 + 7] = 0.0;
+    f_flags[fi] = FF_USED | FF_PARTIAL;
+    attempted[fi] = 0; successful[fi] = 0;
+    n_slots[b] = label + 1;
+    // template: copy_into_patch (:1240-1251) + the packed form the search kernels read
+    const uint8_t* img = frames + (size_t)b * seq_stride;
+    uint8_t* pt = patch + fi * kPatchStride;
+    int s0 = 0, s0sq = 0;
+    for (int r = 0; r < 11; ++r)
+      for (int c = 0; c < 11; ++c) {
+        const int g = img[(size_t)(r + vv - 5) * cam.width + c + uu - 5];
+        pt[r * 11 + c] = (uint8_t)g;
+        s0 += g; s0sq += g * g;
+      }
+    for (int p = 121; p < kPatchPackedOffset; ++p) pt[p] = 0;
+    unsigned* packed = (unsigned*)(pt + kPatchPackedOffset);
+    for (int r = 0; r < 11; ++r)
+      for (int d = 0; d < 3; ++d) {
+        unsigned v = 0;
+        for (int k = 0; k < 4; ++k) {
+          const int col = 4 * d + k;
+          if (col < 11) v |= (unsigned)pt[r * 11 + col] << (8 * k);
+        }
+        packed[r * 3 + d] = v;
+      }
+    {
+      const double g0bar = (double)s0 / 121.0;
+      const double varg0 = (double)s0sq / 121.0 - (g0bar * g0bar);
+      const double sigmag0 = sqrt(varg0);
+      packed[33] = (unsigned)s0; packed[34] = (unsigned)s0sq;
+      packed[35] = (sigmag0 < kCorrelationSigmaThreshold) ? 0u : 1u;
+      for (int k = 36; k < (kPatchStride - kPatchPackedOffset) / 4; ++k) packed[k] = 0u;
+    }
+    patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
+    // particle set: uniform prior over [min_lambda, max_lambda) (:1222-1236)
+    const double lambda_step = (1.0 / double(mp.n_particles)) * (mp.max_lambda - mp.min_lambda);
+    const double uniform_probability = 1.0 / double(mp.n_particles);
+    double lambda = mp.min_lambda;
+    double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
+    for (int i = 0; i < mp.n_particles; ++i) {
+      double* o = pp + (size_t)i * kParticleDoubles;
+      for (int k = 0; k < kParticleDoubles; ++k) o[k] = 0.0;
+      o[0] = lambda; o[1] = uniform_probability;
+      lambda += lambda_step;
+    }
+    pi[kPartActive] = 1; pi[kPartLabel] = label; pi[kPartAttempts] = 0; pi[kPartNp] = mp.n_particles; pi[kPartMaking] = 0;
+    pi[kPartCreated] = 1;
+    pi[kPartInitialised] += 1;
+    pd[0] = 0.0; pd[1] = 0.0;
+    for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xb[k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_map_particles: one workgroup per sequence, one thread per particle.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
+                                                                 int* __restrict__ part_i, double* __restrict__ particles,
+                                                                 int* __restrict__ me_desc, double* __restrict__ last_r,
+                                                                 CameraParams cam, int ld, int ppos) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int* pi = part_i + (size_t)b * kPartInts;
+  if (!pi[kPartActive]) return;
+  __shared__ int s_making;
+  if (tid == 0) {
+    const int att = pi[kPartAttempts];
+    pi[kPartAttempts] = att + 1;                 // number_of_match_attempts_++ != 0  (Q29)
+    s_making = (att != 0) ? 1 : 0;
+    pi[kPartMaking] = s_making;
+  }
+  __syncthreads();
+  if (!s_making) return;
+  const double* xb = x + (size_t)b * ld;
+  const double* Pb = P + (size_t)b * ld * ld;
+  if (tid == 0)
+    for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xb[k];   // func_zeroedyi -> func_r(xp), Q12
+  const int np = pi[kPartNp];
+  if (tid >= np) return;
+  double xp[7], ypi[6];
+  for (int i = 0; i < 7; ++i) xp[i] = xb[i];
+  for (int i = 0; i < 6; ++i) ypi[i] = xb[ppos + i];
+  double* o = particles + ((size_t)b * kMaxParticles + tid) * kParticleDoubles;
+  double h[2], Hx[14], Hy[12], Rn;
+  part_measurement_model(cam, xp, ypi, o[0], h, Hx, Hy, &Rn);
+  double Pxx7[49], Pxy7[42], Pyy[36], S[4];
+  for (int r = 0; r < 7; ++r) {
+    for (int c = 0; c < 7; ++c) Pxx7[r * 7 + c] = Pb[(size_t)r * ld + c];
+    for (int c = 0; c < 6; ++c) Pxy7[r * 6 + c] = Pb[(size_t)r * ld + ppos + c];
+  }
+  for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c) Pyy[r * 6 + c] = Pb[(size_t)(ppos + r) * ld + ppos + c];
+  innovation_cov6(Hx, Hy, Rn, Pxx7, Pxy7, Pyy, S);
+  double a, bq, c;
+  sinv_from_S(S, &a, &bq, &c);
+  o[3] = h[0]; o[4] = h[1];
+  o[7] = a; o[8] = bq; o[9] = c;
+  o[10] = det2_partial_pivot_lu(S);
+  me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * kMaxParticles + tid) * 8);
+}
+
+__global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
+                                                       const uint8_t* __restrict__ patch, const int* __restrict__ part_i,
+                                                       const int* __restrict__ me_desc, const double* __restrict__ particles,
+                                                       double* __restrict__ score_map, int N, int height) {
+  const int b = blockIdx.y, p = blockIdx.x;
+  const int* pi = part_i + (size_t)b * kPartInts;
+  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
+  const size_t fi = (size_t)b * N + pi[kPartLabel];
+  me_score_ellipse_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, 0, p, me_desc + (size_t)b * kMaxParticles * 8,
+                      particles + (size_t)b * kMaxParticles * kParticleDoubles + 7, kParticleDoubles,
+                      score_map + (size_t)b * width * height);
+}
+
+__global__ void __launch_bounds__(64) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
+                                                      const int* __restrict__ me_desc, double* __restrict__ particles,
+                                                      const double* __restrict__ score_map) {
+  const int b = blockIdx.y, p = blockIdx.x;
+  const int* pi = part_i + (size_t)b * kPartInts;
+  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
+  double* o = particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles;
+  __shared__ int s_res[3];
+  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
+  if (threadIdx.x == 0) {
+    if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
+      o[5] = (double)s_res[1];
+      o[6] = (double)s_res[2];
+      o[11] = 1.0;
+    } else {
+      o[11] = 0.0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// k_map_update: one wavefront per sequence.  Lane 0 walks the particle list exactly like the reference
+// (Bayes update, normalise, prune, normalise, mean / covariance, conversion and sell-by tests); the
+// covariance surgery of a conversion / deletion is done by all lanes.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, double* __restrict__ P, int* __restrict__ f_flags,
+                                                   const int* __restrict__ n_slots, int* __restrict__ part_i,
+                                                   double* __restrict__ part_d, double* __restrict__ particles,
+                                                   double* __restrict__ traj, int* __restrict__ traj_count,
+                                                   const double* __restrict__ last_r, MapParams mp, int N, int ld, int ppos) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int* pi = part_i + (size_t)b * kPartInts;
+  double* pd = part_d + (size_t)b * kPartDoubles;
+  double* xb = x + (size_t)b * ld;
+  double* Pb = P + (size_t)b * ld * ld;
+  __shared__ int s_action;         // 0 none, 1 convert, 2 delete
+  __shared__ double s_lambda, s_plambda;
+  if (lane == 0) {
+    int action = 0;
+    if (pi[kPartActive]) {
+      double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
+      int np = pi[kPartNp];
+      if (pi[kPartMaking]) {
+        // update_partially_initialised_feature_probabilities (:1449-1497)
+        for (int i = 0; i < np; ++i) {
+          double* o = pp + (size_t)i * kParticleDoubles;
+          double likelihood = 0.0;
+          if (o[11] != 0.0) likelihood = particle_likelihood(o + 5, o + 3, o + 7, o[10]);
+          o[1] = o[1] * likelihood;
+        }
+        double total = 0.0;
+        for (int i = 0; i < np; ++i) total += pp[(size_t)i * kParticleDoubles + 1];
+        if (total == 0.0) {
+          action = 2;                  // every match failed: the feature goes (:1490-1494)
+        } else {
+          double cum = 0.0;
+          for (int i = 0; i < np; ++i) {
+            double* o = pp + (size_t)i * kParticleDoubles;
+            o[1] = o[1] / total;
+            o[2] = cum + o[1];
+            cum += o[1];
+          }
+          // prune_particle_vector (feature_init_info.cpp:131-147)
+          const double prune_threshold = mp.prune_threshold / double(np);
+          int kept = 0;
+          for (int i = 0; i < np; ++i) {
+            const double* src = pp + (size_t)i * kParticleDoubles;
+            if (src[1] < prune_threshold) continue;
+            if (kept != i) {
+              double* dst = pp + (size_t)kept * kParticleDoubles;
+              for (int k = 0; k < kParticleDoubles; ++k) dst[k] = src[k];
+            }
+            ++kept;
+          }
+          np = kept;
+          pi[kPartNp] = np;
+          total = 0.0;
+          for (int i = 0; i < np; ++i) total += pp[(size_t)i * kParticleDoubles + 1];
+          if (total != 0.0) {
+            cum = 0.0;
+            for (int i = 0; i < np; ++i) {
+              double* o = pp + (size_t)i * kParticleDoubles;
+              o[1] = o[1] / total;
+              o[2] = cum + o[1];
+              cum += o[1];
+            }
+          }
+          // calculate_mean_and_covariance (feature_init_info.cpp:157-174)
+          double mean = 0.0, e2 = 0.0;
+          for (int i = 0; i < np; ++i) {
+            const double* o = pp + (size_t)i * kParticleDoubles;
+            mean += o[1] * o[0];
+            e2 += o[1] * (o[0] * o[0]);
+          }
+          pd[0] = mean;
+          pd[1] = e2 - (mean * mean);
+          // conversion test (:1320-1332)
+          const double mean_sd_ratio = sqrt(pd[1]) / pd[0];
+          if (mean_sd_ratio < mp.sd_ratio && np > mp.min_particles) action = 1;
+        }
+      }
+      // delete_partially_initialised_features_past_sell_by_date (:1506-1521)
+      if (action == 0 && (pi[kPartAttempts] > mp.erase_after || np <= mp.min_particles)) action = 2;
+    }
+    s_action = action;
+    s_lambda = pd[0];
+    s_plambda = pd[1];
+  }
+  __syncthreads();
+  const int action = s_action;
+  if (action != 0) {
+    const int label = pi[kPartLabel];
+    const int fpos = 13 + 3 * label;
+    const int n_rows = 13 + 3 * n_slots[b];
+    if (action == 1) {
+      // convert_from_partially_to_fully_initialised (feature.cpp:204-269): J = [I3 | lambda I3], d = hhat
+      const double lam = s_lambda;
+      for (int c = lane; c < n_rows; c += 64) {
+        if (c >= fpos && c < fpos + 3) continue;
+        for (int k = 0; k < 3; ++k) {
+          // sum over the six partial states; only m = k and m = 3 + k are non-zero in J
+          double acc = 0.0;
+          for (int m = 0; m < 6; ++m) {
+            const double j = (m == k) ? 1.0 : ((m == 3 + k) ? lam : 0.0);
+            acc += Pb[(size_t)c * ld + ppos + m] * j;
+          }
+          Pb[(size_t)c * ld + fpos + k] = acc;
+          Pb[(size_t)(fpos + k) * ld + c] = acc;
+        }
+      }
+      if (lane == 0) {
+        double Pyy6[36], JP[18], d[3], y3[3];
+        for (int r = 0; r < 6; ++r)
+          for (int c = 0; c < 6; ++c) Pyy6[r * 6 + c] = Pb[(size_t)(ppos + r) * ld + ppos + c];
+        for (int k = 0; k < 3; ++k)
+          for (int c = 0; c < 6; ++c) {
+            double acc = 0.0;
+            for (int m = 0; m < 6; ++m) {
+              const double j = (m == k) ? 1.0 : ((m == 3 + k) ? lam : 0.0);
+              acc += j * Pyy6[m * 6 + c];
+            }
+            JP[k * 6 + c] = acc;
+          }
+        for (int k = 0; k < 3; ++k) { d[k] = xb[ppos + 3 + k]; y3[k] = xb[ppos + k] + lam * xb[ppos + 3 + k]; }
+        for (int k = 0; k < 3; ++k)
+          for (int l = 0; l < 3; ++l) {
+            double a1 = 0.0;
+            for (int m = 0; m < 6; ++m) {
+              const double j = (m == l) ? 1.0 : ((m == 3 + l) ? lam : 0.0);
+              a1 += JP[k * 6 + m] * j;
+            }
+            const double a2 = (d[k] * s_plambda) * d[l];
+            Pb[(size_t)(fpos + k) * ld + fpos + l] = a1 + a2;
+          }
+        for (int k = 0; k < 3; ++k) xb[fpos + k] = y3[k];
+        f_flags[(size_t)b * N + label] = FF_USED | FF_ACTIVE;
+        pi[kPartConverted] += 1;
+      }
+    } else if (lane == 0) {
+      f_flags[(size_t)b * N + label] = FF_USED;     // delete_feature(): the label is consumed
+      pi[kPartDeleted] += 1;
+    }
+    __syncthreads();
+    // the six partial rows / columns are released (zero = absent)
+    for (int c = lane; c < ld; c += 64)
+      for (int k = 0; k < 6; ++k) {
+        Pb[(size_t)c * ld + ppos + k] = 0.0;
+        Pb[(size_t)(ppos + k) * ld + c] = 0.0;
+      }
+    if (lane == 0) {
+      for (int k = 0; k < 6; ++k) xb[ppos + k] = 0.0;
+      pi[kPartActive] = 0; pi[kPartMaking] = 0; pi[kPartNp] = 0;
+    }
+  }
+  if (lane == 0 && mp.save_trajectory) {   // monoslam.cpp:172-177, after the mapping tail (stale rRES_, Q12)
+    const int c = traj_count[b];
+    double* t = traj + ((size_t)b * kTrajCapacity + (c % kTrajCapacity)) * 3;
+    for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
+    traj_count[b] = c + 1;
+  }
+}
+
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
+  const int B = e->B;
+  MapParams mp;
+  mp.enable_mapping = enable_mapping; mp.save_trajectory = save_trajectory;
+  mp.keep_visible = e->prm.number_of_features_to_keep_visible;
+  mp.n_particles = e->prm.number_of_particles;
+  mp.min_particles = e->prm.min_number_of_particles;
+  mp.erase_after = e->prm.erase_partially_init_feature_after_this_many_attempts;
+  mp.min_lambda = e->prm.min_lambda; mp.max_lambda = e->prm.max_lambda;
+  mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
+  mp.dt = e->prm.delta_t;
+  const int W = e->cam.width, H = e->cam.height;
+  if (!e->score_map) {
+    SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * (size_t)B * W * H));
+  }
+  {
+    LaunchScope ls(e, "k_map_region");
+    hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
+                       e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_detect");
+    hipLaunchKernelGGL(k_map_detect, dim3(B), dim3(kDetThreads), 0, e->stream, e->cur_frames, e->cur_stride, W, H, e->part_i, e->part_d);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_create");
+    hipLaunchKernelGGL(k_map_create, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch, e->patch_sums,
+                       e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->part_i, e->part_d, e->particles,
+                       e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_particles");
+    hipLaunchKernelGGL(k_map_particles, dim3(B), dim3(kMaxParticles), 0, e->stream, e->x, e->P, e->part_i, e->particles, e->me_desc,
+                       e->last_r, e->cam, e->ld, e->ppos);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_search");
+    hipLaunchKernelGGL(k_map_me_scores, dim3(mp.n_particles, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
+                       e->part_i, e->me_desc, e->particles, e->score_map, e->N, H);
+    hipLaunchKernelGGL(k_map_me_argmin, dim3(mp.n_particles, B), dim3(64), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
+                       e->score_map);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_update");
+    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i, e->part_d,
+                       e->particles, e->traj, e->traj_count, e->last_r, mp, e->N, e->ld, e->ppos);
+    SL2_HIP(hipGetLastError());
+  }
+  return SL2_OK;
+}
+
+}  // namespace sl2

@@ -152,8 +152,27 @@ class Engine:
                             y=np.array(f.y[:]), h=np.array(f.h[:]), z=np.array(f.z[:]), nu=np.array(f.nu[:]),
                             R=float(f.R), S=np.array(f.S[:]).reshape(2, 2),
                             dh_by_dxp=np.array(f.dh_by_dxp[:]).reshape(2, 7),
-                            dh_by_dy=np.array(f.dh_by_dy[:]).reshape(2, 3), xp_org=np.array(f.xp_org[:])))
+                            dh_by_dy=np.array(f.dh_by_dy[:]).reshape(2, 3), xp_org=np.array(f.xp_org[:]),
+                            fully_initialised=bool(f.fully_initialised_flag), state_size=int(f.state_size),
+                            y_direction=np.array(f.y_direction[:])))
         return out
+
+    def partial_feature(self, seq, capacity=128):
+        """The partially initialised feature of a sequence (FeatureInitInfo + particles), or None; plus the mapping
+        counters of the sequence under key 'info' either way."""
+        ints = np.zeros(16, dtype=np.int32)
+        dbl = np.zeros(9)
+        parts = np.zeros((capacity, 12))
+        _lib.check(self.L.sl2_get_partial_feature(self.h, seq, _lib.ip(ints), _lib.dp(dbl), _lib.dp(parts), capacity))
+        info = dict(n_partial=int(ints[0]), initialised=int(ints[12]), converted=int(ints[13]), deleted=int(ints[14]),
+                    uu=int(ints[5]), vv=int(ints[6]), region_defined=int(ints[7]), ustart=int(ints[8]), vstart=int(ints[9]),
+                    ufinish=int(ints[10]), vfinish=int(ints[11]), created=int(ints[15]), evbest=float(dbl[8]))
+        if not ints[0]:
+            return dict(info=info, pf=None)
+        n = int(ints[3])
+        return dict(info=info, pf=dict(label=int(ints[1]), n_particles=n, attempts=int(ints[2]), making=bool(ints[4]),
+                                       mean=float(dbl[0]), covariance=float(dbl[1]), y=dbl[2:8].copy(),
+                                       particles=parts[:n].copy()))
 
     def selection(self, seq):
         labels = np.zeros(self.max_features, dtype=np.int32)
@@ -232,7 +251,7 @@ class Feature:
         self.attempted_measurements_of_feature_ = d["attempted"]
         self.successful_measurements_of_feature_ = d["successful"]
         self.position_in_total_state_vector_ = d["pos"]
-        self.fully_initialised_flag_ = True
+        self.fully_initialised_flag_ = d.get("fully_initialised", True)
         self.patch_ = patch
 
 

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     from scenelib2_amd import _lib
     assert C.sizeof(_lib.sl2_camera) == 56          # 2 x i32, 5 x f64, i32 (+pad)
     assert C.sizeof(_lib.sl2_params) == 88
-    assert C.sizeof(_lib.sl2_feature_info) == 8 * 4 + 8 * (3 + 2 + 2 + 2 + 1 + 4 + 14 + 6 + 7)
+    assert C.sizeof(_lib.sl2_feature_info) == 8 * 4 + 8 * (3 + 2 + 2 + 2 + 1 + 4 + 14 + 6 + 7) + 2 * 4 + 8 * 3
 
 
 def test_no_gpu_means_loud_failure():

@@ -1,0 +1,79 @@
+"""GPU parity of GoOneStep(enable_mapping = true): the engine against the oracle's restatement of the feature-
+initialisation path on a synthetic sequence that initialises, matches, converts and deletes features."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from mapping_helpers import make_mapping_sequence, oracle_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cam, params, spec, templates, max_features=32, batch=1):
+    from scenelib2_amd import Engine
+    eng = Engine(cam, params, batch, max_features)
+    eng.set_vehicle_state(np.tile(spec.xv0, (batch, 1)), np.tile(spec.Pxx0, (batch, 1, 1)))
+    eng.add_known_features(np.tile(spec.feat_y, (batch, 1, 1)), np.tile(spec.xp_org(), (batch, 1, 1)),
+                           np.tile(templates, (batch, 1, 1, 1)))
+    return eng
+
+
+def test_mapping_step_by_step_matches_oracle():
+    cam, params, spec, frames, templates = make_mapping_sequence()
+    s = oracle_for(cam, params, spec, templates, oa)
+    eng = _engine(cam, params, spec, templates)
+    n_events = dict(initialised=0, converted=0, deleted=0)
+    for k in range(1, spec.n_frames + 1):
+        s.go_one_step(frames[k], True, True)
+        eng.go_one_step(frames[k][None], save_trajectory=True, enable_mapping=True)
+        info = s.mapping_info()
+        got = eng.partial_feature(0)
+        for key in ("initialised", "converted", "deleted", "n_partial"):
+            assert got["info"][key] == info[key], (k, key, got["info"], info)
+        if info["region_defined"]:
+            assert (got["info"]["ustart"], got["info"]["vstart"], got["info"]["ufinish"], got["info"]["vfinish"]) == \
+                   (info["ustart"], info["vstart"], info["ufinish"], info["vfinish"]), k
+            assert (got["info"]["uu"], got["info"]["vv"]) == (info["uu"], info["vv"]), k
+        pf = s.partial_feature(0)
+        if pf is not None:
+            g = got["pf"]
+            assert g["label"] == pf["label"] and g["n_particles"] == pf["n_particles"] and g["attempts"] == pf["attempts"], k
+            assert g["making"] == pf["making"], k
+            assert np.allclose(g["y"], pf["y"], rtol=0, atol=1e-10), k
+            a, b = g["particles"], pf["particles"]
+            assert np.array_equal(a[:, 0], b[:, 0]), k                                  # lambda grid
+            assert np.allclose(a[:, 1], b[:, 1], rtol=1e-9, atol=1e-300), k             # probabilities
+            if pf["making"]:
+                assert np.allclose(a[:, 3:5], b[:, 3:5], rtol=0, atol=1e-8), k          # predicted measurements
+                assert np.allclose(a[:, 7:11], b[:, 7:11], rtol=1e-8), k                # S^-1, det S
+                assert np.array_equal(a[:, 11], b[:, 11]), k                            # match flags
+                ok = b[:, 11] != 0
+                assert np.array_equal(a[ok, 5:7], b[ok, 5:7]), k                        # measured positions
+                assert abs(g["mean"] - pf["mean"]) < 1e-9 and abs(g["covariance"] - pf["covariance"]) < 1e-9, k
+        # total state / covariance in the reference's order (partial feature: six states at its place in the list)
+        x0, P0 = s.total_state(), s.total_covariance()
+        assert eng.total_state_sizes(0, 1)[0] == x0.size, k
+        x1, P1 = eng.total_state(0), eng.total_covariance(0)
+        assert np.abs(x1 - x0).max() < 1e-9, (k, np.abs(x1 - x0).max())
+        assert np.linalg.norm(P1 - P0) <= 1e-8 * max(np.linalg.norm(P0), 1e-12), k
+        kinds = s.feature_kinds()
+        feats = eng.features(0)
+        assert [f["label"] for f in feats] == list(kinds[:, 2]) and [f["state_size"] for f in feats] == list(kinds[:, 0]), k
+    last = s.mapping_info()
+    assert last["initialised"] >= 2 and last["converted"] >= 1 and last["deleted"] >= 1
+    t0, t1 = s.trajectory(), eng.trajectory(0)
+    assert t0.shape == t1.shape and np.abs(t0 - t1).max() < 1e-9       # trajectory_store_ incl. its stale-scratch entries (Q12)
+
+
+def test_mapping_rejects_unsupported_settings_and_needs_flag():
+    from scenelib2_amd import _lib
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=3)
+    p2 = dict(params); p2["max_features_to_init_at_once"] = 2
+    eng = _engine(cam, p2, spec, templates)
+    with pytest.raises(_lib.Sl2Error):
+        eng.go_one_step(frames[1][None], enable_mapping=True)
+    # mapping off: nothing is ever initialised
+    eng = _engine(cam, params, spec, templates)
+    for k in range(1, 4):
+        eng.go_one_step(frames[k][None], enable_mapping=False)
+    assert eng.partial_feature(0)["info"]["initialised"] == 0 and len(eng.features(0)) == spec.n_features

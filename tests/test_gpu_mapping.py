@@ -77,3 +77,27 @@ def test_mapping_rejects_unsupported_settings_and_needs_flag():
     for k in range(1, 4):
         eng.go_one_step(frames[k][None], enable_mapping=False)
     assert eng.partial_feature(0)["info"]["initialised"] == 0 and len(eng.features(0)) == spec.n_features
+
+
+def test_mapping_batch_of_different_sequences():
+    """Three sequences with different paths / textures stepped together: each must follow its own oracle
+    (own generator state, own partial feature, own map growth)."""
+    from scenelib2_amd import Engine
+    seqs = [make_mapping_sequence(seed=sd, n_frames=24, v_amp=va) for sd, va in ((7, 0.45), (11, 0.4), (23, 0.5))]
+    cam, params = seqs[0][0], seqs[0][1]
+    oracles = [oracle_for(cam, params, q[2], q[4], oa) for q in seqs]
+    eng = Engine(cam, params, 3, 32)
+    eng.set_vehicle_state(np.stack([q[2].xv0 for q in seqs]), np.stack([q[2].Pxx0 for q in seqs]))
+    eng.add_known_features(np.stack([q[2].feat_y for q in seqs]), np.stack([q[2].xp_org() for q in seqs]),
+                           np.stack([q[4] for q in seqs]))
+    for k in range(1, 25):
+        eng.go_one_step(np.stack([q[3][k] for q in seqs]), enable_mapping=True)
+        for b, s in enumerate(oracles):
+            s.go_one_step(seqs[b][3][k], False, True)
+            info, got = s.mapping_info(), eng.partial_feature(b)["info"]
+            assert [got[key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
+                   [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], (k, b)
+            x0, x1 = s.total_state(), eng.total_state(b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
+    assert sum(s.mapping_info()["initialised"] for s in oracles) >= 5
+    assert not eng.status_flags().any()

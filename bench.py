@@ -51,12 +51,17 @@ def main():
 
     rank, world, local_rank = sharding.env_rank_world()
     if world > 1:
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        # RCCL ("nccl" on ROCm).  SL2_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU on a
+        # single-GPU box to exercise this multi-rank code path (collectives then run on host tensors).
+        backend = os.environ.get("SL2_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        dist.init_process_group(backend)
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     tdev = torch.device("cuda", dev)
+    if world > 1 and dist.get_backend() != "nccl":
+        tdev = None
 
     B, N, W, H = args.batch, args.features, args.width, args.height
     K, Wm = args.steps, args.warmup

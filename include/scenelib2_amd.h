@@ -203,6 +203,25 @@ int sl2_search_multiple_overlapping_ellipses_batch(int device, const uint8_t* im
                                                    const int32_t* ellipse_count, const double* puinv, const double* centre,
                                                    int32_t* result, double* corrmax, double* kernel_ms);
 
+/* ------------------------------------------------------------- frame ingest */
+
+/* FileGrabber::ProcessFiles (framegrabber/filegrabber.cpp:63-83): every regular file below `dir`, recursively,
+ * sorted by full path.  buf receives the paths separated by '\n' (may be NULL to query *count only).  Host only. */
+int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count);
+/* One binary PGM (P5, maxval <= 255) -> 8-bit grey, row-major, step == width (the frame contract of GoOneStep;
+ * the reference decodes with cv::imread(path, 0), filegrabber.cpp:105-108).  out may be NULL to query the size.  Host only. */
+int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
+/* FileGrabber + FrameGrabber for a batch: dirs[s] is the frame directory of sequence s.  A producer thread decodes
+ * ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of
+ * every sequence asynchronously on `stream` into one of two device buffers and returns it for
+ * sl2_go_one_step(frames_on_device = 1).  The returned pointer stays valid until the next-but-one call on the same
+ * stream.  SL2_ERR_CAPACITY = the shortest sequence is exhausted (sl2_ingest_frame_count). */
+typedef struct sl2_ingest sl2_ingest;
+int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, int device, int depth, sl2_ingest** out);
+int sl2_ingest_frame_count(const sl2_ingest* g);
+int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride);
+void sl2_ingest_close(sl2_ingest* g);
+
 /* ----------------------------------------------------------------- state access */
 
 /* total_state_size_ per sequence (13 + 3 * live features). */

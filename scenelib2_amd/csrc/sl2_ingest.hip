@@ -1,0 +1,260 @@
+// Frame ingest: the FileGrabber / FrameGrabber pair of the reference
+// (framegrabber/filegrabber.cpp:53-109, framegrabber/framegrabber.cpp:73-104) for a batch of
+// sequences, feeding sl2_go_one_step(frames_on_device = 1).
+//
+//   * listing: every regular file below the sequence's directory, recursively, sorted by full path
+//     (byte-wise std::sort on the path strings, filegrabber.cpp:63-83);
+//   * decode: 8-bit single-channel, row-major, step == width — the only contract GoOneStep relies on
+//     (SURVEY 2, row 14).  Container: binary PGM (P5, maxval <= 255), the format of the reference's own
+//     fixtures; the reference decodes through cv::imread(path, 0), which is not re-implemented;
+//   * a producer thread decodes ahead into pinned host buffers (the reference queues <= 50 frames,
+//     framegrabber.cpp:93-104; here `depth` batches), the consumer uploads one batch per call with an
+//     asynchronous copy into one of two device buffers, so the copy of frame k+1 overlaps the step on
+//     frame k when both are issued on different streams.
+#include <dirent.h>
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "sl2_common.hpp"
+
+namespace sl2 {
+
+static bool list_files_recursive(const std::string& dir, std::vector<std::string>& out) {
+  DIR* d = opendir(dir.c_str());
+  if (!d) return false;
+  while (dirent* ent = readdir(d)) {
+    const std::string name = ent->d_name;
+    if (name == "." || name == "..") continue;
+    const std::string path = dir + "/" + name;
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) continue;
+    if (S_ISDIR(st.st_mode)) {
+      if (!list_files_recursive(path, out)) { closedir(d); return false; }
+    } else {
+      out.push_back(path);
+    }
+  }
+  closedir(d);
+  std::sort(out.begin(), out.end());
+  return true;
+}
+
+// binary PGM -> grey bytes.  Returns false (and sets the error string) on anything else.
+static bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_error(("cannot open " + path).c_str()); return false; }
+  auto token = [&](std::string& t) -> bool {
+    t.clear();
+    int c;
+    for (;;) {
+      c = fgetc(f);
+      if (c == '#') { while (c != '\n' && c != EOF) c = fgetc(f); continue; }
+      if (c == EOF) return false;
+      if (c != ' ' && c != '\t' && c != '\n' && c != '\r') break;
+    }
+    while (c != EOF && c != ' ' && c != '\t' && c != '\n' && c != '\r') { t.push_back((char)c); c = fgetc(f); }
+    return !t.empty();
+  };
+  std::string magic, sw, sh, smax;
+  bool ok = token(magic) && magic == "P5" && token(sw) && token(sh) && token(smax);
+  int W = 0, H = 0, maxval = 0;
+  if (ok) { W = atoi(sw.c_str()); H = atoi(sh.c_str()); maxval = atoi(smax.c_str()); }
+  ok = ok && W > 0 && H > 0 && maxval > 0 && maxval <= 255;
+  if (ok) {
+    px.resize((size_t)W * H);
+    ok = fread(px.data(), 1, px.size(), f) == px.size();
+  }
+  fclose(f);
+  if (!ok) { set_error(("not a binary 8-bit PGM: " + path).c_str()); return false; }
+  *w = W; *h = H;
+  return true;
+}
+
+}  // namespace sl2
+
+struct sl2_ingest {
+  int device = 0, nseq = 0, width = 0, height = 0, depth = 0;
+  std::vector<std::vector<std::string>> files;   // per sequence, sorted
+  int n_frames = 0;                               // min over sequences
+  // ring of `depth` pinned host batches [nseq][W*H]
+  std::vector<uint8_t*> host;
+  std::vector<int> state;        // 0 free, 1 decoded, 2 in flight (uploaded, waiting for its event)
+  std::vector<hipEvent_t> done;
+  int produced = 0, consumed = 0;
+  bool stop = false, failed = false;
+  std::string fail_msg;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread producer;
+  uint8_t* dev[2] = {nullptr, nullptr};
+  int flip = 0;
+
+  void run() {
+    const size_t fb = (size_t)width * height;
+    std::vector<uint8_t> px;
+    for (int k = 0; k < n_frames; ++k) {
+      const int slot = k % depth;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || state[slot] == 0; });
+        if (stop) return;
+      }
+      for (int s = 0; s < nseq; ++s) {
+        int w = 0, h = 0;
+        if (!sl2::read_pgm(files[s][k], px, &w, &h) || w != width || h != height) {
+          std::lock_guard<std::mutex> lk(mu);
+          failed = true;
+          fail_msg = "frame " + files[s][k] + " is not a " + std::to_string(width) + "x" + std::to_string(height) + " binary PGM";
+          cv.notify_all();
+          return;
+        }
+        memcpy(host[slot] + (size_t)s * fb, px.data(), fb);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        state[slot] = 1;
+        ++produced;
+      }
+      cv.notify_all();
+    }
+  }
+};
+
+extern "C" {
+
+int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count) {
+  using namespace sl2;
+  if (!dir || !count) return SL2_ERR_INVALID;
+  std::vector<std::string> files;
+  if (!list_files_recursive(dir, files)) { set_error("sl2_list_frames: provided directory doesn't exist"); return SL2_ERR_INVALID; }
+  *count = (int)files.size();
+  size_t need = 1;
+  for (const auto& f : files) need += f.size() + 1;
+  if (!buf) return SL2_OK;
+  if (need > capacity) return SL2_ERR_CAPACITY;
+  char* p = buf;
+  for (const auto& f : files) { memcpy(p, f.c_str(), f.size()); p += f.size(); *p++ = '\n'; }
+  *p = 0;
+  return SL2_OK;
+}
+
+int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, int* height) {
+  using namespace sl2;
+  if (!path || !width || !height) return SL2_ERR_INVALID;
+  std::vector<uint8_t> px;
+  if (!read_pgm(path, px, width, height)) return SL2_ERR_INVALID;
+  if (!out) return SL2_OK;
+  if (px.size() > capacity) return SL2_ERR_CAPACITY;
+  memcpy(out, px.data(), px.size());
+  return SL2_OK;
+}
+
+int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, int device, int depth, sl2_ingest** out) {
+  using namespace sl2;
+  if (!dirs || !out || nseq <= 0 || width <= 0 || height <= 0) return SL2_ERR_INVALID;
+  if (depth < 2) depth = 2;
+  if (depth > 50) depth = 50;      // FrameGrabber::IsFrameBufferFull (framegrabber.cpp:93-104)
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device (the engine has no CPU fallback)"); return SL2_ERR_NO_DEVICE; }
+  SL2_HIP(hipSetDevice(device));
+  sl2_ingest* g = new sl2_ingest();
+  g->device = device; g->nseq = nseq; g->width = width; g->height = height; g->depth = depth;
+  g->files.resize(nseq);
+  int nmin = -1;
+  for (int s = 0; s < nseq; ++s) {
+    if (!dirs[s] || !list_files_recursive(dirs[s], g->files[s])) {
+      delete g;
+      set_error("sl2_ingest_open: provided directory doesn't exist");
+      return SL2_ERR_INVALID;
+    }
+    const int n = (int)g->files[s].size();
+    nmin = (nmin < 0 || n < nmin) ? n : nmin;
+  }
+  g->n_frames = nmin;
+  const size_t batch = (size_t)nseq * width * height;
+  g->host.assign(depth, nullptr);
+  g->state.assign(depth, 0);
+  g->done.assign(depth, nullptr);
+  for (int i = 0; i < depth; ++i) {
+    if (hipHostMalloc((void**)&g->host[i], batch, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) {
+      set_error("sl2_ingest_open: pinned allocation failed");
+      return SL2_ERR_HIP;
+    }
+  }
+  for (int i = 0; i < 2; ++i) SL2_HIP(hipMalloc((void**)&g->dev[i], batch));
+  g->producer = std::thread([g] { g->run(); });
+  *out = g;
+  return SL2_OK;
+}
+
+int sl2_ingest_frame_count(const sl2_ingest* g) { return g ? g->n_frames : 0; }
+
+int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride) {
+  using namespace sl2;
+  if (!g || !d_frames || !seq_stride) return SL2_ERR_INVALID;
+  if (g->consumed >= g->n_frames) return SL2_ERR_CAPACITY;     // end of the shortest sequence
+  SL2_HIP(hipSetDevice(g->device));
+  const int slot = g->consumed % g->depth;
+  {
+    // the slot this call needs may still be marked "in flight" from `depth` calls ago: hand it back to the
+    // producer first (its copy was issued long ago; this wait is normally free)
+    bool fly;
+    { std::lock_guard<std::mutex> lk(g->mu); fly = g->state[slot] == 2; }
+    if (fly) {
+      SL2_HIP(hipEventSynchronize(g->done[slot]));
+      { std::lock_guard<std::mutex> lk(g->mu); g->state[slot] = 0; }
+      g->cv.notify_all();
+    }
+  }
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return g->failed || g->state[slot] == 1; });
+    if (g->failed) { set_error(g->fail_msg.c_str()); return SL2_ERR_INVALID; }
+  }
+  const size_t batch = (size_t)g->nseq * g->width * g->height;
+  uint8_t* dst = g->dev[g->flip];
+  g->flip ^= 1;
+  hipStream_t st = (hipStream_t)stream;
+  SL2_HIP(hipMemcpyAsync(dst, g->host[slot], batch, hipMemcpyHostToDevice, st));
+  SL2_HIP(hipEventRecord(g->done[slot], st));
+  { std::lock_guard<std::mutex> lk(g->mu); g->state[slot] = 2; }
+  ++g->consumed;
+  // pinned batches whose copies have completed go back to the producer (decode-ahead)
+  for (int i = 0; i < g->depth; ++i) {
+    bool f2;
+    { std::lock_guard<std::mutex> lk(g->mu); f2 = g->state[i] == 2; }
+    if (f2 && i != slot && hipEventQuery(g->done[i]) == hipSuccess) {
+      { std::lock_guard<std::mutex> lk(g->mu); g->state[i] = 0; }
+      g->cv.notify_all();
+    }
+  }
+  *d_frames = dst;
+  *seq_stride = (size_t)g->width * g->height;
+  return SL2_OK;
+}
+
+void sl2_ingest_close(sl2_ingest* g) {
+  if (!g) return;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->stop = true;
+  }
+  g->cv.notify_all();
+  if (g->producer.joinable()) g->producer.join();
+  hipSetDevice(g->device);
+  hipDeviceSynchronize();
+  for (auto p : g->host) if (p) hipHostFree(p);
+  for (auto e : g->done) if (e) hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) if (g->dev[i]) hipFree(g->dev[i]);
+  delete g;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+"""The headless C++ example (examples/headless_monoslam.cpp) driven end to end on a GPU: cfg file +
+PGM frame directory in, total state out; must equal the oracle fed the same bytes."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from mapping_helpers import make_mapping_sequence, oracle_for
+from scenelib2_amd import ingest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_scene(d, cam, params, spec, frames, templates):
+    lines = ["cam.%s = %.17g;" % (k, cam[k]) for k in ("width", "height", "fku", "fkv", "u0", "v0", "kd1", "sd")]
+    for k in ("delta_t", "number_of_features_to_select", "number_of_features_to_keep_visible", "max_features_to_init_at_once",
+              "min_lambda", "max_lambda", "number_of_particles", "standard_deviation_depth_ratio", "min_number_of_particles",
+              "prune_probability_threshold", "erase_partially_init_feature_after_this_many_attempts"):
+        lines.append("params.%s = %.17g;" % (k, params[k]))
+    names = ["rw_x", "rw_y", "rw_z", "qwr_w", "qwr_x", "qwr_y", "qwr_z", "vw_x", "vw_y", "vw_z", "ww_x", "ww_y", "ww_z"]
+    lines += ["state.%s = %.17g;" % (n, v) for n, v in zip(names, spec.xv0)]
+    for r in range(13):
+        for c in range(13):
+            if spec.Pxx0[r, c] != 0.0:
+                lines.append("state.pxx%d_%d = %.17g;" % (r, c, spec.Pxx0[r, c]))
+    xo = spec.xp_org()
+    for i in range(spec.n_features):
+        p = "f%d." % (i + 1)
+        lines += ["%syi_%s = %.17g;" % (p, ax, spec.feat_y[i, j]) for j, ax in enumerate("xyz")]
+        lines += ["%sxp_org_%d = %.17g;" % (p, j, xo[i, j]) for j in range(7)]
+        lines.append("%sidentifier = patch%d.pgm;   # 11x11 template" % (p, i))
+        ingest.write_pgm(os.path.join(d, "patch%d.pgm" % i), templates[i])
+    with open(os.path.join(d, "scene.cfg"), "w") as f:
+        f.write("# written by the test\n" + "\n".join(lines) + "\n")
+    fd = os.path.join(d, "frames")
+    os.makedirs(fd)
+    for k in range(1, frames.shape[0]):
+        ingest.write_pgm(os.path.join(fd, "%05d.pgm" % k), frames[k])
+    return os.path.join(d, "scene.cfg"), fd
+
+
+@pytest.mark.parametrize("mapping", [False, True])
+def test_headless_example_matches_oracle(tmp_path, mapping):
+    exe = os.path.join(ROOT, "examples", "headless_monoslam")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=20)
+    cfg, fd = _write_scene(str(tmp_path), cam, params, spec, frames, templates)
+    dump = os.path.join(str(tmp_path), "state.txt")
+    cmd = [exe, "--cfg", cfg, "--frames", fd, "--dump", dump] + (["--mapping"] if mapping else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "%d known features, 20 frames" % spec.n_features in out.stdout
+    x = np.loadtxt(dump)
+    s = oracle_for(cam, params, spec, templates, oa)
+    for k in range(1, 21):
+        s.go_one_step(frames[k], True, mapping)
+    x0 = s.total_state()
+    assert x.size == x0.size and np.abs(x - x0).max() < 1e-9
+    if mapping:
+        assert s.mapping_info()["initialised"] >= 2

@@ -152,11 +152,9 @@ int sl2_set_groups(sl2_engine* e, int groups);
  * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
- * chol_variant 1 = fused one-launch Cholesky, four waves per sequence (default, <= 12 blocks of 32),
- *              2 = the two-wave version of it, 0 = three launches per block column;
- * fwd_variant  3 = forward substitution with L streamed through LDS and the solved rows in registers
- *              (default, <= 8 blocks, else falls back to 0), 0 = operands re-read from memory,
- *              1 / 2 = solved rows in registers only, 16 / 32 state columns per wavefront. */
+ * chol_variant 1 = one-launch fused Cholesky (default, <= 12 blocks of 32), 0 = three launches per block column;
+ * fwd_variant  1 = forward substitution with L streamed through LDS and the solved rows in registers (default,
+ *              <= 8 blocks), 0 = operands re-read from memory.  Larger systems always take variant 0. */
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);

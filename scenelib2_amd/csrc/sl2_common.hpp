@@ -114,10 +114,10 @@ struct sl2_engine {
   int* status = nullptr;      // [B]
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
   long long steps_done = 0;
-  int chol_variant = 1;       // 1 = fused two-wave Cholesky when it applies, 0 = launch-per-block kernels
+  int chol_variant = 1;       // 1 = one-launch fused Cholesky when it applies (<= 12 blocks), 0 = launch-per-block kernels
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
   int build_variant = 1;      // 1 = A and S in one pass (state <= 512 columns), 0 = k_build_A then k_build_S
-  int fwd_variant = 3;        // forward substitution: 3 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory, 1/2 = register-resident only (16/32 columns per wave)
+  int fwd_variant = 1;        // forward substitution: 1 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory (any size)
   // ---- feature initialisation ----
   int ppos = 0;                          // first column of the partial feature's six states (13 + 3N)
   int* part_i = nullptr;                 // [B][kPartInts]

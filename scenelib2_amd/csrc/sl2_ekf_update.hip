@@ -404,170 +404,15 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
         Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r];
 }
 
-// ---------------------------------------------------------------------------
-// k_chol_fused: the whole blocked Cholesky of one sequence in ONE launch, by a
-// two-wave workgroup (used when the number of 32-blocks is small enough that the
-// launch-per-block version is latency-bound, nblk_max <= kFusedMaxBlocks):
-//   wave D ("diagonal")  factors + inverts the 32x32 diagonal blocks in registers
-//                        (the ~35 us scalar dependency chain per block);
-//   wave M ("matrix")    does every MFMA tile: panel solves L[I][J] = S[I][J] L_JJ^-T
-//                        and trailing updates S[I][K] -= L[I][J] L[K][J]^T.
-// Per block column J the waves meet twice:  A_J — L_JJ^-1 is in LDS (D -> M);
-// B_J — the next diagonal tile (J+1,J+1) is updated and in LDS (M -> D).  M does the
-// panel tile I = J+1 and the tile (J+1,J+1) FIRST, so D starts the next diagonal block
-// while M still works through the rest of column J: the scalar chain of D (the
-// critical path) is overlapped with all of M's work instead of being three
-// serialised launches per block.
-// ---------------------------------------------------------------------------
-constexpr int kFusedMaxBlocks = 12;
-
-__device__ __forceinline__ void diag_factor_regs(double a[32], double x[32], int r) {
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const double piv = readlane_f64(a[c], c);
-    const double dinv = fast_rsqrt(piv);
-    const double d = piv * dinv;
-    const double l = (r == c) ? d : a[c] * dinv;
-    a[c] = (r >= c) ? l : 0.0;
-#pragma unroll
-    for (int cc = c + 1; cc < 32; ++cc) {
-      const double lcc = readlane_f64(a[c], cc);   // L[cc][c]
-      a[cc] -= l * lcc;                            // meaningful for r >= cc
-    }
-  }
-  double diag = 1.0;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) diag = (r == c) ? a[c] : diag;
-  const double rinv = fast_rcp(diag);
-#pragma unroll
-  for (int p = 31; p >= 0; --p) {
-    double sacc = (r == p) ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = p + 1; i < 32; ++i) sacc -= x[i] * readlane_f64(a[p], i);
-    x[p] = sacc * readlane_f64(rinv, p);
-  }
-}
-
-__global__ void __launch_bounds__(128, 2) k_chol_fused(double* __restrict__ St, double* __restrict__ LinvT,
-                                                    const int* __restrict__ m_count, int mld, int nblk_max) {
-  const int b = blockIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
-  const int lane = threadIdx.x & 63;
-  const bool isD = (threadIdx.x >> 6) == 0;
-  const int lo = lane & 15, hi = lane >> 4;
-  __shared__ double sTile[32][33];     // next diagonal tile, sTile[r][c] = S[r][c]   (M -> D)
-  __shared__ double sLinv[32 * 32];    // LinvT of the current block, [p][k]          (D -> M)
-  double* Sb = St + (size_t)b * mld * mld;
-  for (int J = 0; J < nblk; ++J) {
-    const int o = J * 32;
-    if (isD) {
-      const int r = lane & 31;
-      double a[32], x[32];
-      if (J == 0) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) a[c] = Sb[(size_t)c * mld + r];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) a[c] = sTile[r][c];
-      }
-      diag_factor_regs(a, x, r);
-      if (lane < 32) {
-        double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          Sb[(size_t)(o + c) * mld + o + r] = a[c];
-          Lb[c * 32 + r] = x[c];
-          sLinv[c * 32 + r] = x[c];
-        }
-      }
-    }
-    __syncthreads();                    // A_J : L_JJ^-1 available to M
-    if (J + 1 >= nblk) break;
-    if (!isD) {
-      // ---- panel tile I = J+1, then the next diagonal tile (J+1, J+1) ----
-      for (int pass = 0; pass < 2; ++pass) {
-        const int Ibeg = (pass == 0) ? J + 1 : J + 2;
-        const int Iend = (pass == 0) ? J + 2 : nblk;
-        for (int I = Ibeg; I < Iend; ++I) {
-          v4d acc[2][2];
-          for (int kt = 0; kt < 2; ++kt) for (int it = 0; it < 2; ++it) acc[kt][it] = (v4d){0, 0, 0, 0};
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) {
-            const int p = 4 * s8 + hi;
-            const double a0 = sLinv[p * 32 + lo], a1 = sLinv[p * 32 + 16 + lo];
-            const double b0 = Sb[(size_t)(o + p) * mld + I * 32 + lo];
-            const double b1 = Sb[(size_t)(o + p) * mld + I * 32 + 16 + lo];
-            acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-            acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-            acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-            acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-          }
-#pragma unroll
-          for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int it = 0; it < 2; ++it)
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4)
-                Sb[(size_t)(o + 16 * kt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo] = acc[kt][it][r4];
-        }
-        // trailing tiles: pass 0 -> only (J+1, J+1); pass 1 -> all the others
-        const int Kbeg = J + 1, Kend = (pass == 0) ? J + 2 : nblk;
-        for (int K = Kbeg; K < Kend; ++K) {
-          const int I0 = (pass == 0) ? K : ((K == J + 1) ? K + 1 : K);
-          const int I1 = (pass == 0) ? K + 1 : nblk;
-          for (int I = I0; I < I1; ++I) {
-            v4d acc[2][2];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-              for (int it = 0; it < 2; ++it)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                  acc[jt][it][r4] = Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo];
-#pragma unroll
-            for (int s8 = 0; s8 < 8; ++s8) {
-              const size_t row = (size_t)(o + 4 * s8 + hi) * mld;
-              const double a0 = -Sb[row + K * 32 + lo], a1 = -Sb[row + K * 32 + 16 + lo];
-              const double b0 = Sb[row + I * 32 + lo], b1 = Sb[row + I * 32 + 16 + lo];
-              acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-              acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-              acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-              acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-            }
-            if (pass == 0) {
-              // hand the finished diagonal tile to D: D fragment (row = column c, col = row r) -> sTile[r][c]
-#pragma unroll
-              for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                  for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = acc[jt][it][r4];
-            } else {
-#pragma unroll
-              for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int it = 0; it < 2; ++it)
-#pragma unroll
-                  for (int r4 = 0; r4 < 4; ++r4)
-                    Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r4) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r4];
-            }
-          }
-        }
-        if (pass == 0) __syncthreads();   // B_J (M side): tile (J+1, J+1) is in LDS
-      }
-    } else {
-      __syncthreads();                    // B_J (D side)
-    }
-  }
-}
+constexpr int kFusedMaxBlocks = 12;   // the one-launch Cholesky is used up to this many 32-blocks
 
 // ---------------------------------------------------------------------------
-// k_chol_fused4: the same one-launch factorisation with a FOUR-wave workgroup
-// (wave 0 = D, waves 1..3 = M0..M2) so that the MFMA tiles of one sequence are spread
-// over three SIMDs instead of one, and with a diagonal-block routine that issues half
-// the instructions:
+// k_chol_fused4: the whole blocked Cholesky of one sequence in ONE launch (used when the number
+// of 32-blocks is small enough that the launch-per-block version is latency-bound), by a FOUR-wave
+// workgroup: wave 0 = D factors + inverts the 32x32 diagonal blocks in registers, waves 1..3 =
+// M0..M2 do every MFMA tile (panel solves, trailing updates), spread over three SIMDs.
+// (The first fused version had one D and one M wave and a two-pass diagonal routine: 0.50 ms per
+// launch at batch 1024 against 0.28 ms for this one.)
 //   * D interleaves the factor step c with step c of the inversion (row c of L^-1 is
 //     final as soon as column c of L is): every broadcast scalar is used exactly once,
 //     so nothing is kept in SGPRs across the block (the two-pass version re-used the
@@ -866,99 +711,11 @@ __global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, d
 }
 
 // ---------------------------------------------------------------------------
-// k_fwdsub_reg<NB, CW>: the same substitution with the solved block rows of V^T kept in
-// REGISTERS (the MFMA D fragment of block K is, unchanged, the B fragment of every later
-// product with it), for maps small enough that NB = mld/32 block rows of a 16*CW-column
-// strip fit the register file (NB*CW*16 VGPRs).  k_fwdsub re-reads every solved block
-// from memory for each later block row: at batch 1024 the PMC counters show 2.9 GB of
-// HBM traffic per launch for 1.1 GB of At + Vt, i.e. the kernel is bound by its own
-// re-reads.  Here HBM sees At once, Vt once and L (shared by the strips of a sequence
-// through L2).
-// ---------------------------------------------------------------------------
-template <int NB, int CW>
-__global__ void __launch_bounds__(256) k_fwdsub_reg(const double* __restrict__ At, double* __restrict__ Vt,
-                                                    const double* __restrict__ St, const double* __restrict__ LinvT,
-                                                    const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
-  constexpr int kStrip = 16 * CW;            // columns per wave
-  constexpr int kWaves = 64 / kStrip;        // waves per 64-column tile
-  int b, ct;
-  if (!xcd_map(ld / 64, B, &b, &ct)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (wave >= kWaves) return;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int m = 2 * cnt;
-  const int nblk = (m + 31) / 32;
-  const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = ct * 64 + wave * kStrip;
-  const double* Ab = At + (size_t)b * mld * ld;
-  double* Vb = Vt + (size_t)b * mld * ld;
-  const double* Sb = St + (size_t)b * mld * mld;
-  v4d V[NB][2][CW];
-#pragma unroll
-  for (int J = 0; J < NB; ++J) {
-    if (J < nblk) {
-      const bool half = (J * 32 + 16 >= m);
-      v4d acc[2][CW];
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < CW; ++it)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[jt][it][r] = (jt == 1 && half) ? 0.0 : Ab[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo];
-      const double* lrow = Sb + (size_t)hi * mld + J * 32 + lo;     // L[J*32 + lo (+16)][k], k = hi + 4 s
-#pragma unroll
-      for (int K = 0; K < J; ++K) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const double a0 = -lrow[(size_t)(K * 32 + 4 * s) * mld];
-          const double a1 = half ? 0.0 : -lrow[(size_t)(K * 32 + 4 * s) * mld + 16];
-#pragma unroll
-          for (int it = 0; it < CW; ++it) {
-            const double bv = V[K][s >> 2][it][s & 3];
-            acc[0][it] = mfma_f64(a0, bv, acc[0][it]);
-            acc[1][it] = mfma_f64(a1, bv, acc[1][it]);
-          }
-        }
-      }
-      const double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-      v4d out[2][CW];
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < CW; ++it) out[jt][it] = (v4d){0, 0, 0, 0};
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int p = 4 * s + hi;
-        const double a0 = Lb[p * 32 + lo];
-        const double a1 = half ? 0.0 : Lb[p * 32 + 16 + lo];
-#pragma unroll
-        for (int it = 0; it < CW; ++it) {
-          const double bv = acc[s >> 2][it][s & 3];
-          out[0][it] = mfma_f64(a0, bv, out[0][it]);
-          out[1][it] = mfma_f64(a1, bv, out[1][it]);
-        }
-      }
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < CW; ++it) {
-          V[J][jt][it] = out[jt][it];
-          if (!(jt == 1 && half)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo] = out[jt][it][r];
-          }
-        }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
 // k_fwdsub_lds<NB>: forward substitution with BOTH operands on chip.  A workgroup of four
 // waves owns a 64-column tile of the state (16 columns per wave):
-//   * the solved block rows of V^T stay in registers (D fragment == B fragment), as in
-//     k_fwdsub_reg;
+//   * the solved block rows of V^T stay in registers: the MFMA D fragment of block K is, unchanged,
+//     the B fragment of every later product with it (NB = mld/32 block rows of a 16-column strip
+//     = NB*16 VGPRs);
 //   * the 32x32 tiles of L (and the inverted diagonal blocks) are streamed once per
 //     workgroup through LDS, double-buffered: the global loads of tile t+1 fly under the
 //     MFMAs of tile t, one barrier per tile (the scheme of k_syrk).
@@ -1068,22 +825,6 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
   case NBV:                                                                                                         \
     hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
                        e->ld, e->mld, e->nblk_max, B);                                                              \
-    return true;
-  switch (e->nblk_max) {
-    SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
-    SL2_FWD_CASE(8)
-    default: return false;
-  }
-#undef SL2_FWD_CASE
-}
-
-template <int CW>
-static bool launch_fwdsub_reg(sl2_engine* e, int B) {
-  const dim3 grid(xcd_grid(e->ld / 64, B)), block(64 * (64 / (16 * CW)));
-#define SL2_FWD_CASE(NBV)                                                                                              \
-  case NBV:                                                                                                            \
-    hipLaunchKernelGGL((k_fwdsub_reg<NBV, CW>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
-                       e->ld, e->mld, e->nblk_max, B);                                                                 \
     return true;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
@@ -1273,11 +1014,8 @@ int launch_update(sl2_engine* e) {
   }
   if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
     LaunchScope ls(e, "k_chol_fused");
-    if (e->root->chol_variant == 1)
-      hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
+    hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
                          (long long*)e->root->chol_trace);
-    else
-      hipLaunchKernelGGL(k_chol_fused, dim3(B), dim3(128), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max);
     SL2_HIP(hipGetLastError());
   } else {
   for (int J = 0; J < e->nblk_max; ++J) {
@@ -1305,9 +1043,7 @@ int launch_update(sl2_engine* e) {
   {
     LaunchScope ls(e, "k_fwdsub", true);
     bool done = false;
-    if (e->root->fwd_variant == 1) done = launch_fwdsub_reg<1>(e, B);
-    else if (e->root->fwd_variant == 2) done = launch_fwdsub_reg<2>(e, B);
-    else if (e->root->fwd_variant == 3) done = launch_fwdsub_lds(e, B);
+    if (e->root->fwd_variant == 1) done = launch_fwdsub_lds(e, B);
     if (!done)
       hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                          e->m_count, e->ld, e->mld, e->nblk_max, B);

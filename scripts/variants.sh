@@ -2,7 +2,7 @@ cd /root/repo
 # A/B of kernel variants through the env overrides read by sl2_create (development aid).
 # usage: VAR=SL2_CHOL_VARIANT VALUES="1 2" bash scripts/variants.sh
 VAR=${VAR:-SL2_FWD_VARIANT}
-for v in ${VALUES:-0 1 2}; do
+for v in ${VALUES:-0 1}; do
   echo "$VAR=$v"; env $VAR=$v python bench.py --cpu-sample ${CPU_SAMPLE:-4} 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['parity']); print({k:round(v['ms_per_step'],3) for k,v in d['kernels'].items()})"
 done

@@ -256,3 +256,16 @@ def test_engine_matches_committed_golden_fixture():
         assert rel_fro(m.construct_total_covariance(), g["P"][k]) < TOL_P
         assert np.array_equal(np.array([f.z_ for f in m.feature_list_]), g["z"][k])
     assert m.successful_measurement_vector_size_ == 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chol_variant,fwd_variant,search_variant", [(0, 0, 0), (1, 0, 1), (0, 1, 2)])
+def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_variant):
+    """The fallback kernels (launch-per-block Cholesky, memory-operand substitution, the two older search kernels)
+    are what larger maps run on: on a small map they must reproduce the default path."""
+    pr = Pair(24, 4, batch=2, feature_sigma=0.004)
+    pr.engine.set_update_variant(chol_variant, fwd_variant)
+    pr.engine.set_search_variant(search_variant)
+    for k in range(4):
+        pr.step_both(k)
+        pr.compare_state(1e-9, 1e-8)

@@ -181,7 +181,9 @@ def main():
                 ach = flops[dom] / dur / 1e12
                 roof = dict(kernel=dom, bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
                             frac=ach / FP64_MFMA_PEAK_TF, traffic=None, algorithmic_flops_per_launch=flops[dom],
-                            avg_launch_ms=dur * 1e3)
+                            avg_launch_ms=dur * 1e3,
+                            measured_ceiling={"fp64_mfma_microbench_TFLOPs": 47.8, "fp64_valu_fma_microbench_TFLOPs": 54.1,
+                                              "source": "profiles/r01_microbench.txt (scripts/microbench.py on this box type)"})
             elif dom in hbm_bytes:
                 dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
                 ach = hbm_bytes[dom] / dur / 1e9

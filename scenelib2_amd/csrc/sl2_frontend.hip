@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   int* __restrict__ status, double* __restrict__ pos_log, int log_slot, int N, int ld,
                                                   int min_attempts, double match_fraction, int save_trajectory,
                                                   const int* __restrict__ part_i, int ppos) {
-  extern __shared__ int s_del[];  // [N] slots deleted this frame
+  extern __shared__ int s_del[];  // [N] slots deleted this frame, then [N] flags
   __shared__ double s_N[16], s_P[169], s_T[169];
   __shared__ int s_ndel;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -283,24 +283,28 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
     for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
     __syncthreads();
   }
-  // (2) deletion bookkeeping, serial like the reference's list walk
+  // (2) deletion bookkeeping.  The scheduling test is per feature (all threads); the list walk with its
+  // skip-after-erase rule is serial like the reference's, but over LDS (a serial walk over global memory
+  // cost one memory round trip per feature: 50 us of this kernel's 60).
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const size_t fi = (size_t)b * N + i;
+    int fl = f_flags[fi];
+    if (fl & FF_ACTIVE) {
+      const int att = attempted[fi], suc = successful[fi];
+      if (att >= min_attempts && double(suc) / double(att) < match_fraction) { fl |= FF_SCHEDULED; f_flags[fi] = fl; }
+    }
+    s_del[N + i] = fl;      // second half of the dynamic LDS: this frame's flags
+  }
+  __syncthreads();
   if (tid == 0) {
     int nd = 0;
-    for (int i = 0; i < ns; ++i) {
-      const size_t fi = (size_t)b * N + i;
-      int fl = f_flags[fi];
-      if (!(fl & FF_ACTIVE)) continue;
-      const int att = attempted[fi], suc = successful[fi];
-      if (att >= min_attempts && double(suc) / double(att) < match_fraction) f_flags[fi] = fl | FF_SCHEDULED;
-    }
     bool skip_next = false;
     for (int i = 0; i < ns; ++i) {
-      const size_t fi = (size_t)b * N + i;
-      const int fl = f_flags[fi];
+      const int fl = s_del[N + i];
       if (!(fl & FF_ACTIVE)) continue;
       if (skip_next) { skip_next = false; continue; }
       if (fl & FF_SCHEDULED) {
-        f_flags[fi] = FF_USED;  // inactive, deselected
+        f_flags[(size_t)b * N + i] = FF_USED;  // inactive, deselected
         s_del[nd++] = i;
         skip_next = true;
       }
@@ -364,7 +368,7 @@ int launch_select(sl2_engine* e, int n) {
 
 int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot) {
   LaunchScope ls(e, "k_finalize");
-  const size_t shm = (size_t)e->N * sizeof(int);
+  const size_t shm = (size_t)e->N * 2 * sizeof(int);
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
                      log_slot, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,

@@ -447,40 +447,7 @@ __device__ __forceinline__ void tile_store(double* __restrict__ Sb, int mld, int
 #pragma unroll
       for (int r = 0; r < 4; ++r) Sb[(size_t)(k0 + 16 * kt + hi + 4 * r) * mld + i0 + 16 * it + lo] = t.f[kt][it][r];
 }
-// In the last block row of S only the first `m - 32 (nblk - 1)` entries are real; when that is <= 16 the tile
-// operations below touch its first 16 columns only (NARROW): the other half is identity / zero padding that
-// no product changes, and skipping it saves a sixth of the kernel's traffic at m = 200.
 // panel tile: out[k][i] = sum_p Linv[k][p] S[o+p][i0+i]
-template <bool NARROW>
-__device__ __forceinline__ void tile_panel_store(const double* sLinv, double* __restrict__ Sb, int mld, int o, int i0, int lo, int hi) {
-  double b0[8], b1[8];
-#pragma unroll
-  for (int s8 = 0; s8 < 8; ++s8) {
-    b0[s8] = Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + lo];
-    b1[s8] = NARROW ? 0.0 : Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + 16 + lo];
-  }
-  v4d f00 = {0, 0, 0, 0}, f01 = {0, 0, 0, 0}, f10 = {0, 0, 0, 0}, f11 = {0, 0, 0, 0};
-#pragma unroll
-  for (int s8 = 0; s8 < 8; ++s8) {
-    const int p = 4 * s8 + hi;
-    const double a0 = sLinv[p * kLinvPitch + lo], a1 = sLinv[p * kLinvPitch + 16 + lo];
-    f00 = mfma_f64(a0, b0[s8], f00);
-    f10 = mfma_f64(a1, b0[s8], f10);
-    if (!NARROW) {
-      f01 = mfma_f64(a0, b1[s8], f01);
-      f11 = mfma_f64(a1, b1[s8], f11);
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Sb[(size_t)(o + hi + 4 * r) * mld + i0 + lo] = f00[r];
-    Sb[(size_t)(o + 16 + hi + 4 * r) * mld + i0 + lo] = f10[r];
-    if (!NARROW) {
-      Sb[(size_t)(o + hi + 4 * r) * mld + i0 + 16 + lo] = f01[r];
-      Sb[(size_t)(o + 16 + hi + 4 * r) * mld + i0 + 16 + lo] = f11[r];
-    }
-  }
-}
 __device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* __restrict__ Sb, int mld, int o, int i0, int lo,
                                              int hi) {
   double b0[8], b1[8];
@@ -506,16 +473,8 @@ __device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* 
   return t;
 }
 // trailing tile (K, I): acc[kk][ii] -= sum_p L[K*32+kk][o+p] L[I*32+ii][o+p], operands from memory
-template <bool NARROW>
 __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int o, int K, int I, int lo, int hi) {
-  v4d c00, c01, c10, c11;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    c00[r] = Sb[(size_t)(K * 32 + hi + 4 * r) * mld + I * 32 + lo];
-    c10[r] = Sb[(size_t)(K * 32 + 16 + hi + 4 * r) * mld + I * 32 + lo];
-    c01[r] = NARROW ? 0.0 : Sb[(size_t)(K * 32 + hi + 4 * r) * mld + I * 32 + 16 + lo];
-    c11[r] = NARROW ? 0.0 : Sb[(size_t)(K * 32 + 16 + hi + 4 * r) * mld + I * 32 + 16 + lo];
-  }
+  Tile32 acc = tile_load(Sb, mld, K * 32, I * 32, lo, hi);
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     double a0[4], a1[4], b0[4], b1[4];
@@ -525,27 +484,17 @@ __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int
       a0[s4] = Sb[row + K * 32 + lo];
       a1[s4] = Sb[row + K * 32 + 16 + lo];
       b0[s4] = Sb[row + I * 32 + lo];
-      b1[s4] = NARROW ? 0.0 : Sb[row + I * 32 + 16 + lo];
+      b1[s4] = Sb[row + I * 32 + 16 + lo];
     }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      c00 = mfma_f64(-a0[s4], b0[s4], c00);
-      c10 = mfma_f64(-a1[s4], b0[s4], c10);
-      if (!NARROW) {
-        c01 = mfma_f64(-a0[s4], b1[s4], c01);
-        c11 = mfma_f64(-a1[s4], b1[s4], c11);
-      }
+      acc.f[0][0] = mfma_f64(-a0[s4], b0[s4], acc.f[0][0]);
+      acc.f[0][1] = mfma_f64(-a0[s4], b1[s4], acc.f[0][1]);
+      acc.f[1][0] = mfma_f64(-a1[s4], b0[s4], acc.f[1][0]);
+      acc.f[1][1] = mfma_f64(-a1[s4], b1[s4], acc.f[1][1]);
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    Sb[(size_t)(K * 32 + hi + 4 * r) * mld + I * 32 + lo] = c00[r];
-    Sb[(size_t)(K * 32 + 16 + hi + 4 * r) * mld + I * 32 + lo] = c10[r];
-    if (!NARROW) {
-      Sb[(size_t)(K * 32 + hi + 4 * r) * mld + I * 32 + 16 + lo] = c01[r];
-      Sb[(size_t)(K * 32 + 16 + hi + 4 * r) * mld + I * 32 + 16 + lo] = c11[r];
-    }
-  }
+  tile_store(Sb, mld, K * 32, I * 32, lo, hi, acc);
 }
 
 __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St, double* __restrict__ LinvT,
@@ -554,7 +503,6 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int nblk = (2 * cnt + 31) / 32;
-  const bool narrow_last = (2 * cnt - 32 * (nblk - 1)) <= 16;   // the last block row has at most 16 real entries
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool isD = wave == 0;
   const int mw = wave - 1;              // 0..2 for the M waves
@@ -644,8 +592,8 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
             for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = dg.f[jt][it][r4];
         // share of the remaining panel tiles: M0 takes every third one, after its critical work
         for (int I = J + 2 + 2; I < nblk; I += 3) {
-          if (narrow_last && I == nblk - 1) tile_panel_store<true>(sLinv, Sb, mld, o, I * 32, lo, hi);
-          else tile_panel_store<false>(sLinv, Sb, mld, o, I * 32, lo, hi);
+          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
         }
       } else {
         if (mw == 2) {   // LinvT block to memory for the forward substitution, coalesced
@@ -654,8 +602,8 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
           for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
         }
         for (int I = J + 2 + (mw - 1); I < nblk; I += 3) {
-          if (narrow_last && I == nblk - 1) tile_panel_store<true>(sLinv, Sb, mld, o, I * 32, lo, hi);
-          else tile_panel_store<false>(sLinv, Sb, mld, o, I * 32, lo, hi);
+          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
         }
       }
     }
@@ -665,11 +613,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
       int idx = 0;
       for (int K = J + 1; K < nblk; ++K)
         for (int I = (K == J + 1) ? K + 1 : K; I < nblk; ++I, ++idx)
-          if (idx % 3 == mw) {
-            // (the tile (last, last) keeps its full width: its lower-right part is the identity the D wave factors)
-            if (narrow_last && I == nblk - 1 && K != I) tile_trail<true>(Sb, mld, o, K, I, lo, hi);
-            else tile_trail<false>(Sb, mld, o, K, I, lo, hi);
-          }
+          if (idx % 3 == mw) tile_trail(Sb, mld, o, K, I, lo, hi);
     }
   }
 }

@@ -152,7 +152,8 @@ int sl2_set_groups(sl2_engine* e, int groups);
  * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
- * chol_variant 1 = one-launch fused Cholesky (default, <= 12 blocks of 32), 0 = three launches per block column;
+ * chol_variant 1 = one-launch left-looking Cholesky (default, <= 12 blocks of 32), 2 = one-launch right-looking,
+ *              0 = three launches per block column;
  * fwd_variant  1 = forward substitution with L streamed through LDS and the solved rows in registers (default,
  *              <= 8 blocks), 0 = operands re-read from memory.  Larger systems always take variant 0. */
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);

@@ -502,7 +502,7 @@ int sl2_debug_chol_trace(sl2_engine* e, long long* out, size_t n) {
 #endif
 
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
-  if (!e || chol_variant < 0 || chol_variant > 1 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
+  if (!e || chol_variant < 0 || chol_variant > 2 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
   e->chol_variant = chol_variant;
   e->fwd_variant = fwd_variant;
   return SL2_OK;

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, c
 }
 
 // ---------------------------------------------------------------------------
-// k_build_AS: k_build_A and k_build_S in one pass (state sizes up to 512 columns): the rows of
+// k_build_AS: k_build_A and k_build_S in one pass (state sizes up to 1024 columns): the rows of
 // At are produced four features (eight rows) at a time, parked in LDS, and S = H A + R for those
 // eight columns of S is formed from LDS before they are overwritten -- At is not read back from
 // memory at all (k_build_S re-reads all of it: 0.8 GB per launch at batch 1024, 100 features).
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, c
 // ---------------------------------------------------------------------------
 constexpr int kASBatch = 4;   // features per LDS batch
 
-__global__ void __launch_bounds__(512) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
+__global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                   const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
                                                   const int* __restrict__ m_count, double* __restrict__ At,
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
         Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r];
 }
 
-constexpr int kFusedMaxBlocks = 12;   // the one-launch Cholesky is used up to this many 32-blocks
+constexpr int kFusedMaxBlocks = 16;   // the one-launch Cholesky is used up to this many 32-blocks
 
 // ---------------------------------------------------------------------------
 // k_chol_fused4: the whole blocked Cholesky of one sequence in ONE launch (used when the number
@@ -846,7 +846,7 @@ __global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, d
 constexpr int kFwdPitch = 48;   // LDS row pitch (doubles): the two k-rows read by a 32-lane group land on disjoint banks
 
 template <int NB>
-__global__ void __launch_bounds__(256, 3) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
+__global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
                                                     const double* __restrict__ St, const double* __restrict__ LinvT,
                                                     const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
   int b, ct;
@@ -948,7 +948,7 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
     return true;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
-    SL2_FWD_CASE(8)
+    SL2_FWD_CASE(8) SL2_FWD_CASE(9) SL2_FWD_CASE(10) SL2_FWD_CASE(11) SL2_FWD_CASE(12) SL2_FWD_CASE(13)
     default: return false;
   }
 #undef SL2_FWD_CASE
@@ -1110,7 +1110,7 @@ int launch_update(sl2_engine* e) {
     hipLaunchKernelGGL(k_compact, dim3(B), dim3(64), 0, e->stream, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
-  if (e->ld <= 512 && e->root->build_variant == 1) {
+  if (e->ld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
     const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
     hipLaunchKernelGGL(k_build_AS, dim3(B), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R, e->succ_idx,

@@ -848,20 +848,25 @@ constexpr int kFwdPitch = 48;   // LDS row pitch (doubles): the two k-rows read 
 template <int NB>
 __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
                                                     const double* __restrict__ St, const double* __restrict__ LinvT,
-                                                    const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
+                                                    const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B,
+                                                    int J0) {
+  // J0: first block row of this launch.  For maps of more than 13 blocks the substitution runs in groups of
+  // NB = 8 block rows: k_fwd_gemm first subtracts the contribution of all earlier groups from the group's
+  // rows of At, then this kernel solves within the group (block indices below are relative to J0).
   int b, ct;
   if (!xcd_map(ld / 64, B, &b, &ct)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int m = 2 * cnt;
+  const int m = 2 * cnt - 32 * J0;          // rows left from block J0 on
+  if (m <= 0) return;
   const int nblk = (m + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 15, hi = lane >> 4;
   const int i0 = ct * 64 + wave * 16;
-  const double* Ab = At + (size_t)b * mld * ld;
-  double* Vb = Vt + (size_t)b * mld * ld;
-  const double* Sb = St + (size_t)b * mld * mld;
-  const double* Lb = LinvT + (size_t)b * nblk_max * 1024;
+  const double* Ab = At + (size_t)b * mld * ld + (size_t)J0 * 32 * ld;
+  double* Vb = Vt + (size_t)b * mld * ld + (size_t)J0 * 32 * ld;
+  const double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
+  const double* Lb = LinvT + ((size_t)b * nblk_max + J0) * 1024;
   __shared__ double sL[2][32 * kFwdPitch];
   // staging role: row `srow` of the tile (contraction index), 4 consecutive doubles at column `sc4`
   const int srow = tid >> 3, sc4 = (tid & 7) * 4;
@@ -944,7 +949,7 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
 #define SL2_FWD_CASE(NBV)                                                                                           \
   case NBV:                                                                                                         \
     hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
-                       e->ld, e->mld, e->nblk_max, B);                                                              \
+                       e->ld, e->mld, e->nblk_max, B, 0);                                                           \
     return true;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
@@ -952,6 +957,85 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
     default: return false;
   }
 #undef SL2_FWD_CASE
+}
+
+constexpr int kSyrkKC = 16;       // K rows per chunk (k_syrk, k_fwd_gemm)
+constexpr int kSyrkPitch = 80;    // doubles per LDS row (64 + 16)
+
+// ---------------------------------------------------------------------------
+// k_fwd_gemm: At[R0 .. R0+256) -= L[R0 .. R0+256)[0 .. R0) * Vt[0 .. R0), the contribution of the already
+// solved block rows to one group of eight block rows (R0 = 32 J0).  64x64 output tiles, four waves of 32x32,
+// both operands streamed through double-buffered LDS in chunks of 16 k-rows like k_syrk (L is stored
+// k-major in St, so both staging reads are row segments).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fwd_gemm(double* __restrict__ At, const double* __restrict__ Vt,
+                                                  const double* __restrict__ St, const int* __restrict__ m_count, int ld, int mld,
+                                                  int B, int J0) {
+  int b, t;
+  const int ntc = ld / 64;
+  if (!xcd_map(4 * ntc, B, &b, &t)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int mp = (2 * cnt + 31) / 32 * 32;
+  const int R0 = J0 * 32;
+  const int r0 = R0 + (t / ntc) * 64, c0 = (t % ntc) * 64;
+  if (r0 >= mp) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  double* Ab = At + (size_t)b * mld * ld;
+  const double* Vb = Vt + (size_t)b * mld * ld;
+  const double* Sb = St + (size_t)b * mld * mld;
+  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
+  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
+  const int kr = tid >> 4, c4 = (tid & 15) * 4;
+  const double* gA = Sb + (size_t)kr * mld + r0 + c4;     // L[r0 + c][k] = St[k][r0 + c]
+  const double* gB = Vb + (size_t)kr * ld + c0 + c4;
+  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  v4d acc[2][2];
+  for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
+  const int nchunk = R0 / kSyrkKC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
+    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
+    __syncthreads();
+    if (ch + 1 < nchunk) {
+      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * mld);
+      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * ld);
+    }
+    const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
+    const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
+#pragma unroll
+    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
+      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
+      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* q = Ab + (size_t)(r0 + wi + 16 * it + hi + 4 * r) * ld + c0 + wj + 16 * jt + lo;
+        *q -= acc[it][jt][r];
+      }
+}
+
+// substitution in groups of eight block rows, for systems of more than 13 blocks
+static void launch_fwdsub_grouped(sl2_engine* e, int B) {
+  for (int J0 = 0; J0 < e->nblk_max; J0 += 8) {
+    if (J0 > 0)
+      hipLaunchKernelGGL(k_fwd_gemm, dim3(xcd_grid(4 * (e->ld / 64), B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->m_count,
+                         e->ld, e->mld, B, J0);
+    hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                       e->m_count, e->ld, e->mld, e->nblk_max, B, J0);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -965,8 +1049,6 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
 // SQ_WAIT_ANY 55 %, MFMA pipe 38 % busy).  LDS row pitch 80 doubles: the two
 // k-rows read by one 32-lane group of a ds_read_b64 land on disjoint banks.
 // ---------------------------------------------------------------------------
-constexpr int kSyrkKC = 16;       // K rows per chunk
-constexpr int kSyrkPitch = 80;    // doubles per LDS row (64 + 16)
 
 __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
                                               const int* __restrict__ m_count, int ld, int mld, int B) {
@@ -1166,7 +1248,10 @@ int launch_update(sl2_engine* e) {
   {
     LaunchScope ls(e, "k_fwdsub", true);
     bool done = false;
-    if (e->root->fwd_variant == 1) done = launch_fwdsub_lds(e, B);
+    if (e->root->fwd_variant == 1) {
+      done = launch_fwdsub_lds(e, B);
+      if (!done) { launch_fwdsub_grouped(e, B); done = true; }
+    }
     if (!done)
       hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                          e->m_count, e->ld, e->mld, e->nblk_max, B);

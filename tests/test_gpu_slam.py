@@ -206,7 +206,7 @@ def test_full_size_batch_properties():
     """BASELINE config 3 shape (320x240, 100 features) at a batch the oracle cannot follow:
     size-independent properties — replicas agree bit for bit, P stays symmetric and finite,
     and sampled sequences still match the oracle."""
-    B, N, F = 96, 100, 4
+    B, N, F = 1024, 100, 4             # BASELINE configs[2]: the full batch
     tex = synth.make_texture()
     cam = synth.default_camera()
     uniq = 3

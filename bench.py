@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--feature-sigma", type=float, default=0.005,
                     help="prior std-dev (m) of every map feature; > 0 makes the covariance dense (0: AddNewKnownFeature zeros)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a HIP graph (small batches are launch-bound)")
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
     return ap.parse_args()
 
@@ -93,6 +94,8 @@ def main():
     eng = Engine(cam, params, B, N, device=dev)
     if args.groups > 0:
         eng.set_groups(args.groups)
+    if args.graph:
+        eng.set_graph_mode(True)
     eng.set_vehicle_state(np.stack([s.xv0 for s in specs]), np.stack([s.Pxx0 for s in specs]))
     eng.add_known_features(np.stack([s.feat_y for s in specs]), np.stack([s.xp_org() for s in specs]), templates)
     if args.feature_sigma > 0.0:

@@ -148,6 +148,10 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  * (latency-bound kernels of one group overlap throughput-bound kernels of another).  Default 1
  * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024); env SL2_GROUPS overrides. */
 int sl2_set_groups(sl2_engine* e, int groups);
+/* Whole-step HIP graphs: when enabled, sl2_go_one_step with device-resident frames captures its launches once per
+ * (frame buffer, flags) and replays the graph (at batch 1 the step is launch-bound: ~12 kernels).  Off by default;
+ * ignored while per-kernel profiling is on or with more than one sequence group. */
+int sl2_set_graph_mode(sl2_engine* e, int enabled);
 /* Which search kernel sl2_make_measurements / sl2_go_one_step use: 2 = packed column walk (default),
  * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
 int sl2_set_search_variant(sl2_engine* e, int variant);

@@ -113,6 +113,7 @@ struct sl2_engine {
   double* last_r = nullptr;   // [B][3] scratch motion_model_->rRES_ (Q12)
   int* status = nullptr;      // [B]
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
+  int* pos_count = nullptr;   // [B] steps logged so far (device-side, so that a captured step needs no per-step argument)
   long long steps_done = 0;
   int chol_variant = 1;       // one-launch Cholesky when it applies (<= 12 blocks): 1 = left-looking (default), 2 = right-looking; 0 = launch-per-block kernels
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
@@ -128,6 +129,10 @@ struct sl2_engine {
   int* me_desc = nullptr;                // [B][kMaxParticles][8] search ellipses of the particles
   double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
   bool mapping_used = false;
+  // ---- whole-step HIP graphs (small batches are launch-bound: ~12 kernels per step) ----
+  struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
+  bool graph_mode = false;
+  std::vector<StepGraph> step_graphs;
   int search_variant = 2;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
@@ -209,7 +214,7 @@ int launch_feature_prediction(sl2_engine* e);
 int launch_select(sl2_engine* e, int n);
 int launch_search(sl2_engine* e);
 int launch_update(sl2_engine* e);
-int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot);
+int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);
 
 }  // namespace sl2

@@ -145,7 +145,7 @@ static int build_groups(sl2_engine* e, int G) {
     g->patch_sums = e->patch_sums + f * N * 2; g->xp_org = e->xp_org + f * N * 8; g->f_flags = e->f_flags + f * N;
     g->n_slots = e->n_slots + f; g->attempted = e->attempted + f * N; g->successful = e->successful + f * N;
     g->traj = e->traj + f * kTrajCapacity * 3; g->traj_count = e->traj_count + f; g->last_r = e->last_r + f * 3;
-    g->status = e->status + f; g->pos_log = e->pos_log + f * kTrajCapacity * 3;
+    g->status = e->status + f; g->pos_log = e->pos_log + f * kTrajCapacity * 3; g->pos_count = e->pos_count + f;
     g->f_h = e->f_h + f * N * 2; g->f_Hx = e->f_Hx + f * N * 14; g->f_Hy = e->f_Hy + f * N * 6; g->f_R = e->f_R + f * N;
     g->f_S = e->f_S + f * N * 4; g->f_score = e->f_score + f * N; g->f_z = e->f_z + f * N * 2; g->f_nu = e->f_nu + f * N * 2;
     g->sel_idx = e->sel_idx + f * N; g->n_sel = e->n_sel + f; g->n_vis = e->n_vis + f; g->meas_ok = e->meas_ok + f * N;
@@ -297,6 +297,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->last_r, B * 3));
   A(dmalloc(&e->status, B));
   A(dmalloc(&e->pos_log, B * kTrajCapacity * 3));
+  A(dmalloc(&e->pos_count, B));
   A(dmalloc(&e->f_h, B * N * 2));
   A(dmalloc(&e->f_Hx, B * N * 14));
   A(dmalloc(&e->f_Hy, B * N * 6));
@@ -368,11 +369,12 @@ void sl2_destroy(sl2_engine* e) {
     delete g;
   }
   if (e->fork_event) hipEventDestroy(e->fork_event);
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->pack_first, e->pack_count, e->n_packs,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->pos_count};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -482,6 +484,8 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
 
 int sl2_set_search_variant(sl2_engine* e, int variant) {
   if (!e || variant < 0 || variant > 2) return SL2_ERR_INVALID;
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  e->step_graphs.clear();
   e->search_variant = variant;
   return SL2_OK;
 }
@@ -503,6 +507,8 @@ int sl2_debug_chol_trace(sl2_engine* e, long long* out, size_t n) {
 
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
   if (!e || chol_variant < 0 || chol_variant > 2 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  e->step_graphs.clear();
   e->chol_variant = chol_variant;
   e->fwd_variant = fwd_variant;
   return SL2_OK;
@@ -541,8 +547,7 @@ int sl2_kalman_filter_update(sl2_engine* e) {
 int sl2_finish_step(sl2_engine* e, int save_trajectory) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  const int slot = (int)(e->steps_done % kTrajCapacity);
-  int rc = for_each_group(e, [=](sl2_engine* g) { return launch_finalize(g, save_trajectory, slot); });
+  int rc = for_each_group(e, [=](sl2_engine* g) { return launch_finalize(g, save_trajectory); });
   e->steps_done += 1;
   return rc;
 }
@@ -562,30 +567,73 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   }
   int rc;
   if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
-  const int slot = (int)(e->steps_done % kTrajCapacity);
   const int nsel = e->prm.number_of_features_to_select;
   // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
-  rc = for_each_group(e, [=](sl2_engine* g) {
-    int r;
-    if ((r = launch_predict(g)) != SL2_OK) return r;
-    if ((r = launch_feature_prediction(g)) != SL2_OK) return r;
-    if ((r = launch_select(g, nsel)) != SL2_OK) return r;
-    if ((r = launch_search(g)) != SL2_OK) return r;
-    if ((r = launch_update(g)) != SL2_OK) return r;
-    return launch_finalize(g, tail ? 0 : save_trajectory, slot);
-  });
-  if (rc == SL2_OK && tail) {
-    sl2_engine* g = e->groups.empty() ? e : e->groups[0];
-    g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
-    g->score_map = e->score_map;
-    rc = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
-    e->score_map = g->score_map;
+  if (tail && !e->score_map)
+    SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * (size_t)e->B * e->cam.width * e->cam.height));
+  auto issue = [=]() -> int {
+    int r = for_each_group(e, [=](sl2_engine* g) {
+      int q;
+      if ((q = launch_predict(g)) != SL2_OK) return q;
+      if ((q = launch_feature_prediction(g)) != SL2_OK) return q;
+      if ((q = launch_select(g, nsel)) != SL2_OK) return q;
+      if ((q = launch_search(g)) != SL2_OK) return q;
+      if ((q = launch_update(g)) != SL2_OK) return q;
+      return launch_finalize(g, tail ? 0 : save_trajectory);
+    });
+    if (r == SL2_OK && tail) {
+      sl2_engine* g = e->groups.empty() ? e : e->groups[0];
+      g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
+      g->score_map = e->score_map;
+      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
+    }
+    return r;
+  };
+  // Whole-step HIP graph: the dozen launches of a step are captured once per (frame buffer, flags) and replayed -
+  // at small batches the step is launch-bound.  Needs device-resident frames (the capture bakes the pointer in; a
+  // double-buffered ingest alternates between two graphs), one sequence group and no per-kernel profiling.
+  const bool use_graph = e->graph_mode && frames_on_device && !e->profiling && e->groups.size() <= 1;
+  if (use_graph) {
+    hipGraphExec_t exec = nullptr;
+    for (const auto& sg : e->step_graphs)
+      if (sg.frames == (const void*)frames && sg.stride == seq_stride && sg.save_trajectory == save_trajectory &&
+          sg.enable_mapping == enable_mapping && sg.tail == (int)tail) { exec = sg.exec; break; }
+    if (!exec) {
+      hipGraph_t graph = nullptr;
+      SL2_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
+      rc = issue();
+      const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+      if (rc != SL2_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+      SL2_HIP(ce);
+      SL2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipGraphDestroy(graph);
+      if (e->step_graphs.size() >= 8) { hipGraphExecDestroy(e->step_graphs.front().exec); e->step_graphs.erase(e->step_graphs.begin()); }
+      e->step_graphs.push_back({(const void*)frames, seq_stride, save_trajectory, enable_mapping, (int)tail, exec});
+    }
+    SL2_HIP(hipGraphLaunch(exec, e->stream));
+    rc = SL2_OK;
+  } else {
+    rc = issue();
   }
   e->steps_done += 1;
   if (rc != SL2_OK) return rc;
   if (e->profiling && e->pending.size() > 8192) return e->fold_events();
+  return SL2_OK;
+}
+
+static void drop_step_graphs(sl2_engine* e) {
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  e->step_graphs.clear();
+}
+
+int sl2_set_graph_mode(sl2_engine* e, int enabled) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  drop_step_graphs(e);
+  e->graph_mode = enabled != 0;
   return SL2_OK;
 }
 

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   int* __restrict__ successful, const int* __restrict__ m_count,
                                                   const int* __restrict__ n_sel, double* __restrict__ traj,
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
-                                                  int* __restrict__ status, double* __restrict__ pos_log, int log_slot, int N, int ld,
+                                                  int* __restrict__ status, double* __restrict__ pos_log, int* __restrict__ pos_count, int N, int ld,
                                                   int min_attempts, double match_fraction, int save_trajectory,
                                                   const int* __restrict__ part_i, int ppos) {
   extern __shared__ int s_del[];  // [N] slots deleted this frame, then [N] flags
@@ -332,6 +332,8 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
       for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
       traj_count[b] = c + 1;
     }
+    const int log_slot = pos_count[b] % kTrajCapacity;   // device-side step counter: the launch carries no per-step argument
+    pos_count[b] += 1;
     for (int k = 0; k < 3; ++k) pos_log[((size_t)b * kTrajCapacity + log_slot) * 3 + k] = xb[k];
     bool bad = false;
     for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]);
@@ -366,12 +368,12 @@ int launch_select(sl2_engine* e, int n) {
   return SL2_OK;
 }
 
-int launch_finalize(sl2_engine* e, int save_trajectory, int log_slot) {
+int launch_finalize(sl2_engine* e, int save_trajectory) {
   LaunchScope ls(e, "k_finalize");
   const size_t shm = (size_t)e->N * 2 * sizeof(int);
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
-                     log_slot, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
+                     e->pos_count, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
                      e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos);
   SL2_HIP(hipGetLastError());
   return SL2_OK;

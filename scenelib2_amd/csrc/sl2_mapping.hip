@@ -506,9 +506,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
   const int W = e->cam.width, H = e->cam.height;
-  if (!e->score_map) {
-    SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * (size_t)B * W * H));
-  }
+  if (!e->score_map) { set_error("launch_mapping: score map not allocated"); return SL2_ERR_INVALID; }
   {
     LaunchScope ls(e, "k_map_region");
     hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,

@@ -91,6 +91,9 @@ class Engine:
     def set_groups(self, groups):
         _lib.check(self.L.sl2_set_groups(self.h, int(groups)))
 
+    def set_graph_mode(self, enabled=True):
+        _lib.check(self.L.sl2_set_graph_mode(self.h, int(bool(enabled))))
+
     def set_search_variant(self, variant):
         _lib.check(self.L.sl2_set_search_variant(self.h, int(variant)))
 

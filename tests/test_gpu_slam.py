@@ -269,3 +269,35 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
     for k in range(4):
         pr.step_both(k)
         pr.compare_state(1e-9, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mapping", [False, True])
+def test_graph_replay_is_bit_identical(mapping):
+    """sl2_set_graph_mode: the captured step replayed from two alternating device frame buffers (what the ingest
+    hands out) must give exactly the state of the directly launched step."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mapping_helpers import make_mapping_sequence
+    from scenelib2_amd import _lib
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=14)
+    W, H = cam["width"], cam["height"]
+    engines = []
+    for graph in (False, True):
+        e = Engine(cam, params, 2, 32)
+        e.set_vehicle_state(np.tile(spec.xv0, (2, 1)), np.tile(spec.Pxx0, (2, 1, 1)))
+        e.add_known_features(np.tile(spec.feat_y, (2, 1, 1)), np.tile(spec.xp_org(), (2, 1, 1)), np.tile(templates, (2, 1, 1, 1)))
+        e.set_graph_mode(graph)
+        engines.append(e)
+    bufs = [_lib.DeviceBuffer(2 * W * H, 0) for _ in range(2)]
+    for k in range(1, 15):
+        buf = bufs[k & 1]
+        buf.upload(np.stack([frames[k], frames[k]]))
+        for e in engines:
+            e.go_one_step(buf.ptr, save_trajectory=True, enable_mapping=mapping, on_device=True, seq_stride=W * H)
+            e.synchronize()
+    a, b = engines
+    assert np.array_equal(a.total_state(0), b.total_state(0)) and np.array_equal(a.total_covariance(1), b.total_covariance(1))
+    assert np.array_equal(a.trajectory(0), b.trajectory(0)) and np.array_equal(a.position_log(0, 2), b.position_log(0, 2))
+    if mapping:
+        assert a.partial_feature(0)["info"] == b.partial_feature(0)["info"] and a.partial_feature(0)["info"]["initialised"] >= 1

@@ -62,3 +62,27 @@ def gather_states(local_states, device=None):
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return torch.cat(out, dim=0).cpu().numpy()
+
+
+def scatter_frames(frames_root, per_rank, frame_shape, root=0, device=None):
+    """Scatter of one step's frames when they originate on ONE rank (a single grabber feeding a node): the root holds
+    uint8 [world * per_rank, H, W] in global sequence order, every rank receives its block [per_rank, H, W].
+    One grouped point-to-point exchange per destination (xGMI is point to point: a root-sourced scatter is bounded by
+    the root's links - SURVEY.md 8(e) prefers per-rank loading; this exists for the case where that is impossible).
+    Identity without torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    H, W = frame_shape
+    if not (dist.is_available() and dist.is_initialized()):
+        return np.ascontiguousarray(frames_root, dtype=np.uint8).reshape(per_rank, H, W)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out = torch.empty((per_rank, H, W), dtype=torch.uint8, device=device if device is not None else "cpu")
+    if rank == root:
+        src = torch.from_numpy(np.ascontiguousarray(frames_root, dtype=np.uint8).reshape(world, per_rank, H, W))
+        if device is not None:
+            src = src.to(device)
+        chunks = [src[r].contiguous() for r in range(world)]
+        dist.scatter(out, chunks, src=root)
+    else:
+        dist.scatter(out, None, src=root)
+    return out if device is not None else out.numpy()

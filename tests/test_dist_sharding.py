@@ -35,6 +35,10 @@ def _worker(rank, world, port, q):
         allrows = sharding.gather_states(local)
         tmax = sharding.max_over_ranks(1.0 + r)
         tsum = sharding.sum_over_ranks(len(ids))
+        # frames originating on rank 0 reach every rank's shard
+        allf = (np.arange(w * 3 * 4 * 5) % 251).astype(np.uint8).reshape(w * 3, 4, 5)
+        mine = sharding.scatter_frames(allf if r == 0 else None, 3, (4, 5))
+        assert np.array_equal(mine, allf[3 * r:3 * r + 3])
         dist.barrier()
         q.put((rank, ids.tolist(), allrows, tmax, tsum, sharding.shard_range(7, w, r)))
     finally:

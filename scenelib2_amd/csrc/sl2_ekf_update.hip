@@ -659,17 +659,22 @@ __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int 
 }
 
 __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, double* __restrict__ LinvT,
-                                                      const int* __restrict__ m_count, int mld, int nblk_max) {
+                                                      const int* __restrict__ m_count, int mld, int nblk_max, int J0, int nb_cap) {
+  // J0 / nb_cap: factor the diagonal sub-matrix of blocks J0 .. J0 + nb_cap - 1 only (panel-wise factorisation of
+  // large systems, launch_chol_panels); block indices below are relative to J0.  (0, any) = the whole matrix.
   const int b = blockIdx.x;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
+  int nblk = (2 * cnt + 31) / 32 - J0;
+  if (nblk <= 0) return;
+  if (nblk > nb_cap) nblk = nb_cap;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool isD = wave == 0;
   const int mw = wave - 1;
   __shared__ double sTile[32][33];
   __shared__ double sLinv[32 * kLinvPitch];
-  double* Sb = St + (size_t)b * mld * mld;
+  double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
+  LinvT += (size_t)J0 * 1024;
   for (int J = 0; J < nblk; ++J) {
     const int o = J * 32;
     int lane_j = lane;
@@ -849,20 +854,23 @@ template <int NB>
 __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
                                                     const double* __restrict__ St, const double* __restrict__ LinvT,
                                                     const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B,
-                                                    int J0) {
+                                                    int J0, int col0, int ntile, int nb_cap) {
   // J0: first block row of this launch.  For maps of more than 13 blocks the substitution runs in groups of
   // NB = 8 block rows: k_fwd_gemm first subtracts the contribution of all earlier groups from the group's
   // rows of At, then this kernel solves within the group (block indices below are relative to J0).
+  // col0 / ntile: the 64-column tiles col0 + 64 t, t < ntile, of the right-hand side (0, ld / 64 for the EKF substitution;
+  // the panel solve of the large-system Cholesky passes the columns below its panel).  nb_cap caps the block rows solved.
   int b, ct;
-  if (!xcd_map(ld / 64, B, &b, &ct)) return;
+  if (!xcd_map(ntile, B, &b, &ct)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int m = 2 * cnt - 32 * J0;          // rows left from block J0 on
+  int m = 2 * cnt - 32 * J0;                // rows left from block J0 on
   if (m <= 0) return;
+  if (m > 32 * nb_cap) m = 32 * nb_cap;
   const int nblk = (m + 31) / 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = ct * 64 + wave * 16;
+  const int i0 = col0 + ct * 64 + wave * 16;
   const double* Ab = At + (size_t)b * mld * ld + (size_t)J0 * 32 * ld;
   double* Vb = Vt + (size_t)b * mld * ld + (size_t)J0 * 32 * ld;
   const double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
@@ -949,7 +957,7 @@ static bool launch_fwdsub_lds(sl2_engine* e, int B) {
 #define SL2_FWD_CASE(NBV)                                                                                           \
   case NBV:                                                                                                         \
     hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
-                       e->ld, e->mld, e->nblk_max, B, 0);                                                           \
+                       e->ld, e->mld, e->nblk_max, B, 0, 0, e->ld / 64, NBV);                                       \
     return true;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
@@ -1027,6 +1035,92 @@ __global__ void __launch_bounds__(256) k_fwd_gemm(double* __restrict__ At, const
       }
 }
 
+// ---------------------------------------------------------------------------
+// Cholesky of systems with more than 16 blocks (launch_chol_panels): right-looking over PANELS of four block columns
+// (128 columns), so that the trailing matrix is read and written once per 128 columns instead of once per 32 (the
+// launch-per-block kernels are bound by exactly that traffic: 22 GB per factorisation at m = 1000, batch 256):
+//   k_chol_left (J0, 4 blocks)      factor the 128x128 diagonal sub-matrix in one launch
+//   k_fwdsub_lds<4> on S itself     panel solve X = S[below][panel] L_dd^-T  (S is k-major: the panel's columns are rows
+//                                   of St, i.e. exactly the right-hand-side layout of the EKF substitution)
+//   k_chol_syrk                     S[below][below] -= X X^T, 64x64 tiles of the lower block triangle, K = 128
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_chol_syrk(double* __restrict__ St, const int* __restrict__ m_count, int mld, int B,
+                                                   int k0, int kp, int c0) {
+  int b, t;
+  const int nt = (mld - c0) / 64;
+  if (!xcd_map(nt * (nt + 1) / 2, B, &b, &t)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int mp = (2 * cnt + 31) / 32 * 32;
+  int ti = 0;
+  while (t > ti) { t -= ti + 1; ++ti; }
+  const int tj = t;                       // tj <= ti : column block j <= row block i (lower triangle, stored St[j][i])
+  const int j0 = c0 + tj * 64, i0 = c0 + ti * 64;
+  if (i0 >= mp && j0 >= mp) return;
+  if (j0 >= mp) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int wj = (wave >> 1) * 32, wi = (wave & 1) * 32;
+  double* Sb = St + (size_t)b * mld * mld;
+  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
+  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
+  const int kr = tid >> 4, c4 = (tid & 15) * 4;
+  const double* gA = Sb + (size_t)(k0 + kr) * mld + j0 + c4;     // X[j0 + c][k] = St[k][j0 + c]
+  const double* gB = Sb + (size_t)(k0 + kr) * mld + i0 + c4;
+  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  v4d acc[2][2];
+  for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0, 0, 0, 0};
+  // rows of the panel beyond this sequence's own (padded) system are never initialised: stop at mp
+  const int kvalid = (mp - k0 < kp) ? mp - k0 : kp;
+  const int nchunk = kvalid / kSyrkKC;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int buf = ch & 1;
+    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
+    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
+    __syncthreads();
+    if (ch + 1 < nchunk) {
+      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * mld);
+      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * mld);
+    }
+    const double* pa = &sA[buf][hi * kSyrkPitch + wj + lo];
+    const double* pb = &sB[buf][hi * kSyrkPitch + wi + lo];
+#pragma unroll
+    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
+      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
+      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double* q = Sb + (size_t)(j0 + wj + 16 * a + hi + 4 * r) * mld + i0 + wi + 16 * c + lo;
+        *q -= acc[a][c][r];
+      }
+}
+
+constexpr int kCholPanelBlocks = 4;
+
+static void launch_chol_panels(sl2_engine* e, int B) {
+  for (int p0 = 0; p0 < e->nblk_max; p0 += kCholPanelBlocks) {
+    const int nb = e->nblk_max - p0 < kCholPanelBlocks ? e->nblk_max - p0 : kCholPanelBlocks;
+    hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb);
+    const int c0 = (p0 + nb) * 32;
+    if (c0 >= e->mld) break;
+    const int ntile = (e->mld - c0) / 64;      // mld is a multiple of 64 for these sizes (sl2_create)
+    hipLaunchKernelGGL((k_fwdsub_lds<kCholPanelBlocks>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
+                       e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
+    hipLaunchKernelGGL(k_chol_syrk, dim3(xcd_grid(ntile * (ntile + 1) / 2, B)), dim3(256), 0, e->stream, e->St, e->m_count, e->mld,
+                       B, p0 * 32, nb * 32, c0);
+  }
+}
+
 // substitution in groups of eight block rows, for systems of more than 13 blocks
 static void launch_fwdsub_grouped(sl2_engine* e, int B) {
   for (int J0 = 0; J0 < e->nblk_max; J0 += 8) {
@@ -1034,7 +1128,7 @@ static void launch_fwdsub_grouped(sl2_engine* e, int B) {
       hipLaunchKernelGGL(k_fwd_gemm, dim3(xcd_grid(4 * (e->ld / 64), B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->m_count,
                          e->ld, e->mld, B, J0);
     hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
-                       e->m_count, e->ld, e->mld, e->nblk_max, B, J0);
+                       e->m_count, e->ld, e->mld, e->nblk_max, B, J0, 0, e->ld / 64, 8);
   }
 }
 
@@ -1214,10 +1308,15 @@ int launch_update(sl2_engine* e) {
       SL2_HIP(hipGetLastError());
     }
   }
-  if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
+  if (e->nblk_max > kFusedMaxBlocks && e->root->chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
+    LaunchScope ls(e, "k_chol_fused");
+    launch_chol_panels(e, B);
+    SL2_HIP(hipGetLastError());
+  } else if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
     LaunchScope ls(e, "k_chol_fused");
     if (e->root->chol_variant == 1)
-      hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max);
+      hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, 0,
+                         e->nblk_max);
     else
       hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
                          (long long*)e->root->chol_trace);

@@ -279,6 +279,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (nsel > max_features) nsel = max_features;
   e->nsel_max = nsel;
   e->mld = round_up(2 * nsel, 32);
+  if (e->mld / 32 > 16) e->mld = round_up(2 * nsel, 128);   // large systems are factored in 128-column panels
   e->nblk_max = e->mld / 32;
   const size_t B = batch, N = max_features, ld = e->ld, mld = e->mld;
   int r = SL2_OK;

@@ -162,6 +162,17 @@ def test_larger_baseline_shapes(width, height, n_features, n_frames, batch):
     assert not pr.engine.status_flags().any()
 
 
+def test_large_ragged_batch_runs_the_panel_kernels():
+    """More than 16 Cholesky blocks (panel-wise factorisation, grouped substitution) with sequences of different map
+    sizes in one batch: the shorter systems end inside a 128-column panel and leave uninitialised padding behind."""
+    cam = synth.default_camera(640, 480)
+    pr = Pair(288, 3, batch=3, cam=cam, feature_counts=[288, 150, 40], feature_sigma=0.004)
+    for k in range(3):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, 2e-8)
+    assert not pr.engine.status_flags().any()
+
+
 def test_monoslam_api_with_shipped_cfg_and_templates():
     """MonoSLAM.Init(cfg) + GoOneStep on the reference's own fixtures (cfg values, known_patch*.pgm)."""
     from scenelib2_amd.config import load_config, read_pgm

@@ -1349,7 +1349,9 @@ int launch_update(sl2_engine* e) {
     bool done = false;
     if (e->root->fwd_variant == 1) {
       done = launch_fwdsub_lds(e, B);
-      if (!done) { launch_fwdsub_grouped(e, B); done = true; }
+      // the grouped form works on 64-row tiles: it needs mld to be a multiple of 64 (sl2_create pads systems of more
+      // than 16 blocks to 128)
+      if (!done && e->mld % 64 == 0) { launch_fwdsub_grouped(e, B); done = true; }
     }
     if (!done)
       hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,

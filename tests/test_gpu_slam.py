@@ -148,7 +148,7 @@ def test_delete_bad_features_matches_reference_walk():
     assert 3 not in [f["label"] for f in pr.engine.features(0)]
 
 
-@pytest.mark.parametrize("width,height,n_features,n_frames,batch", [(640, 480, 200, 3, 2), (1280, 720, 500, 2, 1)])
+@pytest.mark.parametrize("width,height,n_features,n_frames,batch", [(640, 480, 200, 3, 2), (640, 480, 224, 2, 1), (1280, 720, 500, 2, 1)])
 def test_larger_baseline_shapes(width, height, n_features, n_frames, batch):
     """BASELINE configs 4 and 5 shapes (640x480 / 200 features, n = 613; 1280x720 / 500 features,
     n = 1513, m up to 1000: 32 Cholesky blocks) at a batch the oracle can follow."""

@@ -11,6 +11,13 @@
 
 namespace sl2 {
 
+#ifdef SL2_FRONT_TRACE
+__device__ long long* g_front_trace = nullptr;     // development only: 8 cycle stamps per workgroup and kernel
+#define FTR(kern, slot) do { if (g_front_trace && threadIdx.x == 0) g_front_trace[((size_t)(kern) * 4096 + blockIdx.x) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FTR(kern, slot) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------
 // k_predict: one workgroup per sequence.  Only the first 13 rows/cols of P change
 // (static map): Pxx <- (F Pxx) F^T + Q, strip P[0:13, j] <- F P[0:13, j], mirrored.
@@ -22,6 +29,7 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
   const int tid = threadIdx.x;
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
+  FTR(0, 0);
   if (tid < 3) prev_r[b * 3 + tid] = xb[tid];   // prev_xp_pos (monoslam.cpp:121-124); xb is rewritten at the very end
   __shared__ double s_f[13], s_A[16], s_B[12], s_P[169], s_T[169];
   if (tid == 0) {
@@ -35,6 +43,7 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
   }
   for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
   __syncthreads();
+  FTR(0, 1);
   for (int e = tid; e < 169; e += blockDim.x) {
     const int i = e / 13, j = e % 13;
     double v[13];
@@ -42,24 +51,41 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
     s_T[e] = frow_dot(i, dt, s_A, s_B, v);
   }
   __syncthreads();
+  FTR(0, 2);
   for (int e = tid; e < 169; e += blockDim.x) {
     const int i = e / 13, j = e % 13;
     double v[13];
     for (int k = 0; k < 13; ++k) v[k] = s_T[i * 13 + k];
     Pb[(size_t)i * ld + j] = frow_dot(j, dt, s_A, s_B, v) + process_noise_entry(i, j, dt, s_B);
   }
+  FTR(0, 3);
   // columns of the map: the 3-D features, and the six states of a partially initialised one at ppos
   const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * n_slots[b];
-  for (int j = 13 + tid; j < n_used; j += blockDim.x) {
-    double v[13], w[13];
-    for (int k = 0; k < 13; ++k) v[k] = Pb[(size_t)k * ld + j];
-    for (int i = 0; i < 13; ++i) w[i] = frow_dot(i, dt, s_A, s_B, v);
-    for (int i = 0; i < 13; ++i) {
-      Pb[(size_t)i * ld + j] = w[i];
-      Pb[(size_t)j * ld + i] = w[i];
+  // The mirrored copy P[j][0..12] goes through LDS so that the 13 entries of a row leave in ONE store instruction
+  // (16 lanes per row): written straight from the column owner they were 13 scattered 8-byte stores per row and
+  // the kernel spent three quarters of its time on them.
+  __shared__ double s_W[128][13];
+  for (int j0 = 13; j0 < n_used; j0 += blockDim.x) {
+    const int j = j0 + tid;
+    if (j < n_used) {
+      double v[13], w[13];
+      for (int k = 0; k < 13; ++k) v[k] = Pb[(size_t)k * ld + j];
+      for (int i = 0; i < 13; ++i) w[i] = frow_dot(i, dt, s_A, s_B, v);
+      for (int i = 0; i < 13; ++i) {
+        Pb[(size_t)i * ld + j] = w[i];
+        s_W[tid][i] = w[i];
+      }
     }
+    __syncthreads();
+    const int rr = tid >> 4, cc = tid & 15;
+    for (int r0 = 0; r0 < (int)blockDim.x; r0 += blockDim.x / 16) {
+      const int jr = j0 + r0 + rr;
+      if (cc < 13 && jr < n_used) Pb[(size_t)jr * ld + cc] = s_W[r0 + rr][cc];
+    }
+    __syncthreads();
   }
   if (tid < 13) xb[tid] = s_f[tid];
+  FTR(0, 4);
 }
 
 // ---------------------------------------------------------------------------
@@ -138,6 +164,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
   int* s_nv = s_nu + N;                    // [N] ... and height
   __shared__ int s_nvis, s_zero_rank, s_last;
   const int b = blockIdx.x, tid = threadIdx.x;
+  FTR(1, 0);
   const int ns = n_slots[b];
   if (tid == 0) { s_nvis = 0; s_zero_rank = 0x7fffffff; s_last = -1; }
   __syncthreads();
@@ -148,17 +175,27 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     if (fl & FF_ACTIVE) atomicMax(&s_last, i);
   }
   __syncthreads();
+  FTR(1, 1);
+  // scores are traces of covariances (>= 0): an invisible feature takes the key -1 and never outranks anyone, so the
+  // rank loop has no branch and its LDS reads pipeline
+  for (int i = tid; i < ns; i += blockDim.x)
+    if (!s_vis[i]) s_score[i] = -1.0;
+  __syncthreads();
   for (int i = tid; i < ns; i += blockDim.x) {
     if (!s_vis[i]) continue;
     const double si = s_score[i];
     int rank = 0;
-    for (int j = 0; j < ns; ++j)
-      if (s_vis[j] && (s_score[j] > si || (s_score[j] == si && j < i))) ++rank;
+#pragma unroll 8
+    for (int j = 0; j < ns; ++j) {
+      const double sj = s_score[j];
+      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+    }
     s_vis[i] = 1 + rank;  // store rank+1
     atomicAdd(&s_nvis, 1);
     if (si == 0.0) atomicMin(&s_zero_rank, rank);
   }
   __syncthreads();
+  FTR(1, 2);
   int limit = n_want;
   if (s_zero_rank < limit) limit = s_zero_rank;
   if (s_nvis < limit) limit = s_nvis;
@@ -173,25 +210,35 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     }
   }
   __syncthreads();
+  FTR(1, 3);
+  // Work list of the packed search kernel: consecutive selected features share one wavefront as
+  // long as their candidate columns fit 64 lanes (<= 8 features, <= 160 window rows of LDS).
+  // A window too large for the LDS tile gets a wavefront of its own (exact baseline path).
+  // The greedy segmentation is a chain, but the length of the pack that STARTS at k depends on k alone: every
+  // thread computes it for its k (<= 8 look-ahead reads), then one thread follows the chain (~25 hops).  (Walked
+  // feature by feature by one thread - in LDS or on the scalar unit - this phase was half of the kernel.)
+  for (int k = tid; k < limit; k += blockDim.x) {
+    int cnt = 0;
+    if (s_nu[k] > kPackMaxNu || s_nv[k] > kPackMaxNv) {
+      cnt = 1;
+    } else {
+      int lanes = 0, rows = 0;
+      while (k + cnt < limit && cnt < 8) {
+        const int nu_c = s_nu[k + cnt], nv_c = s_nv[k + cnt];
+        const int w = nu_c > 0 ? nu_c : 1, hh = (nv_c > 0 ? nv_c : 0) + 10;
+        if (nu_c > kPackMaxNu || nv_c > kPackMaxNv) break;
+        if (lanes + w > 64 || rows + hh > kPackMaxRows) break;
+        lanes += w; rows += hh; ++cnt;
+      }
+      if (cnt == 0) cnt = 1;
+    }
+    s_vis[k] = cnt;          // s_vis (the ranks) is free again
+  }
+  __syncthreads();
   if (tid == 0) {
-    // Work list of the packed search kernel: consecutive selected features share one wavefront as
-    // long as their candidate columns fit 64 lanes (<= 8 features, <= 160 window rows of LDS).
-    // A window too large for the LDS tile gets a wavefront of its own (exact baseline path).
     int np = 0, k = 0;
     while (k < limit) {
-      const bool big = s_nu[k] > kPackMaxNu || s_nv[k] > kPackMaxNv;
-      int lanes = 0, rows = 0, cnt = 0;
-      if (big) {
-        cnt = 1;
-      } else {
-        while (k + cnt < limit && cnt < 8) {
-          const int w = s_nu[k + cnt] > 0 ? s_nu[k + cnt] : 1, hh = (s_nv[k + cnt] > 0 ? s_nv[k + cnt] : 0) + 10;
-          if (s_nu[k + cnt] > kPackMaxNu || s_nv[k + cnt] > kPackMaxNv) break;
-          if (lanes + w > 64 || rows + hh > kPackMaxRows) break;
-          lanes += w; rows += hh; ++cnt;
-        }
-        if (cnt == 0) cnt = 1;
-      }
+      const int cnt = s_vis[k];
       pack_first[(size_t)b * N + np] = k;
       pack_count[(size_t)b * N + np] = cnt;
       ++np;
@@ -199,6 +246,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     }
     n_packs[b] = np;
   }
+  FTR(1, 4);
   if (tid == 0) {
     n_sel[b] = limit;
     n_vis[b] = s_nvis;
@@ -340,6 +388,14 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
     if (bad) status[b] |= 1;
   }
 }
+
+#ifdef SL2_FRONT_TRACE
+}  // namespace sl2
+extern "C" int sl2_debug_front_trace(long long* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(sl2::g_front_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 2;
+}
+namespace sl2 {
+#endif
 
 int launch_predict(sl2_engine* e) {
   LaunchScope ls(e, "k_predict");

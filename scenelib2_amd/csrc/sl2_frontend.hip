@@ -22,7 +22,7 @@ __device__ long long* g_front_trace = nullptr;     // development only: 8 cycle 
 // k_predict: one workgroup per sequence.  Only the first 13 rows/cols of P change
 // (static map): Pxx <- (F Pxx) F^T + Q, strip P[0:13, j] <- F P[0:13, j], mirrored.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
+__global__ void __launch_bounds__(256) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
                                                  double* __restrict__ prev_r, const int* __restrict__ part_i, int ppos, int ld,
                                                  double dt) {
   const int b = blockIdx.x;
@@ -31,6 +31,11 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
   double* Pb = P + (size_t)b * ld * ld;
   FTR(0, 0);
   if (tid < 3) prev_r[b * 3 + tid] = xb[tid];   // prev_xp_pos (monoslam.cpp:121-124); xb is rewritten at the very end
+  // columns of the map: the 3-D features, and the six states of a partially initialised one at ppos
+  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * n_slots[b];
+  // the first batch of strip columns is fetched now: its memory latency hides behind the serial motion model
+  double v0[13];
+  for (int k = 0; k < 13; ++k) v0[k] = (13 + tid < n_used) ? Pb[(size_t)k * ld + 13 + tid] : 0.0;
   __shared__ double s_f[13], s_A[16], s_B[12], s_P[169], s_T[169];
   if (tid == 0) {
     double xv[13];
@@ -59,17 +64,15 @@ __global__ void __launch_bounds__(128) k_predict(double* __restrict__ x, double*
     Pb[(size_t)i * ld + j] = frow_dot(j, dt, s_A, s_B, v) + process_noise_entry(i, j, dt, s_B);
   }
   FTR(0, 3);
-  // columns of the map: the 3-D features, and the six states of a partially initialised one at ppos
-  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * n_slots[b];
   // The mirrored copy P[j][0..12] goes through LDS so that the 13 entries of a row leave in ONE store instruction
   // (16 lanes per row): written straight from the column owner they were 13 scattered 8-byte stores per row and
   // the kernel spent three quarters of its time on them.
-  __shared__ double s_W[128][13];
+  __shared__ double s_W[256][13];
   for (int j0 = 13; j0 < n_used; j0 += blockDim.x) {
     const int j = j0 + tid;
     if (j < n_used) {
       double v[13], w[13];
-      for (int k = 0; k < 13; ++k) v[k] = Pb[(size_t)k * ld + j];
+      for (int k = 0; k < 13; ++k) v[k] = (j0 == 13) ? v0[k] : Pb[(size_t)k * ld + j];
       for (int i = 0; i < 13; ++i) w[i] = frow_dot(i, dt, s_A, s_B, v);
       for (int i = 0; i < 13; ++i) {
         Pb[(size_t)i * ld + j] = w[i];
@@ -399,7 +402,7 @@ namespace sl2 {
 
 int launch_predict(sl2_engine* e) {
   LaunchScope ls(e, "k_predict");
-  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(128), 0, e->stream, e->x, e->P, e->n_slots, e->prev_r, e->part_i, e->ppos, e->ld,
+  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(256), 0, e->stream, e->x, e->P, e->n_slots, e->prev_r, e->part_i, e->ppos, e->ld,
                      e->prm.delta_t);
   SL2_HIP(hipGetLastError());
   return SL2_OK;

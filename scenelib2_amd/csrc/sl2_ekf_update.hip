@@ -626,14 +626,15 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
 // launch at batch 1024, m = 200, against 0.23 GB of matrix): here tile (I, J) is read once, updated
 // with all its J products L[I][K] L[J][K]^T from finished columns, solved and written once.
 // Per block column J (waves: D = 0, M0..M2 = 1..3; tiles I = J, J+1, ... dealt M0, M1, M2, M0, ...):
-//   P1  M0 updates the diagonal tile -> LDS; M1 / M2 update their first tile          barrier X1
-//   P2  D factors + inverts the diagonal block while the M waves update their other tiles   X2
+//   P1  M0 updates the diagonal tile -> LDS                                             barrier X1
+//   P2  D factors + inverts the diagonal block while the M waves update the tiles below it  X2
 //   P3  panel solves L[I][J] = T[I][J] L_JJ^-T of every tile below the diagonal             X3
 // ---------------------------------------------------------------------------
 // acc(I, J) -= sum_{K < J} L[J][K-block] L[I][K-block]^T ; result stored back (or returned for the diagonal)
 __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int lo, int hi) {
   Tile32 acc = tile_load(Sb, mld, J * 32, I * 32, lo, hi);
-  // (an explicit register prefetch of the next half-step's operands measured slower: 0.275 vs 0.243 ms)
+  // (measured slower: an explicit register prefetch of the next half-step's operands, 0.275 vs 0.243 ms; all 32 operand
+  // loads of a product in one batch, 0.271 vs 0.266)
   for (int K = 0; K < J; ++K) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -659,7 +660,8 @@ __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int 
 }
 
 __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, double* __restrict__ LinvT,
-                                                      const int* __restrict__ m_count, int mld, int nblk_max, int J0, int nb_cap) {
+                                                      const int* __restrict__ m_count, int mld, int nblk_max, int J0, int nb_cap,
+                                                      long long* trace) {
   // J0 / nb_cap: factor the diagonal sub-matrix of blocks J0 .. J0 + nb_cap - 1 only (panel-wise factorisation of
   // large systems, launch_chol_panels); block indices below are relative to J0.  (0, any) = the whole matrix.
   const int b = blockIdx.x;
@@ -675,31 +677,34 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
   __shared__ double sLinv[32 * kLinvPitch];
   double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
   LinvT += (size_t)J0 * 1024;
+#ifdef SL2_CHOL_TRACE
+#define TRL(slot) do { if (trace && lane == 0 && J < 8) trace[(((size_t)b * 4 + wave) * 8 + J) * 4 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TRL(slot) do { } while (0)
+#endif
   for (int J = 0; J < nblk; ++J) {
     const int o = J * 32;
     int lane_j = lane;
     asm volatile("" : "+v"(lane_j));      // see k_chol_fused4
     const int lo = lane_j & 15, hi = lane_j >> 4;
-    // ---- P1 ----
-    if (!isD) {
-      const int I = J + mw;
-      if (I < nblk) {
-        const Tile32 t = tile_left_update(Sb, mld, J, I, lo, hi);
-        if (mw == 0) {
+    TRL(0);
+    // ---- P1 ---- only the diagonal tile: everything else can wait until the D wave is busy
+    if (mw == 0) {
+      const Tile32 t = tile_left_update(Sb, mld, J, J, lo, hi);
 #pragma unroll
-          for (int jt = 0; jt < 2; ++jt)
+      for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = t.f[jt][it][r4];
-        } else {
-          tile_store(Sb, mld, o, I * 32, lo, hi, t);
-        }
-      }
+          for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = t.f[jt][it][r4];
     }
+    TRL(1);
     __syncthreads();                       // X1: the updated diagonal tile is in LDS
     // ---- P2 ----
     if (isD) {
+      // the diagonal factorisation is the critical path of the whole kernel (its wave shares a SIMD with MFMA waves of
+      // other sequences and was measured 2x slower under that contention): let the scheduler prefer it
+      __builtin_amdgcn_s_setprio(3);
       const int r = lane_j & 31;
       const bool low = lane_j < 32;
       double a[32];
@@ -721,12 +726,15 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 #pragma unroll
         for (int c = 0; c < 32; ++c) sLinv[r * kLinvPitch + c] = a[c];
       }
+      __builtin_amdgcn_s_setprio(0);
     } else {
-      for (int I = J + mw + 3; I < nblk; I += 3) {
+      // tiles below the diagonal, dealt M1, M2, M0, M1, ... (M0 has just done the diagonal one)
+      for (int I = J + 1 + (mw + 2) % 3; I < nblk; I += 3) {
         const Tile32 t = tile_left_update(Sb, mld, J, I, lo, hi);
         tile_store(Sb, mld, o, I * 32, lo, hi, t);
       }
     }
+    TRL(2);
     __syncthreads();                       // X2: L_JJ^-1 is in LDS, every tile of column J is updated
     // ---- P3 ----
     if (!isD) {
@@ -735,15 +743,16 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 #pragma unroll
         for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
       }
-      for (int I = J + mw; I < nblk; I += 3) {
-        if (I == J) continue;
+      for (int I = J + 1 + (mw + 2) % 3; I < nblk; I += 3) {
         const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
         tile_store(Sb, mld, o, I * 32, lo, hi, t);
       }
     }
+    TRL(3);
     if (J + 1 < nblk) __syncthreads();     // X3: column J of L is complete
   }
 }
+#undef TRL
 
 // ---------------------------------------------------------------------------
 // k_fwdsub: Vt = L^-1 At by blocked forward substitution.  Columns are
@@ -1110,7 +1119,8 @@ constexpr int kCholPanelBlocks = 4;
 static void launch_chol_panels(sl2_engine* e, int B) {
   for (int p0 = 0; p0 < e->nblk_max; p0 += kCholPanelBlocks) {
     const int nb = e->nblk_max - p0 < kCholPanelBlocks ? e->nblk_max - p0 : kCholPanelBlocks;
-    hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb);
+    hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb,
+                       (long long*)nullptr);
     const int c0 = (p0 + nb) * 32;
     if (c0 >= e->mld) break;
     const int ntile = (e->mld - c0) / 64;      // mld is a multiple of 64 for these sizes (sl2_create)
@@ -1316,7 +1326,7 @@ int launch_update(sl2_engine* e) {
     LaunchScope ls(e, "k_chol_fused");
     if (e->root->chol_variant == 1)
       hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, 0,
-                         e->nblk_max);
+                         e->nblk_max, (long long*)e->root->chol_trace);
     else
       hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
                          (long long*)e->root->chol_trace);

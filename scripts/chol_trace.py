@@ -68,6 +68,19 @@ def main():
         for w in range(4):
             print(" wave", w)
             print(np.array2string(rel[b, w].astype(np.int64), max_line_width=150))
+    if os.environ.get("SL2_TRACE_LEFT", "1") == "1":
+        # k_chol_left stamps: [loop top, before X1, before X2, before X3]
+        np.set_printoptions(precision=0, suppress=True)
+        for w, nm in ((0, "D "), (1, "M0"), (2, "M1"), (3, "M2")):
+            t = tr[:, w].astype(np.float64)
+            ok = tr[:, 0, :, 1] != 0
+            p1 = np.where(ok, t[:, :, 1] - t[:, :, 0], np.nan).mean(0)
+            p2 = np.where(ok, t[:, :, 2] - t[:, :, 1], np.nan).mean(0)
+            p3 = np.where(ok, t[:, :, 3] - t[:, :, 2], np.nan).mean(0)
+            print(nm, "P1 (incl. wait X0):", p1[:7], " X1->before X2:", p2[:7], " X2->before X3:", p3[:7])
+        tot = (tr[:, 0, :, 3].max(1) - tr[:, 0, 0, 0]).astype(np.float64)
+        print("mean total cycles per sequence:", tot.mean(), "max", tot.max())
+        return
     # averages over sequences
     dfac = (tr[:, 0, :, 1] - tr[:, 0, :, 0]).astype(np.float64)          # D: factor duration
     m0 = (tr[:, 1, :, 3] - tr[:, 1, :, 2]).astype(np.float64)            # M0: A..B work

@@ -128,6 +128,7 @@ struct sl2_engine {
   double* prev_r = nullptr;              // [B][3] camera position before the prediction (speed estimate, :121-124)
   int* me_desc = nullptr;                // [B][kMaxParticles][8] search ellipses of the particles
   double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
+  int* owner_map = nullptr;              // [B][H][W] which particle ellipse scores a position (kOwnerFree between searches)
   bool mapping_used = false;
   // ---- whole-step HIP graphs (small batches are launch-bound: ~12 kernels per step) ----
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };

@@ -375,7 +375,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->pack_first, e->pack_count, e->n_packs,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->pos_count};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -572,8 +572,12 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
-  if (tail && !e->score_map)
-    SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * (size_t)e->B * e->cam.width * e->cam.height));
+  if (tail && !e->score_map) {
+    const size_t px = (size_t)e->B * e->cam.width * e->cam.height;
+    SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));
+    SL2_HIP(hipMalloc((void**)&e->owner_map, sizeof(int) * px));
+    SL2_HIP(hipMemsetAsync(e->owner_map, 0x7f, sizeof(int) * px, e->stream));   // 0x7f7f7f7f: above every particle index
+  }
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
@@ -588,6 +592,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       sl2_engine* g = e->groups.empty() ? e : e->groups[0];
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
+      g->owner_map = e->owner_map;
       r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
     }
     return r;

@@ -45,24 +45,30 @@ __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ p
   me_describe(puinv[3 * e], puinv[3 * e + 1], puinv[3 * e + 2], centre[2 * e], centre[2 * e + 1], width, height, desc + 8 * (size_t)e);
 }
 
+__global__ void __launch_bounds__(256) k_me_mark(int width, int height, const int* __restrict__ ell_job, const int* __restrict__ desc,
+                                                 const double* __restrict__ puinv, int* __restrict__ owner) {
+  const int e = blockIdx.x;
+  me_mark_ellipse_wg(desc + 8 * (size_t)e, puinv + 3 * (size_t)e, width, owner + (size_t)ell_job[e] * width * height, e);
+}
+
 __global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ images, int width, int height,
                                                    const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
-                                                   const int* __restrict__ ell_job, const int* __restrict__ job_first,
-                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
+                                                   const int* __restrict__ ell_job, const int* __restrict__ desc,
+                                                   const double* __restrict__ puinv, const int* __restrict__ owner,
                                                    double* __restrict__ score_map) {
   const int e = blockIdx.x;
   const int job = ell_job[e];
-  me_score_ellipse_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121, job_first[job], e, desc,
-                      puinv, 3, score_map + (size_t)job * width * height);
+  me_score_ellipse_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121, desc + 8 * (size_t)e,
+                      puinv + 3 * (size_t)e, owner + (size_t)job * width * height, e, score_map + (size_t)job * width * height);
 }
 
 __global__ void __launch_bounds__(64) k_me_argmin(int width, int height, const int* __restrict__ ell_job,
                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
-                                                  const double* __restrict__ score_map, int* __restrict__ result,
-                                                  double* __restrict__ corrmax) {
+                                                  const double* __restrict__ score_map, int* __restrict__ owner,
+                                                  int* __restrict__ result, double* __restrict__ corrmax) {
   const int e = blockIdx.x;
   me_argmin_wave(width, desc + 8 * (size_t)e, puinv + 3 * (size_t)e, score_map + (size_t)ell_job[e] * width * height,
-                 result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
+                 owner + (size_t)ell_job[e] * width * height, result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
 }
 
 static int check_device(int device) {
@@ -141,12 +147,13 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   std::vector<int> ell_job(total);
   for (int j = 0; j < njobs; ++j)
     for (int e = first[j]; e < first[j + 1]; ++e) ell_job[e] = j;
-  DevBuf d_img, d_idx, d_pat, d_job, d_first, d_pu, d_ce, d_desc, d_map, d_res, d_corr;
+  DevBuf d_img, d_idx, d_pat, d_job, d_first, d_pu, d_ce, d_desc, d_map, d_own, d_res, d_corr;
   const size_t img_bytes = (size_t)nimages * width * height;
   if (d_img.alloc(img_bytes) || d_idx.alloc(sizeof(int) * njobs) || d_pat.alloc((size_t)njobs * 121) ||
       d_job.alloc(sizeof(int) * total) || d_first.alloc(sizeof(int) * (njobs + 1)) || d_pu.alloc(sizeof(double) * 3 * total) ||
       d_ce.alloc(sizeof(double) * 2 * total) || d_desc.alloc(sizeof(int) * 8 * total) ||
-      d_map.alloc(sizeof(double) * (size_t)njobs * width * height) || d_res.alloc(sizeof(int) * 3 * total) ||
+      d_map.alloc(sizeof(double) * (size_t)njobs * width * height) || d_own.alloc(sizeof(int) * (size_t)njobs * width * height) ||
+      d_res.alloc(sizeof(int) * 3 * total) ||
       d_corr.alloc(sizeof(double) * total)) {
     set_error("hipMalloc failed");
     return SL2_ERR_HIP;
@@ -158,17 +165,19 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipMemcpy(d_first.p, first.data(), sizeof(int) * (njobs + 1), hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pu.p, puinv, sizeof(double) * 3 * total, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_ce.p, centre, sizeof(double) * 2 * total, hipMemcpyHostToDevice));
+  SL2_HIP(hipMemset(d_own.p, 0x7f, sizeof(int) * (size_t)njobs * width * height));   // ~kOwnerFree; any value > total works
   hipEvent_t ev0, ev1;
   SL2_HIP(hipEventCreate(&ev0));
   SL2_HIP(hipEventCreate(&ev1));
   SL2_HIP(hipEventRecord(ev0, 0));
   hipLaunchKernelGGL(k_me_describe, dim3((total + 63) / 64), dim3(64), 0, 0, d_pu.as<double>(), d_ce.as<double>(), total, width,
                      height, d_desc.as<int>());
+  hipLaunchKernelGGL(k_me_mark, dim3(total), dim3(256), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
+                     d_own.as<int>());
   hipLaunchKernelGGL(k_me_scores, dim3(total), dim3(256), 0, 0, d_img.as<uint8_t>(), width, height, d_idx.as<int>(),
-                     d_pat.as<uint8_t>(), d_job.as<int>(), d_first.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
-                     d_map.as<double>());
+                     d_pat.as<uint8_t>(), d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(), d_own.as<int>(), d_map.as<double>());
   hipLaunchKernelGGL(k_me_argmin, dim3(total), dim3(64), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
-                     d_map.as<double>(), d_res.as<int>(), d_corr.as<double>());
+                     d_map.as<double>(), d_own.as<int>(), d_res.as<int>(), d_corr.as<double>());
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipEventRecord(ev1, 0));
   SL2_HIP(hipDeviceSynchronize());

@@ -110,13 +110,30 @@ __device__ __forceinline__ double me_score_position(const uint8_t* __restrict__ 
   return corr;
 }
 
-// Score every position ellipse `e` visits that no earlier ellipse first..e-1 of the same job visits.
-// Workgroup-collective (256 threads).  desc / puinv are indexed by ellipse.
+// The union of a job's ellipses is scored once.  Ownership of a position = whichever visiting ellipse's plain store to an
+// int map lands last (which one does not matter - a position's score does not depend on who asks; an atomicMin here
+// cost 0.75 ms per search at batch 1024: the ellipses overlap heavily and the atomics serialise); the scoring pass
+// computes a position only in its owner's workgroup, and the arg-min pass hands the map back clean.
+// (The first version tested every earlier ellipse of the job for every position: with 100 overlapping particle
+// ellipses that test, not the correlation, was 90 % of the multi-ellipse search.)
+constexpr int kOwnerFree = 0x7fffffff;
+
+__device__ __forceinline__ void me_mark_ellipse_wg(const int* __restrict__ d, const double* __restrict__ pu, int width,
+                                                   int* __restrict__ owner, int index) {
+  const int nu = d[3], nv = d[5];
+  if (nu <= 0 || nv <= 0) return;
+  for (int idx = threadIdx.x; idx < nu * nv; idx += blockDim.x) {
+    const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
+    if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
+    owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any one visitor may win
+  }
+}
+
+// Workgroup-collective (256 threads): score the positions of this ellipse that it owns.
 __device__ __forceinline__ void me_score_ellipse_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
-                                                    int first, int e, const int* __restrict__ desc,
-                                                    const double* __restrict__ puinv, int pu_stride, double* __restrict__ map) {
+                                                    const int* __restrict__ d, const double* __restrict__ pu,
+                                                    const int* __restrict__ owner, int index, double* __restrict__ map) {
   const int tid = threadIdx.x;
-  const int* d = desc + 8 * (size_t)e;
   const int nu = d[3], nv = d[5];
   if (nu <= 0 || nv <= 0) return;
   __shared__ int s_patch[121];
@@ -130,23 +147,37 @@ __device__ __forceinline__ void me_score_ellipse_wg(const uint8_t* __restrict__ 
   }
   __syncthreads();
   const int Sg0 = s_sums[0], Sg0sq = s_sums[1];
-  const double* pu = puinv + (size_t)pu_stride * e;
-  for (int idx = tid; idx < nu * nv; idx += 256) {
-    const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-    if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-    const int x = d[0] + urel, y = d[1] + vrel;
-    bool owned = true;
-    for (int q = first; q < e; ++q)
-      if (me_visits(desc + 8 * (size_t)q, puinv + (size_t)pu_stride * q, x, y)) { owned = false; break; }
-    if (!owned) continue;
-    map[(size_t)y * width + x] = me_score_position(img, width, s_patch, Sg0, Sg0sq, x, y);
+  // Owned positions are few and scattered (a particle ellipse shares most of its area with its neighbours): they are
+  // first compacted into an LDS list so that the 121-tap correlations run on full wavefronts, not on the odd lane.
+  constexpr int kListCap = 1024;
+  __shared__ int s_list[kListCap];
+  __shared__ int s_n;
+  for (int base = 0; base < nu * nv; base += kListCap) {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int end = (base + kListCap < nu * nv) ? base + kListCap : nu * nv;
+    for (int idx = base + tid; idx < end; idx += 256) {
+      const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
+      if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
+      const int x = d[0] + urel, y = d[1] + vrel;
+      if (owner[(size_t)y * width + x] != index) continue;
+      s_list[atomicAdd(&s_n, 1)] = (y << 16) | x;
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int k = tid; k < n; k += 256) {
+      const int x = s_list[k] & 0xffff, y = s_list[k] >> 16;
+      map[(size_t)y * width + x] = me_score_position(img, width, s_patch, Sg0, Sg0sq, x, y);
+    }
+    __syncthreads();
   }
 }
 
 // Arg-min of ellipse e over its positions in scan order (u outer, v inner), "corr <= corrmax" => last minimum
 // wins.  One wavefront.  out = (flag, u, v); returns the best score in *best_out (lane 0).
 __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict__ d, const double* __restrict__ pu,
-                                               const double* __restrict__ map, int* __restrict__ out, double* best_out) {
+                                               const double* __restrict__ map, int* __restrict__ owner, int* __restrict__ out,
+                                               double* best_out) {
   const int lane = threadIdx.x & 63;
   const int nu = d[3], nv = d[5];
   double best = 1000000.0;   // cpp:156
@@ -155,7 +186,9 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
     for (int idx = lane; idx < nu * nv; idx += 64) {
       const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
       if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-      const double corr = map[(size_t)(d[1] + vrel) * width + (d[0] + urel)];
+      const size_t pos = (size_t)(d[1] + vrel) * width + (d[0] + urel);
+      const double corr = map[pos];
+      owner[pos] = kOwnerFree;        // (idempotent: the ownership map is clean again for the next search)
       if (corr <= best) { best = corr; order = idx; }
     }
   }

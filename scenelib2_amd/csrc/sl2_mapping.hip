@@ -299,28 +299,39 @@ __global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* _
   me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * kMaxParticles + tid) * 8);
 }
 
+__global__ void __launch_bounds__(256) k_map_me_mark(int width, int height, const int* __restrict__ part_i,
+                                                     const int* __restrict__ me_desc, const double* __restrict__ particles,
+                                                     int* __restrict__ owner) {
+  const int b = blockIdx.y, p = blockIdx.x;
+  const int* pi = part_i + (size_t)b * kPartInts;
+  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
+  me_mark_ellipse_wg(me_desc + ((size_t)b * kMaxParticles + p) * 8,
+                     particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
+}
+
 __global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
                                                        const uint8_t* __restrict__ patch, const int* __restrict__ part_i,
                                                        const int* __restrict__ me_desc, const double* __restrict__ particles,
-                                                       double* __restrict__ score_map, int N, int height) {
+                                                       const int* __restrict__ owner, double* __restrict__ score_map, int N, int height) {
   const int b = blockIdx.y, p = blockIdx.x;
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
   const size_t fi = (size_t)b * N + pi[kPartLabel];
-  me_score_ellipse_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, 0, p, me_desc + (size_t)b * kMaxParticles * 8,
-                      particles + (size_t)b * kMaxParticles * kParticleDoubles + 7, kParticleDoubles,
+  me_score_ellipse_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + ((size_t)b * kMaxParticles + p) * 8,
+                      particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, owner + (size_t)b * width * height, p,
                       score_map + (size_t)b * width * height);
 }
 
 __global__ void __launch_bounds__(64) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
                                                       const int* __restrict__ me_desc, double* __restrict__ particles,
-                                                      const double* __restrict__ score_map) {
+                                                      const double* __restrict__ score_map, int* __restrict__ owner) {
   const int b = blockIdx.y, p = blockIdx.x;
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
   double* o = particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles;
   __shared__ int s_res[3];
-  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
+  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height,
+                 owner + (size_t)b * width * height, s_res, nullptr);
   if (threadIdx.x == 0) {
     if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
       o[5] = (double)s_res[1];
@@ -506,7 +517,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
   const int W = e->cam.width, H = e->cam.height;
-  if (!e->score_map) { set_error("launch_mapping: score map not allocated"); return SL2_ERR_INVALID; }
+  if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
   {
     LaunchScope ls(e, "k_map_region");
     hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
@@ -532,11 +543,21 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
     SL2_HIP(hipGetLastError());
   }
   {
-    LaunchScope ls(e, "k_map_search");
+    LaunchScope ls(e, "k_map_me_mark");
+    hipLaunchKernelGGL(k_map_me_mark, dim3(mp.n_particles, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
+                       e->owner_map);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_me_scores");
     hipLaunchKernelGGL(k_map_me_scores, dim3(mp.n_particles, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
-                       e->part_i, e->me_desc, e->particles, e->score_map, e->N, H);
+                       e->part_i, e->me_desc, e->particles, e->owner_map, e->score_map, e->N, H);
+    SL2_HIP(hipGetLastError());
+  }
+  {
+    LaunchScope ls(e, "k_map_me_argmin");
     hipLaunchKernelGGL(k_map_me_argmin, dim3(mp.n_particles, B), dim3(64), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->score_map);
+                       e->score_map, e->owner_map);
     SL2_HIP(hipGetLastError());
   }
   {

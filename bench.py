@@ -248,6 +248,16 @@ def main():
                        sample="%d sequences x %d frames (320x240, %d features) of this run's input, one oracle instance per thread"
                               % (sample, n_frames, N),
                        seconds=secs, single_thread_frames_per_s=None)
+            # 8(d)(i): one sequence on one thread (the reference's own single-threaded design)
+            s1 = oa.OracleSLAM(cam, params["delta_t"], N)
+            s1.set_state(specs[0].xv0, specs[0].Pxx0)
+            xo = specs[0].xp_org()
+            for i in range(N):
+                s1.add_known_feature(specs[0].feat_y[i], xo[i], templates[0][i])
+                if args.feature_sigma > 0.0:
+                    s1.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
+            secs1, _ = oa.run_sequences([s1], frames_list[:1], nthreads=1)
+            cpu["single_thread_frames_per_s"] = n_frames / secs1
             d = slams[0].diag()
             tt = sum(d["times"].values())
             cpu["stage_split"] = {k: float(v / tt) for k, v in d["times"].items()}

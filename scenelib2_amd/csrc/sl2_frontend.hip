@@ -181,8 +181,12 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
   FTR(1, 1);
   // scores are traces of covariances (>= 0): an invisible feature takes the key -1 and never outranks anyone, so the
   // rank loop has no branch and its LDS reads pipeline
-  for (int i = tid; i < ns; i += blockDim.x)
+  // (a NaN score - the omega == 0 hazard, Q10 - compares false both ways: it takes the key -0.5, so that the ranks stay a
+  // permutation and an all-NaN map keeps list order, which is what the reference's insertion does with it)
+  for (int i = tid; i < ns; i += blockDim.x) {
     if (!s_vis[i]) s_score[i] = -1.0;
+    else if (s_score[i] != s_score[i]) s_score[i] = -0.5;
+  }
   __syncthreads();
   for (int i = tid; i < ns; i += blockDim.x) {
     if (!s_vis[i]) continue;
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
     pos_count[b] += 1;
     for (int k = 0; k < 3; ++k) pos_log[((size_t)b * kTrajCapacity + log_slot) * 3 + k] = xb[k];
     bool bad = false;
-    for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]);
+    for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]) || !isfinite(s_P[k * 13 + k]);   // (Q10 poisons Pxx first)
     if (bad) status[b] |= 1;
   }
 }

@@ -312,3 +312,34 @@ def test_graph_replay_is_bit_identical(mapping):
     assert np.array_equal(a.trajectory(0), b.trajectory(0)) and np.array_equal(a.position_log(0, 2), b.position_log(0, 2))
     if mapping:
         assert a.partial_feature(0)["info"] == b.partial_feature(0)["info"] and a.partial_feature(0)["info"]["initialised"] >= 1
+
+
+def test_zero_angular_velocity_raises_the_status_flag_for_that_sequence_only():
+    """Q10: dqomegadt_by_domega divides by |omega| with no guard (motion_model.cpp:318-349); with omega == 0
+    exactly the reference's state turns NaN.  The engine reproduces that (no silent guard) and reports it per
+    sequence through sl2_get_status_flags bit 0; the neighbouring sequence in the batch is untouched."""
+    pr = Pair(20, 3, batch=2)
+    xv = np.stack([s.xv0 for s in pr.specs])
+    Pxx = np.stack([s.Pxx0 for s in pr.specs])
+    xv[1, 10:13] = 0.0
+    pr.engine.set_vehicle_state(xv, Pxx)
+    pr.oracles[1].set_state(xv[1], Pxx[1])
+    for k in range(3):
+        pr.step_both(k)
+    flags = pr.engine.status_flags()
+    assert flags[0] == 0 and (flags[1] & 1) == 1
+    _, Po = pr.oracles[1].get_state()
+    assert not np.isfinite(Po).all()                         # the restated reference goes NaN too
+    _, Pe = pr.engine.get_vehicle_state(1, 1)
+    assert not np.isfinite(Pe[0]).all()
+    sel, _ = pr.engine.selection(1)
+    assert list(sel) == list(pr.oracles[1].selected_labels())      # NaN scores: the insertion keeps list order
+    for i, fe in enumerate(pr.engine.features(1)):
+        fo = pr.oracles[1].feature(i)
+        assert (fe["attempted"], fe["successful"]) == (fo["attempted"], fo["successful"])
+    xo, _ = pr.oracles[1].get_state()
+    xe, _ = pr.engine.get_vehicle_state(1, 1)
+    assert np.allclose(xe[0], xo, rtol=0, atol=1e-12)             # the state itself stays finite: pure prediction
+    o = pr.oracles[0]
+    assert np.abs(pr.engine.total_state(0) - o.total_state()).max() <= TOL_X
+    assert rel_fro(pr.engine.total_covariance(0), o.total_covariance()) <= TOL_P

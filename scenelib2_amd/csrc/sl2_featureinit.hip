@@ -53,22 +53,21 @@ __global__ void __launch_bounds__(256) k_me_mark(int width, int height, const in
 
 __global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ images, int width, int height,
                                                    const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
-                                                   const int* __restrict__ ell_job, const int* __restrict__ desc,
-                                                   const double* __restrict__ puinv, const int* __restrict__ owner,
-                                                   double* __restrict__ score_map) {
-  const int e = blockIdx.x;
-  const int job = ell_job[e];
-  me_score_ellipse_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121, desc + 8 * (size_t)e,
-                      puinv + 3 * (size_t)e, owner + (size_t)job * width * height, e, score_map + (size_t)job * width * height);
+                                                   const int* __restrict__ first, const int* __restrict__ desc,
+                                                   int* __restrict__ owner, double* __restrict__ score_map) {
+  const int job = blockIdx.y;
+  me_score_union_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121,
+                    desc + 8 * (size_t)first[job], first[job + 1] - first[job], owner + (size_t)job * width * height,
+                    score_map + (size_t)job * width * height, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(64) k_me_argmin(int width, int height, const int* __restrict__ ell_job,
                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
-                                                  const double* __restrict__ score_map, int* __restrict__ owner,
-                                                  int* __restrict__ result, double* __restrict__ corrmax) {
+                                                  const double* __restrict__ score_map, int* __restrict__ result,
+                                                  double* __restrict__ corrmax) {
   const int e = blockIdx.x;
   me_argmin_wave(width, desc + 8 * (size_t)e, puinv + 3 * (size_t)e, score_map + (size_t)ell_job[e] * width * height,
-                 owner + (size_t)ell_job[e] * width * height, result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
+                 result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
 }
 
 static int check_device(int device) {
@@ -165,7 +164,7 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipMemcpy(d_first.p, first.data(), sizeof(int) * (njobs + 1), hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pu.p, puinv, sizeof(double) * 3 * total, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_ce.p, centre, sizeof(double) * 2 * total, hipMemcpyHostToDevice));
-  SL2_HIP(hipMemset(d_own.p, 0x7f, sizeof(int) * (size_t)njobs * width * height));   // ~kOwnerFree; any value > total works
+  SL2_HIP(hipMemset(d_own.p, 0x7f, sizeof(int) * (size_t)njobs * width * height));   // = kOwnerFree
   hipEvent_t ev0, ev1;
   SL2_HIP(hipEventCreate(&ev0));
   SL2_HIP(hipEventCreate(&ev1));
@@ -174,10 +173,11 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
                      height, d_desc.as<int>());
   hipLaunchKernelGGL(k_me_mark, dim3(total), dim3(256), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
                      d_own.as<int>());
-  hipLaunchKernelGGL(k_me_scores, dim3(total), dim3(256), 0, 0, d_img.as<uint8_t>(), width, height, d_idx.as<int>(),
-                     d_pat.as<uint8_t>(), d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(), d_own.as<int>(), d_map.as<double>());
+  const int nslices = njobs >= 512 ? 2 : (njobs >= 64 ? 4 : 16);
+  hipLaunchKernelGGL(k_me_scores, dim3(nslices, njobs), dim3(256), 0, 0, d_img.as<uint8_t>(), width, height, d_idx.as<int>(),
+                     d_pat.as<uint8_t>(), d_first.as<int>(), d_desc.as<int>(), d_own.as<int>(), d_map.as<double>());
   hipLaunchKernelGGL(k_me_argmin, dim3(total), dim3(64), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
-                     d_map.as<double>(), d_own.as<int>(), d_res.as<int>(), d_corr.as<double>());
+                     d_map.as<double>(), d_res.as<int>(), d_corr.as<double>());
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipEventRecord(ev1, 0));
   SL2_HIP(hipDeviceSynchronize());

@@ -110,13 +110,14 @@ __device__ __forceinline__ double me_score_position(const uint8_t* __restrict__ 
   return corr;
 }
 
-// The union of a job's ellipses is scored once.  Ownership of a position = whichever visiting ellipse's plain store to an
-// int map lands last (which one does not matter - a position's score does not depend on who asks; an atomicMin here
-// cost 0.75 ms per search at batch 1024: the ellipses overlap heavily and the atomics serialise); the scoring pass
-// computes a position only in its owner's workgroup, and the arg-min pass hands the map back clean.
-// (The first version tested every earlier ellipse of the job for every position: with 100 overlapping particle
-// ellipses that test, not the correlation, was 90 % of the multi-ellipse search.)
-constexpr int kOwnerFree = 0x7fffffff;
+// The union of a job's ellipses is scored once (the reference's per-call score cache, cpp:114,160-181).  Pass 1: every
+// ellipse stamps the positions it visits in an int map (plain stores - the stamp only says "somebody visits this",
+// so which store lands last is irrelevant; an atomicMin here cost 0.75 ms per search at batch 1024: the ellipses overlap
+// heavily and the atomics serialise).  Pass 2: ONE scan over the union's bounding box per job finds the stamped
+// positions, clears the stamps and scores each position once.  Pass 3: per-ellipse arg-min over the score map.
+// (History: testing every earlier ellipse of the job for every position - 90 % of the search with 100 particle ellipses;
+// then one workgroup per ellipse scoring the positions it owned - each re-scanned its own box, 0.31 ms of 0.55.)
+constexpr int kOwnerFree = 0x7f7f7f7f;    // = memset(0x7f): above every ellipse index
 
 __device__ __forceinline__ void me_mark_ellipse_wg(const int* __restrict__ d, const double* __restrict__ pu, int width,
                                                    int* __restrict__ owner, int index) {
@@ -125,42 +126,56 @@ __device__ __forceinline__ void me_mark_ellipse_wg(const int* __restrict__ d, co
   for (int idx = threadIdx.x; idx < nu * nv; idx += blockDim.x) {
     const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
     if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-    owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any one visitor may win
+    owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any visitor's stamp will do
   }
 }
 
-// Workgroup-collective (256 threads): score the positions of this ellipse that it owns.
-__device__ __forceinline__ void me_score_ellipse_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
-                                                    const int* __restrict__ d, const double* __restrict__ pu,
-                                                    const int* __restrict__ owner, int index, double* __restrict__ map) {
+// Workgroup-collective (256 threads): score every stamped position of rows slice / nslices of the bounding box of the
+// job's n_ell ellipses (descriptors desc[8 e]), clearing the stamps on the way.
+__device__ __forceinline__ void me_score_union_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
+                                                  const int* __restrict__ desc, int n_ell, int* __restrict__ owner,
+                                                  double* __restrict__ map, int slice, int nslices) {
   const int tid = threadIdx.x;
-  const int nu = d[3], nv = d[5];
-  if (nu <= 0 || nv <= 0) return;
   __shared__ int s_patch[121];
   __shared__ int s_sums[2];
+  __shared__ int s_box[4];
   if (tid < 121) s_patch[tid] = patch121[tid];
+  if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
   __syncthreads();
+  for (int e = tid; e < n_ell; e += 256) {
+    const int* d = desc + 8 * (size_t)e;
+    if (d[3] <= 0 || d[5] <= 0) continue;
+    atomicMin(&s_box[0], d[0] + d[2]);
+    atomicMin(&s_box[1], d[1] + d[4]);
+    atomicMax(&s_box[2], d[0] + d[2] + d[3]);
+    atomicMax(&s_box[3], d[1] + d[4] + d[5]);
+  }
   if (tid == 0) {
     int s0 = 0, s0q = 0;
     for (int p = 0; p < 121; ++p) { s0 += s_patch[p]; s0q += s_patch[p] * s_patch[p]; }
     s_sums[0] = s0; s_sums[1] = s0q;
   }
   __syncthreads();
+  if (s_box[2] < 0) return;
   const int Sg0 = s_sums[0], Sg0sq = s_sums[1];
-  // Owned positions are few and scattered (a particle ellipse shares most of its area with its neighbours): they are
-  // first compacted into an LDS list so that the 121-tap correlations run on full wavefronts, not on the odd lane.
+  const int x0 = s_box[0], bw = s_box[2] - s_box[0];
+  const int rows = s_box[3] - s_box[1], per = (rows + nslices - 1) / nslices;
+  const int ys = s_box[1] + slice * per;
+  const int ye = (ys + per < s_box[3]) ? ys + per : s_box[3];
+  const int total = bw * (ye - ys);
+  // Stamped positions are first compacted into an LDS list so that the 121-tap correlations run on full wavefronts.
   constexpr int kListCap = 1024;
   __shared__ int s_list[kListCap];
   __shared__ int s_n;
-  for (int base = 0; base < nu * nv; base += kListCap) {
+  for (int base = 0; base < total; base += kListCap) {
     if (tid == 0) s_n = 0;
     __syncthreads();
-    const int end = (base + kListCap < nu * nv) ? base + kListCap : nu * nv;
+    const int end = (base + kListCap < total) ? base + kListCap : total;
     for (int idx = base + tid; idx < end; idx += 256) {
-      const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-      if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
-      const int x = d[0] + urel, y = d[1] + vrel;
-      if (owner[(size_t)y * width + x] != index) continue;
+      const int y = ys + idx / bw, x = x0 + idx % bw;
+      const size_t pos = (size_t)y * width + x;
+      if (owner[pos] >= kOwnerFree) continue;
+      owner[pos] = kOwnerFree;          // the stamp map is clean again for the next search
       s_list[atomicAdd(&s_n, 1)] = (y << 16) | x;
     }
     __syncthreads();
@@ -176,8 +191,7 @@ __device__ __forceinline__ void me_score_ellipse_wg(const uint8_t* __restrict__ 
 // Arg-min of ellipse e over its positions in scan order (u outer, v inner), "corr <= corrmax" => last minimum
 // wins.  One wavefront.  out = (flag, u, v); returns the best score in *best_out (lane 0).
 __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict__ d, const double* __restrict__ pu,
-                                               const double* __restrict__ map, int* __restrict__ owner, int* __restrict__ out,
-                                               double* best_out) {
+                                               const double* __restrict__ map, int* __restrict__ out, double* best_out) {
   const int lane = threadIdx.x & 63;
   const int nu = d[3], nv = d[5];
   double best = 1000000.0;   // cpp:156
@@ -188,7 +202,6 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
       if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
       const size_t pos = (size_t)(d[1] + vrel) * width + (d[0] + urel);
       const double corr = map[pos];
-      owner[pos] = kOwnerFree;        // (idempotent: the ownership map is clean again for the next search)
       if (corr <= best) { best = corr; order = idx; }
     }
   }

@@ -311,27 +311,25 @@ __global__ void __launch_bounds__(256) k_map_me_mark(int width, int height, cons
 
 __global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
                                                        const uint8_t* __restrict__ patch, const int* __restrict__ part_i,
-                                                       const int* __restrict__ me_desc, const double* __restrict__ particles,
-                                                       const int* __restrict__ owner, double* __restrict__ score_map, int N, int height) {
-  const int b = blockIdx.y, p = blockIdx.x;
+                                                       const int* __restrict__ me_desc, int* __restrict__ owner,
+                                                       double* __restrict__ score_map, int N, int height) {
+  const int b = blockIdx.y;
   const int* pi = part_i + (size_t)b * kPartInts;
-  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
+  if (!pi[kPartActive] || !pi[kPartMaking]) return;
   const size_t fi = (size_t)b * N + pi[kPartLabel];
-  me_score_ellipse_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + ((size_t)b * kMaxParticles + p) * 8,
-                      particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, owner + (size_t)b * width * height, p,
-                      score_map + (size_t)b * width * height);
+  me_score_union_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + (size_t)b * kMaxParticles * 8,
+                    pi[kPartNp], owner + (size_t)b * width * height, score_map + (size_t)b * width * height, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(64) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
                                                       const int* __restrict__ me_desc, double* __restrict__ particles,
-                                                      const double* __restrict__ score_map, int* __restrict__ owner) {
+                                                      const double* __restrict__ score_map) {
   const int b = blockIdx.y, p = blockIdx.x;
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
   double* o = particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles;
   __shared__ int s_res[3];
-  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height,
-                 owner + (size_t)b * width * height, s_res, nullptr);
+  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
   if (threadIdx.x == 0) {
     if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
       o[5] = (double)s_res[1];
@@ -550,14 +548,15 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_me_scores");
-    hipLaunchKernelGGL(k_map_me_scores, dim3(mp.n_particles, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
-                       e->part_i, e->me_desc, e->particles, e->owner_map, e->score_map, e->N, H);
+    const int nslices = B >= 512 ? 2 : (B >= 64 ? 4 : 16);     // row slices of the union's bounding box per sequence
+    hipLaunchKernelGGL(k_map_me_scores, dim3(nslices, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
+                       e->part_i, e->me_desc, e->owner_map, e->score_map, e->N, H);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_me_argmin");
     hipLaunchKernelGGL(k_map_me_argmin, dim3(mp.n_particles, B), dim3(64), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->score_map, e->owner_map);
+                       e->score_map);
     SL2_HIP(hipGetLastError());
   }
   {

@@ -357,75 +357,102 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
   __shared__ int s_action;         // 0 none, 1 convert, 2 delete
-  __shared__ double s_lambda, s_plambda;
-  if (lane == 0) {
-    int action = 0;
-    if (pi[kPartActive]) {
-      double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
-      int np = pi[kPartNp];
-      if (pi[kPartMaking]) {
-        // update_partially_initialised_feature_probabilities (:1449-1497)
-        for (int i = 0; i < np; ++i) {
-          double* o = pp + (size_t)i * kParticleDoubles;
-          double likelihood = 0.0;
-          if (o[11] != 0.0) likelihood = particle_likelihood(o + 5, o + 3, o + 7, o[10]);
-          o[1] = o[1] * likelihood;
-        }
-        double total = 0.0;
-        for (int i = 0; i < np; ++i) total += pp[(size_t)i * kParticleDoubles + 1];
-        if (total == 0.0) {
-          action = 2;                  // every match failed: the feature goes (:1490-1494)
-        } else {
-          double cum = 0.0;
-          for (int i = 0; i < np; ++i) {
-            double* o = pp + (size_t)i * kParticleDoubles;
-            o[1] = o[1] / total;
-            o[2] = cum + o[1];
-            cum += o[1];
-          }
-          // prune_particle_vector (feature_init_info.cpp:131-147)
-          const double prune_threshold = mp.prune_threshold / double(np);
-          int kept = 0;
-          for (int i = 0; i < np; ++i) {
-            const double* src = pp + (size_t)i * kParticleDoubles;
-            if (src[1] < prune_threshold) continue;
-            if (kept != i) {
-              double* dst = pp + (size_t)kept * kParticleDoubles;
-              for (int k = 0; k < kParticleDoubles; ++k) dst[k] = src[k];
-            }
-            ++kept;
-          }
-          np = kept;
-          pi[kPartNp] = np;
-          total = 0.0;
-          for (int i = 0; i < np; ++i) total += pp[(size_t)i * kParticleDoubles + 1];
-          if (total != 0.0) {
-            cum = 0.0;
-            for (int i = 0; i < np; ++i) {
-              double* o = pp + (size_t)i * kParticleDoubles;
-              o[1] = o[1] / total;
-              o[2] = cum + o[1];
-              cum += o[1];
-            }
-          }
-          // calculate_mean_and_covariance (feature_init_info.cpp:157-174)
-          double mean = 0.0, e2 = 0.0;
-          for (int i = 0; i < np; ++i) {
-            const double* o = pp + (size_t)i * kParticleDoubles;
-            mean += o[1] * o[0];
-            e2 += o[1] * (o[0] * o[0]);
-          }
-          pd[0] = mean;
-          pd[1] = e2 - (mean * mean);
-          // conversion test (:1320-1332)
-          const double mean_sd_ratio = sqrt(pd[1]) / pd[0];
-          if (mean_sd_ratio < mp.sd_ratio && np > mp.min_particles) action = 1;
-        }
-      }
-      // delete_partially_initialised_features_past_sell_by_date (:1506-1521)
-      if (action == 0 && (pi[kPartAttempts] > mp.erase_after || np <= mp.min_particles)) action = 2;
+  __shared__ int s_np;
+  __shared__ double s_lambda, s_plambda, s_total;
+  __shared__ double s_p[kMaxParticles * kParticleDoubles];
+  // The particle list lives in LDS for the duration of the update: the per-particle arithmetic (likelihood, division
+  // by the total, pruning test, compaction) runs on all lanes; every SUM is formed by lane 0 in list order, which is
+  // the reference's order (the sums decide the bits of the weights, and through them pruning and conversion).
+  const bool active = pi[kPartActive] != 0, making = active && pi[kPartMaking] != 0;
+  double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
+  int np = active ? pi[kPartNp] : 0;
+  if (lane == 0) { s_action = 0; s_np = np; }
+  if (making) {
+    for (int idx = lane; idx < np * kParticleDoubles; idx += 64) s_p[idx] = pp[idx];
+    __syncthreads();
+    // update_partially_initialised_feature_probabilities (:1449-1497)
+    for (int i = lane; i < np; i += 64) {
+      double* o = s_p + i * kParticleDoubles;
+      double likelihood = 0.0;
+      if (o[11] != 0.0) likelihood = particle_likelihood(o + 5, o + 3, o + 7, o[10]);
+      o[1] = o[1] * likelihood;
     }
-    s_action = action;
+    __syncthreads();
+    if (lane == 0) {
+      double total = 0.0;
+      for (int i = 0; i < np; ++i) total += s_p[i * kParticleDoubles + 1];
+      s_total = total;
+      if (total == 0.0) s_action = 2;   // every match failed: the feature goes (:1490-1494)
+    }
+    __syncthreads();
+    if (s_action == 0) {
+      double total = s_total;
+      for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
+      __syncthreads();
+      // (the cumulative column is rewritten after pruning; only its final values are ever read)
+      // prune_particle_vector (feature_init_info.cpp:131-147): order-preserving compaction, 64 particles per round; a
+      // round's destinations lie below its own sources and below every later round's sources
+      const double prune_threshold = mp.prune_threshold / double(np);
+      int kept = 0;
+      for (int i0 = 0; i0 < np; i0 += 64) {
+        const int i = i0 + lane;
+        double v[kParticleDoubles];
+        bool keep = false;
+        if (i < np) {
+#pragma unroll
+          for (int k = 0; k < kParticleDoubles; ++k) v[k] = s_p[i * kParticleDoubles + k];
+          keep = !(v[1] < prune_threshold);
+        }
+        const unsigned long long mask = __ballot(keep);
+        __syncthreads();
+        if (keep) {
+          const int dst = kept + __popcll(mask & ((1ull << lane) - 1ull));
+#pragma unroll
+          for (int k = 0; k < kParticleDoubles; ++k) s_p[dst * kParticleDoubles + k] = v[k];
+        }
+        kept += __popcll(mask);
+        __syncthreads();
+      }
+      np = kept;
+      if (lane == 0) {
+        double tot2 = 0.0;
+        for (int i = 0; i < np; ++i) tot2 += s_p[i * kParticleDoubles + 1];
+        s_total = tot2;
+      }
+      __syncthreads();
+      total = s_total;
+      if (total != 0.0)
+        for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
+      __syncthreads();
+      if (lane == 0) {
+        double cum = 0.0;
+        for (int i = 0; i < np; ++i) {
+          cum += s_p[i * kParticleDoubles + 1];
+          s_p[i * kParticleDoubles + 2] = cum;
+        }
+        // (a zero total after pruning would need a zero pruning threshold, which prunes nothing: not reachable)
+        // calculate_mean_and_covariance (feature_init_info.cpp:157-174)
+        double mean = 0.0, e2 = 0.0;
+        for (int i = 0; i < np; ++i) {
+          const double* o = s_p + i * kParticleDoubles;
+          mean += o[1] * o[0];
+          e2 += o[1] * (o[0] * o[0]);
+        }
+        pd[0] = mean;
+        pd[1] = e2 - (mean * mean);
+        pi[kPartNp] = np;
+        s_np = np;
+        // conversion test (:1320-1332)
+        const double mean_sd_ratio = sqrt(pd[1]) / pd[0];
+        if (mean_sd_ratio < mp.sd_ratio && np > mp.min_particles) s_action = 1;
+      }
+      __syncthreads();
+      for (int idx = lane; idx < np * kParticleDoubles; idx += 64) pp[idx] = s_p[idx];
+    }
+  }
+  if (lane == 0) {
+    // delete_partially_initialised_features_past_sell_by_date (:1506-1521)
+    if (active && s_action == 0 && (pi[kPartAttempts] > mp.erase_after || s_np <= mp.min_particles)) s_action = 2;
     s_lambda = pd[0];
     s_plambda = pd[1];
   }

@@ -45,10 +45,11 @@ __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ p
   me_describe(puinv[3 * e], puinv[3 * e + 1], puinv[3 * e + 2], centre[2 * e], centre[2 * e + 1], width, height, desc + 8 * (size_t)e);
 }
 
-__global__ void __launch_bounds__(256) k_me_mark(int width, int height, const int* __restrict__ ell_job, const int* __restrict__ desc,
-                                                 const double* __restrict__ puinv, int* __restrict__ owner) {
-  const int e = blockIdx.x;
-  me_mark_ellipse_wg(desc + 8 * (size_t)e, puinv + 3 * (size_t)e, width, owner + (size_t)ell_job[e] * width * height, e);
+__global__ void __launch_bounds__(256) k_me_mark(int width, int height, int total, const int* __restrict__ ell_job,
+                                                 const int* __restrict__ desc, const double* __restrict__ puinv, int* __restrict__ owner) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);                       // one ellipse per wavefront
+  if (e >= total) return;
+  me_mark_ellipse_wave(desc + 8 * (size_t)e, puinv + 3 * (size_t)e, width, owner + (size_t)ell_job[e] * width * height, e);
 }
 
 __global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ images, int width, int height,
@@ -61,11 +62,12 @@ __global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ i
                     score_map + (size_t)job * width * height, blockIdx.x, gridDim.x);
 }
 
-__global__ void __launch_bounds__(64) k_me_argmin(int width, int height, const int* __restrict__ ell_job,
-                                                  const int* __restrict__ desc, const double* __restrict__ puinv,
-                                                  const double* __restrict__ score_map, int* __restrict__ result,
-                                                  double* __restrict__ corrmax) {
-  const int e = blockIdx.x;
+__global__ void __launch_bounds__(256) k_me_argmin(int width, int height, int total, const int* __restrict__ ell_job,
+                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
+                                                   const double* __restrict__ score_map, int* __restrict__ result,
+                                                   double* __restrict__ corrmax) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);                       // one ellipse per wavefront
+  if (e >= total) return;
   me_argmin_wave(width, desc + 8 * (size_t)e, puinv + 3 * (size_t)e, score_map + (size_t)ell_job[e] * width * height,
                  result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
 }
@@ -171,12 +173,12 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipEventRecord(ev0, 0));
   hipLaunchKernelGGL(k_me_describe, dim3((total + 63) / 64), dim3(64), 0, 0, d_pu.as<double>(), d_ce.as<double>(), total, width,
                      height, d_desc.as<int>());
-  hipLaunchKernelGGL(k_me_mark, dim3(total), dim3(256), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
+  hipLaunchKernelGGL(k_me_mark, dim3((total + 3) / 4), dim3(256), 0, 0, width, height, total, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
                      d_own.as<int>());
   const int nslices = njobs >= 512 ? 2 : (njobs >= 64 ? 4 : 16);
   hipLaunchKernelGGL(k_me_scores, dim3(nslices, njobs), dim3(256), 0, 0, d_img.as<uint8_t>(), width, height, d_idx.as<int>(),
                      d_pat.as<uint8_t>(), d_first.as<int>(), d_desc.as<int>(), d_own.as<int>(), d_map.as<double>());
-  hipLaunchKernelGGL(k_me_argmin, dim3(total), dim3(64), 0, 0, width, height, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
+  hipLaunchKernelGGL(k_me_argmin, dim3((total + 3) / 4), dim3(256), 0, 0, width, height, total, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
                      d_map.as<double>(), d_res.as<int>(), d_corr.as<double>());
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipEventRecord(ev1, 0));

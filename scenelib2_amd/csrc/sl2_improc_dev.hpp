@@ -119,13 +119,28 @@ __device__ __forceinline__ double me_score_position(const uint8_t* __restrict__ 
 // then one workgroup per ellipse scoring the positions it owned - each re-scanned its own box, 0.31 ms of 0.55.)
 constexpr int kOwnerFree = 0x7f7f7f7f;    // = memset(0x7f): above every ellipse index
 
-__device__ __forceinline__ void me_mark_ellipse_wg(const int* __restrict__ d, const double* __restrict__ pu, int width,
-                                                   int* __restrict__ owner, int index) {
+// idx = q * n + r for 0 <= idx < 2^22, 0 < n: a float reciprocal estimate, corrected (the integer division sequence is ~40
+// instructions, and the box scans below do little else)
+__device__ __forceinline__ void box_divmod(int idx, int n, float rcp, int* q, int* r) {
+  int qq = (int)((float)idx * rcp);
+  int rr = idx - qq * n;
+  if (rr < 0) { --qq; rr += n; }
+  if (rr >= n) { ++qq; rr -= n; }
+  *q = qq; *r = rr;
+}
+
+// One wavefront stamps one ellipse.
+__device__ __forceinline__ void me_mark_ellipse_wave(const int* __restrict__ d, const double* __restrict__ pu, int width,
+                                                     int* __restrict__ owner, int index) {
   const int nu = d[3], nv = d[5];
   if (nu <= 0 || nv <= 0) return;
-  for (int idx = threadIdx.x; idx < nu * nv; idx += blockDim.x) {
-    const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-    if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
+  const float rcp = 1.0f / (float)nv;
+  const double a = pu[0], b = pu[1], c = pu[2];
+  for (int idx = threadIdx.x & 63; idx < nu * nv; idx += 64) {
+    int q, r;
+    box_divmod(idx, nv, rcp, &q, &r);
+    const int urel = d[2] + q, vrel = d[4] + r;
+    if (!in_ellipse(a, b, c, urel, vrel)) continue;
     owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any visitor's stamp will do
   }
 }
@@ -197,9 +212,13 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
   double best = 1000000.0;   // cpp:156
   int order = -1;
   if (nu > 0 && nv > 0) {
+    const float rcp = 1.0f / (float)nv;
+    const double a = pu[0], b = pu[1], c = pu[2];
     for (int idx = lane; idx < nu * nv; idx += 64) {
-      const int urel = d[2] + idx / nv, vrel = d[4] + idx % nv;
-      if (!in_ellipse(pu[0], pu[1], pu[2], urel, vrel)) continue;
+      int q, r;
+      box_divmod(idx, nv, rcp, &q, &r);
+      const int urel = d[2] + q, vrel = d[4] + r;
+      if (!in_ellipse(a, b, c, urel, vrel)) continue;
       const size_t pos = (size_t)(d[1] + vrel) * width + (d[0] + urel);
       const double corr = map[pos];
       if (corr <= best) { best = corr; order = idx; }

@@ -302,11 +302,11 @@ __global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* _
 __global__ void __launch_bounds__(256) k_map_me_mark(int width, int height, const int* __restrict__ part_i,
                                                      const int* __restrict__ me_desc, const double* __restrict__ particles,
                                                      int* __restrict__ owner) {
-  const int b = blockIdx.y, p = blockIdx.x;
+  const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6);      // one particle ellipse per wavefront
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
-  me_mark_ellipse_wg(me_desc + ((size_t)b * kMaxParticles + p) * 8,
-                     particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
+  me_mark_ellipse_wave(me_desc + ((size_t)b * kMaxParticles + p) * 8,
+                       particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
 }
 
 __global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
@@ -321,16 +321,18 @@ __global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict
                     pi[kPartNp], owner + (size_t)b * width * height, score_map + (size_t)b * width * height, blockIdx.x, gridDim.x);
 }
 
-__global__ void __launch_bounds__(64) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
-                                                      const int* __restrict__ me_desc, double* __restrict__ particles,
-                                                      const double* __restrict__ score_map) {
-  const int b = blockIdx.y, p = blockIdx.x;
+__global__ void __launch_bounds__(256) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
+                                                       const int* __restrict__ me_desc, double* __restrict__ particles,
+                                                       const double* __restrict__ score_map) {
+  const int wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, p = blockIdx.x * 4 + wave;                     // one particle ellipse per wavefront
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
   double* o = particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles;
-  __shared__ int s_res[3];
+  __shared__ int s_res4[4][4];
+  int* s_res = s_res4[wave];
   me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
-  if (threadIdx.x == 0) {
+  if ((threadIdx.x & 63) == 0) {
     if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
       o[5] = (double)s_res[1];
       o[6] = (double)s_res[2];
@@ -569,7 +571,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_me_mark");
-    hipLaunchKernelGGL(k_map_me_mark, dim3(mp.n_particles, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
+    hipLaunchKernelGGL(k_map_me_mark, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
                        e->owner_map);
     SL2_HIP(hipGetLastError());
   }
@@ -582,7 +584,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_me_argmin");
-    hipLaunchKernelGGL(k_map_me_argmin, dim3(mp.n_particles, B), dim3(64), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
+    hipLaunchKernelGGL(k_map_me_argmin, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
                        e->score_map);
     SL2_HIP(hipGetLastError());
   }

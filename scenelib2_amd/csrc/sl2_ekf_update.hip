@@ -625,17 +625,20 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
 // kernel above reads and re-writes every trailing tile once per block column (1.6 GB of traffic per
 // launch at batch 1024, m = 200, against 0.23 GB of matrix): here tile (I, J) is read once, updated
 // with all its J products L[I][K] L[J][K]^T from finished columns, solved and written once.
-// Per block column J (waves: D = 0, M0..M2 = 1..3; tiles I = J, J+1, ... dealt M0, M1, M2, M0, ...):
-//   P1  M0 updates the diagonal tile -> LDS                                             barrier X1
-//   P2  D factors + inverts the diagonal block while the M waves update the tiles below it  X2
-//   P3  panel solves L[I][J] = T[I][J] L_JJ^-T of every tile below the diagonal             X3
+// Per block column J (waves: D = 0, M0..M2 = 1..3), two barriers:
+//   P2  D factors + inverts the diagonal block (from LDS) while the M waves update the tiles below it; M0 takes tile
+//       (J+1, J) and also forms the next diagonal tile (J+1, J+1) up to its products K < J, parked in LDS             X2
+//   P3  panel solves L[I][J] = T[I][J] L_JJ^-T; M0 solves (J+1, J) first, subtracts its square (still in registers)
+//       from the next diagonal tile and leaves that in LDS in the layout D reads                                     X3
+// (The first version updated the whole diagonal tile in a phase of its own at the top of the column, M0 alone with
+// three waves waiting: 0.8 + 2.6 J kcycles of a 20-40 kcycle column, scripts/chol_trace.py.)
 // ---------------------------------------------------------------------------
-// acc(I, J) -= sum_{K < J} L[J][K-block] L[I][K-block]^T ; result stored back (or returned for the diagonal)
-__device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int lo, int hi) {
+// acc(I, J) -= sum_{K < kend} L[J][K-block] L[I][K-block]^T (kend = J: the complete left-looking update)
+__device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int kend, int lo, int hi) {
   Tile32 acc = tile_load(Sb, mld, J * 32, I * 32, lo, hi);
   // (measured slower: an explicit register prefetch of the next half-step's operands, 0.275 vs 0.243 ms; all 32 operand
   // loads of a product in one batch, 0.271 vs 0.266)
-  for (int K = 0; K < J; ++K) {
+  for (int K = 0; K < kend; ++K) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       double a0[4], a1[4], b0[4], b1[4];
@@ -658,6 +661,17 @@ __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int 
   }
   return acc;
 }
+// diagonal tile: acc -= l^T l for the k-major panel tile l = L[I][J-block] held in registers (A and B fragments coincide)
+__device__ __forceinline__ void tile_diag_sub_regs(Tile32& acc, const Tile32& l) {
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const double v0 = l.f[s8 >> 2][0][s8 & 3], v1 = l.f[s8 >> 2][1][s8 & 3];
+    acc.f[0][0] = mfma_f64(-v0, v0, acc.f[0][0]);
+    acc.f[0][1] = mfma_f64(-v0, v1, acc.f[0][1]);
+    acc.f[1][0] = mfma_f64(-v1, v0, acc.f[1][0]);
+    acc.f[1][1] = mfma_f64(-v1, v1, acc.f[1][1]);
+  }
+}
 
 __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, double* __restrict__ LinvT,
                                                       const int* __restrict__ m_count, int mld, int nblk_max, int J0, int nb_cap,
@@ -675,6 +689,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
   const int mw = wave - 1;
   __shared__ double sTile[32][33];
   __shared__ double sLinv[32 * kLinvPitch];
+  __shared__ double sNext[1024];      // the next diagonal tile (partial), MFMA fragment order
   double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
   LinvT += (size_t)J0 * 1024;
 #ifdef SL2_CHOL_TRACE
@@ -682,24 +697,24 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 #else
 #define TRL(slot) do { } while (0)
 #endif
+  auto diag_to_lds = [&](const Tile32& t, int lo, int hi) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = t.f[jt][it][r4];
+  };
+  if (mw == 0) diag_to_lds(tile_load(Sb, mld, 0, 0, lane & 15, lane >> 4), lane & 15, lane >> 4);
+  __syncthreads();
   for (int J = 0; J < nblk; ++J) {
     const int o = J * 32;
     int lane_j = lane;
     asm volatile("" : "+v"(lane_j));      // see k_chol_fused4
     const int lo = lane_j & 15, hi = lane_j >> 4;
+    const bool more = J + 1 < nblk;
     TRL(0);
-    // ---- P1 ---- only the diagonal tile: everything else can wait until the D wave is busy
-    if (mw == 0) {
-      const Tile32 t = tile_left_update(Sb, mld, J, J, lo, hi);
-#pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = t.f[jt][it][r4];
-    }
     TRL(1);
-    __syncthreads();                       // X1: the updated diagonal tile is in LDS
     // ---- P2 ----
     if (isD) {
       // the diagonal factorisation is the critical path of the whole kernel (its wave shares a SIMD with MFMA waves of
@@ -728,28 +743,48 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       }
       __builtin_amdgcn_s_setprio(0);
     } else {
-      // tiles below the diagonal, dealt M1, M2, M0, M1, ... (M0 has just done the diagonal one)
-      for (int I = J + 1 + (mw + 2) % 3; I < nblk; I += 3) {
-        const Tile32 t = tile_left_update(Sb, mld, J, I, lo, hi);
+      // tiles below the diagonal: (J+1, J) to M0, the others dealt M1, M2, M0, M1, ...
+      if (mw == 0 && more) {
+        const Tile32 t = tile_left_update(Sb, mld, J, J + 1, J, lo, hi);
+        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, t);
+      }
+      for (int I = J + 2 + (mw + 2) % 3; I < nblk; I += 3) {
+        const Tile32 t = tile_left_update(Sb, mld, J, I, J, lo, hi);
         tile_store(Sb, mld, o, I * 32, lo, hi, t);
+      }
+      // ... and the next diagonal tile as far as finished columns go; parked in LDS in fragment order (registers held
+      // across the barrier and the panel solve spilled)
+      if (mw == 0 && more) {
+        const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sNext[q * 64 + lane_j] = dn.f[q >> 3][(q >> 2) & 1][q & 3];
       }
     }
     TRL(2);
     __syncthreads();                       // X2: L_JJ^-1 is in LDS, every tile of column J is updated
     // ---- P3 ----
     if (!isD) {
+      if (mw == 0 && more) {
+        const Tile32 l = tile_panel(sLinv, Sb, mld, o, (J + 1) * 32, lo, hi);
+        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, l);
+        Tile32 dn;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dn.f[q >> 3][(q >> 2) & 1][q & 3] = sNext[q * 64 + lane_j];
+        tile_diag_sub_regs(dn, l);
+        diag_to_lds(dn, lo, hi);
+      }
       if (mw == 2) {   // LinvT block to memory for the forward substitution, coalesced
         double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
 #pragma unroll
         for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
       }
-      for (int I = J + 1 + (mw + 2) % 3; I < nblk; I += 3) {
+      for (int I = J + 2 + (mw + 2) % 3; I < nblk; I += 3) {
         const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
         tile_store(Sb, mld, o, I * 32, lo, hi, t);
       }
     }
     TRL(3);
-    if (J + 1 < nblk) __syncthreads();     // X3: column J of L is complete
+    if (more) __syncthreads();             // X3: column J of L is complete, the next diagonal tile is in LDS
   }
 }
 #undef TRL
@@ -1173,11 +1208,27 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   double* Pb = P + (size_t)b * ld * ld;
   __shared__ double sA[2][kSyrkKC * kSyrkPitch];
   __shared__ double sB[2][kSyrkKC * kSyrkPitch];
-  // staging role of this thread: row kr of the chunk, 4 consecutive doubles at column c4
-  const int kr = tid >> 4, c4 = (tid & 15) * 4;
-  const double* gA = Vb + (size_t)kr * ld + ti * 64 + c4;
-  const double* gB = Vb + (size_t)kr * ld + tj * 64 + c4;
-  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  // staging role of this thread: row kr of the chunk, columns c2, c2+1 and 32+c2, 33+c2: sixteen lanes write 256
+  // CONTIGUOUS bytes per ds_write_b128 (four consecutive doubles per lane put lanes 0 and 8 of a row on the same banks:
+  // 2.6e7 conflict cycles per launch, three per LDS instruction)
+  const int kr = tid >> 4, c2 = (tid & 15) * 2;
+  const double* gA = Vb + (size_t)kr * ld + ti * 64 + c2;
+  const double* gB = Vb + (size_t)kr * ld + tj * 64 + c2;
+  struct Stage { double2 a0, a1, b0, b1; };
+  auto stage_load = [&](int chunk) {
+    Stage r;
+    const size_t off = (size_t)chunk * kSyrkKC * ld;
+    r.a0 = *(const double2*)(gA + off); r.a1 = *(const double2*)(gA + off + 32);
+    r.b0 = *(const double2*)(gB + off); r.b1 = *(const double2*)(gB + off + 32);
+    return r;
+  };
+  auto stage_store = [&](int buf, const Stage& r) {
+    *(double2*)&sA[buf][kr * kSyrkPitch + c2] = r.a0;
+    *(double2*)&sA[buf][kr * kSyrkPitch + 32 + c2] = r.a1;
+    *(double2*)&sB[buf][kr * kSyrkPitch + c2] = r.b0;
+    *(double2*)&sB[buf][kr * kSyrkPitch + 32 + c2] = r.b1;
+  };
+  Stage r0 = stage_load(0);
   // In a diagonal tile the sub-block (wi = 32, wj = 0) is the mirror of (0, 32): that wave only stages.
   const bool idle = (ti == tj) && (wi > wj);
   const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
@@ -1185,12 +1236,9 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
   const int nchunk = mp / kSyrkKC;
   // register prefetch runs TWO chunks ahead of the MFMAs (one chunk of work does not cover an
-  // HBM round trip under load); chunks alternate between the register pairs (ra, rb) / (ra2, rb2).
-  double4 ra2 = ra, rb2 = rb;
-  if (nchunk > 1) {
-    ra2 = *(const double4*)(gA + (size_t)kSyrkKC * ld);
-    rb2 = *(const double4*)(gB + (size_t)kSyrkKC * ld);
-  }
+  // HBM round trip under load); chunks alternate between the register sets r0 / r1.
+  Stage r1 = r0;
+  if (nchunk > 1) r1 = stage_load(1);
   auto chunk_mfma = [&](int buf) {
     const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
     const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
@@ -1205,24 +1253,16 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
     }
   };
   for (int ch = 0; ch < nchunk; ch += 2) {
-    // even chunk: registers (ra, rb) -> buffer 0
-    *(double4*)&sA[0][kr * kSyrkPitch + c4] = ra;
-    *(double4*)&sB[0][kr * kSyrkPitch + c4] = rb;
+    // even chunk: registers r0 -> buffer 0
+    stage_store(0, r0);
     __syncthreads();
-    if (ch + 2 < nchunk) {
-      ra = *(const double4*)(gA + (size_t)(ch + 2) * kSyrkKC * ld);
-      rb = *(const double4*)(gB + (size_t)(ch + 2) * kSyrkKC * ld);
-    }
+    if (ch + 2 < nchunk) r0 = stage_load(ch + 2);
     if (!idle) chunk_mfma(0);
     if (ch + 1 >= nchunk) break;
-    // odd chunk: registers (ra2, rb2) -> buffer 1
-    *(double4*)&sA[1][kr * kSyrkPitch + c4] = ra2;
-    *(double4*)&sB[1][kr * kSyrkPitch + c4] = rb2;
+    // odd chunk: registers r1 -> buffer 1
+    stage_store(1, r1);
     __syncthreads();
-    if (ch + 3 < nchunk) {
-      ra2 = *(const double4*)(gA + (size_t)(ch + 3) * kSyrkKC * ld);
-      rb2 = *(const double4*)(gB + (size_t)(ch + 3) * kSyrkKC * ld);
-    }
+    if (ch + 3 < nchunk) r1 = stage_load(ch + 3);
     if (!idle) chunk_mfma(1);
     // a buffer is rewritten two chunks after it was read, with a barrier in between: one barrier per chunk suffices
   }

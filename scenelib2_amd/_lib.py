@@ -66,7 +66,7 @@ EXPORTED_SYMBOLS = [
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
     "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
-    "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_ingest_open",
+    "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
     "sl2_get_trajectory", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_get_status_flags", "sl2_set_profiling",
@@ -134,6 +134,7 @@ def load():
     L.sl2_get_partial_feature.argtypes = [vp, C.c_int, c_ip, c_dp, c_dp, C.c_int]
     L.sl2_list_frames.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, c_ip]
     L.sl2_read_pgm.argtypes = [C.c_char_p, c_u8p, C.c_size_t, c_ip, c_ip]
+    L.sl2_read_image.argtypes = [C.c_char_p, c_u8p, C.c_size_t, c_ip, c_ip]
     L.sl2_ingest_open.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.sl2_ingest_frame_count.argtypes = [vp]
     L.sl2_ingest_next.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]

@@ -5,14 +5,20 @@
 //   * listing: every regular file below the sequence's directory, recursively, sorted by full path
 //     (byte-wise std::sort on the path strings, filegrabber.cpp:63-83);
 //   * decode: 8-bit single-channel, row-major, step == width — the only contract GoOneStep relies on
-//     (SURVEY 2, row 14).  Container: binary PGM (P5, maxval <= 255), the format of the reference's own
-//     fixtures; the reference decodes through cv::imread(path, 0), which is not re-implemented;
+//     (SURVEY 2, row 14).  The reference decodes through cv::imread(path, 0) (filegrabber.cpp:106-109), a third-party
+//     call that is not re-implemented in general; two containers are read here, chosen by the file's magic bytes:
+//       - binary PGM (P5, maxval <= 255), the format of the reference's own fixtures;
+//       - PNG (the format of the MonoSLAM test sequences): non-interlaced, 8 bits per sample (grey, grey + alpha, RGB,
+//         RGBA, palette) or 1/2/4-bit grey / palette; IDAT inflated with zlib, the five scan-line filters undone here.
+//         Grey PNGs are delivered byte for byte.  Colour goes to grey the way cv::imread(.., 0) gets it from libpng
+//         (png_set_rgb_to_gray, 8-bit path): (9797 R + 19234 G + 3737 B + 16384) >> 15; alpha is dropped;
 //   * a producer thread decodes ahead into pinned host buffers (the reference queues <= 50 frames,
 //     framegrabber.cpp:93-104; here `depth` batches), the consumer uploads one batch per call with an
 //     asynchronous copy into one of two device buffers, so the copy of frame k+1 overlaps the step on
 //     frame k when both are issued on different streams.
 #include <dirent.h>
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -78,6 +84,129 @@ static bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int* w, 
   return true;
 }
 
+// PNG -> grey bytes (see the header comment for what is covered).
+static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
+  auto fail = [&](const char* why) { set_error((std::string(why) + ": " + path).c_str()); return false; };
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return fail("cannot open");
+  std::vector<uint8_t> file;
+  {
+    uint8_t buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) file.insert(file.end(), buf, buf + n);
+    fclose(f);
+  }
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) return fail("not a PNG");
+  auto be32 = [&](size_t o) { return ((uint32_t)file[o] << 24) | ((uint32_t)file[o + 1] << 16) | ((uint32_t)file[o + 2] << 8) | file[o + 3]; };
+  uint32_t W = 0, H = 0;
+  int depth = 0, ctype = -1, interlace = 0;
+  std::vector<uint8_t> idat, plte;
+  bool seen_end = false;
+  for (size_t o = 8; o + 12 <= file.size() && !seen_end;) {
+    const uint32_t len = be32(o);
+    if (o + 12 + (size_t)len > file.size()) return fail("truncated PNG");
+    const char* type = (const char*)&file[o + 4];
+    const uint8_t* data = &file[o + 8];
+    if (!memcmp(type, "IHDR", 4)) {
+      if (len < 13) return fail("bad IHDR");
+      W = be32(o + 8); H = be32(o + 12);
+      depth = data[8]; ctype = data[9]; interlace = data[12];
+      if (data[10] != 0 || data[11] != 0) return fail("unknown PNG compression / filter method");
+    } else if (!memcmp(type, "PLTE", 4)) {
+      plte.assign(data, data + len);
+    } else if (!memcmp(type, "IDAT", 4)) {
+      idat.insert(idat.end(), data, data + len);
+    } else if (!memcmp(type, "IEND", 4)) {
+      seen_end = true;
+    }
+    o += 12 + (size_t)len;
+  }
+  if (W == 0 || H == 0 || W > 65535 || H > 65535 || idat.empty()) return fail("PNG without image data");
+  if (interlace != 0) return fail("interlaced PNG not supported");
+  int channels;
+  switch (ctype) {
+    case 0: channels = 1; break;
+    case 2: channels = 3; break;
+    case 3: channels = 1; break;
+    case 4: channels = 2; break;
+    case 6: channels = 4; break;
+    default: return fail("unknown PNG colour type");
+  }
+  const bool sub_byte = depth == 1 || depth == 2 || depth == 4;
+  if (!(depth == 8 || (sub_byte && (ctype == 0 || ctype == 3)))) return fail("PNG bit depth not supported (8, or 1/2/4 grey / palette)");
+  if (ctype == 3 && plte.size() < 3) return fail("palette PNG without PLTE");
+  const size_t bpp = (size_t)std::max(1, channels * depth / 8);            // filter distance in bytes
+  const size_t stride = ((size_t)W * channels * depth + 7) / 8;
+  std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+  {
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return fail("PNG inflate failed");
+  }
+  // undo the scan-line filters in place (PNG specification, section 9: None, Sub, Up, Average, Paeth)
+  std::vector<uint8_t> zero(stride, 0);
+  for (size_t y = 0; y < H; ++y) {
+    uint8_t* cur = &raw[y * (stride + 1) + 1];
+    const uint8_t* up = y ? &raw[(y - 1) * (stride + 1) + 1] : zero.data();
+    const int ft = raw[y * (stride + 1)];
+    for (size_t x = 0; x < stride; ++x) {
+      const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
+      int pred;
+      switch (ft) {
+        case 0: pred = 0; break;
+        case 1: pred = a; break;
+        case 2: pred = b; break;
+        case 3: pred = (a + b) >> 1; break;
+        case 4: {
+          const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: return fail("bad PNG filter type");
+      }
+      cur[x] = (uint8_t)(cur[x] + pred);
+    }
+  }
+  auto to_grey = [](int r, int g, int b) { return (uint8_t)((9797 * r + 19234 * g + 3737 * b + 16384) >> 15); };
+  px.resize((size_t)W * H);
+  for (size_t y = 0; y < H; ++y) {
+    const uint8_t* row = &raw[y * (stride + 1) + 1];
+    uint8_t* out = &px[y * W];
+    for (size_t x = 0; x < W; ++x) {
+      int v;     // the sample (or palette index) of pixel x
+      if (sub_byte) {
+        const size_t bit = x * depth;
+        v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+      } else {
+        v = row[x * channels];
+      }
+      switch (ctype) {
+        case 0: out[x] = sub_byte ? (uint8_t)(v * 255 / ((1 << depth) - 1)) : (uint8_t)v; break;
+        case 4: out[x] = (uint8_t)v; break;
+        case 3: {
+          if ((size_t)v * 3 + 2 >= plte.size()) return fail("PNG palette index out of range");
+          out[x] = to_grey(plte[3 * v], plte[3 * v + 1], plte[3 * v + 2]);
+          break;
+        }
+        default: out[x] = to_grey(row[x * channels], row[x * channels + 1], row[x * channels + 2]); break;
+      }
+    }
+  }
+  *w = (int)W; *h = (int)H;
+  return true;
+}
+
+// container chosen by the magic bytes
+static bool read_image(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_error(("cannot open " + path).c_str()); return false; }
+  uint8_t m[2] = {0, 0};
+  const size_t n = fread(m, 1, 2, f);
+  fclose(f);
+  if (n == 2 && m[0] == 0x89 && m[1] == 'P') return read_png(path, px, w, h);
+  return read_pgm(path, px, w, h);
+}
+
 }  // namespace sl2
 
 struct sl2_ingest {
@@ -109,10 +238,10 @@ struct sl2_ingest {
       }
       for (int s = 0; s < nseq; ++s) {
         int w = 0, h = 0;
-        if (!sl2::read_pgm(files[s][k], px, &w, &h) || w != width || h != height) {
+        if (!sl2::read_image(files[s][k], px, &w, &h) || w != width || h != height) {
           std::lock_guard<std::mutex> lk(mu);
           failed = true;
-          fail_msg = "frame " + files[s][k] + " is not a " + std::to_string(width) + "x" + std::to_string(height) + " binary PGM";
+          fail_msg = "frame " + files[s][k] + " is not a " + std::to_string(width) + "x" + std::to_string(height) + " binary PGM / PNG";
           cv.notify_all();
           return;
         }
@@ -151,6 +280,17 @@ int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, in
   if (!path || !width || !height) return SL2_ERR_INVALID;
   std::vector<uint8_t> px;
   if (!read_pgm(path, px, width, height)) return SL2_ERR_INVALID;
+  if (!out) return SL2_OK;
+  if (px.size() > capacity) return SL2_ERR_CAPACITY;
+  memcpy(out, px.data(), px.size());
+  return SL2_OK;
+}
+
+int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, int* height) {
+  using namespace sl2;
+  if (!path || !width || !height) return SL2_ERR_INVALID;
+  std::vector<uint8_t> px;
+  if (!read_image(path, px, width, height)) return SL2_ERR_INVALID;
   if (!out) return SL2_OK;
   if (px.size() > capacity) return SL2_ERR_CAPACITY;
   memcpy(out, px.data(), px.size());

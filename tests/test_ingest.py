@@ -43,6 +43,86 @@ def test_read_pgm_fixtures_and_comments(tmp_path):
         ingest.read_pgm(path)
 
 
+def _grey_like_libpng(rgb):
+    r, g, b = (rgb[..., k].astype(np.int64) for k in range(3))
+    return ((9797 * r + 19234 * g + 3737 * b + 16384) >> 15).astype(np.uint8)
+
+
+def test_read_png_grey_is_byte_exact_for_every_filter_type(tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (37, 53)).astype(np.uint8)
+    img[5:20, 7:30] = np.arange(23, dtype=np.uint8)[None, :] * 3          # smooth part: the predictors matter
+    for filters in (None, [0] * 37, [1] * 37, [2] * 37, [3] * 37, [4] * 37):
+        path = os.path.join(str(tmp_path), "g.png")
+        ingest.write_png(path, img, filters=filters, chunk=97)               # IDAT split into many chunks
+        assert np.array_equal(ingest.read_image(path), img)
+    # the decoder agrees with an independent writer where one is at hand
+    try:
+        import PIL.Image as Image
+    except ImportError:
+        Image = None
+    if Image is not None:
+        path = os.path.join(str(tmp_path), "pil.png")
+        Image.fromarray(img).save(path)
+        assert np.array_equal(ingest.read_image(path), img)
+
+
+def test_read_png_colour_alpha_palette_and_packed_depths(tmp_path):
+    rng = np.random.default_rng(3)
+    d = str(tmp_path)
+    rgb = rng.integers(0, 256, (19, 23, 3)).astype(np.uint8)
+    ingest.write_png(os.path.join(d, "rgb.png"), rgb)
+    assert np.array_equal(ingest.read_image(os.path.join(d, "rgb.png")), _grey_like_libpng(rgb))
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (19, 23, 1)).astype(np.uint8)], axis=2)
+    ingest.write_png(os.path.join(d, "rgba.png"), rgba)
+    assert np.array_equal(ingest.read_image(os.path.join(d, "rgba.png")), _grey_like_libpng(rgb))
+    grey = np.repeat(rng.integers(0, 256, (19, 23, 1)).astype(np.uint8), 3, axis=2)
+    ingest.write_png(os.path.join(d, "eq.png"), grey)                         # R == G == B must come back unchanged
+    assert np.array_equal(ingest.read_image(os.path.join(d, "eq.png")), grey[..., 0])
+    ga = rng.integers(0, 256, (19, 23, 2)).astype(np.uint8)
+    ingest.write_png(os.path.join(d, "ga.png"), ga)
+    assert np.array_equal(ingest.read_image(os.path.join(d, "ga.png")), ga[..., 0])
+    pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)
+    idx = rng.integers(0, 16, (19, 23)).astype(np.uint8)
+    for depth in (8, 4):
+        ingest.write_png(os.path.join(d, "pal.png"), idx, palette=pal, bit_depth=depth)
+        assert np.array_equal(ingest.read_image(os.path.join(d, "pal.png")), _grey_like_libpng(pal[idx]))
+    for depth in (1, 2, 4):
+        v = rng.integers(0, 1 << depth, (19, 23)).astype(np.uint8)
+        ingest.write_png(os.path.join(d, "packed.png"), v, bit_depth=depth)
+        want = (v.astype(np.int32) * 255 // ((1 << depth) - 1)).astype(np.uint8)
+        assert np.array_equal(ingest.read_image(os.path.join(d, "packed.png")), want)
+    # read_image also takes the PGM container
+    ingest.write_pgm(os.path.join(d, "x.pgm"), idx)
+    assert np.array_equal(ingest.read_image(os.path.join(d, "x.pgm")), idx)
+
+
+def test_read_png_rejects_what_it_does_not_decode(tmp_path):
+    import struct
+    import zlib
+    d = str(tmp_path)
+    img = np.arange(12, dtype=np.uint8).reshape(3, 4)
+    good = os.path.join(d, "good.png")
+    ingest.write_png(good, img)
+    data = open(good, "rb").read()
+    bad = os.path.join(d, "bad.png")
+    with open(bad, "wb") as f:                       # truncated file
+        f.write(data[:len(data) // 2])
+    with pytest.raises(_lib.Sl2Error):
+        ingest.read_image(bad)
+    ihdr_at = data.index(b"IHDR")
+    for off, val in ((12, 1), (8, 16)):              # interlaced; 16 bits per sample
+        hdr = bytearray(data[ihdr_at + 4:ihdr_at + 17])
+        hdr[off] = val
+        patched = data[:ihdr_at + 4] + bytes(hdr) + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(hdr)) & 0xFFFFFFFF) + data[ihdr_at + 21:]
+        with open(bad, "wb") as f:
+            f.write(patched)
+        with pytest.raises(_lib.Sl2Error):
+            ingest.read_image(bad)
+    with pytest.raises(_lib.Sl2Error):
+        ingest.read_image(os.path.join(d, "missing.png"))
+
+
 @pytest.mark.gpu
 def test_batched_ingest_delivers_every_frame_in_order(tmp_path):
     rng = np.random.default_rng(1)
@@ -53,7 +133,10 @@ def test_batched_ingest_delivers_every_frame_in_order(tmp_path):
         os.makedirs(d)
         frames = rng.integers(0, 256, (nfr + s, H, W)).astype(np.uint8)      # ragged lengths: the shortest one decides
         for k in range(frames.shape[0]):
-            ingest.write_pgm(os.path.join(d, "%04d.pgm" % k), frames[k])
+            if (k + s) % 2:                                                  # the two containers mixed in one sequence
+                ingest.write_png(os.path.join(d, "%04d.png" % k), frames[k])
+            else:
+                ingest.write_pgm(os.path.join(d, "%04d.pgm" % k), frames[k])
         dirs.append(d); want.append(frames)
     g = ingest.FrameIngest(dirs, W, H, depth=3)
     assert g.frame_count == nfr

@@ -1,0 +1,343 @@
+// MonoSLAM-shaped C++ adapter over the C ABI.
+//
+// Header-only.  It carries the public surface of SceneLib2::MonoSLAM that the reference's example and its GraphicTool use
+// (monoslam.h:69-219, examples/MonoSlamSceneLib1.cpp:55-142, graphic/graphictool.cpp:130-358) under the reference's member
+// names, so that a driver written against the reference reads the same here:
+//
+//     SceneLib2Amd::MonoSLAM slam;
+//     slam.Init("SceneLib2.cfg");                                       // monoslam.cpp:1574-1969
+//     while (grabber.GetFrame(k++, &frame))                             // examples/MonoSlamSceneLib1.cpp:132-142
+//       slam.GoOneStep(frame, save_trajectory, enable_mapping);         // monoslam.cpp:108-180
+//     slam.xv_, slam.Pxx_, slam.feature_list_[i]->y_, ->h_, ->S_, ...   // what GraphicTool draws
+//
+// Differences, all forced by the absence of Eigen / OpenCV / Pangolin in this build environment:
+//   * vectors and matrices are std::array / std::vector<double> (row-major) instead of Eigen types;
+//   * a frame is a `Frame` view (pointer, width, height) instead of cv::Mat — `Frame{mat.data, mat.cols, mat.rows}` at an
+//     integrator's site; frames must be 8-bit, single channel, continuous;
+//   * Init() parses the cfg itself ("name = value;", '#' comments: the pangolin::Var file format), absent keys read 0.
+// The per-frame arithmetic happens on the GPU behind sl2_go_one_step; after every call the public members are refreshed
+// from the engine (refresh_public_members), so reads between frames see what the reference's members would hold.
+#ifndef SCENELIB2_AMD_MONOSLAM_HPP
+#define SCENELIB2_AMD_MONOSLAM_HPP
+
+#include <scenelib2_amd.h>
+
+#include <array>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace SceneLib2Amd {
+
+struct Frame {                 // stands in for cv::Mat (8-bit, 1 channel, continuous)
+  const uint8_t* data = nullptr;
+  int cols = 0, rows = 0;
+  bool on_device = false;      // true: `data` is device memory (e.g. from sl2_ingest_next)
+};
+
+struct Camera {                // camera.h:61-77
+  int width_ = 0, height_ = 0;
+  double fku_ = 0, fkv_ = 0, kd1_ = 0;
+  std::array<double, 2> centre_{{0, 0}};
+  int measurement_sd_ = 0;
+};
+
+struct Feature {               // feature.h:56-143 (the members read from outside)
+  int label_ = 0;
+  bool fully_initialised_flag_ = true;
+  bool selected_flag_ = false;
+  bool successful_measurement_flag_ = false;
+  int attempted_measurements_of_feature_ = 0;
+  int successful_measurements_of_feature_ = 0;
+  int position_in_total_state_vector_ = 0;
+  int state_size_ = 3;                         // FeatureModel::kFeatureStateSize_: 3 full, 6 partial
+  std::vector<double> y_;                      // 3, or 6 while partially initialised
+  std::array<double, 7> xp_org_{};
+  std::array<double, 2> h_{}, z_{}, nu_{};
+  std::array<double, 4> S_{}, R_{};            // 2x2 row-major
+  std::array<double, 26> dh_by_dxv_{};         // 2x13 (columns 7..12 are zero, monoslam.cpp:298-300)
+  std::array<double, 6> dh_by_dy_{};           // 2x3
+  std::vector<double> Pxy_;                    // 13 x state_size_
+  std::vector<double> Pyy_;                    // state_size_ x state_size_
+  std::array<uint8_t, SL2_PATCH_BYTES> patch_{};
+};
+
+struct Particle {              // feature_init_info.h:46-75
+  double lambda_ = 0, probability_ = 0, cumulative_probability_ = 0;
+  std::array<double, 2> m_h_{}, m_z_{};
+  std::array<double, 4> m_SInv_{};
+  double m_detS_ = 0;
+  bool m_successful_measurement_flag_ = false;
+};
+
+struct FeatureInitInfo {       // feature_init_info.h:77-118
+  Feature* fp_ = nullptr;
+  std::vector<Particle> particle_vector_;
+  double mean_ = 0, covariance_ = 0;
+  int number_of_match_attempts_ = 0;
+  bool making_measurement_on_this_step_flag_ = false;
+};
+
+class MonoSLAM {
+ public:
+  explicit MonoSLAM(int max_features = 128, int device = 0) : max_features_(max_features), device_(device) {}
+  ~MonoSLAM() { if (eng_) sl2_destroy(eng_); }
+  MonoSLAM(const MonoSLAM&) = delete;
+  MonoSLAM& operator=(const MonoSLAM&) = delete;
+
+  // MonoSLAM::Init (monoslam.cpp:1574-1969).  Template files (fK.identifier, 11x11 binary PGM or PNG) are looked up
+  // beside the cfg.  Throws std::runtime_error like FileGrabber does for a missing directory (filegrabber.cpp:81).
+  void Init(const std::string& config_path) {
+    const auto kv = parse_vars(config_path);
+    const std::string base = config_path.find('/') == std::string::npos ? "." : config_path.substr(0, config_path.rfind('/'));
+    camera_.reset(new Camera());
+    camera_->width_ = (int)num(kv, "cam.width"); camera_->height_ = (int)num(kv, "cam.height");
+    camera_->fku_ = (int)num(kv, "cam.fku"); camera_->fkv_ = (int)num(kv, "cam.fkv");       // Var<int>, monoslam.cpp:1597-1602
+    camera_->centre_ = {{(double)(int)num(kv, "cam.u0"), (double)(int)num(kv, "cam.v0")}};
+    camera_->kd1_ = num(kv, "cam.kd1"); camera_->measurement_sd_ = (int)num(kv, "cam.sd");
+    kDeltaT_ = num(kv, "params.delta_t");
+    kNumberOfFeaturesToSelect_ = (int)num(kv, "params.number_of_features_to_select");
+    kNumberOfFeaturesToKeepVisible_ = (int)num(kv, "params.number_of_features_to_keep_visible");
+    kMaxFeaturesToInitAtOnce_ = (int)num(kv, "params.max_features_to_init_at_once");
+    kMinLambda_ = num(kv, "params.min_lambda"); kMaxLambda_ = num(kv, "params.max_lambda");
+    kNumberOfParticles_ = (int)num(kv, "params.number_of_particles");
+    kStandardDeviationDepthRatio_ = num(kv, "params.standard_deviation_depth_ratio");
+    kMinNumberOfParticles_ = (int)num(kv, "params.min_number_of_particles");
+    kPruneProbabilityThreshold_ = num(kv, "params.prune_probability_threshold");
+    kErasePartiallyInitFeatureAfterThisManyAttempts_ = (int)num(kv, "params.erase_partially_init_feature_after_this_many_attempts");
+    minimum_attempted_measurements_of_feature_ = 10;       // monoslam.cpp:1875-1876
+    successful_match_fraction_ = 0.5;
+
+    sl2_camera cam;
+    cam.width = camera_->width_; cam.height = camera_->height_; cam.fku = camera_->fku_; cam.fkv = camera_->fkv_;
+    cam.u0 = camera_->centre_[0]; cam.v0 = camera_->centre_[1]; cam.kd1 = camera_->kd1_; cam.sd = camera_->measurement_sd_;
+    sl2_params prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.delta_t = kDeltaT_;
+    prm.number_of_features_to_select = kNumberOfFeaturesToSelect_;
+    prm.number_of_features_to_keep_visible = kNumberOfFeaturesToKeepVisible_;
+    prm.max_features_to_init_at_once = kMaxFeaturesToInitAtOnce_;
+    prm.min_lambda = kMinLambda_; prm.max_lambda = kMaxLambda_;
+    prm.number_of_particles = kNumberOfParticles_;
+    prm.standard_deviation_depth_ratio = kStandardDeviationDepthRatio_;
+    prm.min_number_of_particles = kMinNumberOfParticles_;
+    prm.prune_probability_threshold = kPruneProbabilityThreshold_;
+    prm.erase_partially_init_feature_after_this_many_attempts = kErasePartiallyInitFeatureAfterThisManyAttempts_;
+    prm.minimum_attempted_measurements_of_feature = minimum_attempted_measurements_of_feature_;
+    prm.successful_match_fraction = successful_match_fraction_;
+    if (sl2_device_count() < 1) throw std::runtime_error("MonoSLAM::Init: no HIP device (the engine has no CPU path)");
+    if (eng_) { sl2_destroy(eng_); eng_ = nullptr; }
+    check(sl2_create(&cam, &prm, 1, max_features_, device_, nullptr, &eng_), "sl2_create");
+
+    static const char* xv_keys[13] = {"state.rw_x", "state.rw_y", "state.rw_z", "state.qwr_w", "state.qwr_x", "state.qwr_y", "state.qwr_z",
+                                      "state.vw_x", "state.vw_y", "state.vw_z", "state.ww_x", "state.ww_y", "state.ww_z"};
+    for (int i = 0; i < 13; ++i) xv_[i] = num(kv, xv_keys[i]);
+    for (int r = 0; r < 13; ++r)
+      for (int c = 0; c < 13; ++c) Pxx_[r * 13 + c] = num(kv, "state.pxx" + std::to_string(r) + "_" + std::to_string(c));
+    check(sl2_set_vehicle_state(eng_, 0, 1, xv_.data(), Pxx_.data()), "sl2_set_vehicle_state");
+    patches_.clear();
+    for (int k = 1; kv.count("f" + std::to_string(k) + ".yi_x"); ++k) {        // monoslam.cpp:1941-1957
+      const std::string p = "f" + std::to_string(k) + ".";
+      const std::array<double, 3> y{{num(kv, p + "yi_x"), num(kv, p + "yi_y"), num(kv, p + "yi_z")}};
+      std::array<double, 7> xp;
+      for (int j = 0; j < 7; ++j) xp[j] = num(kv, p + "xp_org_" + std::to_string(j));
+      auto it = kv.find(p + "identifier");
+      AddNewKnownFeature(y, xp, base + "/" + (it == kv.end() ? std::string("empty") : it->second));
+    }
+    refresh_public_members();
+  }
+
+  // MonoSLAM::AddNewKnownFeature (monoslam.cpp:1278-1291; Feature ctor feature.cpp:106-142): identifier = template file.
+  void AddNewKnownFeature(const std::array<double, 3>& y_new, const std::array<double, 7>& xp_o, const std::string& identifier) {
+    std::array<uint8_t, SL2_PATCH_BYTES> patch;
+    int w = 0, h = 0;
+    check(sl2_read_image(identifier.c_str(), patch.data(), patch.size(), &w, &h), "sl2_read_image");
+    if (w != SL2_PATCH_SIZE || h != SL2_PATCH_SIZE) throw std::runtime_error(identifier + " is not an 11x11 template");
+    check(sl2_add_known_features(eng_, 0, 1, 1, y_new.data(), xp_o.data(), patch.data()), "sl2_add_known_features");
+    patches_.push_back(patch);
+  }
+
+  // MonoSLAM::GoOneStep (monoslam.cpp:108-180).  Always true, like the reference (:179).
+  bool GoOneStep(const Frame& frame, bool save_trajectory, bool enable_mapping) {
+    if (!eng_ || !frame.data || frame.cols != camera_->width_ || frame.rows != camera_->height_)
+      throw std::runtime_error("MonoSLAM::GoOneStep: frame does not match the camera");
+    check(sl2_go_one_step(eng_, frame.data, (size_t)frame.cols * frame.rows, frame.on_device ? 1 : 0, save_trajectory ? 1 : 0,
+                          enable_mapping ? 1 : 0),
+          "sl2_go_one_step");
+    refresh_public_members();
+    return true;
+  }
+
+  // construct_total_state / construct_total_covariance (monoslam.cpp:501-546)
+  void construct_total_state(std::vector<double>& V) {
+    V.assign(total_state_size_, 0.0);
+    check(sl2_get_total_state(eng_, 0, V.data(), total_state_size_), "sl2_get_total_state");
+  }
+  void construct_total_covariance(std::vector<double>& M) {
+    M.assign((size_t)total_state_size_ * total_state_size_, 0.0);
+    check(sl2_get_total_covariance(eng_, 0, M.data(), total_state_size_), "sl2_get_total_covariance");
+  }
+
+  sl2_engine* engine() { return eng_; }
+
+  // ---- public data members, names as in monoslam.h:158-218 ----
+  std::unique_ptr<Camera> camera_;
+  std::array<double, 13> xv_{};
+  std::array<double, 169> Pxx_{};                             // 13x13 row-major
+  std::vector<std::unique_ptr<Feature>> feature_list_;
+  std::vector<Feature*> selected_feature_list_;
+  std::vector<FeatureInitInfo> feature_init_info_vector_;
+  std::vector<std::array<double, 3>> trajectory_store_;       // keeps the reference's stale-scratch entries
+  int number_of_visible_features_ = 0;
+  int next_free_label_ = 0;
+  int total_state_size_ = 13;
+  int successful_measurement_vector_size_ = 0;
+  double kDeltaT_ = 0;
+  int kNumberOfFeaturesToSelect_ = 0, kNumberOfFeaturesToKeepVisible_ = 0, kMaxFeaturesToInitAtOnce_ = 0;
+  double kMinLambda_ = 0, kMaxLambda_ = 0;
+  int kNumberOfParticles_ = 0;
+  double kStandardDeviationDepthRatio_ = 0;
+  int kMinNumberOfParticles_ = 0;
+  double kPruneProbabilityThreshold_ = 0;
+  int kErasePartiallyInitFeatureAfterThisManyAttempts_ = 0;
+  int init_feature_search_ustart_ = 0, init_feature_search_vstart_ = 0, init_feature_search_ufinish_ = 0, init_feature_search_vfinish_ = 0;
+  bool init_feature_search_region_defined_flag_ = false;
+  int minimum_attempted_measurements_of_feature_ = 10;
+  double successful_match_fraction_ = 0.5;
+  int uu_ = 0, vv_ = 0;
+  bool location_selected_flag_ = false;
+  const int kBoxSize_ = SL2_PATCH_SIZE;                       // monoslam.cpp:48
+  const double kNoSigma_ = 3.0, kCorrThresh2_ = 0.40, kCorrelationSigmaThreshold_ = 10.0;
+
+ private:
+  static void check(int rc, const char* what) {
+    if (rc != SL2_OK) throw std::runtime_error(std::string(what) + ": " + sl2_last_error());
+  }
+  static std::map<std::string, std::string> parse_vars(const std::string& path) {
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("MonoSLAM::Init: cannot read " + path);
+    std::map<std::string, std::string> kv;
+    std::string line;
+    auto trim = [](std::string s) {
+      const char* ws = " \t\r\n;";
+      const size_t a = s.find_first_not_of(ws);
+      if (a == std::string::npos) return std::string();
+      return s.substr(a, s.find_last_not_of(ws) - a + 1);
+    };
+    while (std::getline(in, line)) {
+      const size_t hash = line.find('#');
+      if (hash != std::string::npos) line.erase(hash);
+      const size_t eq = line.find('=');
+      if (eq != std::string::npos) kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
+    }
+    return kv;
+  }
+  static double num(const std::map<std::string, std::string>& kv, const std::string& k) {
+    auto it = kv.find(k);
+    return it == kv.end() ? 0.0 : std::atof(it->second.c_str());
+  }
+
+  // What the reference's members hold after a step, read back through the C ABI.
+  void refresh_public_members() {
+    check(sl2_get_vehicle_state(eng_, 0, 1, xv_.data(), Pxx_.data()), "sl2_get_vehicle_state");
+    int32_t size = 13;
+    check(sl2_get_total_state_sizes(eng_, 0, 1, &size), "sl2_get_total_state_sizes");
+    total_state_size_ = size;
+    std::vector<double> P((size_t)size * size);
+    check(sl2_get_total_covariance(eng_, 0, P.data(), size), "sl2_get_total_covariance");
+    std::vector<sl2_feature_info> fi(max_features_);
+    int n = 0;
+    check(sl2_get_features(eng_, 0, fi.data(), max_features_, 0, &n), "sl2_get_features");
+    feature_list_.clear();
+    next_free_label_ = 0;
+    for (int i = 0; i < n; ++i) {
+      std::unique_ptr<Feature> f(new Feature());
+      const sl2_feature_info& s = fi[i];
+      f->label_ = s.label;
+      f->fully_initialised_flag_ = s.fully_initialised_flag != 0;
+      f->selected_flag_ = s.selected_flag != 0;
+      f->successful_measurement_flag_ = s.successful_measurement_flag != 0;
+      f->attempted_measurements_of_feature_ = s.attempted_measurements_of_feature;
+      f->successful_measurements_of_feature_ = s.successful_measurements_of_feature;
+      f->position_in_total_state_vector_ = s.position_in_total_state_vector;
+      f->state_size_ = s.state_size;
+      f->y_.assign(s.y, s.y + 3);
+      if (s.state_size == 6) f->y_.insert(f->y_.end(), s.y_direction, s.y_direction + 3);
+      std::memcpy(f->xp_org_.data(), s.xp_org, sizeof(s.xp_org));
+      for (int k = 0; k < 2; ++k) { f->h_[k] = s.h[k]; f->z_[k] = s.z[k]; f->nu_[k] = s.nu[k]; }
+      for (int k = 0; k < 4; ++k) f->S_[k] = s.S[k];
+      f->R_ = {{s.R, 0.0, 0.0, s.R}};
+      for (int r = 0; r < 2; ++r)
+        for (int c = 0; c < 7; ++c) f->dh_by_dxv_[r * 13 + c] = s.dh_by_dxp[r * 7 + c];
+      for (int k = 0; k < 6; ++k) f->dh_by_dy_[k] = s.dh_by_dy[k];
+      const int pos = s.position_in_total_state_vector, d = s.state_size;
+      f->Pxy_.resize((size_t)13 * d);
+      f->Pyy_.resize((size_t)d * d);
+      for (int r = 0; r < 13; ++r)
+        for (int c = 0; c < d; ++c) f->Pxy_[(size_t)r * d + c] = P[(size_t)r * size + pos + c];
+      for (int r = 0; r < d; ++r)
+        for (int c = 0; c < d; ++c) f->Pyy_[(size_t)r * d + c] = P[(size_t)(pos + r) * size + pos + c];
+      if ((size_t)s.label < patches_.size()) f->patch_ = patches_[s.label];
+      if (s.label >= next_free_label_) next_free_label_ = s.label + 1;
+      feature_list_.push_back(std::move(f));
+    }
+    std::vector<int32_t> labels(max_features_);
+    int32_t counters[3] = {0, 0, 0};
+    check(sl2_get_selection(eng_, 0, labels.data(), max_features_, counters), "sl2_get_selection");
+    number_of_visible_features_ = counters[0];
+    successful_measurement_vector_size_ = counters[2];
+    selected_feature_list_.clear();
+    for (int k = 0; k < counters[1]; ++k)
+      for (auto& f : feature_list_)
+        if (f->label_ == labels[k]) { selected_feature_list_.push_back(f.get()); break; }
+    std::vector<double> tr(3 * 1000);
+    int cnt = 0;
+    check(sl2_get_trajectory(eng_, 0, tr.data(), 1000, &cnt), "sl2_get_trajectory");
+    trajectory_store_.resize(cnt);
+    for (int k = 0; k < cnt; ++k) trajectory_store_[k] = {{tr[3 * k], tr[3 * k + 1], tr[3 * k + 2]}};
+    // feature_init_info_vector_ (at most one entry: max_features_to_init_at_once = 1 is what the device path runs)
+    int32_t pi[16];
+    double pd[9];
+    std::vector<double> parts((size_t)128 * 12);
+    check(sl2_get_partial_feature(eng_, 0, pi, pd, parts.data(), 128), "sl2_get_partial_feature");
+    feature_init_info_vector_.clear();
+    uu_ = pi[5]; vv_ = pi[6];
+    init_feature_search_region_defined_flag_ = pi[7] != 0;
+    init_feature_search_ustart_ = pi[8]; init_feature_search_vstart_ = pi[9];
+    init_feature_search_ufinish_ = pi[10]; init_feature_search_vfinish_ = pi[11];
+    location_selected_flag_ = pi[15] != 0;
+    if (pi[0]) {
+      FeatureInitInfo info;
+      for (auto& f : feature_list_)
+        if (f->label_ == pi[1]) info.fp_ = f.get();
+      info.number_of_match_attempts_ = pi[2];
+      info.making_measurement_on_this_step_flag_ = pi[4] != 0;
+      info.mean_ = pd[0]; info.covariance_ = pd[1];
+      info.particle_vector_.resize(pi[3]);
+      for (int k = 0; k < pi[3]; ++k) {
+        const double* o = &parts[(size_t)k * 12];
+        Particle& p = info.particle_vector_[k];
+        p.lambda_ = o[0]; p.probability_ = o[1]; p.cumulative_probability_ = o[2];
+        p.m_h_ = {{o[3], o[4]}}; p.m_z_ = {{o[5], o[6]}};
+        p.m_SInv_ = {{o[7], o[8], o[8], o[9]}};
+        p.m_detS_ = o[10];
+        p.m_successful_measurement_flag_ = o[11] != 0.0;
+      }
+      feature_init_info_vector_.push_back(std::move(info));
+    }
+  }
+
+  int max_features_, device_;
+  sl2_engine* eng_ = nullptr;
+  std::vector<std::array<uint8_t, SL2_PATCH_BYTES>> patches_;      // by label, for Feature::patch_
+};
+
+}  // namespace SceneLib2Amd
+
+#endif  // SCENELIB2_AMD_MONOSLAM_HPP

@@ -62,3 +62,45 @@ def test_headless_example_matches_oracle(tmp_path, mapping):
     assert x.size == x0.size and np.abs(x - x0).max() < 1e-9
     if mapping:
         assert s.mapping_info()["initialised"] >= 2
+
+
+@pytest.mark.parametrize("mapping", [False, True])
+def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mapping):
+    """examples/monoslam_adapter.cpp: the reference example's loop written against include/scenelib2_amd_monoslam.hpp
+    (Init / GoOneStep / xv_, feature_list_, selected_feature_list_, trajectory_store_ ...).  Its read-out must be what the
+    oracle's members hold after the same frames."""
+    exe = os.path.join(ROOT, "examples", "monoslam_adapter")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=20)
+    cfg, fd = _write_scene(str(tmp_path), cam, params, spec, frames, templates)
+    dump = os.path.join(str(tmp_path), "members.txt")
+    cmd = [exe, "--cfg", cfg, "--frames", fd, "--dump", dump] + (["--mapping"] if mapping else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "%d known features" % spec.n_features in out.stdout
+    v = np.loadtxt(dump)
+    s = oracle_for(cam, params, spec, templates, oa)
+    for k in range(1, 21):
+        s.go_one_step(frames[k], True, mapping)
+    n = int(v[0])
+    assert n == s.total_state_size
+    x0, P0 = s.total_state(), s.total_covariance()
+    assert np.abs(v[1:1 + n] - x0).max() < 1e-9
+    at = 1 + n
+    kinds = s.feature_kinds()                      # per feature: state size, fully initialised, label
+    assert s.num_features >= spec.n_features
+    for i in range(s.num_features):
+        fo = s.feature(i)
+        label, fully, attempted, successful, pos = (int(t) for t in v[at:at + 5])
+        at += 5
+        d = int(kinds[i][0])
+        assert (label, fully, d) == (fo["label"], int(kinds[i][1]), 3 if fully else 6)
+        assert (attempted, successful, pos) == (fo["attempted"], fo["successful"], fo["pos"])
+        Pyy = v[at:at + d * d].reshape(d, d)
+        at += d * d
+        ref = P0[pos:pos + d, pos:pos + d]
+        assert np.abs(Pyy - ref).max() <= 1e-8 * max(np.abs(ref).max(), 1e-12)
+    traj = v[at:].reshape(-1, 3)
+    t0 = s.trajectory()
+    assert traj.shape == t0.shape and np.abs(traj - t0).max() < 1e-9

@@ -104,82 +104,95 @@ __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, c
 // Thread i plays two roles: column i of At, and row a = i of H (its 10 non-zeros in registers).
 // The summation order of every entry is that of the two separate kernels.
 // ---------------------------------------------------------------------------
-constexpr int kASBatch = 4;   // features per LDS batch
+constexpr int kASBatch = 4;   // features per LDS batch (state sizes up to 1024 columns)
 
+// NQ: columns per thread (thread t owns columns t, t + 1024, ...: NQ = 1 for ld <= 1024, 2 up to 2048 - the 1280x720 /
+// 500-feature configuration, ld = 1536); BATCH: features per LDS batch (2 * BATCH * ld doubles of LDS).
+template <int NQ, int BATCH>
 __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                   const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
                                                   const int* __restrict__ m_count, double* __restrict__ At,
                                                   double* __restrict__ St, int N, int ld, int mld) {
-  extern __shared__ double sAt[];   // [2 * kASBatch][ld]
+  extern __shared__ double sAt[];   // [2 * BATCH][ld]
   const int b = blockIdx.x;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
-  const int i = threadIdx.x;        // blockDim.x == ld
+  const int t = threadIdx.x;        // blockDim.x * NQ >= ld; the S role below needs blockDim.x >= mp
   double* Ab = At + (size_t)b * mld * ld;
   double* Sb = St + (size_t)b * mld * mld;
   const double* Pb = P + (size_t)b * ld * ld;
   const int* sidx = succ_idx + (size_t)b * N;
-  // role "column i of At"
-  double pc[7];
+  // role "columns i of At"
+  double pc[NQ][7];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
-  // role "row a = i of H"
+  for (int q = 0; q < NQ; ++q) {
+    const int i = t + q * (int)blockDim.x;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) pc[q][c] = (i >= ld) ? 0.0 : ((i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i]);
+  }
+  // role "row a = t of H"
   double hx[7], hy[3], Rn = 0.0;
   int posa = 0;
-  if (i < m) {
-    const int fa = sidx[i >> 1];
+  if (t < m) {
+    const int fa = sidx[t >> 1];
     const size_t fia = (size_t)b * N + fa;
     posa = 13 + 3 * fa;
 #pragma unroll
-    for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fia * 14 + (i & 1) * 7 + c];
+    for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fia * 14 + (t & 1) * 7 + c];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fia * 6 + (i & 1) * 3 + c];
+    for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fia * 6 + (t & 1) * 3 + c];
     Rn = f_R[fia];
   }
-  for (int j0 = 0; j0 < cnt; j0 += kASBatch) {
-    const int nb = (cnt - j0 < kASBatch) ? cnt - j0 : kASBatch;
+  for (int j0 = 0; j0 < cnt; j0 += BATCH) {
+    const int nb = (cnt - j0 < BATCH) ? cnt - j0 : BATCH;
 #pragma unroll
-    for (int jj = 0; jj < kASBatch; ++jj) {
+    for (int jj = 0; jj < BATCH; ++jj) {
       if (jj < nb) {
         const int f = sidx[j0 + jj];
         const size_t fi = (size_t)b * N + f;
         const int pos = 13 + 3 * f;
-        double py[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+        for (int q = 0; q < NQ; ++q) {
+          const int i = t + q * (int)blockDim.x;
+          if (i < ld) {
+            double py[3];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          double acc = 0.0;
+            for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
 #pragma unroll
-          for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
+            for (int r = 0; r < 2; ++r) {
+              double acc = 0.0;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
-          if (i == ld - 1) acc = f_nu[fi * 2 + r];
-          Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
-          sAt[(2 * jj + r) * ld + i] = acc;
+              for (int c = 0; c < 7; ++c) acc += pc[q][c] * f_Hx[fi * 14 + r * 7 + c];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
+              if (i == ld - 1) acc = f_nu[fi * 2 + r];
+              Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
+              sAt[(2 * jj + r) * ld + i] = acc;
+            }
+          }
         }
       }
     }
     __syncthreads();
-    if (i < mp) {
+    if (t < mp) {
 #pragma unroll
-      for (int kk = 0; kk < 2 * kASBatch; ++kk) {
+      for (int kk = 0; kk < 2 * BATCH; ++kk) {
         const int k = 2 * j0 + kk;
-        if (kk < 2 * nb && (i | 31) >= k) {     // blocks on and below the block diagonal
+        if (kk < 2 * nb && (t | 31) >= k) {     // blocks on and below the block diagonal
           double v = 0.0;
-          if (i < m) {
+          if (t < m) {
             const double* arow = sAt + kk * ld;
             double acc = 0.0;
 #pragma unroll
             for (int c = 0; c < 7; ++c) acc += hx[c] * arow[c];
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc += hy[c] * arow[posa + c];
-            if (i == k) acc += Rn;
+            if (t == k) acc += Rn;
             v = acc;
           }
-          Sb[(size_t)k * mld + i] = v;
+          Sb[(size_t)k * mld + t] = v;
         }
       }
     }
@@ -187,8 +200,12 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   }
   // padding: rows of At up to the 32-multiple are zero, S is the identity there
   for (int k = m; k < mp; ++k) {
-    Ab[(size_t)k * ld + i] = 0.0;
-    if (i < mp && (i | 31) >= k) Sb[(size_t)k * mld + i] = (i == k) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int i = t + q * (int)blockDim.x;
+      if (i < ld) Ab[(size_t)k * ld + i] = 0.0;
+    }
+    if (t < mp && (t | 31) >= k) Sb[(size_t)k * mld + t] = (t == k) ? 1.0 : 0.0;
   }
 }
 
@@ -1336,11 +1353,17 @@ int launch_update(sl2_engine* e) {
     hipLaunchKernelGGL(k_compact, dim3(B), dim3(64), 0, e->stream, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
-  if (e->ld <= 1024 && e->root->build_variant == 1) {
+  if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
-    const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
-    hipLaunchKernelGGL(k_build_AS, dim3(B), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R, e->succ_idx,
-                       e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+    if (e->ld <= 1024) {
+      const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
+      hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
+                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+    } else {
+      const size_t shm = sizeof(double) * 2 * 2 * e->ld;      // <= 64 KB
+      hipLaunchKernelGGL((k_build_AS<2, 2>), dim3(B), dim3(1024), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
+                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+    }
     SL2_HIP(hipGetLastError());
   } else {
     {

@@ -126,45 +126,12 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
                                                        const SearchBounds sb, double a, double b, double c,
                                                        unsigned* s_win) {
   const int lane = threadIdx.x & 63;
-  const int nu = sb.urelfinish - sb.urelstart + 1;
-  const int nv = sb.vrelfinish - sb.vrelstart + 1;
+  const int nu_all = sb.urelfinish - sb.urelstart + 1;
+  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
   SearchResult res;
   res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
   res.S1 = res.S2 = res.X = 0;
-  if (nu <= 0 || nv <= 0) return res;
-  if (nu > kMaxNu || nv > kMaxNv) { res.code = -1; return res; }
-
-  // ---- stage the window: coalesced dword-aligned row loads, 8 row passes in flight at a time ----
-  const int x0 = sb.ucentre + sb.urelstart - 5, y0 = sb.vcentre + sb.vrelstart - 5;
-  const int Hw = nv + 10;
-  const size_t base_addr = (size_t)image + (size_t)y0 * width + x0;
-  {
-    const int k = lane & 15, rsub = lane >> 4;   // 16 dwords per row, 4 rows per pass
-    for (int r0 = 0; r0 < Hw; r0 += 32) {
-      unsigned val[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + 4 * u + rsub;
-        unsigned v = 0;
-        if (r < Hw) {
-          const size_t addr = base_addr + (size_t)r * width;
-          const size_t al = addr & ~(size_t)3;
-          const int o = (int)(addr & 3);
-          const int need = (o + nu + 10 + 3) >> 2;     // <= 16
-          if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
-        }
-        val[u] = v;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int r = r0 + 4 * u + rsub;
-        if (r < Hw) {
-          s_win[r * kWinPitchDw + k] = val[u];
-          if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
-        }
-      }
-    }
-  }
+  if (nu_all <= 0 || nv_all <= 0) return res;
 
   // ---- template -> 33 wave-uniform dwords (row r: bytes 0..10, byte 11 = 0) ----
   unsigned tv = 0;
@@ -198,96 +165,141 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
     const double sigmag0 = sqrt(varg0);
     patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
   }
+  const int D0 = 121 * Sg0sq - Sg0 * Sg0;          // n^2 var0 > 0 when patch_ok
+  const float d0f = (float)D0;
 
-  // ---- ellipse membership (exact FP64 test): lane u builds the bit mask over v of its column ----
-  unsigned long long colmask = 0ull;
-  if (lane < nu) {
-    const int urel = sb.urelstart + lane;
-    for (int vi = 0; vi < nv; ++vi)
-      if (in_ellipse(a, b, c, urel, sb.vrelstart + vi)) colmask |= 1ull << vi;
-  }
-  int ncand = __popcll(colmask);
-  for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
-  res.ncand = ncand;
-  if (!patch_ok) return res;                       // every candidate is skipped (sdpatch < 10)
-  const int D0 = 121 * Sg0sq - Sg0 * Sg0;          // n^2 var0 > 0 here
-  __syncthreads();                                 // window is in LDS
-
-  // ---- column walk ----
-  const int nseg = 64 / nu;                       // >= 1
-  const int vs = (nv + nseg - 1) / nseg;          // rows of candidates per segment
-  const int seg = lane / nu, ui = lane - seg * nu;
-  const int vstart = seg * vs;
-  const bool active = (seg < nseg) && (vstart < nv);
-  const int vlen = active ? min(vs, nv - vstart) : 0;
-  unsigned long long mymask;
-  {
-    const unsigned lo = (unsigned)__shfl((int)(unsigned)(colmask & 0xffffffffull), ui, 64);
-    const unsigned hi = (unsigned)__shfl((int)(unsigned)(colmask >> 32), ui, 64);
-    mymask = active ? (((unsigned long long)hi << 32) | lo) : 0ull;
-  }
-  const int wmod = width & 3;
-  const int o_first = (int)(base_addr & 3);
-  const int tmax = vs + 10;
-
-  unsigned ring[11][3];
-  int rs1[11], rs2[11];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) { rs1[i] = 0; rs2[i] = 0; ring[i][0] = ring[i][1] = ring[i][2] = 0; }
-  int S1 = 0, S2 = 0;
+  // running per-lane state over every block of the window
   float best_q = -3.0e38f, second_q = -3.0e38f;
   int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
   int need_exact = 0;
-  const float d0f = (float)D0;
+  int ncand_lane = 0;
 
-  for (int tb = 0; tb < tmax; tb += 11) {
+  // A window larger than the LDS tile (kMaxNu x kMaxNv candidates) is walked block by block: each block is staged and
+  // walked like a window of its own, the lanes keep their two best candidates across blocks, and the decision is taken
+  // once at the end.  (Windows of this size are the rule at 1280x720; the exact baseline kernel they used to fall
+  // back to costs ten times as much per candidate.)
+  for (int ub = 0; ub < nu_all; ub += kMaxNu) {
+    const int nu = min(kMaxNu, nu_all - ub);
+    for (int vb = 0; vb < nv_all; vb += kMaxNv) {
+      const int nv = min(kMaxNv, nv_all - vb);
+      if (ub + vb > 0) __syncthreads();            // the previous block's walk is done with the tile
+
+      // ---- stage the block: coalesced dword-aligned row loads, 8 row passes in flight at a time ----
+      const int x0 = sb.ucentre + sb.urelstart + ub - 5, y0 = sb.vcentre + sb.vrelstart + vb - 5;
+      const int Hw = nv + 10;
+      const size_t base_addr = (size_t)image + (size_t)y0 * width + x0;
+      {
+        const int k = lane & 15, rsub = lane >> 4;   // 16 dwords per row, 4 rows per pass
+        for (int r0 = 0; r0 < Hw; r0 += 32) {
+          unsigned val[8];
 #pragma unroll
-    for (int s = 0; s < 11; ++s) {
-      const int t = tb + s;
-      if (t < tmax) {
-        const bool row_ok = active && (t < vlen + 10);
-        // fetch window row (vstart + t), bytes ui .. ui+11
-        unsigned r0 = 0, r1 = 0, r2 = 0;
-        if (row_ok) {
-          const int wr = vstart + t;
-          const int bo = ((o_first + wr * wmod) & 3) + ui;
-          const int k0 = bo >> 2, sh = bo & 3;
-          const unsigned* rowp = s_win + wr * kWinPitchDw + k0;
-          const unsigned d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3];
-          r0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-          r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-          r2 = __builtin_amdgcn_alignbyte(d3, d2, sh) & 0x00ffffffu;
-        }
-        const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
-        const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
-        S1 += n1 - rs1[s];
-        S2 += n2 - rs2[s];
-        rs1[s] = n1; rs2[s] = n2;
-        ring[s][0] = r0; ring[s][1] = r1; ring[s][2] = r2;
-        if (t >= 10) {
-          const int vi = vstart + t - 10;
-          const bool cand = row_ok && ((mymask >> vi) & 1ull);
-          if (cand) {
-            unsigned X0 = 0, X1 = 0, X2 = 0;      // three independent accumulation chains
-#pragma unroll
-            for (int j = 0; j < 11; ++j) {
-              const int slot = (s + 1 + j) % 11;
-              X0 = udot4(ring[slot][0], T[3 * j + 0], X0);
-              X1 = udot4(ring[slot][1], T[3 * j + 1], X1);
-              X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
+          for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u + rsub;
+            unsigned v = 0;
+            if (r < Hw) {
+              const size_t addr = base_addr + (size_t)r * width;
+              const size_t al = addr & ~(size_t)3;
+              const int o = (int)(addr & 3);
+              const int need = (o + nu + 10 + 3) >> 2;     // <= 16
+              if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
             }
-            const unsigned X = X0 + X1 + X2;
-            const int D1 = mul24(121, S2) - mul24(S1, S1);   // n^2 var1, exact (all factors < 2^24)
-            if (D1 == 1464100) need_exact = 1;            // sigma1 == 10 boundary: decided in FP64 only
-            if (D1 > 1464100) {                           // sigma1 >= 10 for certain
-              const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);   // n^2 cov, exact
-              const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);   // ~ rho
-              const int idx = ui * nv + vi;
-              if (q > best_q) {
-                second_q = best_q;
-                best_q = q; best_idx = idx; best_S1 = S1; best_S2 = S2; best_X = (int)X;
-              } else if (q > second_q) {
-                second_q = q;
+            val[u] = v;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int r = r0 + 4 * u + rsub;
+            if (r < Hw) {
+              s_win[r * kWinPitchDw + k] = val[u];
+              if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
+            }
+          }
+        }
+      }
+
+      // ---- ellipse membership (exact FP64 test): lane u builds the bit mask over v of its column ----
+      unsigned long long colmask = 0ull;
+      if (lane < nu) {
+        const int urel = sb.urelstart + ub + lane;
+        for (int vi = 0; vi < nv; ++vi)
+          if (in_ellipse(a, b, c, urel, sb.vrelstart + vb + vi)) colmask |= 1ull << vi;
+      }
+      ncand_lane += __popcll(colmask);
+      __syncthreads();                                 // block is in LDS
+      if (!patch_ok) continue;                         // every candidate is skipped (sdpatch < 10): only counted
+
+      // ---- column walk ----
+      const int nseg = 64 / nu;                       // >= 1
+      const int vs = (nv + nseg - 1) / nseg;          // rows of candidates per segment
+      const int seg = lane / nu, ui = lane - seg * nu;
+      const int vstart = seg * vs;
+      const bool active = (seg < nseg) && (vstart < nv);
+      const int vlen = active ? min(vs, nv - vstart) : 0;
+      unsigned long long mymask;
+      {
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)(colmask & 0xffffffffull), ui, 64);
+        const unsigned hi = (unsigned)__shfl((int)(unsigned)(colmask >> 32), ui, 64);
+        mymask = active ? (((unsigned long long)hi << 32) | lo) : 0ull;
+      }
+      const int wmod = width & 3;
+      const int o_first = (int)(base_addr & 3);
+      const int tmax = vs + 10;
+
+      unsigned ring[11][3];
+      int rs1[11], rs2[11];
+#pragma unroll
+      for (int i = 0; i < 11; ++i) { rs1[i] = 0; rs2[i] = 0; ring[i][0] = ring[i][1] = ring[i][2] = 0; }
+      int S1 = 0, S2 = 0;
+
+      for (int tb = 0; tb < tmax; tb += 11) {
+#pragma unroll
+        for (int s = 0; s < 11; ++s) {
+          const int t = tb + s;
+          if (t < tmax) {
+            const bool row_ok = active && (t < vlen + 10);
+            // fetch window row (vstart + t), bytes ui .. ui+11
+            unsigned r0 = 0, r1 = 0, r2 = 0;
+            if (row_ok) {
+              const int wr = vstart + t;
+              const int bo = ((o_first + wr * wmod) & 3) + ui;
+              const int k0 = bo >> 2, sh = bo & 3;
+              const unsigned* rowp = s_win + wr * kWinPitchDw + k0;
+              const unsigned d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3];
+              r0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+              r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+              r2 = __builtin_amdgcn_alignbyte(d3, d2, sh) & 0x00ffffffu;
+            }
+            const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
+            const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
+            S1 += n1 - rs1[s];
+            S2 += n2 - rs2[s];
+            rs1[s] = n1; rs2[s] = n2;
+            ring[s][0] = r0; ring[s][1] = r1; ring[s][2] = r2;
+            if (t >= 10) {
+              const int vi = vstart + t - 10;
+              const bool cand = row_ok && ((mymask >> vi) & 1ull);
+              if (cand) {
+                unsigned X0 = 0, X1 = 0, X2 = 0;      // three independent accumulation chains
+#pragma unroll
+                for (int j = 0; j < 11; ++j) {
+                  const int slot = (s + 1 + j) % 11;
+                  X0 = udot4(ring[slot][0], T[3 * j + 0], X0);
+                  X1 = udot4(ring[slot][1], T[3 * j + 1], X1);
+                  X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
+                }
+                const unsigned X = X0 + X1 + X2;
+                const int D1 = mul24(121, S2) - mul24(S1, S1);   // n^2 var1, exact (all factors < 2^24)
+                if (D1 == 1464100) need_exact = 1;            // sigma1 == 10 boundary: decided in FP64 only
+                if (D1 > 1464100) {                           // sigma1 >= 10 for certain
+                  const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);   // n^2 cov, exact
+                  const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);   // ~ rho
+                  const int idx = (ub + ui) * nv_all + (vb + vi);
+                  if (q > best_q) {
+                    second_q = best_q;
+                    best_q = q; best_idx = idx; best_S1 = S1; best_S2 = S2; best_X = (int)X;
+                  } else if (q > second_q) {
+                    second_q = q;
+                  }
+                }
               }
             }
           }
@@ -295,6 +307,10 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
       }
     }
   }
+  int ncand = ncand_lane;
+  for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
+  res.ncand = ncand;
+  if (!patch_ok) return res;
   // ---- decide ----
   float gmax = best_q;
   for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
@@ -308,8 +324,8 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
   const int w_idx = __shfl(best_idx, wl, 64);
   res.S1 = __shfl(best_S1, wl, 64); res.S2 = __shfl(best_S2, wl, 64); res.X = __shfl(best_X, wl, 64);
   res.found = 1;
-  res.u = sb.ucentre + sb.urelstart + w_idx / nv;
-  res.v = sb.vcentre + sb.vrelstart + w_idx % nv;
+  res.u = sb.ucentre + sb.urelstart + w_idx / nv_all;
+  res.v = sb.vcentre + sb.vrelstart + w_idx % nv_all;
   if (DEFER) { res.code = 1; return res; }
   double sd0, sd1;
   const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
@@ -419,7 +435,8 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
     const double* sd = srch_d + ((size_t)b * N + d_f) * 4;
     d_a = sd[0]; d_b = sd[1]; d_c = sd[2];
   }
-  // a window too large for the LDS tile comes alone: exact baseline path
+  // a window too large for the pack tile comes alone: the blocked column walk (search_core_v1), and only if that cannot
+  // decide exactly, the baseline path
   {
     const int nu0 = __shfl(d_nu, 0, 64), nv0 = __shfl(d_nv, 0, 64);
     if (cnt == 1 && (nu0 > kPackMaxNu || nv0 > kPackMaxNv)) {
@@ -429,10 +446,19 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
       sb.vrelstart = __shfl(d_vs, 0, 64); sb.vrelfinish = sb.vrelstart + nv0 - 1;
       sb.halfwidth = __shfl(d_hw, 0, 64); sb.halfheight = __shfl(d_hh, 0, 64);
       const int f0 = __shfl(d_f, 0, 64);
-      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + f0) * kPatchStride, sb, __shfl(d_a, 0, 64),
-                                            __shfl(d_b, 0, 64), __shfl(d_c, 0, 64));
+      const uint8_t* pbytes = patch + ((size_t)b * N + f0) * kPatchStride;
+      const double a0 = __shfl(d_a, 0, 64), b0 = __shfl(d_b, 0, 64), c0 = __shfl(d_c, 0, 64);
+      SearchResult r = search_core_v1<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a0, b0, c0, s_win);
+      int* o = srch_res + ((size_t)b * N + first) * 8;
+      if (r.code >= 0) {
+        if (lane == 0) {
+          o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand; o[7] = r.found ? 1 : 0;
+          meas_score[(size_t)b * N + first] = 1000000.0;
+        }
+        return;
+      }
+      r = search_core_v0(img, width, pbytes, sb, a0, b0, c0);
       if (lane == 0) {
-        int* o = srch_res + ((size_t)b * N + first) * 8;
         o[0] = 0; o[1] = r.u; o[2] = r.v; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = r.ncand;
         o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
         meas_score[(size_t)b * N + first] = r.score;

@@ -111,6 +111,46 @@ def test_elliptical_search_batch_matches_oracle_exactly(variant):
     assert n_ok > 20
 
 
+def test_elliptical_search_windows_larger_than_the_tile_are_walked_in_blocks():
+    """3-sigma windows of a few hundred columns / rows (the rule at 1280x720): the column-walk kernel goes through them
+    block by block (search_core_v1) and must still return the reference's answer bit for bit."""
+    rng = np.random.default_rng(7)
+    W, H = 512, 384
+    tex = synth.make_texture(size=1024)
+    images, idx, patches, centres, puinv = [], [], [], [], []
+    for t in range(20):
+        oy, ox = int(rng.integers(0, 1024 - H)), int(rng.integers(0, 1024 - W))
+        img = tex[oy:oy + H, ox:ox + W].copy()
+        if t % 5 == 4:
+            img = rng.integers(0, 256, (H, W), dtype=np.uint8)            # noise: many near-ties, exercises the fallback
+        cy, cx = int(rng.integers(40, H - 40)), int(rng.integers(40, W - 40))
+        patch = img[cy - 5:cy + 6, cx - 5:cx + 6].copy()
+        s0, s1 = rng.uniform(400, 4000, 2)                                # half-widths 60 .. 190 pixels
+        r = rng.uniform(-0.7, 0.7) * np.sqrt(s0 * s1)
+        a, b, c = oa.sinv_from_S(np.array([[s0, r], [r, s1]]))
+        ce = np.array([cx + rng.uniform(-30, 30), cy + rng.uniform(-30, 30)])
+        if t % 5 == 3:
+            ce = np.array([rng.uniform(-20, 30), rng.uniform(H - 30, H + 20)])   # clamped by the border
+        images.append(img); idx.append(t); patches.append(patch.reshape(121)); centres.append(ce); puinv.append([a, b, c])
+    images, idx, patches = np.stack(images), np.array(idx, np.int32), np.stack(patches)
+    centres, puinv = np.array(centres), np.array(puinv)
+    n = len(idx)
+    for variant in (1, 0):
+        ok = np.zeros(n, np.int32)
+        uv = np.full((n, 2), -7, np.int32)
+        score = np.zeros(n)
+        _lib.check(_lib.load().sl2_elliptical_search_batch(0, _lib.u8p(images), n, W, H, _lib.ip(idx), _lib.u8p(patches),
+                                                           _lib.dp(centres), _lib.dp(puinv), n, _lib.ip(ok), _lib.ip(uv),
+                                                           _lib.dp(score), variant))
+        for t in range(n):
+            want = oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t])
+            assert bool(ok[t]) == want["ok"], "variant %d case %d ok" % (variant, t)
+            assert score[t] == want["corr"], "variant %d case %d score %r vs %r" % (variant, t, score[t], want["corr"])
+            if want["corr"] < 1e6:
+                assert (uv[t, 0], uv[t, 1]) == (want["u"], want["v"]), "variant %d case %d uv" % (variant, t)
+        assert ok.sum() >= 10
+
+
 def test_device_renderer_matches_host_bytes():
     tex = synth.make_texture(size=512)
     cam = synth.default_camera()

@@ -1289,7 +1289,6 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   // every other 32x32 block takes the branch-free path.
   if (i0 + 32 < ld && j0 + 32 < ld) {
     double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;       // element (i0 + hi, j0 + lo)
-    double* pcol = Pb + (size_t)(j0 + lo) * ld + i0 + hi;       // its mirror
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -1299,8 +1298,28 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
           double* q = prow + (size_t)(16 * it + 4 * r) * ld + 16 * jt;
           const double pn = *q - acc[it][jt][r];
           *q = pn;
-          if (mirror) pcol[(size_t)(16 * jt) * ld + 16 * it + 4 * r] = pn;
+          acc[it][jt][r] = pn;
         }
+    if (mirror) {
+      // The mirror block goes through LDS so that its stores are row segments of 128 bytes like the direct ones (written
+      // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
+      // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past
+      // the barrier that followed its last read.  Wave-private region, LDS operations of a wave execute in order.
+      const int other = nchunk & 1;
+      double* sM = ((wave < 2) ? sA[other] : sB[other]) + (wave & 1) * (32 * 17);
+      double* pm = Pb + (size_t)(j0 + hi) * ld + i0 + lo;       // element (j0 + hi, i0 + lo)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sM[(16 * jt + lo) * 17 + 4 * r + hi] = acc[it][jt][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pm[(size_t)(4 * k) * ld + 16 * it] = sM[(4 * k + hi) * 17 + lo];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
     return;
   }
   double* xb = x + (size_t)b * ld;

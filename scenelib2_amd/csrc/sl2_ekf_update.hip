@@ -1269,25 +1269,44 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
     }
   };
+  // The P tile is fetched under the MFMAs of the LAST chunk (an epilogue that starts these loads after the last MFMA
+  // exposes an HBM round trip per tile).  (Peeling the last chunk out of the loop made the compiler copy the prefetch
+  // registers and wait for every load on the spot: 1.40 ms.)
+  const bool interior = (i0 + 32 < ld && j0 + 32 < ld);
+  double pold[2][2][4];
+  auto fetch_tile = [&]() {
+    const double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pold[it][jt][r] = prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt];
+  };
+  const bool want_tile = !idle && interior;
+  const int cfetch = nchunk - 1;     // (fetching three chunks early measured no better: 0.550 vs 0.545 ms)
   for (int ch = 0; ch < nchunk; ch += 2) {
     // even chunk: registers r0 -> buffer 0
     stage_store(0, r0);
     __syncthreads();
     if (ch + 2 < nchunk) r0 = stage_load(ch + 2);
+    if (want_tile && ch == cfetch) fetch_tile();
     if (!idle) chunk_mfma(0);
     if (ch + 1 >= nchunk) break;
     // odd chunk: registers r1 -> buffer 1
     stage_store(1, r1);
     __syncthreads();
     if (ch + 3 < nchunk) r1 = stage_load(ch + 3);
+    if (want_tile && ch + 1 == cfetch) fetch_tile();
     if (!idle) chunk_mfma(1);
     // a buffer is rewritten two chunks after it was read, with a barrier in between: one barrier per chunk suffices
   }
+  const int lastbuf = (nchunk - 1) & 1;
   if (idle) return;
   const bool mirror = (ti != tj) || (wi != wj);
   // Row / column ld-1 (the innovation column riding along) only exists in the last tile row / column:
   // every other 32x32 block takes the branch-free path.
-  if (i0 + 32 < ld && j0 + 32 < ld) {
+  if (interior) {
     double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;       // element (i0 + hi, j0 + lo)
 #pragma unroll
     for (int it = 0; it < 2; ++it)
@@ -1295,9 +1314,8 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          double* q = prow + (size_t)(16 * it + 4 * r) * ld + 16 * jt;
-          const double pn = *q - acc[it][jt][r];
-          *q = pn;
+          const double pn = pold[it][jt][r] - acc[it][jt][r];
+          prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt] = pn;
           acc[it][jt][r] = pn;
         }
     if (mirror) {
@@ -1305,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
       // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past
       // the barrier that followed its last read.  Wave-private region, LDS operations of a wave execute in order.
-      const int other = nchunk & 1;
+      const int other = lastbuf ^ 1;
       double* sM = ((wave < 2) ? sA[other] : sB[other]) + (wave & 1) * (32 * 17);
       double* pm = Pb + (size_t)(j0 + hi) * ld + i0 + lo;       // element (j0 + hi, i0 + lo)
 #pragma unroll

@@ -145,8 +145,13 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
     for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fia * 6 + (t & 1) * 3 + c];
     Rn = f_R[fia];
   }
-  for (int j0 = 0; j0 < cnt; j0 += BATCH) {
-    const int nb = (cnt - j0 < BATCH) ? cnt - j0 : BATCH;
+  // gridDim.y workgroups share a sequence (small batches: one workgroup walking all the features is a chain of ~25 HBM
+  // round trips, 86 us at batch 1): each takes a contiguous range of feature batches = rows of At and columns of S
+  const int nbatch = (cnt + BATCH - 1) / BATCH, per = (nbatch + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int jbeg = (int)blockIdx.y * per * BATCH;
+  const int jend = (jbeg + per * BATCH < cnt) ? jbeg + per * BATCH : cnt;
+  for (int j0 = jbeg; j0 < jend; j0 += BATCH) {
+    const int nb = (jend - j0 < BATCH) ? jend - j0 : BATCH;
 #pragma unroll
     for (int jj = 0; jj < BATCH; ++jj) {
       if (jj < nb) {
@@ -199,6 +204,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
     __syncthreads();
   }
   // padding: rows of At up to the 32-multiple are zero, S is the identity there
+  if (blockIdx.y != 0) return;
   for (int k = m; k < mp; ++k) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -1392,13 +1398,17 @@ int launch_update(sl2_engine* e) {
   }
   if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
+    // workgroups per sequence: enough to put ~512 on the chip
+    int nsplit = B >= 512 ? 1 : (512 + B - 1) / B;
+    const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
+    if (nsplit > nbatch_max) nsplit = nbatch_max;
     if (e->ld <= 1024) {
       const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
-      hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
+      hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
                          e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
     } else {
       const size_t shm = sizeof(double) * 2 * 2 * e->ld;      // <= 64 KB
-      hipLaunchKernelGGL((k_build_AS<2, 2>), dim3(B), dim3(1024), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
+      hipLaunchKernelGGL((k_build_AS<2, 2>), dim3(B, nsplit), dim3(1024), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
                          e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
     }
     SL2_HIP(hipGetLastError());

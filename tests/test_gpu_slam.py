@@ -343,3 +343,37 @@ def test_zero_angular_velocity_raises_the_status_flag_for_that_sequence_only():
     o = pr.oracles[0]
     assert np.abs(pr.engine.total_state(0) - o.total_state()).max() <= TOL_X
     assert rel_fro(pr.engine.total_covariance(0), o.total_covariance()) <= TOL_P
+
+
+def test_two_engines_on_two_host_threads_do_not_interfere():
+    """Threading contract of the ABI (include/scenelib2_amd.h: one engine per host thread / stream, no global mutable
+    state): two engines stepped concurrently from two threads give exactly what each gives alone."""
+    import threading
+    n_frames = 8
+    pairs = [Pair(30, n_frames, batch=2, seq0=0), Pair(30, n_frames, batch=2, seq0=5)]
+    alone = []
+    for pr in pairs:
+        ref = Pair(30, n_frames, batch=2, seq0=0 if pr is pairs[0] else 5, make_engine=True)
+        for k in range(n_frames):
+            ref.engine.go_one_step(ref.frame_batch(k), True)
+        alone.append([(ref.engine.total_state(b).copy(), ref.engine.total_covariance(b).copy()) for b in range(2)])
+    errors = []
+
+    def run(pr):
+        try:
+            for k in range(n_frames):
+                pr.engine.go_one_step(pr.frame_batch(k), True)
+                pr.engine.total_state(0)          # a synchronising read-out in the middle of the other thread's work
+        except Exception as ex:                   # noqa: BLE001
+            errors.append(ex)
+
+    threads = [threading.Thread(target=run, args=(pr,)) for pr in pairs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for pr, want in zip(pairs, alone):
+        for b in range(2):
+            assert np.array_equal(pr.engine.total_state(b), want[b][0])
+            assert np.array_equal(pr.engine.total_covariance(b), want[b][1])

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_api as oa
+from conftest import rel_fro
 from mapping_helpers import make_mapping_sequence, oracle_for
 
 pytestmark = pytest.mark.gpu
@@ -101,3 +102,40 @@ def test_mapping_batch_of_different_sequences():
             assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
     assert sum(s.mapping_info()["initialised"] for s in oracles) >= 5
     assert not eng.status_flags().any()
+
+
+def test_mapping_soak_160_frames():
+    """A long run with the map growing, features converting and being retired: the engine must stay on the oracle's
+    trajectory of EVENTS (every initialisation, conversion, deletion at the same frame) and of values."""
+    from scenelib2_amd import Engine
+    n = 160
+    seqs = [make_mapping_sequence(seed=sd, n_frames=n, v_amp=va) for sd, va in ((7, 0.45), (31, 0.35))]
+    cam, params = seqs[0][0], seqs[0][1]
+    oracles = [oracle_for(cam, params, q[2], q[4], oa) for q in seqs]
+    eng = Engine(cam, params, 2, 96)
+    eng.set_vehicle_state(np.stack([q[2].xv0 for q in seqs]), np.stack([q[2].Pxx0 for q in seqs]))
+    eng.add_known_features(np.stack([q[2].feat_y for q in seqs]), np.stack([q[2].xp_org() for q in seqs]),
+                           np.stack([q[4] for q in seqs]))
+    worst = 0.0
+    for k in range(1, n + 1):
+        eng.go_one_step(np.stack([q[3][k] for q in seqs]), save_trajectory=True, enable_mapping=True)
+        for b, s in enumerate(oracles):
+            s.go_one_step(seqs[b][3][k], True, True)
+            info, got = s.mapping_info(), eng.partial_feature(b)["info"]
+            assert [got[key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
+                   [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], (k, b)
+            if k % 8 == 0 or k == n:
+                x0, x1 = s.total_state(), eng.total_state(b)
+                assert x0.size == x1.size, (k, b)
+                worst = max(worst, float(np.abs(x0 - x1).max()))
+                assert np.abs(x0 - x1).max() < 1e-8, (k, b)
+                feats = eng.features(b)
+                assert [f["label"] for f in feats] == [s.feature(i)["label"] for i in range(s.num_features)]
+                assert [(f["attempted"], f["successful"]) for f in feats] == \
+                       [(s.feature(i)["attempted"], s.feature(i)["successful"]) for i in range(s.num_features)]
+    for b, s in enumerate(oracles):
+        assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-7
+        assert np.abs(eng.trajectory(b) - s.trajectory()).max() < 1e-8
+    total = [s.mapping_info() for s in oracles]
+    assert sum(t["initialised"] for t in total) >= 12 and sum(t["converted"] for t in total) >= 4
+    assert not (eng.status_flags() & 1).any()

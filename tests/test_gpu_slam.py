@@ -377,3 +377,31 @@ def test_two_engines_on_two_host_threads_do_not_interfere():
         for b in range(2):
             assert np.array_equal(pr.engine.total_state(b), want[b][0])
             assert np.array_equal(pr.engine.total_covariance(b), want[b][1])
+
+
+def test_abi_error_behaviour():
+    """The reference's members return bool and throw nothing on this path; the ABI returns status codes
+    with a message and never throws: bad ranges / null pointers -> SL2_ERR_INVALID (1), capacities -> SL2_ERR_CAPACITY (3),
+    and a failed call leaves the engine usable."""
+    import ctypes as C
+    from scenelib2_amd import _lib
+    pr = Pair(8, 2, batch=2, max_features=8)
+    e, L = pr.engine, pr.engine.L
+    xv, Pxx = np.zeros((2, 13)), np.zeros((2, 13, 13))
+    assert L.sl2_set_vehicle_state(e.h, 1, 2, _lib.dp(xv), _lib.dp(Pxx)) == 1            # sequences 1..2 of a batch of 2
+    assert L.sl2_set_vehicle_state(e.h, 0, 2, None, _lib.dp(Pxx)) == 1
+    y, xp, patch = np.zeros((1, 1, 3)), np.zeros((1, 1, 7)), np.zeros((1, 1, 121), np.uint8)
+    assert L.sl2_add_known_features(e.h, 0, 1, 1, _lib.dp(y), _lib.dp(xp), _lib.u8p(patch)) == 3   # the map is full (8 of 8)
+    assert b"capacity" in L.sl2_last_error()
+    x = np.zeros(13 + 3 * 8)
+    assert L.sl2_get_total_state(e.h, 0, _lib.dp(x), 5) == 3
+    assert L.sl2_get_total_state(e.h, 2, _lib.dp(x), x.size) == 1
+    assert L.sl2_get_total_state(e.h, 0, _lib.dp(x), x.size) == 0
+    assert L.sl2_set_groups(e.h, 0) == 1
+    assert L.sl2_go_one_step(e.h, None, 0, 0, 0, 0) == 1                                  # no frame
+    assert L.sl2_go_one_step(None, None, 0, 0, 0, 0) == 1
+    cnt = C.c_int(0)
+    assert L.sl2_get_trajectory(e.h, 0, None, 10, C.byref(cnt)) == 1
+    # ... and the engine still steps and still agrees with the oracle
+    pr.step_both(0)
+    pr.compare_state(TOL_X, TOL_P)

@@ -1229,8 +1229,12 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   const double* Vb = Vt + (size_t)b * mld * ld;
   double* Pb = P + (size_t)b * ld * ld;
-  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
-  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
+  // LDS: [buffer][A | B][16 k-rows x 64 columns], 32 KB, so that FIVE workgroups share a CU (the 80-double row pitch of
+  // the first version cost 40 KB = three: with m = 200 a tile has only 13 chunks, and a third of its life is prologue
+  // and epilogue, which only other resident workgroups can cover).  Instead of padding, the odd k-rows swap their two
+  // 16-column halves within each 32-column group (column ^ 16): the two k-rows read by one 32-lane group still land on
+  // disjoint banks.
+  __shared__ double sAB[2][2][kSyrkKC * 64];
   // staging role of this thread: row kr of the chunk, columns c2, c2+1 and 32+c2, 33+c2: sixteen lanes write 256
   // CONTIGUOUS bytes per ds_write_b128 (four consecutive doubles per lane put lanes 0 and 8 of a row on the same banks:
   // 2.6e7 conflict cycles per launch, three per LDS instruction)
@@ -1246,10 +1250,11 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
     return r;
   };
   auto stage_store = [&](int buf, const Stage& r) {
-    *(double2*)&sA[buf][kr * kSyrkPitch + c2] = r.a0;
-    *(double2*)&sA[buf][kr * kSyrkPitch + 32 + c2] = r.a1;
-    *(double2*)&sB[buf][kr * kSyrkPitch + c2] = r.b0;
-    *(double2*)&sB[buf][kr * kSyrkPitch + 32 + c2] = r.b1;
+    const int cs = c2 ^ ((kr & 1) << 4);
+    *(double2*)&sAB[buf][0][kr * 64 + cs] = r.a0;
+    *(double2*)&sAB[buf][0][kr * 64 + 32 + cs] = r.a1;
+    *(double2*)&sAB[buf][1][kr * 64 + cs] = r.b0;
+    *(double2*)&sAB[buf][1][kr * 64 + 32 + cs] = r.b1;
   };
   Stage r0 = stage_load(0);
   // In a diagonal tile the sub-block (wi = 32, wj = 0) is the mirror of (0, 32): that wave only stages.
@@ -1263,21 +1268,24 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   Stage r1 = r0;
   if (nchunk > 1) r1 = stage_load(1);
   auto chunk_mfma = [&](int buf) {
-    const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
-    const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
+    // k-row 4 ks + hi has the parity of hi: its first / second 16 columns sit at sw / sw ^ 16
+    const int sw = (hi & 1) << 4;
+    const double* pa = &sAB[buf][0][hi * 64 + wi + lo];
+    const double* pb = &sAB[buf][1][hi * 64 + wj + lo];
 #pragma unroll
     for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
-      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
-      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
+      const double a0 = pa[ks * 256 + sw], a1 = pa[ks * 256 + (sw ^ 16)];
+      const double b0 = pb[ks * 256 + sw], b1 = pb[ks * 256 + (sw ^ 16)];
       acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
       acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
       acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
       acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
     }
   };
-  // The P tile is fetched under the MFMAs of the LAST chunk (an epilogue that starts these loads after the last MFMA
-  // exposes an HBM round trip per tile).  (Peeling the last chunk out of the loop made the compiler copy the prefetch
-  // registers and wait for every load on the spot: 1.40 ms.)
+  // The P tile of an interior block is fetched in one burst right after the K loop.  (Fetching it under the MFMAs of the
+  // last chunk gained 2 % at three workgroups per CU, but holds 32 more registers through the loop: with the 32 KB LDS
+  // layout the kernel is better off at 74 registers and more workgroups per CU, 0.535 vs 0.552 ms.  Peeling the last
+  // chunk out of the loop made the compiler copy the prefetch registers and wait for every load on the spot: 1.40 ms.)
   const bool interior = (i0 + 32 < ld && j0 + 32 < ld);
   double pold[2][2][4];
   auto fetch_tile = [&]() {
@@ -1290,24 +1298,22 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
         for (int r = 0; r < 4; ++r) pold[it][jt][r] = prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt];
   };
   const bool want_tile = !idle && interior;
-  const int cfetch = nchunk - 1;     // (fetching three chunks early measured no better: 0.550 vs 0.545 ms)
   for (int ch = 0; ch < nchunk; ch += 2) {
     // even chunk: registers r0 -> buffer 0
     stage_store(0, r0);
     __syncthreads();
     if (ch + 2 < nchunk) r0 = stage_load(ch + 2);
-    if (want_tile && ch == cfetch) fetch_tile();
     if (!idle) chunk_mfma(0);
     if (ch + 1 >= nchunk) break;
     // odd chunk: registers r1 -> buffer 1
     stage_store(1, r1);
     __syncthreads();
     if (ch + 3 < nchunk) r1 = stage_load(ch + 3);
-    if (want_tile && ch + 1 == cfetch) fetch_tile();
     if (!idle) chunk_mfma(1);
     // a buffer is rewritten two chunks after it was read, with a barrier in between: one barrier per chunk suffices
   }
   const int lastbuf = (nchunk - 1) & 1;
+  if (want_tile) fetch_tile();
   if (idle) return;
   const bool mirror = (ti != tj) || (wi != wj);
   // Row / column ld-1 (the innovation column riding along) only exists in the last tile row / column:
@@ -1330,19 +1336,19 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past
       // the barrier that followed its last read.  Wave-private region, LDS operations of a wave execute in order.
       const int other = lastbuf ^ 1;
-      double* sM = ((wave < 2) ? sA[other] : sB[other]) + (wave & 1) * (32 * 17);
+      double* sM = &sAB[other][0][0] + wave * (16 * 17);          // 16 x 16 block at pitch 17, one per wave
       double* pm = Pb + (size_t)(j0 + hi) * ld + i0 + lo;       // element (j0 + hi, i0 + lo)
 #pragma unroll
-      for (int it = 0; it < 2; ++it) {
+      for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sM[(16 * jt + lo) * 17 + 4 * r + hi] = acc[it][jt][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          for (int r = 0; r < 4; ++r) sM[lo * 17 + 4 * r + hi] = acc[it][jt][r];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pm[(size_t)(4 * k) * ld + 16 * it] = sM[(4 * k + hi) * 17 + lo];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+          for (int k = 0; k < 4; ++k) pm[(size_t)(16 * jt + 4 * k) * ld + 16 * it] = sM[(4 * k + hi) * 17 + lo];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     }
     return;
   }

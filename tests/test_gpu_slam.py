@@ -405,3 +405,24 @@ def test_abi_error_behaviour():
     # ... and the engine still steps and still agrees with the oracle
     pr.step_both(0)
     pr.compare_state(TOL_X, TOL_P)
+
+
+@pytest.mark.parametrize("width,height,n_features,n_frames,batch,sigma", [
+    (322, 242, 37, 4, 2, 0.004),      # width not a multiple of 4 (dword staging of the search windows), odd map size
+    (351, 263, 101, 3, 2, 0.003),     # 13 + 3 * 101 = 316 states: the last 64-column tile is almost empty
+    (160, 120, 1, 5, 3, 0.01),        # a single feature: one measurement block, mostly padding
+    (321, 241, 17, 4, 1, 0.0),        # exactly one 64-column state tile (13 + 3 * 17 = 64)
+    (400, 300, 86, 3, 2, 0.004),      # 2 * 86 = 172 measurement rows: the last Cholesky block is half padding
+])
+def test_awkward_shapes(width, height, n_features, n_frames, batch, sigma):
+    """Sizes that sit on the edges of the tilings (state tiles of 64, measurement blocks of 32 / 16, dword-aligned window
+    rows): same parity bar as everywhere."""
+    cam = synth.default_camera(width, height)
+    pr = Pair(n_features, n_frames, batch=batch, cam=cam, feature_sigma=sigma)
+    matched = 0
+    for k in range(n_frames):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, 2e-8)
+        matched += pr.engine.selection(0)[1]["measurement_size"]
+    assert matched >= n_frames * n_features          # at least half of the measurements succeed
+    assert not pr.engine.status_flags().any()

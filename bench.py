@@ -64,6 +64,13 @@ def main():
     if world > 1 and dist.get_backend() != "nccl":
         tdev = None
 
+    def barrier():
+        # RCCL needs to know which device this rank drives (otherwise it guesses from the rank and warns)
+        if tdev is not None:
+            dist.barrier(device_ids=[dev])
+        else:
+            dist.barrier()
+
     B, N, W, H = args.batch, args.features, args.width, args.height
     K, Wm = args.steps, args.warmup
     E = 0 if args.no_profile else 4          # extra untimed steps for the full per-kernel breakdown
@@ -116,14 +123,14 @@ def main():
 
     # ---- timed region: exactly K steps ----
     if world > 1:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
         step(k)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        barrier()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, tdev if world > 1 else None)
 
@@ -285,7 +292,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
     return out
 

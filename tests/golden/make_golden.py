@@ -5,6 +5,10 @@
                             known_patch*.pgm) for three GoOneStep calls on a deterministic frame.
                             The reference itself cannot be run here (no Eigen/OpenCV/Pangolin), so this
                             pins the oracle against regressions; it is not a reference output.
+* oracle_mapping.npz      — the ORACLE's event log of a 40-frame mapping run (tests/mapping_helpers.py, seed 7): per frame
+                            the counters (partial features, initialised, converted, deleted), the selected pixel, the
+                            total state size and the camera position; final total state and covariance.  The frames come
+                            from the synthetic generator (pinned by its own checksum); same status as above.
 """
 import hashlib
 import os
@@ -56,6 +60,18 @@ def main():
         Ps.append(o.total_covariance())
         zs.append(np.array([o.feature(i)["z"] for i in range(o.num_features)]))
     np.savez_compressed(os.path.join(HERE, "oracle_shipped.npz"), frame=frame, x=np.array(xs), P=np.array(Ps), z=np.array(zs))
+    from mapping_helpers import make_mapping_sequence, oracle_for
+    cam_m, params_m, spec_m, frames_m, templates_m = make_mapping_sequence(n_frames=40)
+    s = oracle_for(cam_m, params_m, spec_m, templates_m, oa)
+    events, pos = [], []
+    for k in range(1, 41):
+        s.go_one_step(frames_m[k], True, True)
+        info = s.mapping_info()
+        events.append([info["n_partial"], info["initialised"], info["converted"], info["deleted"], info["uu"], info["vv"],
+                       s.total_state_size])
+        pos.append(s.get_state()[0][:3])
+    np.savez_compressed(os.path.join(HERE, "oracle_mapping.npz"), events=np.array(events, np.int32), pos=np.array(pos),
+                        x=s.total_state(), P=s.total_covariance(), frames_sha256=hashlib.sha256(frames_m.tobytes()).hexdigest())
     print("golden fixtures written")
 
 

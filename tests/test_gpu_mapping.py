@@ -139,3 +139,24 @@ def test_mapping_soak_160_frames():
     total = [s.mapping_info() for s in oracles]
     assert sum(t["initialised"] for t in total) >= 12 and sum(t["converted"] for t in total) >= 4
     assert not (eng.status_flags() & 1).any()
+
+
+def test_engine_matches_committed_mapping_golden():
+    """The HIP path against the committed event log of the 40-frame mapping run (tests/golden/oracle_mapping.npz)."""
+    from conftest import golden_path
+    from scenelib2_amd import Engine
+    g = np.load(golden_path("oracle_mapping.npz"))
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
+    eng = Engine(cam, params, 1, 32)
+    eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
+    eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
+    for k in range(1, 41):
+        eng.go_one_step(frames[k][None], save_trajectory=True, enable_mapping=True)
+        info = eng.partial_feature(0)["info"]
+        got = [info["n_partial"], info["initialised"], info["converted"], info["deleted"], info["uu"], info["vv"],
+               int(eng.total_state_sizes(0, 1)[0])]
+        assert got == list(g["events"][k - 1]), k
+        xe, _ = eng.get_vehicle_state(0, 1)
+        assert np.allclose(xe[0][:3], g["pos"][k - 1], rtol=0, atol=1e-10)
+    assert np.abs(eng.total_state(0) - g["x"]).max() < 1e-9
+    assert rel_fro(eng.total_covariance(0), g["P"]) < 1e-8

@@ -67,3 +67,22 @@ def test_camera_still_tracks_with_mapping_on(run):
     cam, params, spec, frames, s, log = run
     err = np.array([np.linalg.norm(e["xv"][:3] - spec.poses[k + 1, :3]) for k, e in enumerate(log)])
     assert err[:20].max() < 0.03, err[:20].max()          # later the fast camera has lost most of the known map
+
+
+def test_oracle_matches_committed_mapping_golden():
+    """Regression pin of the feature-initialisation oracle: the per-frame event log and the final state of the 40-frame
+    mapping run committed in tests/golden/oracle_mapping.npz (tests/golden/make_golden.py)."""
+    import hashlib
+    from conftest import golden_path
+    g = np.load(golden_path("oracle_mapping.npz"))
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])     # same input bytes
+    s = oracle_for(cam, params, spec, templates, oa)
+    for k in range(1, 41):
+        s.go_one_step(frames[k], True, True)
+        info = s.mapping_info()
+        got = [info["n_partial"], info["initialised"], info["converted"], info["deleted"], info["uu"], info["vv"], s.total_state_size]
+        assert got == list(g["events"][k - 1]), k
+        assert np.allclose(s.get_state()[0][:3], g["pos"][k - 1], rtol=0, atol=1e-13)
+    assert np.allclose(s.total_state(), g["x"], rtol=0, atol=1e-12)
+    assert np.allclose(s.total_covariance(), g["P"], rtol=1e-9, atol=1e-16)

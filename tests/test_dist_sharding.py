@@ -75,3 +75,42 @@ def test_shard_range_partitions_exactly():
                 f, c = shard_range(total, world, r)
                 got += list(range(f, f + c))
             assert got == list(range(total))
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch
+    import torch.distributed as dist
+    from scenelib2_amd import sharding
+    dist.init_process_group("nccl", rank=0, world_size=1)      # "nccl" is RCCL on ROCm
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.barrier(device_ids=[0])
+        local = np.arange(4 * 14, dtype=np.float64).reshape(4, 14)
+        rows = sharding.gather_states(local, dev)
+        tmax = sharding.max_over_ranks(2.5, dev)
+        tsum = sharding.sum_over_ranks(4, dev)
+        allf = (np.arange(3 * 4 * 5) % 251).astype(np.uint8).reshape(3, 4, 5)
+        mine = sharding.scatter_frames(allf, 3, (4, 5), device=dev)
+        q.put((rows, tmax, tsum, mine.cpu().numpy(), str(mine.device)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_collective_helpers_over_rccl_on_device_tensors():
+    """The edge collectives of bench.py (MAX / SUM reduce, all-gather of states, frame scatter) through RCCL with tensors
+    resident on the GPU - one rank, which is what a one-GPU box can run; the multi-rank logic is covered on gloo above."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    rows, tmax, tsum, mine, where = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert np.array_equal(rows, np.arange(4 * 14, dtype=np.float64).reshape(4, 14))
+    assert tmax == 2.5 and tsum == 4.0
+    assert np.array_equal(mine, (np.arange(3 * 4 * 5) % 251).astype(np.uint8).reshape(3, 4, 5)) and where.startswith("cuda")

@@ -220,3 +220,61 @@ def test_oracle_matches_committed_golden_run(oracle):
         assert np.allclose(o.total_covariance(), g["P"][k], rtol=1e-11, atol=1e-18)
         assert np.array_equal(np.array([o.feature(i)["z"] for i in range(4)]), g["z"][k])
     assert o.measurement_size == 8       # all four shipped templates are found
+
+
+def _synthetic_oracle(oracle, n_features=12, sigma=0.004):
+    from slam_helpers import Pair
+    pr = Pair(n_features, 2, batch=1, make_engine=False, feature_sigma=sigma)
+    return pr, pr.oracles[0]
+
+
+def test_update_equals_the_textbook_formula_in_numpy(oracle):
+    """An independent restatement of Kalman::KalmanFilterUpdate (kalman.cpp:72-119) in numpy from the oracle's OWN
+    pre-update quantities: nu, H (dh_by_dxv | dh_by_dy at the feature's position), R, P -> S = H P H^T + R,
+    W = P H^T S^-1, x += W nu, P -= W S W^T.  The oracle must land on the same posterior."""
+    pr, s = _synthetic_oracle(oracle)
+    s.kalman_filter_predict()
+    s.auto_select_n_features(12)
+    s.make_measurements(pr.frames[0][0])
+    n = s.total_state_size
+    x0, P0 = s.total_state(), s.total_covariance()
+    rows_H, nus, Rs = [], [], []
+    by_label = {s.feature(i)["label"]: s.feature(i) for i in range(s.num_features)}
+    for lab in s.selected_labels():                       # construct_total_measurement_stuff: selection order, successes only
+        f = by_label[int(lab)]
+        if not f["success"]:
+            continue
+        H = np.zeros((2, n))
+        H[:, :13] = f["dh_by_dxv"]
+        H[:, f["pos"]:f["pos"] + 3] = f["dh_by_dy"]
+        rows_H.append(H); nus.append(f["z"] - f["h"]); Rs.append(f["R"])
+    assert len(rows_H) >= 8
+    H = np.vstack(rows_H)
+    nu = np.concatenate(nus)
+    R = np.kron(np.diag(Rs), np.eye(2))
+    S = H @ P0 @ H.T + R
+    W = P0 @ H.T @ np.linalg.inv(S)
+    x1 = x0 + W @ nu
+    P1 = P0 - W @ S @ W.T
+    s.kalman_filter_update()
+    assert s.measurement_size == 2 * len(rows_H)
+    assert np.abs(s.total_state() - x1).max() < 1e-12
+    assert np.abs(s.total_covariance() - P1).max() <= 1e-12 * np.abs(P0).max()
+
+
+def test_predict_equals_F_P_Ft_plus_Q_in_numpy(oracle):
+    """Kalman::KalmanFilterPredict (kalman.cpp:50-69) against numpy: Pxx' = F Pxx F^T + Q, Pxy_i' = F Pxy_i, the rest of P
+    untouched, with F and Q from the oracle's motion model (whose Jacobian is checked against finite differences above)."""
+    pr, s = _synthetic_oracle(oracle)
+    xv, _ = s.get_state()
+    P0 = s.total_covariance()
+    n = s.total_state_size
+    f, F, Q = oracle.motion_model(xv, pr.params["delta_t"])
+    Fbig = np.eye(n)
+    Fbig[:13, :13] = F
+    want = Fbig @ P0 @ Fbig.T
+    want[:13, :13] += Q
+    s.kalman_filter_predict()
+    xv1, _ = s.get_state()
+    assert np.array_equal(xv1, f)
+    assert np.abs(s.total_covariance() - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-30)

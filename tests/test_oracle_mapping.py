@@ -86,3 +86,44 @@ def test_oracle_matches_committed_mapping_golden():
         assert np.allclose(s.get_state()[0][:3], g["pos"][k - 1], rtol=0, atol=1e-13)
     assert np.allclose(s.total_state(), g["x"], rtol=0, atol=1e-12)
     assert np.allclose(s.total_covariance(), g["P"], rtol=1e-9, atol=1e-16)
+
+
+def test_particle_update_equals_numpy_bayes_rule():
+    """update_partially_initialised_feature_probabilities + prune + calculate_mean_and_covariance (monoslam.cpp:1449-1497,
+    feature_init_info.cpp:131-174) re-evaluated in numpy from the particle set of the frame before and the measurements
+    (z, h, S^-1, |S|) stored with the surviving particles: posterior = prior x N(z; h, S), normalised, pruned at
+    threshold / n, re-normalised; mean and variance of lambda."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=30)
+    s = oracle_for(cam, params, spec, templates, oa)
+    checked = 0
+    prev = None
+    for k in range(1, 31):
+        s.go_one_step(frames[k], False, True)
+        cur = s.partial_feature(0)
+        if cur is not None and prev is not None and cur["label"] == prev["label"] and cur["making"]:
+            prior = {float(p[0]): float(p[1]) for p in prev["particles"]}            # lambda -> probability
+            n_prev = prev["n_particles"]
+            post = {}
+            for p in cur["particles"]:                                              # survivors carry this frame's measurement
+                lam, z, h = float(p[0]), p[5:7], p[3:5]
+                Sinv = np.array([[p[7], p[8]], [p[8], p[9]]])
+                nu = z - h
+                like = np.exp(-0.5 * nu @ Sinv @ nu) / np.sqrt(2.0 * np.pi * p[10]) if p[11] != 0.0 else 0.0
+                post[lam] = prior[lam] * like
+            # the pruned particles' mass is unknown from the survivors alone, but pruning keeps exactly those with
+            # normalised weight >= threshold / n: ratios between survivors are preserved by both normalisations
+            w = np.array([post[float(p[0])] for p in cur["particles"]])
+            got = cur["particles"][:, 1]
+            assert np.all(w > 0)
+            assert np.allclose(w / w.sum(), got, rtol=1e-10, atol=0), k
+            assert np.allclose(np.cumsum(got), cur["particles"][:, 2], rtol=1e-12, atol=1e-15)
+            lam = cur["particles"][:, 0]
+            mean = float((got * lam).sum())
+            assert abs(mean - cur["mean"]) <= 1e-12 * abs(mean)
+            assert abs(float((got * lam * lam).sum()) - mean * mean - cur["covariance"]) <= 1e-10 * mean * mean
+            # nobody below the pruning threshold survived (re-normalising after the pruning only raises the weights)
+            assert got.min() >= params["prune_probability_threshold"] / n_prev * 0.999999
+            assert cur["n_particles"] <= n_prev
+            checked += 1
+        prev = cur
+    assert checked >= 8

@@ -33,6 +33,8 @@
 
 namespace sl2 {
 
+constexpr size_t kMaxFramePixels = (size_t)64 << 20;   // a header that asks for more is treated as corrupt, not allocated
+
 static bool list_files_recursive(const std::string& dir, std::vector<std::string>& out) {
   DIR* d = opendir(dir.c_str());
   if (!d) return false;
@@ -73,7 +75,7 @@ static bool read_pgm(const std::string& path, std::vector<uint8_t>& px, int* w, 
   bool ok = token(magic) && magic == "P5" && token(sw) && token(sh) && token(smax);
   int W = 0, H = 0, maxval = 0;
   if (ok) { W = atoi(sw.c_str()); H = atoi(sh.c_str()); maxval = atoi(smax.c_str()); }
-  ok = ok && W > 0 && H > 0 && maxval > 0 && maxval <= 255;
+  ok = ok && W > 0 && H > 0 && maxval > 0 && maxval <= 255 && (size_t)W * (size_t)H <= kMaxFramePixels;
   if (ok) {
     px.resize((size_t)W * H);
     ok = fread(px.data(), 1, px.size(), f) == px.size();
@@ -123,6 +125,7 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, 
     o += 12 + (size_t)len;
   }
   if (W == 0 || H == 0 || W > 65535 || H > 65535 || idat.empty()) return fail("PNG without image data");
+  if ((size_t)W * H > kMaxFramePixels) return fail("PNG larger than 64 M pixels");
   if (interlace != 0) return fail("interlaced PNG not supported");
   int channels;
   switch (ctype) {
@@ -238,7 +241,9 @@ struct sl2_ingest {
       }
       for (int s = 0; s < nseq; ++s) {
         int w = 0, h = 0;
-        if (!sl2::read_image(files[s][k], px, &w, &h) || w != width || h != height) {
+        bool ok = false;
+        try { ok = sl2::read_image(files[s][k], px, &w, &h); } catch (const std::exception&) { ok = false; }
+        if (!ok || w != width || h != height) {
           std::lock_guard<std::mutex> lk(mu);
           failed = true;
           fail_msg = "frame " + files[s][k] + " is not a " + std::to_string(width) + "x" + std::to_string(height) + " binary PGM / PNG";
@@ -276,25 +281,35 @@ int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count) {
 }
 
 int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, int* height) {
-  using namespace sl2;
-  if (!path || !width || !height) return SL2_ERR_INVALID;
-  std::vector<uint8_t> px;
-  if (!read_pgm(path, px, width, height)) return SL2_ERR_INVALID;
-  if (!out) return SL2_OK;
-  if (px.size() > capacity) return SL2_ERR_CAPACITY;
-  memcpy(out, px.data(), px.size());
-  return SL2_OK;
+  try {
+    using namespace sl2;
+    if (!path || !width || !height) return SL2_ERR_INVALID;
+    std::vector<uint8_t> px;
+    if (!read_pgm(path, px, width, height)) return SL2_ERR_INVALID;
+    if (!out) return SL2_OK;
+    if (px.size() > capacity) return SL2_ERR_CAPACITY;
+    memcpy(out, px.data(), px.size());
+    return SL2_OK;
+  } catch (const std::exception& ex) {   // (allocation failure on a hostile header: never across the ABI)
+    sl2::set_error(ex.what());
+    return SL2_ERR_INVALID;
+  }
 }
 
 int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, int* height) {
-  using namespace sl2;
-  if (!path || !width || !height) return SL2_ERR_INVALID;
-  std::vector<uint8_t> px;
-  if (!read_image(path, px, width, height)) return SL2_ERR_INVALID;
-  if (!out) return SL2_OK;
-  if (px.size() > capacity) return SL2_ERR_CAPACITY;
-  memcpy(out, px.data(), px.size());
-  return SL2_OK;
+  try {
+    using namespace sl2;
+    if (!path || !width || !height) return SL2_ERR_INVALID;
+    std::vector<uint8_t> px;
+    if (!read_image(path, px, width, height)) return SL2_ERR_INVALID;
+    if (!out) return SL2_OK;
+    if (px.size() > capacity) return SL2_ERR_CAPACITY;
+    memcpy(out, px.data(), px.size());
+    return SL2_OK;
+  } catch (const std::exception& ex) {   // (allocation failure on a hostile header: never across the ABI)
+    sl2::set_error(ex.what());
+    return SL2_ERR_INVALID;
+  }
 }
 
 int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, int device, int depth, sl2_ingest** out) {

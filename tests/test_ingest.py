@@ -151,3 +151,55 @@ def test_batched_ingest_delivers_every_frame_in_order(tmp_path):
     with pytest.raises(_lib.Sl2Error):
         g.next()
     g.close()
+
+
+def test_decoders_survive_random_corruption(tmp_path):
+    """Fuzz: random byte flips / truncations of valid PNG and PGM files must end in a decoded image of the declared size or in
+    an error code - never in a crash, a hang or an exception across the ABI (hostile IHDR sizes, broken zlib streams, bad
+    filter bytes, short files)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(11)
+    d = str(tmp_path)
+    img = rng.integers(0, 256, (23, 31)).astype(np.uint8)
+    good_png, good_pgm = os.path.join(d, "g.png"), os.path.join(d, "g.pgm")
+    ingest.write_png(good_png, img)
+    ingest.write_pgm(good_pgm, img)
+    outcomes = {"ok": 0, "err": 0}
+    for src in (good_png, good_pgm):
+        data = bytearray(open(src, "rb").read())
+        for trial in range(150):
+            b = bytearray(data)
+            kind = trial % 3
+            if kind == 0:
+                for _ in range(int(rng.integers(1, 6))):
+                    b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+            elif kind == 1:
+                b = b[:int(rng.integers(0, len(b)))]
+            else:
+                pos = int(rng.integers(0, len(b)))
+                b[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 9))).astype(np.uint8))
+            path = os.path.join(d, "fuzz.bin")
+            with open(path, "wb") as f:
+                f.write(bytes(b))
+            try:
+                out = ingest.read_image(path)
+                assert out.ndim == 2 and out.dtype == np.uint8
+                outcomes["ok"] += 1
+            except _lib.Sl2Error:
+                outcomes["err"] += 1
+    # a header that announces a gigantic image is refused, not allocated
+    data = open(good_png, "rb").read()
+    at = data.index(b"IHDR")
+    hdr = bytearray(data[at + 4:at + 17])
+    hdr[0:8] = struct.pack(">II", 60000, 60000)
+    huge = data[:at + 4] + bytes(hdr) + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(hdr)) & 0xFFFFFFFF) + data[at + 21:]
+    with open(os.path.join(d, "huge.png"), "wb") as f:
+        f.write(huge)
+    with pytest.raises(_lib.Sl2Error):
+        ingest.read_image(os.path.join(d, "huge.png"))
+    with open(os.path.join(d, "huge.pgm"), "wb") as f:
+        f.write(b"P5\n100000 100000\n255\n" + b"\0" * 64)
+    with pytest.raises(_lib.Sl2Error):
+        ingest.read_image(os.path.join(d, "huge.pgm"))
+    assert outcomes["err"] > 50 and outcomes["ok"] + outcomes["err"] == 300

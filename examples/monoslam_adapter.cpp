@@ -6,7 +6,7 @@
 //
 // The dump lists, one value per line: total_state_size_, the total state (construct_total_state), then per feature in
 // feature_list_ order: label_, fully_initialised_flag_, attempted_, successful_, position_in_total_state_vector_, Pyy_
-// (row-major); then trajectory_store_.  tests/test_gpu_headless_example.py compares it with the oracle.
+// (row-major), patch_ (121 bytes); then trajectory_store_.  tests/test_gpu_headless_example.py compares it with the oracle.
 #include <scenelib2_amd_monoslam.hpp>
 
 #include <cstdio>
@@ -63,6 +63,7 @@ int main(int argc, char** argv) {
         fprintf(f, "%d\n%d\n%d\n%d\n%d\n", ft->label_, ft->fully_initialised_flag_ ? 1 : 0, ft->attempted_measurements_of_feature_,
                 ft->successful_measurements_of_feature_, ft->position_in_total_state_vector_);
         for (double v : ft->Pyy_) fprintf(f, "%.17g\n", v);
+        for (uint8_t v : ft->patch_) fprintf(f, "%d\n", (int)v);
       }
       for (const auto& r : slam.trajectory_store_) fprintf(f, "%.17g\n%.17g\n%.17g\n", r[0], r[1], r[2]);
       fclose(f);

@@ -248,6 +248,10 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
  * particles [capacity][12] = lambda_, probability_, cumulative_probability_, m_h_(2), m_z_(2), m_SInv_(00,01,11), m_detS_,
  * m_successful_measurement_flag_ (may be NULL). */
 int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, double* particles, int capacity);
+/* Feature::patch_ (feature.h:118; 11x11, row-major) of the feature with this label: the template given to
+ * sl2_add_known_features, or the one copy_into_patch cut from the frame when the feature was initialised
+ * (monoslam.cpp:1236-1250).  Labels of deleted features keep their last template. */
+int sl2_get_feature_patch(sl2_engine* e, int seq, int label, uint8_t* patch121);
 /* selected_feature_list_ (labels, selection order) and per-step counters:
  * counters[0] = number_of_visible_features_, [1] = #selected,
  * [2] = successful_measurement_vector_size_. */

@@ -141,7 +141,6 @@ class MonoSLAM {
     for (int r = 0; r < 13; ++r)
       for (int c = 0; c < 13; ++c) Pxx_[r * 13 + c] = num(kv, "state.pxx" + std::to_string(r) + "_" + std::to_string(c));
     check(sl2_set_vehicle_state(eng_, 0, 1, xv_.data(), Pxx_.data()), "sl2_set_vehicle_state");
-    patches_.clear();
     for (int k = 1; kv.count("f" + std::to_string(k) + ".yi_x"); ++k) {        // monoslam.cpp:1941-1957
       const std::string p = "f" + std::to_string(k) + ".";
       const std::array<double, 3> y{{num(kv, p + "yi_x"), num(kv, p + "yi_y"), num(kv, p + "yi_z")}};
@@ -160,7 +159,6 @@ class MonoSLAM {
     check(sl2_read_image(identifier.c_str(), patch.data(), patch.size(), &w, &h), "sl2_read_image");
     if (w != SL2_PATCH_SIZE || h != SL2_PATCH_SIZE) throw std::runtime_error(identifier + " is not an 11x11 template");
     check(sl2_add_known_features(eng_, 0, 1, 1, y_new.data(), xp_o.data(), patch.data()), "sl2_add_known_features");
-    patches_.push_back(patch);
   }
 
   // MonoSLAM::GoOneStep (monoslam.cpp:108-180).  Always true, like the reference (:179).
@@ -283,7 +281,7 @@ class MonoSLAM {
         for (int c = 0; c < d; ++c) f->Pxy_[(size_t)r * d + c] = P[(size_t)r * size + pos + c];
       for (int r = 0; r < d; ++r)
         for (int c = 0; c < d; ++c) f->Pyy_[(size_t)r * d + c] = P[(size_t)(pos + r) * size + pos + c];
-      if ((size_t)s.label < patches_.size()) f->patch_ = patches_[s.label];
+      check(sl2_get_feature_patch(eng_, 0, s.label, f->patch_.data()), "sl2_get_feature_patch");
       if (s.label >= next_free_label_) next_free_label_ = s.label + 1;
       feature_list_.push_back(std::move(f));
     }
@@ -335,7 +333,6 @@ class MonoSLAM {
 
   int max_features_, device_;
   sl2_engine* eng_ = nullptr;
-  std::vector<std::array<uint8_t, SL2_PATCH_BYTES>> patches_;      // by label, for Feature::patch_
 };
 
 }  // namespace SceneLib2Amd

@@ -817,6 +817,17 @@ int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int
   return SL2_OK;
 }
 
+int sl2_get_feature_patch(sl2_engine* e, int seq, int label, uint8_t* patch121) {
+  if (!range_ok(e, seq, 1) || !patch121 || label < 0 || label >= e->N) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  int flags = 0;
+  SL2_HIP(hipMemcpy(&flags, e->f_flags + (size_t)seq * e->N + label, sizeof(int), hipMemcpyDeviceToHost));
+  if (!(flags & FF_USED)) { set_error("sl2_get_feature_patch: no feature with this label"); return SL2_ERR_INVALID; }
+  SL2_HIP(hipMemcpy(patch121, e->patch + ((size_t)seq * e->N + label) * kPatchStride, SL2_PATCH_BYTES, hipMemcpyDeviceToHost));
+  return SL2_OK;
+}
+
 int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count) {
   if (!range_ok(e, seq, 1) || !out || !count) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));

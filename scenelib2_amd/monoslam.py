@@ -201,6 +201,12 @@ class Engine:
     def set_feature_counters(self, seq, label, attempted, successful):
         _lib.check(self.L.sl2_set_feature_counters(self.h, seq, label, attempted, successful))
 
+    def feature_patch(self, seq, label):
+        """Feature::patch_ of the feature with this label (11x11 uint8)."""
+        out = np.zeros((11, 11), dtype=np.uint8)
+        _lib.check(self.L.sl2_get_feature_patch(self.h, int(seq), int(label), _lib.u8p(out)))
+        return out
+
     def status_flags(self):
         out = np.zeros(self.batch, dtype=np.int32)
         _lib.check(self.L.sl2_get_status_flags(self.h, 0, self.batch, _lib.ip(out)))

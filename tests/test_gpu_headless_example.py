@@ -101,6 +101,9 @@ def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mappin
         at += d * d
         ref = P0[pos:pos + d, pos:pos + d]
         assert np.abs(Pyy - ref).max() <= 1e-8 * max(np.abs(ref).max(), 1e-12)
+        patch = v[at:at + 121].astype(np.uint8).reshape(11, 11)
+        at += 121
+        assert np.array_equal(patch, s.feature_patch(i)), "patch_ of feature %d" % label
     traj = v[at:].reshape(-1, 3)
     t0 = s.trajectory()
     assert traj.shape == t0.shape and np.abs(traj - t0).max() < 1e-9

@@ -5,6 +5,7 @@ import pytest
 
 import oracle_api as oa
 from conftest import rel_fro
+from scenelib2_amd import _lib
 from mapping_helpers import make_mapping_sequence, oracle_for
 
 pytestmark = pytest.mark.gpu
@@ -160,3 +161,13 @@ def test_engine_matches_committed_mapping_golden():
         assert np.allclose(xe[0][:3], g["pos"][k - 1], rtol=0, atol=1e-10)
     assert np.abs(eng.total_state(0) - g["x"]).max() < 1e-9
     assert rel_fro(eng.total_covariance(0), g["P"]) < 1e-8
+    # Feature::patch_ of every live feature, the ones cut from the frames by the initialisation included
+    s = oracle_for(cam, params, spec, templates, oa)
+    for k in range(1, 41):
+        s.go_one_step(frames[k], True, True)
+    feats = eng.features(0)
+    assert len(feats) == s.num_features > spec.n_features
+    for i, f in enumerate(feats):
+        assert np.array_equal(eng.feature_patch(0, f["label"]), s.feature_patch(i)), f["label"]
+    with pytest.raises(_lib.Sl2Error):
+        eng.feature_patch(0, 31)                     # label never handed out

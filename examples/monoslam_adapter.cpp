@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
       }
     }
     sl2_ingest_close(grab);
+    slam.print_robot_state();                                          // the example's "Print Robot State" button (:196-197)
     if (!dump.empty()) {
       FILE* f = fopen(dump.c_str(), "w");
       if (!f) { fprintf(stderr, "cannot write %s\n", dump.c_str()); return 5; }

@@ -24,6 +24,7 @@
 
 #include <array>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -182,6 +183,17 @@ class MonoSLAM {
     check(sl2_get_total_covariance(eng_, 0, M.data(), total_state_size_), "sl2_get_total_covariance");
   }
 
+  // MonoSLAM::print_robot_state (monoslam.cpp: "[Robot state]" xv_, "[Robot covariance]" Pxx_)
+  void print_robot_state(FILE* out = stdout) const {
+    std::fprintf(out, "[Robot state]\n");
+    for (double v : xv_) std::fprintf(out, "%g\n", v);
+    std::fprintf(out, "[Robot covariance]\n");
+    for (int r = 0; r < 13; ++r) {
+      for (int c = 0; c < 13; ++c) std::fprintf(out, c ? " %g" : "%g", Pxx_[r * 13 + c]);
+      std::fprintf(out, "\n");
+    }
+  }
+
   sl2_engine* engine() { return eng_; }
 
   // ---- public data members, names as in monoslam.h:158-218 ----
@@ -194,6 +206,7 @@ class MonoSLAM {
   std::vector<std::array<double, 3>> trajectory_store_;       // keeps the reference's stale-scratch entries
   int number_of_visible_features_ = 0;
   int next_free_label_ = 0;
+  int marked_feature_label_ = -1;                             // GUI selection (graphictool.cpp); nothing here sets it
   int total_state_size_ = 13;
   int successful_measurement_vector_size_ = 0;
   double kDeltaT_ = 0;

@@ -263,6 +263,11 @@ int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* c
  * reference's trajectory_store_ holds a stale scratch value instead):
  * out [nseq][count][3], count = min(capacity, steps done, 1000). */
 int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int capacity, int* count);
+/* MonoSLAM::mark_feature_by_lab(label) + delete_feature() (monoslam.cpp:743-812) for one feature per sequence:
+ * labels [nseq], -1 = leave that sequence alone.  deleted [nseq] (may be NULL) receives the reference's bool: 1 if a live,
+ * fully initialised feature with that label existed and was removed (partially initialised ones are removed by the engine's
+ * own sell-by / conversion logic only).  The label is not reused.  Synchronises. */
+int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels, int32_t* deleted);
 /* Feature::attempted_/successful_measurements (test hook for delete_bad_features). */
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful);
 /* Non-zero bits: 1 = NaN/Inf seen in the state (e.g. the omega == 0 hazard, Q10). */

@@ -183,6 +183,16 @@ class MonoSLAM {
     check(sl2_get_total_covariance(eng_, 0, M.data(), total_state_size_), "sl2_get_total_covariance");
   }
 
+  // MonoSLAM::mark_feature_by_lab + delete_feature (monoslam.cpp:743-812): removes the feature marked_feature_label_
+  bool delete_feature() {
+    if (marked_feature_label_ == -1) return false;
+    const int32_t lab = marked_feature_label_;
+    int32_t done = 0;
+    check(sl2_delete_features(eng_, 0, 1, &lab, &done), "sl2_delete_features");
+    if (done) { marked_feature_label_ = -1; refresh_public_members(); }
+    return done != 0;
+  }
+
   // MonoSLAM::print_robot_state (monoslam.cpp: "[Robot state]" xv_, "[Robot covariance]" Pxx_)
   void print_robot_state(FILE* out = stdout) const {
     std::fprintf(out, "[Robot state]\n");
@@ -206,7 +216,7 @@ class MonoSLAM {
   std::vector<std::array<double, 3>> trajectory_store_;       // keeps the reference's stale-scratch entries
   int number_of_visible_features_ = 0;
   int next_free_label_ = 0;
-  int marked_feature_label_ = -1;                             // GUI selection (graphictool.cpp); nothing here sets it
+  int marked_feature_label_ = -1;                             // GUI selection (graphictool.cpp); delete_feature() acts on it
   int total_state_size_ = 13;
   int successful_measurement_vector_size_ = 0;
   double kDeltaT_ = 0;

@@ -222,6 +222,12 @@ int orc_make_measurements(void* h, const uint8_t* frame) { return ((MonoSLAM*)h)
 void orc_kalman_filter_update(void* h) { ((MonoSLAM*)h)->KalmanFilterUpdate(); }
 void orc_normalise_state(void* h) { ((MonoSLAM*)h)->normalise_state(); }
 void orc_delete_bad_features(void* h) { ((MonoSLAM*)h)->delete_bad_features(); }
+// mark_feature_by_lab(label) + delete_feature() (monoslam.cpp:743-812)
+int orc_delete_feature(void* h, int label) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->mark_feature_by_lab(label);
+  return m->delete_feature() ? 1 : 0;
+}
 // Feature::Pyy_ (feature.h:84), row-major 3x3: a known feature with a prior uncertainty
 void orc_set_feature_Pyy(void* h, int idx, const double* Pyy9) {
   Feature* f = ((MonoSLAM*)h)->feature_list[idx];

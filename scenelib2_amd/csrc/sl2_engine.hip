@@ -875,6 +875,51 @@ int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, i
   return SL2_OK;
 }
 
+// mark_feature_by_lab + delete_feature for one feature per sequence (monoslam.cpp:743-812): the slot is retired
+// (inactive, deselected, its label never reused) and its rows / columns of P are zeroed, which is what removing them from
+// the total state amounts to in this layout (k_finalize does the same for delete_bad_features).
+__global__ void __launch_bounds__(256) k_delete_feature(double* __restrict__ P, int* __restrict__ f_flags, const int* __restrict__ labels,
+                                                        int* __restrict__ done, int N, int ld) {
+  const int b = blockIdx.x;
+  const int lab = labels[b];
+  if (lab < 0 || lab >= N) { if (threadIdx.x == 0) done[b] = 0; return; }
+  const size_t fi = (size_t)b * N + lab;
+  const int fl = f_flags[fi];
+  const bool ok = (fl & FF_ACTIVE) && !(fl & FF_PARTIAL);
+  __syncthreads();
+  if (threadIdx.x == 0) { done[b] = ok ? 1 : 0; if (ok) f_flags[fi] = FF_USED; }
+  if (!ok) return;
+  double* Pb = P + (size_t)b * ld * ld;
+  const int pos = 13 + 3 * lab;
+  for (int j = threadIdx.x; j < ld; j += blockDim.x)
+    for (int r = 0; r < 3; ++r) {
+      Pb[(size_t)(pos + r) * ld + j] = 0.0;
+      Pb[(size_t)j * ld + pos + r] = 0.0;
+    }
+}
+
+int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels, int32_t* deleted) {
+  if (!range_ok(e, seq0, nseq) || !labels) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  int *d_lab = nullptr, *d_done = nullptr;
+  SL2_HIP(hipMalloc((void**)&d_lab, sizeof(int) * nseq));
+  if (hipMalloc((void**)&d_done, sizeof(int) * nseq) != hipSuccess) { hipFree(d_lab); set_error("hipMalloc failed"); return SL2_ERR_HIP; }
+  hipError_t err = hipMemcpy(d_lab, labels, sizeof(int) * nseq, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_delete_feature, dim3(nseq), dim3(256), 0, e->stream, e->P + (size_t)seq0 * e->ld * e->ld,
+                       e->f_flags + (size_t)seq0 * e->N, d_lab, d_done, e->N, e->ld);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  std::vector<int32_t> done(nseq, 0);
+  if (err == hipSuccess) err = hipMemcpy(done.data(), d_done, sizeof(int) * nseq, hipMemcpyDeviceToHost);
+  hipFree(d_lab); hipFree(d_done);
+  if (err != hipSuccess) { set_error(hipGetErrorString(err)); return SL2_ERR_HIP; }
+  if (deleted) for (int i = 0; i < nseq; ++i) deleted[i] = done[i];
+  return SL2_OK;
+}
+
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags) {
   if (!range_ok(e, seq0, nseq) || !flags) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));

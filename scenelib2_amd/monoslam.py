@@ -201,6 +201,13 @@ class Engine:
     def set_feature_counters(self, seq, label, attempted, successful):
         _lib.check(self.L.sl2_set_feature_counters(self.h, seq, label, attempted, successful))
 
+    def delete_features(self, labels, seq0=0):
+        """mark_feature_by_lab + delete_feature, one label per sequence (-1: none); returns the per-sequence bool."""
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        done = np.zeros(lab.size, dtype=np.int32)
+        _lib.check(self.L.sl2_delete_features(self.h, int(seq0), lab.size, _lib.ip(lab), _lib.ip(done)))
+        return done.astype(bool)
+
     def feature_patch(self, seq, label):
         """Feature::patch_ of the feature with this label (11x11 uint8)."""
         out = np.zeros((11, 11), dtype=np.uint8)

@@ -67,6 +67,7 @@ def lib():
         L.orc_kalman_filter_update.argtypes = [C.c_void_p]
         L.orc_normalise_state.argtypes = [C.c_void_p]
         L.orc_delete_bad_features.argtypes = [C.c_void_p]
+        L.orc_delete_feature.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_feature_Pyy.argtypes = [C.c_void_p, C.c_int, c_dp]
         L.orc_set_feature_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_correlate2_warning.restype = C.c_double
@@ -208,6 +209,9 @@ class OracleSLAM:
 
     def delete_bad_features(self):
         self.L.orc_delete_bad_features(self.h)
+
+    def delete_feature(self, label):
+        return bool(self.L.orc_delete_feature(self.h, int(label)))
 
     def set_feature_Pyy(self, idx, Pyy):
         P = np.ascontiguousarray(Pyy, dtype=np.float64).reshape(9)

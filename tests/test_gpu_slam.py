@@ -426,3 +426,22 @@ def test_awkward_shapes(width, height, n_features, n_frames, batch, sigma):
         matched += pr.engine.selection(0)[1]["measurement_size"]
     assert matched >= n_frames * n_features          # at least half of the measurements succeed
     assert not pr.engine.status_flags().any()
+
+
+def test_manual_delete_feature_matches_mark_and_delete():
+    """sl2_delete_features = mark_feature_by_lab + delete_feature (monoslam.cpp:743-812): the feature leaves the total state
+    (later features move up), its label is never reused, the filter carries on exactly as the oracle's."""
+    pr = Pair(16, 5, batch=2, feature_sigma=0.003)
+    for k in range(2):
+        pr.step_both(k)
+    done = pr.engine.delete_features([5, -1])
+    assert list(done) == [True, False]
+    assert pr.oracles[0].delete_feature(5)
+    pr.compare_state(TOL_X, TOL_P)
+    assert [f["label"] for f in pr.engine.features(0)] == [i for i in range(16) if i != 5]
+    assert list(pr.engine.delete_features([5, 99])) == [False, False]          # already gone / no such label
+    assert not pr.oracles[0].delete_feature(5)
+    for k in range(2, 5):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+    assert int(pr.engine.total_state_sizes(0, 1)[0]) == 13 + 3 * 15

@@ -116,11 +116,29 @@ def main():
     def step(k):  # frame k (0-based) = pose k+1, resident in HBM
         eng.go_one_step(d_frames.ptr + (k + 1) * B * fb, on_device=True, seq_stride=fb)
 
-    # ---- warm-up ----
-    for k in range(Wm):
+    # ---- warm-up ----  (its last steps, when there are enough, carry a bracket on EVERY launch: they tell which kernel
+    # dominates, so that the timed region brackets only that one and the search kernel - each bracket is two event markers
+    # on the stream, and bracketing the four large kernels cost 1-3 % of the step)
+    MAJOR = ("k_syrk", "k_fwdsub", "k_build_A", "k_search")
+    focus = "k_syrk,k_search"
+    n_probe = 3 if (not args.no_profile and Wm >= 6) else 0
+    for k in range(Wm - n_probe):
         step(k)
+    if n_probe:
+        eng.synchronize()
+        eng.set_profiling(2)
+        eng.reset_kernel_times()
+        for k in range(Wm - n_probe, Wm):
+            step(k)
+        eng.synchronize()
+        probe = eng.kernel_times()
+        eng.set_profiling(0)
+        cand = {n: probe[n]["total_ms"] for n in MAJOR if n in probe}
+        if cand:
+            focus = max(cand, key=cand.get) + ",k_search"
     eng.synchronize()
     if not args.no_profile:
+        eng.set_profile_focus(focus)
         eng.set_profiling(1)          # timed region: only the roofline kernels carry event brackets
         eng.reset_kernel_times()
 
@@ -139,6 +157,7 @@ def main():
 
     ktimes = eng.kernel_times() if not args.no_profile else {}
     eng.set_profiling(0)
+    eng.set_profile_focus("")
     work = eng.step_work()       # algorithmic work of the last timed step, summed over this rank's batch
     xv_final, _ = eng.get_vehicle_state()
     # untimed extra steps with EVERY launch bracketed: the full per-kernel breakdown

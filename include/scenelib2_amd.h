@@ -279,6 +279,9 @@ int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
  * events on the engine's stream (8 events per step); enabled = 2: every kernel launch is; sl2_get_kernel_times returns accumulated milliseconds and
  * launch counts per kernel name since the last reset. */
 int sl2_set_profiling(sl2_engine* e, int enabled);
+/* Level 1 brackets only the kernels named here (comma separated scope names, e.g. "k_syrk,k_search"; NULL or "" = the
+ * four large ones): every bracket is two event markers on the stream, and four of them cost 1-3 % of a step. */
+int sl2_set_profile_focus(sl2_engine* e, const char* names);
 int sl2_reset_kernel_times(sl2_engine* e);
 int sl2_kernel_count(sl2_engine* e);
 int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total_ms, int64_t* launches);

@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
-    "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling",
+    "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
     "sl2_dev_download", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench",
@@ -152,6 +152,7 @@ def load():
     L.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.sl2_get_status_flags.argtypes = [vp, C.c_int, C.c_int, c_ip]
     L.sl2_set_profiling.argtypes = [vp, C.c_int]
+    L.sl2_set_profile_focus.argtypes = [vp, C.c_char_p]
     L.sl2_reset_kernel_times.argtypes = [vp]
     L.sl2_kernel_count.argtypes = [vp]
     L.sl2_get_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_dp, C.POINTER(C.c_int64)]

@@ -173,6 +173,7 @@ struct sl2_engine {
   // profiling
   bool profiling = false;
   int profile_level = 2;
+  std::string profile_focus;  // level 1: bracket only these kernels (",name,name,"); empty = the four major ones
   std::vector<sl2::KernelTimer> timers;
   std::vector<sl2::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
@@ -201,7 +202,14 @@ struct LaunchScope {
   bool on;
   size_t slot = 0;
   // level 1 = only the roofline kernels (cheap: 4 event pairs per step), level 2 = every launch
-  LaunchScope(sl2_engine* eng, const char* name, bool major = false) : e(eng), on(eng->root->profiling && (major || eng->root->profile_level >= 2)) {
+  static bool wanted(const sl2_engine* r, const char* name, bool major) {
+    if (!r->profiling) return false;
+    if (r->profile_level >= 2) return true;
+    if (!major) return false;
+    if (r->profile_focus.empty()) return true;
+    return r->profile_focus.find(std::string(",") + name + ",") != std::string::npos;
+  }
+  LaunchScope(sl2_engine* eng, const char* name, bool major = false) : e(eng), on(wanted(eng->root, name, major)) {
     if (on) { e->root->prof_begin(e->root->timer_id(name), e->stream); slot = e->root->pending.size() - 1; }
   }
   ~LaunchScope() {

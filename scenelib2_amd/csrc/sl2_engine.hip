@@ -937,6 +937,11 @@ int sl2_set_profiling(sl2_engine* e, int enabled) {
   if (enabled) e->profile_level = enabled >= 2 ? 2 : 1;
   return SL2_OK;
 }
+int sl2_set_profile_focus(sl2_engine* e, const char* names) {
+  if (!e) return SL2_ERR_INVALID;
+  e->profile_focus = (names && *names) ? std::string(",") + names + "," : std::string();
+  return SL2_OK;
+}
 int sl2_reset_kernel_times(sl2_engine* e) {
   if (!e) return SL2_ERR_INVALID;
   int rc = e->fold_events();

@@ -220,6 +220,9 @@ class Engine:
         return out
 
     # ---- profiling -----------------------------------------------------------
+    def set_profile_focus(self, names=""):
+        _lib.check(self.L.sl2_set_profile_focus(self.h, names.encode() if names else None))
+
     def set_profiling(self, level):
         """0 off, 1 roofline kernels only, 2 every launch."""
         _lib.check(self.L.sl2_set_profiling(self.h, int(level)))

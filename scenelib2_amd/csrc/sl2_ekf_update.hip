@@ -722,6 +722,11 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 #else
 #define TRL(slot) do { } while (0)
 #endif
+#ifdef SL2_CHOL_TRACE
+  if (trace && lane == 0) trace[(size_t)gridDim.x * 4 * 8 * 4 + b * 4 + wave] = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+#endif
+  // (Wave 0 = D of consecutive workgroups already lands on rotating SIMDs - 250 / 255 / 257 / 262 of 1024 per SIMD - ; an
+  // explicit per-CU ticket that picks the D wave by SIMD id made the launch 6 % slower.)
   auto diag_to_lds = [&](const Tile32& t, int lo, int hi) {
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)

@@ -445,3 +445,30 @@ def test_manual_delete_feature_matches_mark_and_delete():
         pr.step_both(k)
         pr.compare_state(TOL_X, TOL_P)
     assert int(pr.engine.total_state_sizes(0, 1)[0]) == 13 + 3 * 15
+
+
+def test_create_step_destroy_does_not_leak_device_memory():
+    """sl2_destroy gives back everything sl2_create and the first steps allocated (state, work buffers, lazily created
+    mapping maps, events, streams): free device memory after twenty engines equals free memory after the first one."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    def one_round(seed):
+        pr = Pair(12, 3, batch=4, seq0=seed)
+        pr.engine.set_profiling(2)
+        for k in range(2):
+            pr.engine.go_one_step(pr.frame_batch(k), True)
+        pr.engine.go_one_step(pr.frame_batch(2), True, enable_mapping=True)     # allocates the score / stamp maps
+        pr.engine.total_state(0)
+        pr.engine.close()
+
+    one_round(0)
+    base = free_bytes()
+    for i in range(20):
+        one_round(i % 3)
+    assert abs(free_bytes() - base) <= (8 << 20), "device memory drifted by %d bytes" % (free_bytes() - base)

@@ -125,17 +125,45 @@ inline bool llt_lower(const Mat& A, Mat& L) {
   return ok;
 }
 
-// Inverse of a lower-triangular matrix by forward substitution, column by
-// column (stands in for `S_L.inverse()` at kalman.cpp:106, monoslam.cpp:373).
-inline Mat lower_inverse(const Mat& L) {
-  const int n = L.r;
+// `S_L.inverse()` at kalman.cpp:106, monoslam.cpp:373 and feature_init_info.cpp:61 is called on a plain
+// Eigen::MatrixXd (the triangular factor has been copied into a dense matrix first), so Eigen runs its general
+// dynamic-size inverse: LU with partial (row) pivoting, then P, L and U solves against the identity.  Restated here
+// with the same pivot rule (first row of largest magnitude in the column); a triangular-aware inverse would differ
+// from it in the last bits and, on badly conditioned S, in the 11th digit of the update.
+inline Mat general_inverse(const Mat& A) {
+  const int n = A.r;
+  Mat lu = A;
+  std::vector<int> row_of(n);
+  for (int i = 0; i < n; ++i) row_of[i] = i;
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    double big = std::fabs(lu(k, k));
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(lu(i, k)) > big) { big = std::fabs(lu(i, k)); piv = i; }
+    if (piv != k) {
+      for (int j = 0; j < n; ++j) { const double t = lu(k, j); lu(k, j) = lu(piv, j); lu(piv, j) = t; }
+      const int t = row_of[k]; row_of[k] = row_of[piv]; row_of[piv] = t;
+    }
+    if (lu(k, k) != 0.0)
+      for (int i = k + 1; i < n; ++i) lu(i, k) /= lu(k, k);
+    for (int j = k + 1; j < n; ++j) {
+      const double ukj = lu(k, j);
+      for (int i = k + 1; i < n; ++i) lu(i, j) -= lu(i, k) * ukj;
+    }
+  }
   Mat X(n, n);
   for (int j = 0; j < n; ++j) {
-    X(j, j) = 1.0 / L(j, j);
-    for (int i = j + 1; i < n; ++i) {
-      double s = 0.0;
-      for (int p = j; p < i; ++p) s -= L(i, p) * X(p, j);
-      X(i, j) = s / L(i, i);
+    for (int i = 0; i < n; ++i) X(i, j) = (row_of[i] == j) ? 1.0 : 0.0;
+    for (int k = 0; k < n; ++k) {           // unit-lower forward sweep
+      const double xk = X(k, j);
+      if (xk != 0.0)
+        for (int i = k + 1; i < n; ++i) X(i, j) -= lu(i, k) * xk;
+    }
+    for (int k = n - 1; k >= 0; --k) {      // upper backward sweep (Eigen's matrix solver scales by 1 / diagonal)
+      X(k, j) *= 1.0 / lu(k, k);
+      const double xk = X(k, j);
+      if (xk != 0.0)
+        for (int i = 0; i < k; ++i) X(i, j) -= lu(i, k) * xk;
     }
   }
   return X;

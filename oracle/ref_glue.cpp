@@ -1,0 +1,441 @@
+// ORACLE / TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+//
+// Flat C interface (`ref_*`) over the REFERENCE ITSELF: this file is linked with the
+// reference's own translation units — monoslam.cpp, kalman.cpp, motion_model.cpp,
+// camera.cpp, feature_model.cpp, full_feature_model.cpp, part_feature_model.cpp,
+// feature.cpp, feature_init_info.cpp, support/{math_util,eigen_util}.cpp,
+// improc/{improc,search_multiple_overlapping_ellipses}.cpp — compiled UNMODIFIED from
+// /root/reference/scenelib2 against the stand-in headers under oracle/ref_shim/ (Eigen,
+// OpenCV, Pangolin, freeglut, boost::thread are not in this image).  `make -C oracle ref`
+// writes oracle/_ref/libref.so.  The entry points mirror oracle/slam_oracle.cpp's `orc_*`
+// one for one (same arguments, same output layouts) so tests/test_oracle_vs_ref.py can
+// drive the restatement and the reference with the same inputs and compare.
+//
+// What is NOT the reference here (and why it does not matter for the comparison):
+//   * GraphicTool / FrameGrabber are stubbed (constructors only): MonoSLAM::Init news them
+//     (monoslam.cpp:1962-1965), nothing on the per-frame path touches them;
+//   * ref_create() performs MonoSLAM::Init's member set-up (monoslam.cpp:1850-1969) from
+//     arguments instead of a cfg file, because Init hard-wires exactly four features f1..f4;
+//     ref_create_from_cfg() calls the reference's Init itself and is compared against the
+//     same cfg run through the oracle;
+//   * the arithmetic of Eigen is the shim's (see ref_shim/Eigen/Eigen).
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "monoslam.h"
+#include "kalman.h"
+#include "improc/improc.h"
+#include "improc/search_multiple_overlapping_ellipses.h"
+#include "support/math_util.h"
+
+namespace SceneLib2 {
+
+// ---- stubs for the two classes Init() instantiates that are off the path ----------------
+GraphicTool::GraphicTool(MonoSLAM* monoslam)
+    : kQR0_(0.0, 0.0, 1.0, 0.0), kMoveClippingPlaneFactor_(0.999999), kSemiInfiniteLineLength_(10.0),
+      kCovariancesNumberOfSigma_(3.0), kDrawNOverlappingEllipses_(10) {
+  monoslam_ptr_ = monoslam;
+  frame_ = NULL;
+  sphere_quad_ = cylinder_quad_ = circle_quad_ = NULL;
+}
+GraphicTool::~GraphicTool() {}
+FrameGrabber::FrameGrabber() : file_grabber_(NULL), usb_cam_grabber_(NULL) {}
+FrameGrabber::~FrameGrabber() {}
+void FrameGrabber::Init(const string&, const bool) {}
+
+}  // namespace SceneLib2
+
+using SceneLib2::Feature;
+using SceneLib2::FeatureInitInfo;
+using SceneLib2::MonoSLAM;
+using SceneLib2::Particle;
+
+namespace {
+
+double now_seconds() {
+  using namespace std::chrono;
+  return duration_cast<duration<double>>(steady_clock::now().time_since_epoch()).count();
+}
+
+std::atomic<int> g_patch_counter(0);
+
+cv::Mat frame_header(const MonoSLAM* m, const uint8_t* frame) {
+  return cv::Mat(m->camera_->height_, m->camera_->width_, CV_8UC1, (void*)frame);
+}
+
+bool flag_of(const bool& b) { return *reinterpret_cast<const unsigned char*>(&b) != 0; }
+
+}  // namespace
+
+extern "C" {
+
+// MonoSLAM::Init's set-up (monoslam.cpp:1850-1889, 1962-1969) from arguments.
+void* ref_create(int width, int height, double fku, double fkv, double u0, double v0, double kd1, int sd,
+                 double delta_t, int n_select) {
+  MonoSLAM* m = new MonoSLAM();
+  m->camera_ = new SceneLib2::Camera();
+  m->camera_->SetCameraParameters(width, height, fku, fkv, u0, v0, kd1, sd);
+  m->motion_model_ = new SceneLib2::MotionModel();
+  m->full_feature_model_ = new SceneLib2::FullFeatureModel(2, 3, 3, m->camera_, m->motion_model_);
+  m->part_feature_model_ = new SceneLib2::PartFeatureModel(2, 6, 6, m->camera_, m->motion_model_, 3);
+  m->kDeltaT_ = delta_t;
+  m->kNumberOfFeaturesToSelect_ = n_select;
+  // shipped values (data/SceneLib2.cfg:59-70); ref_set_mapping_params overrides
+  m->kNumberOfFeaturesToKeepVisible_ = 12;
+  m->kMaxFeaturesToInitAtOnce_ = 1;
+  m->kMinLambda_ = 0.5;
+  m->kMaxLambda_ = 5.0;
+  m->kNumberOfParticles_ = 100;
+  m->kStandardDeviationDepthRatio_ = 0.3;
+  m->kMinNumberOfParticles_ = 20;
+  m->kPruneProbabilityThreshold_ = 0.05;
+  m->kErasePartiallyInitFeatureAfterThisManyAttempts_ = 10;
+  m->number_of_visible_features_ = 0;
+  m->minimum_attempted_measurements_of_feature_ = 10;
+  m->successful_match_fraction_ = 0.5;
+  m->next_free_label_ = 0;
+  m->marked_feature_label_ = -1;
+  m->total_state_size_ = m->motion_model_->kStateSize_;
+  m->successful_measurement_vector_size_ = 0;
+  m->xv_.resize(13);
+  m->xv_.setZero();
+  m->xv_(3) = 1.0;
+  m->Pxx_.resize(13, 13);
+  m->Pxx_.setZero();
+  m->kalman_ = new SceneLib2::Kalman();
+  m->init_feature_search_region_defined_flag_ = false;
+  m->location_selected_flag_ = false;
+  m->uu_ = m->vv_ = 0;
+  m->init_feature_search_ustart_ = m->init_feature_search_vstart_ = 0;
+  m->init_feature_search_ufinish_ = m->init_feature_search_vfinish_ = 0;
+  srand48(0);
+  return m;
+}
+
+// The reference's own Init (cfg parsing, four known features read with cv::imread, srand48(0)).
+void* ref_create_from_cfg(const char* cfg_path) {
+  MonoSLAM* m = new MonoSLAM();
+  pangolin::shim_vars().clear();
+  m->Init(cfg_path);
+  m->uu_ = m->vv_ = 0;
+  m->successful_measurement_vector_size_ = 0;
+  return m;
+}
+
+void ref_destroy(void* h) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (size_t i = 0; i < m->feature_list_.size(); ++i) delete m->feature_list_[i];
+  delete m;
+}
+
+void ref_set_state(void* h, const double* xv, const double* Pxx) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (int i = 0; i < 13; ++i) m->xv_(i) = xv[i];
+  for (int i = 0; i < 13; ++i) for (int j = 0; j < 13; ++j) m->Pxx_(i, j) = Pxx[i * 13 + j];
+}
+void ref_get_state(void* h, double* xv, double* Pxx) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (int i = 0; i < 13; ++i) xv[i] = m->xv_(i);
+  for (int i = 0; i < 13; ++i) for (int j = 0; j < 13; ++j) Pxx[i * 13 + j] = m->Pxx_(i, j);
+}
+void ref_add_known_feature(void* h, const double* y, const double* xp, const uint8_t* patch) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  cv::Mat p(11, 11, CV_8UC1);
+  std::memcpy(p.data, patch, 121);
+  const std::string name = "mem:patch" + std::to_string(g_patch_counter.fetch_add(1));
+  cv::shim_register_image(name, p);
+  Eigen::VectorXd yv(3), xpv(7);
+  for (int i = 0; i < 3; ++i) yv(i) = y[i];
+  for (int i = 0; i < 7; ++i) xpv(i) = xp[i];
+  m->AddNewKnownFeature(yv, xpv, name);
+  cv::shim_registry().erase(name);
+}
+int ref_go_one_step(void* h, const uint8_t* frame, int save_trajectory, int enable_mapping) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  return m->GoOneStep(frame_header(m, frame), save_trajectory != 0, enable_mapping != 0) ? 1 : 0;
+}
+int ref_num_features(void* h) { return (int)((MonoSLAM*)h)->feature_list_.size(); }
+int ref_num_selected(void* h) { return (int)((MonoSLAM*)h)->selected_feature_list_.size(); }
+int ref_total_state_size(void* h) { return ((MonoSLAM*)h)->total_state_size_; }
+int ref_num_visible(void* h) { return ((MonoSLAM*)h)->number_of_visible_features_; }
+int ref_measurement_size(void* h) { return ((MonoSLAM*)h)->successful_measurement_vector_size_; }
+void ref_get_total_state(void* h, double* x) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  Eigen::VectorXd v(m->total_state_size_);
+  v.setZero();
+  m->construct_total_state(v);
+  for (int i = 0; i < m->total_state_size_; ++i) x[i] = v(i);
+}
+void ref_get_total_covariance(void* h, double* P) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  const int n = m->total_state_size_;
+  Eigen::MatrixXd M(n, n);
+  M.setZero();
+  m->construct_total_covariance(M);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) P[(size_t)i * n + j] = M(i, j);
+}
+// same layout as orc_get_feature
+void ref_get_feature(void* h, int idx, int* ints, double* dbl) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  const Feature* f = m->feature_list_[idx];
+  ints[0] = f->label_; ints[1] = flag_of(f->selected_flag_); ints[2] = flag_of(f->successful_measurement_flag_);
+  ints[3] = f->attempted_measurements_of_feature_; ints[4] = f->successful_measurements_of_feature_;
+  ints[5] = f->position_in_total_state_vector_;
+  int k = 0;
+  for (int i = 0; i < 3; ++i) dbl[k++] = f->y_(i);
+  for (int i = 0; i < 2; ++i) dbl[k++] = f->h_(i);
+  for (int i = 0; i < 2; ++i) dbl[k++] = f->z_(i);
+  for (int i = 0; i < 2; ++i) dbl[k++] = f->nu_(i);
+  dbl[k++] = f->R_(0, 0);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) dbl[k++] = f->S_(i, j);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 13; ++j) dbl[k++] = f->dh_by_dxv_(i, j);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) dbl[k++] = f->dh_by_dy_(i, j);
+}
+void ref_set_mapping_params(void* h, const int* ip, const double* dp) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->kNumberOfFeaturesToKeepVisible_ = ip[0]; m->kMaxFeaturesToInitAtOnce_ = ip[1]; m->kNumberOfParticles_ = ip[2];
+  m->kMinNumberOfParticles_ = ip[3]; m->kErasePartiallyInitFeatureAfterThisManyAttempts_ = ip[4];
+  m->kMinLambda_ = dp[0]; m->kMaxLambda_ = dp[1]; m->kStandardDeviationDepthRatio_ = dp[2];
+  m->kPruneProbabilityThreshold_ = dp[3];
+}
+// ints as orc_get_mapping_info; the three event counters are the oracle's own bookkeeping: ints[1] holds
+// next_free_label_ (labels handed out so far), ints[2] = ints[3] = -1
+void ref_get_mapping_info(void* h, int* ints) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  ints[0] = (int)m->feature_init_info_vector_.size(); ints[1] = m->next_free_label_; ints[2] = -1; ints[3] = -1;
+  ints[4] = m->uu_; ints[5] = m->vv_; ints[6] = m->location_selected_flag_;
+  ints[7] = m->init_feature_search_region_defined_flag_; ints[8] = m->init_feature_search_ustart_;
+  ints[9] = m->init_feature_search_vstart_; ints[10] = m->init_feature_search_ufinish_;
+  ints[11] = m->init_feature_search_vfinish_;
+}
+int ref_get_partial_feature(void* h, int k, int* ints, double* dbl, double* particles, int max_particles) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  if (k < 0 || k >= (int)m->feature_init_info_vector_.size()) return 0;
+  const FeatureInitInfo& f = m->feature_init_info_vector_[k];
+  ints[0] = f.fp_->label_; ints[1] = (int)f.particle_vector_.size(); ints[2] = f.number_of_match_attempts_;
+  ints[3] = flag_of(f.making_measurement_on_this_step_flag_);
+  dbl[0] = f.mean_(0); dbl[1] = f.covariance_(0, 0);
+  for (int i = 0; i < 6; ++i) dbl[2 + i] = f.fp_->y_(i);
+  for (int i = 0; i < (int)f.particle_vector_.size() && i < max_particles; ++i) {
+    const Particle& p = f.particle_vector_[i];
+    double* o = particles + 12 * (size_t)i;
+    o[0] = p.lambda_(0); o[1] = p.probability_; o[2] = p.cumulative_probability_; o[3] = p.m_h_(0); o[4] = p.m_h_(1);
+    o[5] = p.m_z_(0); o[6] = p.m_z_(1); o[7] = p.m_SInv_(0, 0); o[8] = p.m_SInv_(0, 1); o[9] = p.m_SInv_(1, 1);
+    o[10] = p.m_detS_; o[11] = flag_of(p.m_successful_measurement_flag_);
+  }
+  return 1;
+}
+void ref_get_feature_kinds(void* h, int* out3) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (size_t i = 0; i < m->feature_list_.size(); ++i) {
+    out3[3 * i] = m->feature_list_[i]->feature_model_->kFeatureStateSize_;
+    out3[3 * i + 1] = flag_of(m->feature_list_[i]->fully_initialised_flag_);
+    out3[3 * i + 2] = m->feature_list_[i]->label_;
+  }
+}
+void ref_get_feature_patch(void* h, int idx, uint8_t* patch121) {
+  const cv::Mat& p = ((MonoSLAM*)h)->feature_list_[idx]->patch_;
+  if (p.empty()) std::memset(patch121, 0, 121);   // cv::imread failed (the reference does not check)
+  else std::memcpy(patch121, p.data, 121);
+}
+void ref_get_selected_labels(void* h, int* labels) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  for (size_t i = 0; i < m->selected_feature_list_.size(); ++i) labels[i] = m->selected_feature_list_[i]->label_;
+}
+int ref_trajectory(void* h, double* out, int max_entries) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  int n = (int)m->trajectory_store_.size();
+  if (n > max_entries) n = max_entries;
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) out[3 * i + k] = m->trajectory_store_[i](k);
+  return n;
+}
+
+// ---- seams --------------------------------------------------------------------------------
+void ref_kalman_filter_predict(void* h) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  Eigen::Vector3d u;
+  u.setZero();
+  m->kalman_->KalmanFilterPredict(m, u);
+}
+int ref_auto_select_n_features(void* h, int n) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->number_of_visible_features_ = m->auto_select_n_features(n);
+  return m->number_of_visible_features_;
+}
+int ref_make_measurements(void* h, const uint8_t* frame) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  return m->make_measurements(frame_header(m, frame));
+}
+void ref_kalman_filter_update(void* h) { MonoSLAM* m = (MonoSLAM*)h; m->kalman_->KalmanFilterUpdate(m); }
+void ref_normalise_state(void* h) { ((MonoSLAM*)h)->normalise_state(); }
+void ref_delete_bad_features(void* h) { ((MonoSLAM*)h)->delete_bad_features(); }
+int ref_delete_feature(void* h, int label) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->mark_feature_by_lab(label);
+  return m->delete_feature() ? 1 : 0;
+}
+void ref_set_feature_Pyy(void* h, int idx, const double* Pyy9) {
+  Feature* f = ((MonoSLAM*)h)->feature_list_[idx];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) f->Pyy_(i, j) = Pyy9[i * 3 + j];
+}
+void ref_set_feature_counters(void* h, int idx, int attempted, int successful) {
+  Feature* f = ((MonoSLAM*)h)->feature_list_[idx];
+  f->attempted_measurements_of_feature_ = attempted;
+  f->successful_measurements_of_feature_ = successful;
+}
+// MonoSLAM::InitialiseFeature at (uu_, vv_) = (u, v) (monoslam.cpp:1211-1235), InitialiseAutoFeature (:1535-1541),
+// mark + SavePatch (:1551-1572; the shim's imwrite keeps the pixels, returned in patch121)
+void ref_initialise_feature(void* h, const uint8_t* frame, int u, int v) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->uu_ = u; m->vv_ = v;
+  m->location_selected_flag_ = true;
+  m->InitialiseFeature(frame_header(m, frame));
+}
+void ref_initialise_auto_feature(void* h, const uint8_t* frame) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->InitialiseAutoFeature(frame_header(m, frame));
+}
+int ref_save_patch(void* h, int label, const char* dir, uint8_t* patch121) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->mark_feature_by_lab(label);
+  char cwd[4096];
+  const bool moved = dir && getcwd(cwd, sizeof cwd) && chdir(dir) == 0;
+  const bool ok = m->SavePatch();
+  if (moved && chdir(cwd) != 0) return -1;
+  if (ok && patch121) std::memcpy(patch121, cv::shim_last_written().data, 121);
+  return ok ? 1 : 0;
+}
+
+// ---- stateless functions ------------------------------------------------------------------
+double ref_correlate2_warning(int x0, int y0, int x0lim, int y0lim, int x1, int y1, const uint8_t* p0, int w0,
+                              const uint8_t* p1, int w1, double* sd0, double* sd1) {
+  // correlate2_warning reads only data and size().width (improc.cpp:63-79): the row counts are placeholders
+  cv::Mat m0(1 << 20, w0, CV_8UC1, (void*)p0), m1(1 << 20, w1, CV_8UC1, (void*)p1);
+  return SceneLib2::correlate2_warning(x0, y0, x0lim, y0lim, x1, y1, m0, m1, sd0, sd1);
+}
+// out_i: u, v, then -1, -1, -1 (the reference does not report candidate counts / half sizes); *best_corr = NaN
+int ref_elliptical_search(const uint8_t* image, int width, int height, const uint8_t* patch, const double* centre,
+                          double a, double b, double c, int* out_i, double* best_corr) {
+  MonoSLAM m;
+  cv::Mat img(height, width, CV_8UC1, (void*)image), pt(11, 11, CV_8UC1, (void*)patch);
+  Eigen::Vector2d ce(centre[0], centre[1]);
+  Eigen::Matrix2d Pu;
+  Pu(0, 0) = a; Pu(0, 1) = b; Pu(1, 0) = b; Pu(1, 1) = c;
+  int u = -1, v = -1;
+  const bool ok = m.elliptical_search(img, pt, ce, Pu, &u, &v, 11);
+  out_i[0] = u; out_i[1] = v; out_i[2] = out_i[3] = out_i[4] = -1;
+  if (best_corr) *best_corr = std::numeric_limits<double>::quiet_NaN();
+  return ok ? 1 : 0;
+}
+void ref_find_best_patch(const uint8_t* image, int width, int height, int ustart, int vstart, int ufinish, int vfinish,
+                         int* io_uv, double* evbest) {
+  MonoSLAM m;
+  cv::Mat img(height, width, CV_8UC1, (void*)image);
+  m.find_best_patch_inside_region(img, &io_uv[0], &io_uv[1], evbest, 11, ustart, vstart, ufinish, vfinish);
+}
+long long ref_search_multiple_ellipses(const uint8_t* image, int width, int height, const uint8_t* patch, int n,
+                                       const double* puinv, const double* centre, int* out_i, double* out_corr) {
+  cv::Mat img(height, width, CV_8UC1, (void*)image), pt(11, 11, CV_8UC1, (void*)patch);
+  SceneLib2::SearchMultipleOverlappingEllipses s(img, pt, 11);
+  for (int i = 0; i < n; ++i) {
+    Eigen::Matrix2d Pu;
+    Pu(0, 0) = puinv[3 * i]; Pu(0, 1) = puinv[3 * i + 1]; Pu(1, 0) = puinv[3 * i + 1]; Pu(1, 1) = puinv[3 * i + 2];
+    s.add_ellipse(Pu, Eigen::Vector2d(centre[2 * i], centre[2 * i + 1]));
+  }
+  s.search();
+  int i = 0;
+  for (SceneLib2::SearchMultipleOverlappingEllipses::SearchData::const_iterator e = s.begin(); e != s.end(); ++e, ++i) {
+    out_i[3 * i] = e->result_flag_ ? 1 : 0;
+    out_i[3 * i + 1] = e->result_u_;
+    out_i[3 * i + 2] = e->result_v_;
+    if (out_corr) out_corr[i] = std::numeric_limits<double>::quiet_NaN();
+  }
+  return -1;
+}
+void ref_drand48_sequence(long seed, int n, double* out) {
+  srand48(seed);
+  for (int i = 0; i < n; ++i) out[i] = drand48();
+}
+// S -> S^-1 as measure_feature / Particle::set_S form it (LLT, matrixL().inverse(), L^-T L^-1); abc = (00, 01, 11),
+// abc[3] (if wanted) = det S
+void ref_sinv_from_S4(const double* S4, double* abc, double* det) {
+  Eigen::VectorXd l(1);
+  l(0) = 1.0;
+  Particle p(l, 1.0, 2);
+  Eigen::MatrixXd S(2, 2);
+  S(0, 0) = S4[0]; S(0, 1) = S4[1]; S(1, 0) = S4[2]; S(1, 1) = S4[3];
+  p.set_S(S);
+  abc[0] = p.m_SInv_(0, 0); abc[1] = p.m_SInv_(0, 1); abc[2] = p.m_SInv_(1, 1);
+  if (det) *det = p.m_detS_;
+}
+void ref_sinv_from_S(const double* S4, double* abc) { ref_sinv_from_S4(S4, abc, nullptr); }
+void ref_motion_model(const double* xv, double dt, double* f, double* F, double* Q) {
+  SceneLib2::MotionModel mm;
+  Eigen::VectorXd x(13), u(3);
+  for (int i = 0; i < 13; ++i) x(i) = xv[i];
+  u.setZero();
+  mm.func_fv_and_dfv_by_dxv(x, u, dt);
+  mm.func_Q(x, u, dt);
+  for (int i = 0; i < 13; ++i) f[i] = mm.fvRES_(i);
+  for (int i = 0; i < 13; ++i) for (int j = 0; j < 13; ++j) { F[i * 13 + j] = mm.dfv_by_dxvRES_(i, j); Q[i * 13 + j] = mm.QxRES_(i, j); }
+}
+void ref_dqnorm_by_dq(const double* q, double* J16) {
+  SceneLib2::MotionModel mm;
+  const Eigen::Matrix4d M = mm.dqnorm_by_dq(Eigen::Quaterniond(q[0], q[1], q[2], q[3]));
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) J16[i * 4 + j] = M(i, j);
+}
+void ref_measurement_model(const double* cam8, const double* xp, const double* y, const double* xp_org, double* out) {
+  SceneLib2::Camera cam;
+  cam.SetCameraParameters((int)cam8[0], (int)cam8[1], cam8[2], cam8[3], cam8[4], cam8[5], cam8[6], (int)cam8[7]);
+  SceneLib2::MotionModel mm;
+  SceneLib2::FullFeatureModel ffm(2, 3, 3, &cam, &mm);
+  Eigen::VectorXd xpv(7), yv(3), xov(7);
+  for (int i = 0; i < 7; ++i) { xpv(i) = xp[i]; xov(i) = xp_org[i]; }
+  for (int i = 0; i < 3; ++i) yv(i) = y[i];
+  ffm.func_hi_and_dhi_by_dxp_and_dhi_by_dyi(yv, xpv);
+  int k = 0;
+  out[k++] = ffm.hiRES_(0); out[k++] = ffm.hiRES_(1);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 7; ++j) out[k++] = ffm.dhi_by_dxpRES_(i, j);
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 3; ++j) out[k++] = ffm.dhi_by_dyiRES_(i, j);
+  const Eigen::VectorXd hi = ffm.hiRES_;
+  ffm.func_Ri(hi);
+  out[k++] = ffm.RiRES_(0, 0);
+  out[k++] = (double)ffm.visibility_test(xpv, yv, xov, hi);
+}
+
+// ---- CPU baseline on the reference itself: nseq independent MonoSLAM objects, one sequence per worker at a time
+// (mapping off: the only process-global state of the reference, drand48, is not touched)
+double ref_run_sequences(void** hs, int nseq, const uint8_t* const* frames, int nframes, size_t frame_bytes,
+                         int nthreads, double* traj) {
+  std::atomic<int> next(0);
+  const double t0 = now_seconds();
+  auto worker = [&]() {
+    for (;;) {
+      const int s = next.fetch_add(1);
+      if (s >= nseq) break;
+      MonoSLAM* m = (MonoSLAM*)hs[s];
+      for (int f = 0; f < nframes; ++f) {
+        m->GoOneStep(frame_header(m, frames[s] + (size_t)f * frame_bytes), false, false);
+        if (traj) for (int i = 0; i < 3; ++i) traj[((size_t)s * nframes + f) * 3 + i] = m->xv_(i);
+      }
+    }
+  };
+  if (nthreads <= 1) {
+    worker();
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthreads; ++t) th.emplace_back(worker);
+    for (auto& t : th) t.join();
+  }
+  return now_seconds() - t0;
+}
+
+}  // extern "C"

@@ -326,7 +326,7 @@ struct FullFeatureModel {
     if (h[0] < 0.0 + kImageSearchBoundary || h[0] > (double)(cam->width - 1 - kImageSearchBoundary)) cant_see |= 1;
     if (h[1] < 0.0 + kImageSearchBoundary || h[1] > (double)(cam->height - 1 - kImageSearchBoundary)) cant_see |= 2;
     func_zeroedyi(yi, xp);
-    if (zeroedyi[2] <= 0) cant_see |= 4;
+    if (zeroedyi[2] <= 0) cant_see |= 16;  // kBehindCameraFail_ (full_feature_model.h:74-78)
     Mat z(3, 1);
     for (int i = 0; i < 3; ++i) z(i) = zeroedyi[i];
     const Mat hLWi = mul(qrot(Quat(xp[3], xp[4], xp[5], xp[6])), z);
@@ -336,11 +336,11 @@ struct FullFeatureModel {
     const double mod = std::sqrt(hLWi(0) * hLWi(0) + hLWi(1) * hLWi(1) + hLWi(2) * hLWi(2));
     const double mod_o = std::sqrt(hLWi_orig(0) * hLWi_orig(0) + hLWi_orig(1) * hLWi_orig(1) + hLWi_orig(2) * hLWi_orig(2));
     const double length_ratio = mod / mod_o;
-    if (length_ratio > kMaximumLengthRatio || length_ratio < (1.0 / kMaximumLengthRatio)) cant_see |= 8;
+    if (length_ratio > kMaximumLengthRatio || length_ratio < (1.0 / kMaximumLengthRatio)) cant_see |= 4;   // kDistanceFail_
     const double dot = hLWi(0) * hLWi_orig(0) + hLWi(1) * hLWi_orig(1) + hLWi(2) * hLWi_orig(2);
     double angle = std::acos(dot / (mod * mod_o));
     angle = (angle >= 0.0 ? angle : -angle);
-    if (angle > kMaximumAngleDifference()) cant_see |= 16;
+    if (angle > kMaximumAngleDifference()) cant_see |= 8;  // kAngleFail_
     return cant_see;
   }
 };
@@ -596,7 +596,7 @@ struct Particle {
   void set_S(const Mat& Si) {
     Mat L;
     llt_lower(Si, L);
-    const Mat Li = lower_inverse(L);
+    const Mat Li = general_inverse(L);
     const Mat Sinv = mul(transpose(Li), Li);
     SInv[0] = Sinv(0, 0); SInv[1] = Sinv(0, 1); SInv[2] = Sinv(1, 1);
     const double a = Si(0, 0), b = Si(0, 1), c = Si(1, 0), d = Si(1, 1);
@@ -793,7 +793,7 @@ struct MonoSLAM {
   static void sinv_from_S(const Mat& S, double& a, double& b, double& c) {
     Mat L;
     llt_lower(S, L);
-    const Mat Li = lower_inverse(L);
+    const Mat Li = general_inverse(L);
     const Mat Sinv = mul(transpose(Li), Li);
     a = Sinv(0, 0); b = Sinv(0, 1); c = Sinv(1, 1);
   }
@@ -909,7 +909,7 @@ struct MonoSLAM {
     S = add(S, R_tot);
     Mat S_L;
     llt_lower(S, S_L);
-    const Mat S_Linv = lower_inverse(S_L);
+    const Mat S_Linv = general_inverse(S_L);
     const Mat Sinv = mul(transpose(S_Linv), S_Linv);
     const Mat W = mul(mul(P, Ht), Sinv);
     x = add(x, mul(W, nu_tot));

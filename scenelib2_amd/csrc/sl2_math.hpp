@@ -330,7 +330,7 @@ SL2_HD int visibility_test(const CameraParams& cam, const double xp[7], const do
   if (h[1] < 0.0 + kImageSearchBoundary || h[1] > (double)(cam.height - 1 - kImageSearchBoundary)) cant_see |= 2;
   double z[3], R[9], a[3], b[3];
   zeroedyi_only(xp, y, z);
-  if (z[2] <= 0) cant_see |= 4;
+  if (z[2] <= 0) cant_see |= 16;  // kBehindCameraFail_ (full_feature_model.h:74-78)
   quat_to_rot(&xp[3], R);
   for (int i = 0; i < 3; ++i) { double acc = 0.0; for (int k = 0; k < 3; ++k) acc += R[i * 3 + k] * z[k]; a[i] = acc; }
   zeroedyi_only(xp_orig, y, z);
@@ -339,27 +339,44 @@ SL2_HD int visibility_test(const CameraParams& cam, const double xp[7], const do
   const double mod = sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
   const double mod_o = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
   const double length_ratio = mod / mod_o;
-  if (length_ratio > kMaximumLengthRatio || length_ratio < (1.0 / kMaximumLengthRatio)) cant_see |= 8;
+  if (length_ratio > kMaximumLengthRatio || length_ratio < (1.0 / kMaximumLengthRatio)) cant_see |= 4;   // kDistanceFail_
   const double dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
   double angle = acos(dot / (mod * mod_o));
   angle = (angle >= 0.0 ? angle : -angle);
-  if (angle > kPi * 45.0 / 180.0) cant_see |= 16;
+  if (angle > kPi * 45.0 / 180.0) cant_see |= 8;  // kAngleFail_
   return cant_see;
 }
 
-// S^-1 of the 2x2 innovation covariance through its lower Cholesky factor
-// (monoslam.cpp:371-374).  Reads S00, S10, S11 only (Eigen::LLT reads the lower
-// triangle).  Returns (a,b,c) = (Sinv00, Sinv01, Sinv11).
+// S^-1 of the 2x2 innovation covariance as the reference forms it (monoslam.cpp:371-374): LLT of S (reads S00, S10, S11:
+// Eigen::LLT reads the lower triangle), the factor copied into a dense MatrixXd, `.inverse()` of THAT - which for a
+// dynamic-size matrix is Eigen's general inverse: LU with partial (row) pivoting, a unit-lower forward solve and an upper
+// backward solve (scaled by the reciprocal of the diagonal) against the permuted identity - and S^-1 = X^T X.  Written out
+// for the 2x2 factor [[p, 0], [q, r]]; oracle/dense.hpp (general_inverse) is the n x n statement of the same steps and
+// tests/test_device_math_host.py holds the two equal bit for bit.  Returns (a, b, c) = (Sinv00, Sinv01, Sinv11).
 SL2_HD void sinv_from_S(const double S[4], double* a, double* b, double* c) {
-  const double L00 = sqrt(S[0]);
-  const double L10 = S[2] / L00;
-  const double L11 = sqrt(S[3] - L10 * L10);
-  const double X00 = 1.0 / L00;
-  const double X11 = 1.0 / L11;
-  const double X10 = (0.0 - L10 * X00) / L11;
+  const double p = sqrt(S[0]);
+  const double q = S[2] / p;
+  const double r = sqrt(S[3] - q * q);
+  double X00, X01, X10, X11;
+  if (fabs(q) > fabs(p)) {  // pivot row 1: LU of [[q, r], [p, 0]]
+    const double l = p / q;
+    const double u11 = 0.0 - l * r;
+    const double iu = 1.0 / u11, iq = 1.0 / q;
+    X10 = 1.0 * iu;
+    X00 = (0.0 - r * X10) * iq;
+    X11 = (0.0 - l * 1.0) * iu;
+    X01 = (1.0 - r * X11) * iq;
+  } else {
+    const double l = q / p;
+    const double ir = 1.0 / r, ip = 1.0 / p;   // u11 = r - l * 0
+    X10 = (0.0 - l * 1.0) * ir;
+    X00 = 1.0 * ip;
+    X11 = 1.0 * ir;
+    X01 = 0.0;
+  }
   *a = X00 * X00 + X10 * X10;
-  *b = X00 * 0.0 + X10 * X11;
-  *c = 0.0 * 0.0 + X11 * X11;
+  *b = X00 * X01 + X10 * X11;
+  *c = X01 * X01 + X11 * X11;
 }
 
 // Search window of elliptical_search (monoslam.cpp:416-439).

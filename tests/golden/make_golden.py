@@ -1,18 +1,27 @@
-"""Regenerates the committed golden fixtures (run from the repo root: python tests/golden/make_golden.py).
+"""Regenerates the committed golden fixtures (run from the repo root, in the container that has /root/reference:
+`python tests/golden/make_golden.py`).
 
-* synth_seq5_sha256.txt   — SHA-256 of three rendered synthetic frames (pins the input generator).
-* oracle_shipped.npz      — the ORACLE's outputs on the reference's shipped scene (cfg values +
-                            known_patch*.pgm) for three GoOneStep calls on a deterministic frame.
-                            The reference itself cannot be run here (no Eigen/OpenCV/Pangolin), so this
-                            pins the oracle against regressions; it is not a reference output.
-* oracle_mapping.npz      — the ORACLE's event log of a 40-frame mapping run (tests/mapping_helpers.py, seed 7): per frame
-                            the counters (partial features, initialised, converted, deleted), the selected pixel, the
-                            total state size and the camera position; final total state and covariance.  The frames come
-                            from the synthetic generator (pinned by its own checksum); same status as above.
+The numeric fixtures are OUTPUTS OF THE REFERENCE ITSELF: oracle/_ref/libref.so is the reference's own translation units
+compiled unmodified from /root/reference (`make -C oracle ref`, see oracle/ref_glue.cpp; Eigen / OpenCV / Pangolin are
+stand-in headers under oracle/ref_shim, so "reference arithmetic" means the reference's code over the shim's fixed-order
+products).  /root/reference does not exist on the GPU box, hence the committed vectors.
+
+* synth_seq5_sha256.txt — SHA-256 of three rendered synthetic frames (pins the input generator).
+* ref_shipped.npz   — MonoSLAM::Init on the shipped cfg (data/SceneLib2.cfg values, known_patch*.pgm) + three GoOneStep
+                      calls on a deterministic frame: total state, total covariance, measurements per step.
+* ref_mapping.npz   — 40-frame run with enable_mapping (tests/mapping_helpers.py, seed 7): per frame the camera position,
+                      the selected pixel, partial-feature count and total state size from the reference; final total state
+                      and covariance from the reference.  The three event counters (initialised / converted / deleted)
+                      are bookkeeping the reference does not keep: they come from the oracle run on the same frames,
+                      which this script first checks against the reference frame by frame.
+* ref_seq100.npz    — 12 frames of a 100-feature sequence (n = 313, the BASELINE headline shape, 5 mm feature prior):
+                      per frame xv, the measured pixels and match flags; final total state; of the final 313 x 313
+                      covariance the vehicle block, the diagonal, the Frobenius norm and 256 sampled entries.
 """
 import hashlib
 import os
 import sys
+import tempfile
 
 import numpy as np
 
@@ -38,6 +47,32 @@ def shipped_scene_frame(oa, cfg, patches):
     return frame
 
 
+def shipped_cfg_with_absolute_identifiers(dst_dir):
+    text = open(os.path.join(HERE, "scenelib2_shipped.cfg")).read()
+    for i in range(4):   # identifiers are relative to the reference's working directory
+        text = text.replace("= known_patch%d.pgm" % i, "= " + os.path.join(HERE, "known_patch%d.pgm" % i))
+    path = os.path.join(dst_dir, "shipped_abs.cfg")
+    open(path, "w").write(text)
+    return path
+
+
+SEQ100 = dict(n_features=100, n_frames=12, seq_index=3, feature_sigma=0.005)
+
+
+def seq100_inputs():
+    from scenelib2_amd import synth
+    cam = synth.default_camera()
+    params = synth.default_params(SEQ100["n_features"])
+    spec, tpl, frames, _ = synth.make_sequence(cam, SEQ100["n_features"], SEQ100["n_frames"], seq_index=SEQ100["seq_index"],
+                                               tex=synth.make_texture())
+    return cam, params, spec, tpl, frames
+
+
+def seq100_sample_index(n=313, count=256):
+    rng = np.random.default_rng(313)
+    return rng.integers(0, n, count), rng.integers(0, n, count)
+
+
 def main():
     import oracle_api as oa
     from scenelib2_amd import synth
@@ -46,32 +81,66 @@ def main():
     cam = synth.default_camera()
     _, _, frames, _ = synth.make_sequence(cam, 24, 3, seq_index=5, tex=tex)
     open(os.path.join(HERE, "synth_seq5_sha256.txt"), "w").write(hashlib.sha256(frames.tobytes()).hexdigest() + "\n")
+
+    # ---- shipped scene through the reference's own Init
     cfg = load_config(os.path.join(HERE, "scenelib2_shipped.cfg"))
     patches = [read_pgm(os.path.join(HERE, "known_patch%d.pgm" % i)) for i in range(4)]
     frame = shipped_scene_frame(oa, cfg, patches)
-    o = oa.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], 10)
-    o.set_state(cfg["xv"], cfg["Pxx"])
-    for f, p in zip(cfg["features"], patches):
-        o.add_known_feature(f["y"], f["xp_org"], p)
+    with tempfile.TemporaryDirectory() as td:
+        r = oa.RefSLAM(cfg["cam"], cfg["params"]["delta_t"], 10, cfg_path=shipped_cfg_with_absolute_identifiers(td))
     xs, Ps, zs = [], [], []
     for _ in range(3):
-        o.go_one_step(frame, True)
-        xs.append(o.total_state())
-        Ps.append(o.total_covariance())
-        zs.append(np.array([o.feature(i)["z"] for i in range(o.num_features)]))
-    np.savez_compressed(os.path.join(HERE, "oracle_shipped.npz"), frame=frame, x=np.array(xs), P=np.array(Ps), z=np.array(zs))
+        r.go_one_step(frame, True)
+        xs.append(r.total_state())
+        Ps.append(r.total_covariance())
+        zs.append(np.array([r.feature(i)["z"] for i in range(r.num_features)]))
+    np.savez_compressed(os.path.join(HERE, "ref_shipped.npz"), frame=frame, x=np.array(xs), P=np.array(Ps), z=np.array(zs))
+
+    # ---- mapping run: reference numbers, oracle counters (cross-checked)
     from mapping_helpers import make_mapping_sequence, oracle_for
     cam_m, params_m, spec_m, frames_m, templates_m = make_mapping_sequence(n_frames=40)
     s = oracle_for(cam_m, params_m, spec_m, templates_m, oa)
+    r = oa.RefSLAM(cam_m, params_m["delta_t"], params_m["number_of_features_to_select"])
+    r.set_mapping_params(params_m)
+    r.set_state(spec_m.xv0, spec_m.Pxx0)
+    for i in range(spec_m.n_features):
+        r.add_known_feature(spec_m.feat_y[i], spec_m.xp_org()[i], templates_m[i])
     events, pos = [], []
     for k in range(1, 41):
         s.go_one_step(frames_m[k], True, True)
-        info = s.mapping_info()
-        events.append([info["n_partial"], info["initialised"], info["converted"], info["deleted"], info["uu"], info["vv"],
-                       s.total_state_size])
-        pos.append(s.get_state()[0][:3])
-    np.savez_compressed(os.path.join(HERE, "oracle_mapping.npz"), events=np.array(events, np.int32), pos=np.array(pos),
-                        x=s.total_state(), P=s.total_covariance(), frames_sha256=hashlib.sha256(frames_m.tobytes()).hexdigest())
+        r.go_one_step(frames_m[k], True, True)
+        info, iref = s.mapping_info(), r.mapping_info()
+        assert info["n_partial"] == iref["n_partial"] and s.total_state_size == r.total_state_size, k
+        assert np.array_equal(s.feature_kinds(), r.feature_kinds()), k
+        if iref["location_selected"]:
+            assert (info["uu"], info["vv"]) == (iref["uu"], iref["vv"]), k
+        events.append([iref["n_partial"], info["initialised"], info["converted"], info["deleted"], info["uu"], info["vv"],
+                       r.total_state_size])
+        pos.append(r.get_state()[0][:3])
+    np.savez_compressed(os.path.join(HERE, "ref_mapping.npz"), events=np.array(events, np.int32), pos=np.array(pos),
+                        x=r.total_state(), P=r.total_covariance(), frames_sha256=hashlib.sha256(frames_m.tobytes()).hexdigest())
+
+    # ---- the headline shape
+    cam, params, spec, tpl, frames = seq100_inputs()
+    N = SEQ100["n_features"]
+    r = oa.RefSLAM(cam, params["delta_t"], N)
+    r.set_state(spec.xv0, spec.Pxx0)
+    for i in range(N):
+        r.add_known_feature(spec.feat_y[i], spec.poses[0], tpl[i])
+    for i in range(N):
+        r.set_feature_Pyy(i, np.eye(3) * SEQ100["feature_sigma"] ** 2)
+    xv, z, ok = [], [], []
+    for k in range(SEQ100["n_frames"]):
+        r.go_one_step(frames[k], False)
+        xv.append(r.get_state()[0])
+        f = [r.feature(i) for i in range(N)]
+        ok.append(np.array([q["selected"] and q["success"] for q in f]))
+        z.append(np.array([q["z"] for q in f]))
+    P = r.total_covariance()
+    ii, jj = seq100_sample_index(P.shape[0])
+    np.savez_compressed(os.path.join(HERE, "ref_seq100.npz"), xv=np.array(xv), z=np.array(z), ok=np.array(ok),
+                        x=r.total_state(), Pxx=P[:13, :13], Pdiag=np.diag(P).copy(), Pfro=np.linalg.norm(P),
+                        Psample=P[ii, jj], frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
     print("golden fixtures written")
 
 

@@ -33,6 +33,62 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
 
 
+def _declare(L):
+    """argtypes / restypes of the flat C interface; `L` answers to the orc_* names (the reference build answers through
+    _Prefixed, which maps them to ref_*)."""
+    L.orc_create.restype = C.c_void_p
+    L.orc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
+                             C.c_double, C.c_int, C.c_double, C.c_int]
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_set_state.argtypes = [C.c_void_p, c_dp, c_dp]
+    L.orc_get_state.argtypes = [C.c_void_p, c_dp, c_dp]
+    L.orc_add_known_feature.argtypes = [C.c_void_p, c_dp, c_dp, c_u8p]
+    L.orc_go_one_step.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
+    for f in ("orc_num_features", "orc_num_selected", "orc_total_state_size", "orc_num_visible",
+              "orc_measurement_size"):
+        getattr(L, f).argtypes = [C.c_void_p]
+        getattr(L, f).restype = C.c_int
+    L.orc_get_total_state.argtypes = [C.c_void_p, c_dp]
+    L.orc_get_total_covariance.argtypes = [C.c_void_p, c_dp]
+    L.orc_get_feature.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
+    L.orc_get_selected_labels.argtypes = [C.c_void_p, c_ip]
+    L.orc_trajectory.argtypes = [C.c_void_p, c_dp, C.c_int]
+    L.orc_trajectory.restype = C.c_int
+    L.orc_kalman_filter_predict.argtypes = [C.c_void_p]
+    L.orc_auto_select_n_features.argtypes = [C.c_void_p, C.c_int]
+    L.orc_auto_select_n_features.restype = C.c_int
+    L.orc_make_measurements.argtypes = [C.c_void_p, c_u8p]
+    L.orc_make_measurements.restype = C.c_int
+    L.orc_kalman_filter_update.argtypes = [C.c_void_p]
+    L.orc_normalise_state.argtypes = [C.c_void_p]
+    L.orc_delete_bad_features.argtypes = [C.c_void_p]
+    L.orc_delete_feature.argtypes = [C.c_void_p, C.c_int]
+    L.orc_set_feature_Pyy.argtypes = [C.c_void_p, C.c_int, c_dp]
+    L.orc_set_feature_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_correlate2_warning.restype = C.c_double
+    L.orc_correlate2_warning.argtypes = [C.c_int] * 6 + [c_u8p, C.c_int, c_u8p, C.c_int, c_dp, c_dp]
+    L.orc_elliptical_search.restype = C.c_int
+    L.orc_elliptical_search.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, c_dp, C.c_double, C.c_double,
+                                        C.c_double, c_ip, c_dp]
+    L.orc_sinv_from_S.argtypes = [c_dp, c_dp]
+    L.orc_set_mapping_params.argtypes = [C.c_void_p, c_ip, c_dp]
+    L.orc_get_mapping_info.argtypes = [C.c_void_p, c_ip]
+    L.orc_get_partial_feature.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, C.c_int]
+    L.orc_get_partial_feature.restype = C.c_int
+    L.orc_get_feature_kinds.argtypes = [C.c_void_p, c_ip]
+    L.orc_get_feature_patch.argtypes = [C.c_void_p, C.c_int, c_u8p]
+    L.orc_find_best_patch.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_dp]
+    L.orc_search_multiple_ellipses.restype = C.c_longlong
+    L.orc_search_multiple_ellipses.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, C.c_int, c_dp, c_dp, c_ip, c_dp]
+    L.orc_drand48_sequence.argtypes = [C.c_long, C.c_int, c_dp]
+    L.orc_motion_model.argtypes = [c_dp, C.c_double, c_dp, c_dp, c_dp]
+    L.orc_dqnorm_by_dq.argtypes = [c_dp, c_dp]
+    L.orc_measurement_model.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.orc_run_sequences.restype = C.c_double
+    L.orc_run_sequences.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(c_u8p), C.c_int, C.c_size_t,
+                                    C.c_int, c_dp]
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -40,67 +96,60 @@ def lib():
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
-        L.orc_create.restype = C.c_void_p
-        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
-                                 C.c_double, C.c_int, C.c_double, C.c_int]
-        L.orc_destroy.argtypes = [C.c_void_p]
-        L.orc_set_state.argtypes = [C.c_void_p, c_dp, c_dp]
-        L.orc_get_state.argtypes = [C.c_void_p, c_dp, c_dp]
-        L.orc_add_known_feature.argtypes = [C.c_void_p, c_dp, c_dp, c_u8p]
-        L.orc_go_one_step.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
-        for f in ("orc_num_features", "orc_num_selected", "orc_total_state_size", "orc_num_visible",
-                  "orc_measurement_size"):
-            getattr(L, f).argtypes = [C.c_void_p]
-            getattr(L, f).restype = C.c_int
-        L.orc_get_total_state.argtypes = [C.c_void_p, c_dp]
-        L.orc_get_total_covariance.argtypes = [C.c_void_p, c_dp]
-        L.orc_get_feature.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
-        L.orc_get_selected_labels.argtypes = [C.c_void_p, c_ip]
-        L.orc_trajectory.argtypes = [C.c_void_p, c_dp, C.c_int]
-        L.orc_trajectory.restype = C.c_int
+        _declare(L)
         L.orc_get_diag.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_dp]
-        L.orc_kalman_filter_predict.argtypes = [C.c_void_p]
-        L.orc_auto_select_n_features.argtypes = [C.c_void_p, C.c_int]
-        L.orc_auto_select_n_features.restype = C.c_int
-        L.orc_make_measurements.argtypes = [C.c_void_p, c_u8p]
-        L.orc_make_measurements.restype = C.c_int
-        L.orc_kalman_filter_update.argtypes = [C.c_void_p]
-        L.orc_normalise_state.argtypes = [C.c_void_p]
-        L.orc_delete_bad_features.argtypes = [C.c_void_p]
-        L.orc_delete_feature.argtypes = [C.c_void_p, C.c_int]
-        L.orc_set_feature_Pyy.argtypes = [C.c_void_p, C.c_int, c_dp]
-        L.orc_set_feature_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-        L.orc_correlate2_warning.restype = C.c_double
-        L.orc_correlate2_warning.argtypes = [C.c_int] * 6 + [c_u8p, C.c_int, c_u8p, C.c_int, c_dp, c_dp]
-        L.orc_elliptical_search.restype = C.c_int
-        L.orc_elliptical_search.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, c_dp, C.c_double, C.c_double,
-                                            C.c_double, c_ip, c_dp]
-        L.orc_sinv_from_S.argtypes = [c_dp, c_dp]
-        L.orc_set_mapping_params.argtypes = [C.c_void_p, c_ip, c_dp]
-        L.orc_get_mapping_info.argtypes = [C.c_void_p, c_ip]
-        L.orc_get_partial_feature.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp, c_dp, C.c_int]
-        L.orc_get_partial_feature.restype = C.c_int
-        L.orc_get_feature_kinds.argtypes = [C.c_void_p, c_ip]
-        L.orc_get_feature_patch.argtypes = [C.c_void_p, C.c_int, c_u8p]
-        L.orc_find_best_patch.argtypes = [c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_dp]
-        L.orc_search_multiple_ellipses.restype = C.c_longlong
-        L.orc_search_multiple_ellipses.argtypes = [c_u8p, C.c_int, C.c_int, c_u8p, C.c_int, c_dp, c_dp, c_ip, c_dp]
-        L.orc_drand48_sequence.argtypes = [C.c_long, C.c_int, c_dp]
-        L.orc_motion_model.argtypes = [c_dp, C.c_double, c_dp, c_dp, c_dp]
-        L.orc_dqnorm_by_dq.argtypes = [c_dp, c_dp]
-        L.orc_measurement_model.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
-        L.orc_run_sequences.restype = C.c_double
-        L.orc_run_sequences.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(c_u8p), C.c_int, C.c_size_t,
-                                        C.c_int, c_dp]
         _LIB = L
     return _LIB
+
+
+class _Prefixed:
+    """The reference build (oracle/_ref/libref.so) exports the same interface under ref_*."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        if name.startswith("orc_"):
+            return getattr(self._cdll, "ref_" + name[4:])
+        return getattr(self._cdll, name)
+
+
+_REF_DIR = os.path.join(_ORACLE_DIR, "_ref")
+_REFLIB = None
+
+
+def ref_available():
+    """libref.so exists (it is built where /root/reference is and travels with the snapshot) or can be built."""
+    return os.path.exists(os.path.join(_REF_DIR, "libref.so")) or os.path.isdir("/root/reference/scenelib2")
+
+
+def ref_lib():
+    """The REFERENCE's own translation units behind the same flat interface (see oracle/ref_glue.cpp)."""
+    global _REFLIB
+    if _REFLIB is None:
+        path = os.path.join(_REF_DIR, "libref.so")
+        if os.path.isdir("/root/reference/scenelib2"):
+            subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "ref"])
+        if not os.path.exists(path):
+            raise FileNotFoundError("oracle/_ref/libref.so is absent and /root/reference is not here to build it")
+        L = _Prefixed(C.CDLL(path))
+        _declare(L)
+        L.ref_create_from_cfg.restype = C.c_void_p
+        L.ref_create_from_cfg.argtypes = [C.c_char_p]
+        L.ref_initialise_feature.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
+        L.ref_initialise_auto_feature.argtypes = [C.c_void_p, c_u8p]
+        L.ref_save_patch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_u8p]
+        L.ref_save_patch.restype = C.c_int
+        L.ref_sinv_from_S4.argtypes = [c_dp, c_dp, c_dp]
+        _REFLIB = L
+    return _REFLIB
 
 
 class OracleSLAM:
     """One MonoSLAM instance of the oracle (single sequence, like the reference)."""
 
-    def __init__(self, cam, delta_t, n_select):
-        self.L = lib()
+    def __init__(self, cam, delta_t, n_select, L=None):
+        self.L = L if L is not None else lib()
         self.cam = dict(cam)
         self.h = self.L.orc_create(cam["width"], cam["height"], cam["fku"], cam["fkv"], cam["u0"], cam["v0"],
                                    cam["kd1"], cam["sd"], delta_t, n_select)
@@ -257,8 +306,37 @@ class OracleSLAM:
         self.L.orc_set_feature_counters(self.h, idx, attempted, successful)
 
 
-def correlate2_warning(patch, image, x1, y1, x0=0, y0=0, x0lim=11, y0lim=11):
-    L = lib()
+class RefSLAM(OracleSLAM):
+    """One MonoSLAM object of the REFERENCE ITSELF (oracle/_ref/libref.so): same interface as OracleSLAM."""
+
+    def __init__(self, cam, delta_t, n_select, cfg_path=None):
+        L = ref_lib()
+        if cfg_path is None:
+            OracleSLAM.__init__(self, cam, delta_t, n_select, L=L)
+        else:  # the reference's own MonoSLAM::Init on a cfg file
+            self.L = L
+            self.cam = dict(cam)
+            self.h = L.ref_create_from_cfg(os.fsencode(cfg_path))
+
+    def diag(self):
+        raise NotImplementedError("the reference keeps no counters")
+
+    def initialise_feature(self, frame, u, v):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        self.L.ref_initialise_feature(self.h, _u8(f), int(u), int(v))
+
+    def initialise_auto_feature(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        self.L.ref_initialise_auto_feature(self.h, _u8(f))
+
+    def save_patch(self, label, directory):
+        p = np.zeros(121, dtype=np.uint8)
+        ok = self.L.ref_save_patch(self.h, int(label), os.fsencode(directory), _u8(p))
+        return bool(ok == 1), p.reshape(11, 11)
+
+
+def correlate2_warning(patch, image, x1, y1, x0=0, y0=0, x0lim=11, y0lim=11, L=None):
+    L = L if L is not None else lib()
     p0 = np.ascontiguousarray(patch, dtype=np.uint8)
     p1 = np.ascontiguousarray(image, dtype=np.uint8)
     sd0 = C.c_double(0)
@@ -268,9 +346,9 @@ def correlate2_warning(patch, image, x1, y1, x0=0, y0=0, x0lim=11, y0lim=11):
     return c, sd0.value, sd1.value
 
 
-def elliptical_search(image, patch, centre, a, b, c):
+def elliptical_search(image, patch, centre, a, b, c, L=None):
     """Returns dict(ok,u,v,ncand,hw,hh,corr) — monoslam.cpp:401-477."""
-    L = lib()
+    L = L if L is not None else lib()
     img = np.ascontiguousarray(image, dtype=np.uint8)
     p = np.ascontiguousarray(patch, dtype=np.uint8).reshape(121)
     ce = np.ascontiguousarray(centre, dtype=np.float64)
@@ -282,10 +360,10 @@ def elliptical_search(image, patch, centre, a, b, c):
                 corr=corr.value)
 
 
-def find_best_patch(image, region, uv_in=(-1, -1)):
+def find_best_patch(image, region, uv_in=(-1, -1), L=None):
     """monoslam.cpp:1070-1192.  region = (ustart, vstart, ufinish, vfinish).  Returns (u, v, evbest); (u, v) keep
     uv_in when no position scores."""
-    L = lib()
+    L = L if L is not None else lib()
     img = np.ascontiguousarray(image, dtype=np.uint8)
     uv = np.array(uv_in, dtype=np.int32)
     ev = C.c_double(0)
@@ -294,10 +372,10 @@ def find_best_patch(image, region, uv_in=(-1, -1)):
     return int(uv[0]), int(uv[1]), ev.value
 
 
-def search_multiple_ellipses(image, patch, puinv, centre):
+def search_multiple_ellipses(image, patch, puinv, centre, L=None):
     """SearchMultipleOverlappingEllipses::search over the given ellipses.  Returns (result [n][3] = flag, u, v;
     corrmax [n]; number of positions correlated)."""
-    L = lib()
+    L = L if L is not None else lib()
     img = np.ascontiguousarray(image, dtype=np.uint8)
     p = np.ascontiguousarray(patch, dtype=np.uint8).reshape(121)
     pu = np.ascontiguousarray(puinv, dtype=np.float64).reshape(-1, 3)
@@ -310,22 +388,22 @@ def search_multiple_ellipses(image, patch, puinv, centre):
     return out, corr, int(ncorr)
 
 
-def drand48_sequence(seed, n):
+def drand48_sequence(seed, n, L=None):
     out = np.zeros(n)
-    lib().orc_drand48_sequence(int(seed), int(n), _dp(out))
+    (L if L is not None else lib()).orc_drand48_sequence(int(seed), int(n), _dp(out))
     return out
 
 
-def sinv_from_S(S):
-    L = lib()
+def sinv_from_S(S, L=None):
+    L = L if L is not None else lib()
     S4 = np.ascontiguousarray(S, dtype=np.float64).reshape(4)
     abc = np.zeros(3)
     L.orc_sinv_from_S(_dp(S4), _dp(abc))
     return abc
 
 
-def motion_model(xv, dt):
-    L = lib()
+def motion_model(xv, dt, L=None):
+    L = L if L is not None else lib()
     xv = np.ascontiguousarray(xv, dtype=np.float64)
     f = np.zeros(13)
     F = np.zeros((13, 13))
@@ -334,8 +412,8 @@ def motion_model(xv, dt):
     return f, F, Q
 
 
-def dqnorm_by_dq(q):
-    L = lib()
+def dqnorm_by_dq(q, L=None):
+    L = L if L is not None else lib()
     q = np.ascontiguousarray(q, dtype=np.float64)
     J = np.zeros((4, 4))
     L.orc_dqnorm_by_dq(_dp(q), _dp(J))
@@ -347,8 +425,8 @@ def cam8(cam):
                      cam["sd"]], dtype=np.float64)
 
 
-def measurement_model(cam, xp, y, xp_org=None):
-    L = lib()
+def measurement_model(cam, xp, y, xp_org=None, L=None):
+    L = L if L is not None else lib()
     xp = np.ascontiguousarray(xp, dtype=np.float64)
     y = np.ascontiguousarray(y, dtype=np.float64)
     xo = xp if xp_org is None else np.ascontiguousarray(xp_org, dtype=np.float64)
@@ -359,9 +437,9 @@ def measurement_model(cam, xp, y, xp_org=None):
                 R=float(out[22]), vis=int(out[23]))
 
 
-def run_sequences(slams, frames_list, nthreads=1, want_traj=True):
+def run_sequences(slams, frames_list, nthreads=1, want_traj=True, L=None):
     """frames_list[s]: uint8 array [nframes][H][W]. Returns (seconds, traj[nseq][nframes][3])."""
-    L = lib()
+    L = L if L is not None else lib()
     nseq = len(slams)
     nframes = frames_list[0].shape[0]
     fb = int(np.prod(frames_list[0].shape[1:]))

@@ -143,10 +143,10 @@ def test_mapping_soak_160_frames():
 
 
 def test_engine_matches_committed_mapping_golden():
-    """The HIP path against the committed event log of the 40-frame mapping run (tests/golden/oracle_mapping.npz)."""
+    """The HIP path against the committed event log of the 40-frame mapping run (tests/golden/ref_mapping.npz)."""
     from conftest import golden_path
     from scenelib2_amd import Engine
-    g = np.load(golden_path("oracle_mapping.npz"))
+    g = np.load(golden_path("ref_mapping.npz"))
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
     eng = Engine(cam, params, 1, 32)
     eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])

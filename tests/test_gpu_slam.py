@@ -256,10 +256,10 @@ def test_full_size_batch_properties():
 
 
 def test_engine_matches_committed_golden_fixture():
-    """The HIP path against the committed golden vectors (tests/golden/oracle_shipped.npz): the
-    reference's shipped scene, three GoOneStep calls."""
+    """The HIP path against REFERENCE outputs (tests/golden/ref_shipped.npz, generated by the reference's own
+    MonoSLAM::Init + GoOneStep compiled into oracle/_ref/libref.so): the shipped scene, three GoOneStep calls."""
     from scenelib2_amd.config import load_config, read_pgm
-    g = np.load(golden_path("oracle_shipped.npz"))
+    g = np.load(golden_path("ref_shipped.npz"))
     m = MonoSLAM(max_features=8).Init(golden_path("scenelib2_shipped.cfg"), template_dirs=[golden_path("")])
     for k in range(3):
         m.GoOneStep(g["frame"], True, False)
@@ -267,6 +267,40 @@ def test_engine_matches_committed_golden_fixture():
         assert rel_fro(m.construct_total_covariance(), g["P"][k]) < TOL_P
         assert np.array_equal(np.array([f.z_ for f in m.feature_list_]), g["z"][k])
     assert m.successful_measurement_vector_size_ == 8
+
+
+def test_engine_matches_reference_golden_at_the_headline_shape():
+    """The HIP path against REFERENCE outputs at n = 313 (100 features, 5 mm prior, 12 frames): tests/golden/ref_seq100.npz
+    was produced by the reference's own translation units (oracle/_ref/libref.so, tests/golden/make_golden.py).  The same
+    sequence runs as sequence 1 of a batch of 3 so that batching cannot hide behind it."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_path(""))
+    import make_golden as mg
+    g = np.load(golden_path("ref_seq100.npz"))
+    cam, params, spec, tpl, frames = mg.seq100_inputs()
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+    N, B = mg.SEQ100["n_features"], 3
+    eng = Engine(cam, params, B, N)
+    eng.set_vehicle_state(np.tile(spec.xv0, (B, 1)), np.tile(spec.Pxx0, (B, 1, 1)))
+    eng.add_known_features(np.tile(spec.feat_y, (B, 1, 1)), np.tile(spec.poses[0], (B, N, 1)), np.tile(tpl, (B, 1, 1, 1)))
+    eng.set_feature_covariances(np.tile(np.eye(3) * mg.SEQ100["feature_sigma"] ** 2, (B, N, 1, 1)))
+    for k in range(mg.SEQ100["n_frames"]):
+        eng.go_one_step(np.tile(frames[k], (B, 1, 1)))
+        xe, _ = eng.get_vehicle_state(1, 1)
+        assert np.abs(xe[0] - g["xv"][k]).max() <= TOL_X, k
+        f = eng.features(1)
+        ok = np.array([q["selected"] and q["success"] for q in f])
+        assert np.array_equal(ok, g["ok"][k]), k
+        assert np.array_equal(np.array([q["z"] for q in f])[ok], g["z"][k][ok]), k
+    P = eng.total_covariance(1)
+    ii, jj = mg.seq100_sample_index(P.shape[0])
+    scale = np.abs(g["Pdiag"]).max()
+    assert np.abs(eng.total_state(1) - g["x"]).max() <= TOL_X
+    assert np.abs(P[:13, :13] - g["Pxx"]).max() <= TOL_P * np.abs(g["Pxx"]).max()
+    assert np.abs(np.diag(P) - g["Pdiag"]).max() <= TOL_P * scale
+    assert abs(np.linalg.norm(P) - float(g["Pfro"])) <= TOL_P * float(g["Pfro"])
+    assert np.abs(P[ii, jj] - g["Psample"]).max() <= TOL_P * scale
 
 
 @pytest.mark.gpu

@@ -204,11 +204,12 @@ def test_deletion_rule_and_skip_quirk(oracle):
 
 
 def test_oracle_matches_committed_golden_run(oracle):
-    """Regression pin: the oracle's three-step run on the shipped scene (tests/golden/make_golden.py)."""
+    """The oracle against REFERENCE outputs: three GoOneStep calls on the shipped scene, generated by the reference's
+    own MonoSLAM::Init + GoOneStep (oracle/_ref/libref.so, tests/golden/make_golden.py)."""
     import os
     from conftest import golden_path
     from scenelib2_amd.config import load_config, read_pgm
-    g = np.load(golden_path("oracle_shipped.npz"))
+    g = np.load(golden_path("ref_shipped.npz"))
     cfg = load_config(golden_path("scenelib2_shipped.cfg"))
     o = oracle.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], 10)
     o.set_state(cfg["xv"], cfg["Pxx"])
@@ -278,3 +279,36 @@ def test_predict_equals_F_P_Ft_plus_Q_in_numpy(oracle):
     xv1, _ = s.get_state()
     assert np.array_equal(xv1, f)
     assert np.abs(s.total_covariance() - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-30)
+
+
+def test_oracle_matches_reference_golden_at_the_headline_shape(oracle):
+    """100 features (n = 313), 12 frames, against tests/golden/ref_seq100.npz = outputs of the reference's own code."""
+    import hashlib
+    import sys
+    from conftest import golden_path
+    sys.path.insert(0, golden_path(""))
+    import make_golden as mg
+    g = np.load(golden_path("ref_seq100.npz"))
+    cam, params, spec, tpl, frames = mg.seq100_inputs()
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+    N = mg.SEQ100["n_features"]
+    o = oracle.OracleSLAM(cam, params["delta_t"], N)
+    o.set_state(spec.xv0, spec.Pxx0)
+    for i in range(N):
+        o.add_known_feature(spec.feat_y[i], spec.poses[0], tpl[i])
+    for i in range(N):
+        o.set_feature_Pyy(i, np.eye(3) * mg.SEQ100["feature_sigma"] ** 2)
+    for k in range(mg.SEQ100["n_frames"]):
+        o.go_one_step(frames[k], False)
+        assert np.abs(o.get_state()[0] - g["xv"][k]).max() <= 1e-12, k
+        f = [o.feature(i) for i in range(N)]
+        ok = np.array([q["selected"] and q["success"] for q in f])
+        assert np.array_equal(ok, g["ok"][k]), k
+        assert np.array_equal(np.array([q["z"] for q in f])[ok], g["z"][k][ok]), k
+    P = o.total_covariance()
+    ii, jj = mg.seq100_sample_index(P.shape[0])
+    assert np.abs(o.total_state() - g["x"]).max() <= 1e-12
+    assert np.abs(P[:13, :13] - g["Pxx"]).max() <= 1e-12 * np.abs(g["Pxx"]).max()
+    assert np.abs(np.diag(P) - g["Pdiag"]).max() <= 1e-12 * np.abs(g["Pdiag"]).max()
+    assert abs(np.linalg.norm(P) - float(g["Pfro"])) <= 1e-12 * float(g["Pfro"])
+    assert np.abs(P[ii, jj] - g["Psample"]).max() <= 1e-12 * np.abs(g["Pdiag"]).max()

@@ -70,11 +70,12 @@ def test_camera_still_tracks_with_mapping_on(run):
 
 
 def test_oracle_matches_committed_mapping_golden():
-    """Regression pin of the feature-initialisation oracle: the per-frame event log and the final state of the 40-frame
-    mapping run committed in tests/golden/oracle_mapping.npz (tests/golden/make_golden.py)."""
+    """The feature-initialisation oracle against REFERENCE outputs: the per-frame log and the final state of the 40-frame
+    mapping run committed in tests/golden/ref_mapping.npz (generated from oracle/_ref/libref.so, the reference's own
+    translation units, by tests/golden/make_golden.py)."""
     import hashlib
     from conftest import golden_path
-    g = np.load(golden_path("oracle_mapping.npz"))
+    g = np.load(golden_path("ref_mapping.npz"))
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])     # same input bytes
     s = oracle_for(cam, params, spec, templates, oa)

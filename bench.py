@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--features", type=int, default=100)
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--height", type=int, default=240)
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per core, max 32; 0: skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per hardware thread of the host; 0: skip)")
     ap.add_argument("--cpu-frames", type=int, default=25, help="frames of the CPU-baseline / parity sample")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--feature-sigma", type=float, default=0.005,
@@ -47,8 +47,74 @@ def parse_args():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_env(rank, n, port, base=None):
+    """Environment of rank `rank` of an n-rank single-node job (what torch.distributed.run would export)."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def visible_devices():
+    """HIP devices visible to this process, without creating a context in the launcher (rocm-smi free): asks a child."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch;print(torch.cuda.device_count())"], capture_output=True,
+                             text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
+def spawn_ranks(n, argv=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU, RCCL between them.
+    Rank 0's stdout (the one JSON line) is passed through; the exit code is non-zero if any rank fails."""
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    ndev = visible_devices()
+    if ndev < n and os.environ.get("SL2_BENCH_BACKEND") != "gloo":
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible\n" % (n, ndev))
+        return 3
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=launcher_env(r, n, port),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    return rc
+
+
+def workload_name(B, W, H, N, world):
+    """Which BASELINE.json configuration a run corresponds to (configs[1..4]); anything else is named by its shape."""
+    shape = "%d independent %dx%d synthetic sequences per GPU, %d features each" % (B, W, H, N)
+    if (W, H, N) == (320, 240, 100):
+        if B == 1:
+            return "BASELINE configs[1]: single 320x240 synthetic sequence, 100 features"
+        return ("BASELINE configs[2]: " if B == 1024 else "BASELINE configs[2] shape at batch %d: " % B) + shape
+    if (W, H, N) == (640, 480, 200):
+        return "BASELINE configs[3] (8192 sequences over 8 GPUs = 1024 per GPU)%s: %s" % ("" if B == 1024 else " at batch %d" % B, shape)
+    if (W, H, N) == (1280, 720, 500):
+        return "BASELINE configs[4] (4096 sequences over 8 GPUs = 512 per GPU)%s: %s" % ("" if B == 512 else " at batch %d" % B, shape)
+    return "custom: " + shape
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
     import torch  # first: one shared HIP runtime (scenelib2_amd/_lib.py)
     import torch.distributed as dist
     from scenelib2_amd import Engine, _lib, sharding, synth
@@ -61,6 +127,8 @@ def main():
         dist.init_process_group(backend)
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if world > torch.cuda.device_count() and os.environ.get("SL2_BENCH_BACKEND") != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d HIP device(s): one rank per GPU" % (world, torch.cuda.device_count()))
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     tdev = torch.device("cuda", dev)
@@ -237,77 +305,108 @@ def main():
         # HBM traffic from the committed PMC pass of this same command (profiles/pmc_traffic.json; rocprofv3
         # cannot be nested inside this process), corrected as MI355X_MICROARCH.md prescribes
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            pmc_file = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc = pmc_file["kernels"]
+            pmc_meta = pmc_file.get("meta", {"shape": [1024, 320, 240, 100], "git": "b0a562c (round 1, v12)"})
             for rf in (roof, roof_search):
                 if rf and rf.get("kernel"):
                     # the profiling scope name is a prefix of the kernel symbol (k_fwdsub -> k_fwdsub_lds, ...)
                     cands = [kn for kn in pmc if kn.startswith(rf["kernel"])]
                     key = max(cands, key=lambda kn: pmc[kn].get("hbm_bytes", 0)) if cands else None
-                    if key and B == 1024 and N == 100:
+                    if key and pmc_meta.get("shape") == [B, W, H, N]:
                         rf["traffic"] = pmc[key]["hbm_bytes"]
-                        rf["traffic_source"] = "profiles/pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+                        rf["traffic_measured_in_run"] = False
+                        rf["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command "
+                                                "(FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, bytes per "
+                                                "launch), library git %s" % pmc_meta.get("git", "unknown"))
         except Exception:
             pass
 
-        # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1 only) ----
+        # ---- CPU baseline on the box's own host cores, in the same run (rank 0, N = 1 only): a bounded sample of the same
+        # workload, one sequence per hardware thread.  kind "reference" = the reference's own translation units
+        # (oracle/_ref/libref.so, built from /root/reference where it exists and shipped with the snapshot); "port" = the
+        # oracle restatement when that library is absent.  Reported baseline, not the target.
         cpu = None
         parity = None
         ncores = os.cpu_count() or 1
-        sample = args.cpu_sample if args.cpu_sample >= 0 else min(ncores, 32, B)
+        sample = args.cpu_sample if args.cpu_sample >= 0 else min(ncores, B)
         if world == 1 and sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_api as oa
-            sample = min(sample, B)
-            # the same bytes the GPU consumed: frames[k][b] for the first `sample` sequences
-            # bounded CPU sample: the first frames of the run (about 25 s of core time at 32 sequences x 25 frames)
-            cpu_frames = min(n_frames, args.cpu_frames)
+            use_ref = oa.ref_available()
+            if use_ref:
+                try:
+                    oa.ref_lib()
+                except Exception:
+                    use_ref = False
+            make = (lambda: oa.RefSLAM(cam, params["delta_t"], N)) if use_ref else (lambda: oa.OracleSLAM(cam, params["delta_t"], N))
+            # bounded: about 10-30 s of wall time (cost per sequence-frame grows like n^3), at most 2 GB of frames on the host
+            n_state = 13 + 3 * N
+            cpu_frames = min(n_frames, args.cpu_frames if N <= 100 else max(2, int(args.cpu_frames * (313.0 / n_state) ** 3 + 0.5)))
+            sample = max(1, min(sample, B, int(2e9 // (fb * (cpu_frames + 1)))))
+            # the same bytes the GPU consumed: frames[k][b] for the first `sample` sequences, the first frames of the run
             allf = np.stack([d_frames.download((sample, H, W), np.uint8, offset=k * B * fb) for k in range(cpu_frames + 1)])
-            slams, frames_list = [], []
-            for b in range(sample):
-                s = oa.OracleSLAM(cam, params["delta_t"], N)
+
+            def build(b):
+                s = make()
                 s.set_state(specs[b].xv0, specs[b].Pxx0)
                 xo = specs[b].xp_org()
                 for i in range(N):
                     s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
-                    if args.feature_sigma > 0.0:
-                        s.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
-                slams.append(s)
-                frames_list.append(np.ascontiguousarray(allf[1:, b]))
-            nthreads = min(ncores, sample)
-            secs, traj = oa.run_sequences(slams, frames_list, nthreads=nthreads)
-            cpu = dict(value=sample * cpu_frames / secs, unit="frames/s", cores=nthreads, kind="port",
-                       sample="%d sequences x %d frames (320x240, %d features) of this run's input, one oracle instance per thread"
-                              % (sample, cpu_frames, N),
-                       seconds=secs, single_thread_frames_per_s=None)
-            # 8(d)(i): one sequence on one thread (the reference's own single-threaded design)
-            s1 = oa.OracleSLAM(cam, params["delta_t"], N)
-            s1.set_state(specs[0].xv0, specs[0].Pxx0)
-            xo = specs[0].xp_org()
-            for i in range(N):
-                s1.add_known_feature(specs[0].feat_y[i], xo[i], templates[0][i])
                 if args.feature_sigma > 0.0:
-                    s1.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
-            secs1, _ = oa.run_sequences([s1], frames_list[:1], nthreads=1)
+                    for i in range(N):
+                        s.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
+                return s
+
+            slams = [build(b) for b in range(sample)]
+            frames_list = [np.ascontiguousarray(allf[1:, b]) for b in range(sample)]
+            nthreads = min(ncores, sample)
+            secs, traj = oa.run_sequences(slams, frames_list, nthreads=nthreads, L=slams[0].L)
+            cpu = dict(value=sample * cpu_frames / secs, unit="frames/s", cores=nthreads, host_hardware_threads=ncores,
+                       kind="reference" if use_ref else "port",
+                       sample="%d sequences x %d frames (%dx%d, %d features) of this run's input, one MonoSLAM object per hardware thread"
+                              % (sample, cpu_frames, W, H, N),
+                       seconds=secs, single_thread_frames_per_s=None,
+                       note=("the reference's own monoslam.cpp / kalman.cpp / improc.cpp etc. compiled unmodified (g++ -O3) against "
+                             "stand-in Eigen / OpenCV headers (oracle/ref_shim): its dense products are plain fixed-order loops, "
+                             "not Eigen's blocked, vectorised GEMM - a real Eigen build would run the EKF update (85-93 % of "
+                             "the CPU time) several times faster.  A reported baseline, not the target."
+                             if use_ref else
+                             "oracle restatement (oracle/*.hpp), naive triple-loop products; oracle/_ref/libref.so was absent"))
+            # 8(d)(i): one sequence on one thread (the reference's own single-threaded design)
+            s1 = build(0)
+            secs1, _ = oa.run_sequences([s1], frames_list[:1], nthreads=1, L=s1.L)
             cpu["single_thread_frames_per_s"] = cpu_frames / secs1
-            d = slams[0].diag()
+            # stage split from the oracle's timers (the reference keeps none)
+            so = oa.OracleSLAM(cam, params["delta_t"], N)
+            so.set_state(specs[0].xv0, specs[0].Pxx0)
+            for i in range(N):
+                so.add_known_feature(specs[0].feat_y[i], specs[0].xp_org()[i], templates[0][i])
+                if args.feature_sigma > 0.0:
+                    so.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
+            oa.run_sequences([so], frames_list[:1], nthreads=1, want_traj=False)
+            d = so.diag()
             tt = sum(d["times"].values())
             cpu["stage_split"] = {k: float(v / tt) for k, v in d["times"].items()}
             # parity of the trajectories on the sample (BASELINE metric: traj RMSE vs ref <= 1e-4)
             log = eng.position_log(0, sample, capacity=n_render)[:, :cpu_frames]
             rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
-            parity = dict(traj_rmse_vs_oracle=rmse, sequences=sample, frames=cpu_frames,
-                          position_maxabs=float(np.abs(log - traj).max()))
+            parity = dict(traj_rmse_vs_oracle=rmse, checker="reference build (oracle/_ref/libref.so)" if use_ref else "oracle",
+                          sequences=sample, frames=cpu_frames, position_maxabs=float(np.abs(log - traj).max()))
 
         out = {
             "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch %d independent %dx%d synthetic sequences per GPU, %d features each, all features selected, map prior sigma %.3g m (dense covariance)"
-                                   % (B, W, H, N, args.feature_sigma),
+            "config": {"workload": workload_name(B, W, H, N, world) + ", all features selected, map prior sigma %.3g m (%s covariance)"
+                                   % (args.feature_sigma, "dense" if args.feature_sigma > 0 else "block-sparse"),
                        "sequences_per_gpu": B, "features": N, "width": W, "height": H,
                        "state_dim": 13 + 3 * N, "feature_prior_sigma_m": args.feature_sigma, "parallelism": "independent sequences sharded across %d GPU(s), no data-path collective" % world},
-            "roofline": roof, "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity,
+            # roofline = the dominant kernel of the step; roofline_search = the NCC search kernel the north star names
+            # (HBM roofline + its VALU-issue roofline); the same object is repeated under roofline["search"]
+            "roofline": (dict(roof, search=roof_search) if roof is not None and roof_search is not None and roof is not roof_search else roof),
+            "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity,
             "kernels": per_kernel,
             "work_per_step": {k: v for k, v in work.items()},
             "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,

@@ -114,3 +114,37 @@ def test_collective_helpers_over_rccl_on_device_tensors():
     assert np.array_equal(rows, np.arange(4 * 14, dtype=np.float64).reshape(4, 14))
     assert tmax == 2.5 and tsum == 4.0
     assert np.array_equal(mine, (np.arange(3 * 4 * 5) % 251).astype(np.uint8).reshape(3, 4, 5)) and where.startswith("cuda")
+
+
+def test_bench_launcher_builds_the_rank_environment():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself: the environment each rank gets is what
+    torch.distributed.run would export (one rank per GPU, rendezvous on 127.0.0.1)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    port = bench.free_port()
+    envs = [bench.launcher_env(r, 2, port, base={"PATH": "/usr/bin"}) for r in range(2)]
+    for r, e in enumerate(envs):
+        assert e["RANK"] == str(r) and e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == "2"
+        assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == str(port)
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/usr/bin"
+    assert envs[0]["MASTER_PORT"] == envs[1]["MASTER_PORT"]
+    for cfg, want in [((1, 320, 240, 100), "configs[1]"), ((1024, 320, 240, 100), "configs[2]:"),
+                      ((1024, 640, 480, 200), "configs[3]"), ((512, 1280, 720, 500), "configs[4]"),
+                      ((256, 1280, 720, 500), "at batch 256"), ((8, 100, 100, 7), "custom")]:
+        assert want in bench.workload_name(cfg[0], cfg[1], cfg[2], cfg[3], 1), cfg
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_mismatched_world():
+    """Exit code is non-zero when fewer than N devices are visible (here: none), and when --gpus disagrees with the
+    launcher's WORLD_SIZE."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SL2_BENCH_BACKEND")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                             capture_output=True, text=True, env=env, timeout=600)
+        assert out.returncode != 0 and "only" in out.stderr and out.stdout.strip() == ""
+    env["WORLD_SIZE"] = "4"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=env, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in out.stderr

@@ -35,3 +35,19 @@ def test_bench_line_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert d["parity"]["traj_rmse_vs_oracle"] <= 1e-4          # BASELINE.json's tolerance
+
+
+def test_bench_self_spawns_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself.  On a 1-GPU box the two ranks share the device
+    through the gloo test hook (the code path - rendezvous, barrier, MAX-reduce, gather - is the one RCCL runs on N GPUs)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SL2_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "16"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gathered_states"] == 32 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+    assert d["cpu_baseline"] is None                      # rank 0 at N = 1 only

@@ -124,7 +124,16 @@ def main():
         # RCCL ("nccl" on ROCm).  SL2_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU on a
         # single-GPU box to exercise this multi-rank code path (collectives then run on host tensors).
         backend = os.environ.get("SL2_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        dist.init_process_group(backend)
+        # gloo's C++ side announces its connections on stdout: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend)
+            dist.barrier()
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if world > torch.cuda.device_count() and os.environ.get("SL2_BENCH_BACKEND") != "gloo":

@@ -134,7 +134,7 @@ struct sl2_engine {
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
   bool graph_mode = false;
   std::vector<StepGraph> step_graphs;
-  int search_variant = 2;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk (default)
+  int search_variant = 3;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk, 3 = int8 matrix-core walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]

@@ -339,6 +339,262 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// Variant 3 ("matrix-core walk", production): the three 11x11 window sums of every candidate come out of the
+// int8 matrix cores instead of a per-lane column walk.
+//
+// For a 16 (rows v) x 16 (columns u) tile of candidates the cross term is a sum of eleven Toeplitz products,
+//     X[v][u] = sum_i  I[v+i][0..31] . Tt_i[0..31][u],     Tt_i[k][u] = T[i][k-u]  (0 <= k-u < 11, else 0),
+// i.e. a 16 x (11*32) by (11*32) x 16 integer GEMM: six v_mfma_i32_16x16x64_i8 (two template rows per instruction).
+// The same A operand against a Toeplitz matrix of ones gives sum(g1); sum(g1^2) uses two more byte planes, the high
+// and the low byte of the squared pixel (g^2 = 256 H + L), against the ones matrix.  Pixels and template are offset by
+// 128 to fit the signed int8 operands and the offsets are taken out again in exact integer arithmetic:
+//     sum g1 = S1' + 128*121,   sum g0 g1 = X' + 128 S1' + 128 sum g0,   sum g1^2 = 256 (H' + 15488) + L' + 15488.
+// 24 MFMAs per 256 candidates replace 33 + 6 v_dot4 per candidate and per row; a lane ends up holding the three
+// exact int32 sums of four candidates (C/D layout: column = lane & 15, row = 4 (lane >> 4) + register), ranks them
+// in FP32 exactly like variant 1 and hands the unique near-best candidate to the FP64 scoring pass.  No ring of image
+// rows, no per-lane template: ~70 VGPRs instead of 156, so twice the wavefronts hide the staging latency.
+//
+// One wavefront per (sequence, selected feature).  The window is staged band by band (16 candidate rows x 32 candidate
+// columns: 27 x 48 bytes per plane) with coalesced, dword-aligned row loads; any window size is walked tile by tile,
+// so nothing falls back for being large.  What the fast path cannot decide exactly (several near-best candidates, the
+// sigma == 10 boundary) returns code -1 and the caller runs search_core_v0, as for variant 1.
+//
+// Which byte of an operand register pairs with which k of the instruction does not matter here: lane group g = lane >> 4
+// and byte e of A always meet lane group g, byte e of B, and both operands are built from (g, e) -> (template row
+// 2p + (g >> 1), window byte 16 (g & 1) + e).
+// ---------------------------------------------------------------------------
+constexpr int kMfPitchDw = 12;                 // 48-byte rows: 32 candidate columns + 10 + pad, 16-byte aligned
+constexpr int kMfRows = 28;                    // 16 candidate rows + 10 + the partner row of template row 10
+constexpr int kMfPlaneDw = kMfRows * kMfPitchDw;
+constexpr int kMfTplDw = 13 * kMfPitchDw + 4;  // 11 template rows + a zero row + the ones row, zero padded
+typedef int mf_v4i __attribute__((ext_vector_type(4)));
+typedef unsigned short mf_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned mf_sq_pairs(unsigned packed_u16x2) {   // (x, y) -> (x^2, y^2), v_pk_mul_lo_u16
+  mf_us2 v;
+  __builtin_memcpy(&v, &packed_u16x2, 4);
+  v = v * v;
+  unsigned r;
+  __builtin_memcpy(&r, &v, 4);
+  return r;
+}
+
+// 16 bytes of padded template row `row` starting at byte `off` (1..32) of its 48-byte LDS row
+__device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int off) {
+  const unsigned* p = s_T + row * kMfPitchDw + (off >> 2);
+  const int sh = off & 3;
+  const unsigned q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
+  mf_v4i r;
+  r.x = (int)__builtin_amdgcn_alignbyte(q1, q0, sh);
+  r.y = (int)__builtin_amdgcn_alignbyte(q2, q1, sh);
+  r.z = (int)__builtin_amdgcn_alignbyte(q3, q2, sh);
+  r.w = (int)__builtin_amdgcn_alignbyte(q4, q3, sh);
+  return r;
+}
+
+// band staging: 27 rows x 12 dwords of the frame -> three byte planes (g - 128, high and low byte of g^2, each - 128).
+// Loads are unconditional (row and dword indices are clamped into the band, so nothing outside the window is touched)
+// and all in flight before the first one is consumed.
+__device__ __forceinline__ void mf_stage_band(const uint8_t* __restrict__ image, int img_lo, int width, int x0, int y0,
+                                              int rows_needed, int bytes_needed, unsigned* s_I, unsigned* s_H, unsigned* s_L,
+                                              int k, int rsub) {
+  unsigned val[7];
+  int osh[7];
+#pragma unroll
+  for (int ps = 0; ps < 7; ++ps) {
+    const int r = min(4 * ps + rsub, rows_needed - 1);
+    const int off = (y0 + r) * width + x0;                  // byte offset in the frame (< 2^31)
+    const int o = (img_lo + off) & 3;
+    const int need = (o + bytes_needed + 3) >> 2;           // <= 12 dwords hold the row's bytes
+    val[ps] = *(const unsigned*)(image + (off - o) + 4 * min(k, need - 1));
+    osh[ps] = o;
+  }
+#pragma unroll
+  for (int ps = 0; ps < 7; ++ps) {
+    const unsigned nxt = (unsigned)__shfl_down((int)val[ps], 1, 64);
+    const unsigned d = __builtin_amdgcn_alignbyte(nxt, val[ps], osh[ps]);
+    const unsigned lo = d & 0x00ff00ffu, hi = (d >> 8) & 0x00ff00ffu;
+    const unsigned sqlo = mf_sq_pairs(lo), sqhi = mf_sq_pairs(hi);
+    const unsigned Hd = ((sqlo >> 8) & 0x00ff00ffu) | (sqhi & 0xff00ff00u);
+    const unsigned Ld = (sqlo & 0x00ff00ffu) | ((sqhi << 8) & 0xff00ff00u);
+    if (k < kMfPitchDw) {
+      const int idx = (4 * ps + rsub) * kMfPitchDw + k;
+      s_I[idx] = d ^ 0x80808080u;
+      s_H[idx] = Hd ^ 0x80808080u;
+      s_L[idx] = Ld ^ 0x80808080u;
+    }
+  }
+}
+
+template <bool DEFER>
+__device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width,
+                                                         const unsigned* __restrict__ tpl, const uint8_t* __restrict__ patch,
+                                                         const SearchBounds sb, double a, double b, double c,
+                                                         unsigned* s_pl, unsigned* s_T) {
+  const int lane = threadIdx.x & 63;
+  const int nu_all = sb.urelfinish - sb.urelstart + 1;
+  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
+  SearchResult res;
+  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
+  res.S1 = res.S2 = res.X = 0;
+  if (nu_all <= 0 || nv_all <= 0) return res;
+
+  // ---- padded template rows in LDS: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones.
+  // Every dword is written once, with its final value (no separate zero pass).
+  int Sg0, Sg0sq;
+  bool patch_ok;
+  if (tpl) {     // packed template (33 dwords: row r = bytes 0..10, byte 11 = 0; then sum g0, sum g0^2, sigma flag)
+    for (int i = lane; i < kMfTplDw; i += 64) {
+      const int r = i / kMfPitchDw, cc = i - r * kMfPitchDw;
+      unsigned val = 0u;
+      if (cc >= 4 && cc <= 6) {
+        if (r < 11) {
+          val = tpl[3 * r + cc - 4] ^ 0x80808080u;
+          if (cc == 6) val &= 0x00ffffffu;
+        } else if (r == 12) {
+          val = (cc == 6) ? 0x00010101u : 0x01010101u;
+        }
+      }
+      s_T[i] = val;
+    }
+    Sg0 = (int)tpl[33]; Sg0sq = (int)tpl[34];
+    patch_ok = tpl[35] != 0;
+  } else {
+    unsigned tv = 0;
+    if (lane < 33) {
+      const int r = lane / 3, d = lane - 3 * r;
+      for (int kk = 0; kk < 4; ++kk) {
+        const int col = 4 * d + kk;
+        const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
+        tv |= byte << (8 * kk);
+      }
+    }
+    unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
+    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    Sg0 = (int)s1; Sg0sq = (int)s2;
+    const double g0bar = (double)Sg0 / 121.0;
+    const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
+    const double sigmag0 = sqrt(varg0);
+    patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
+    for (int i = lane; i < kMfTplDw; i += 64) s_T[i] = 0u;
+    __syncthreads();
+    if (lane < 33) {
+      const int r = lane / 3, d = lane - 3 * r;
+      unsigned val = tv ^ 0x80808080u;
+      if (d == 2) val &= 0x00ffffffu;
+      s_T[r * kMfPitchDw + 4 + d] = val;
+    }
+    if (lane < 3) s_T[12 * kMfPitchDw + 4 + lane] = (lane == 2) ? 0x00010101u : 0x01010101u;
+  }
+  const int D0 = 121 * Sg0sq - Sg0 * Sg0;
+  const float d0f = (float)D0;
+
+  const int j = lane & 15, g = lane >> 4;
+  const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
+  const int img_lo = (int)((size_t)image & 3);
+
+  unsigned* s_I = s_pl;
+  unsigned* s_H = s_pl + kMfPlaneDw;
+  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
+
+  float best_q = -3.0e38f, second_q = -3.0e38f;
+  int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
+  int need_exact = 0;
+  int ncand_lane = 0;
+  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+  const double au0 = 2 * b;                                // in_ellipse: ((a u) u) + (((2 b) u) v) + ((c v) v) < 9
+
+  for (int vt = 0; vt < TV; ++vt) {
+    const int rows_needed = min(nv_all - 16 * vt, 16) + 10;            // <= 26
+    for (int up = 0; up < TU; up += 2) {
+      if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
+      mf_stage_band(image, img_lo, width, sb.ucentre + sb.urelstart + 16 * up - 5, sb.vcentre + sb.vrelstart + 16 * vt - 5,
+                    rows_needed, min(nu_all - 16 * up, 32) + 10, s_I, s_H, s_L, j, g);
+      __syncthreads();
+      const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+      for (int ut = up; ut < min(up + 2, TU); ++ut) {
+        mf_v4i accX = {0, 0, 0, 0}, acc1 = accX, accH = accX, accL = accX;
+        if (patch_ok) {                      // (a flat template: every candidate is skipped, they are only counted)
+          const int abase = j * (kMfPitchDw * 4) + 16 * ((ut - up) + (g & 1)) + (g >> 1) * (kMfPitchDw * 4);
+#pragma unroll 2
+          for (int p = 0; p < 6; ++p) {
+            const int aoff = abase + 2 * p * (kMfPitchDw * 4);            // multiple of 16
+            const mf_v4i aI = *(const mf_v4i*)((const char*)s_I + aoff);
+            const mf_v4i aH = *(const mf_v4i*)((const char*)s_H + aoff);
+            const mf_v4i aL = *(const mf_v4i*)((const char*)s_L + aoff);
+            const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
+            mf_v4i bo = b_ones;
+            if (p == 5 && (g >> 1)) bo = mf_v4i{0, 0, 0, 0};               // template row 11 does not exist
+            accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, accX, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, acc1, 0, 0, 0);
+            accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, accH, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, accL, 0, 0, 0);
+          }
+        }
+        // ---- the lane's four candidates: column ui, rows 16 vt + 4 g + reg ----
+        const int ui = 16 * ut + j;
+        const double du = (double)(sb.urelstart + ui);
+        const double e_uu = a * du * du, e_u = au0 * du;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int vi = 16 * vt + 4 * g + reg;
+          const double dv = (double)(sb.vrelstart + vi);
+          const bool cand = ui < nu_all && vi < nv_all && (e_uu + e_u * dv + c * dv * dv < kNoSigma * kNoSigma);
+          if (cand) {
+            ++ncand_lane;
+            const int s1p = acc1[reg];
+            const int S1 = s1p + 15488;
+            const int S2 = ((accH[reg] + 15488) << 8) + accL[reg] + 15488;
+            const int X = accX[reg] + 128 * s1p + 128 * Sg0;
+            const int D1 = mul24(121, S2) - mul24(S1, S1);
+            if (D1 == 1464100) need_exact = 1;                 // sigma1 == 10 boundary: decided in FP64 only
+            if (D1 > 1464100 && patch_ok) {
+              const int Nc = mul24(121, X) - mul24(Sg0, S1);
+              const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
+              if (q > best_q) {
+                second_q = best_q;
+                best_q = q; best_idx = ui * nv_all + vi; best_S1 = S1; best_S2 = S2; best_X = X;
+              } else if (q > second_q) {
+                second_q = q;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  int ncand = ncand_lane;
+  for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
+  res.ncand = ncand;
+  if (!patch_ok) return res;
+  // ---- decide (as variant 1) ----
+  float gmax = best_q;
+  for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+  const float thr = gmax - 4.0e-6f;
+  const bool lane_amb = (second_q >= thr) && (best_idx >= 0);
+  const bool lane_near = (best_idx >= 0) && (best_q >= thr);
+  const unsigned long long near_mask = __ballot(lane_near);
+  if (__any(need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
+  if (near_mask == 0ull) return res;
+  const int wl = __ffsll((long long)near_mask) - 1;
+  const int w_idx = __shfl(best_idx, wl, 64);
+  res.S1 = __shfl(best_S1, wl, 64); res.S2 = __shfl(best_S2, wl, 64); res.X = __shfl(best_X, wl, 64);
+  res.found = 1;
+  res.u = sb.ucentre + sb.urelstart + w_idx / nv_all;
+  res.v = sb.vcentre + sb.vrelstart + w_idx % nv_all;
+  if (DEFER) { res.code = 1; return res; }
+  double sd0, sd1;
+  const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
+  if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {
+    res.found = 0; res.u = res.v = 0;
+    return res;
+  }
+  res.score = corr;
+  res.ok = !(corr > kCorrThresh2) ? 1 : 0;
+  return res;
+}
+
+// ---------------------------------------------------------------------------
 // Engine kernels.  k_search: one wave per (sequence, selected position), XCD-mapped so
 // that all windows of one frame go through one XCD's L2.  It writes a compact result
 // record; k_search_score (one THREAD per selected position, all lanes busy) evaluates
@@ -369,7 +625,40 @@ __global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frame
   if ((threadIdx.x & 63) == 0) {
     int* o = srch_res + ((size_t)b * N + k) * 8;
     o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
-    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | ((VARIANT == 1 && fell_back) ? 4 : 0);
+    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | ((VARIANT != 0 && fell_back) ? 4 : 0);
+    meas_score[(size_t)b * N + k] = r.score;
+  }
+}
+
+// Variant 3 engine kernel: one wavefront per (sequence, selected position), XCD-mapped like k_search.  Held to the
+// register budget of SL2_MF_WAVES wavefronts per SIMD: the kernel is a chain of short latency-bound phases per feature,
+// and it is the number of features in flight that hides them.
+#ifndef SL2_MF_WAVES
+#define SL2_MF_WAVES 5
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
+k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, const uint8_t* __restrict__ patch,
+              const int* __restrict__ srch_i, const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
+              const int* __restrict__ n_sel, int* __restrict__ srch_res, double* __restrict__ meas_score, int N, int nsel_max,
+              int B) {
+  int b, k;
+  if (!xcd_map(nsel_max, B, &b, &k)) return;
+  if (k >= n_sel[b]) return;
+  __shared__ __attribute__((aligned(16))) unsigned s_pl[3 * kMfPlaneDw];
+  __shared__ unsigned s_tpl[kMfTplDw];
+  const int f = sel_idx[(size_t)b * N + k];
+  const size_t fi = (size_t)b * N + f;
+  const SearchBounds sb = bounds_from_desc(srch_i + fi * 8);
+  const double a = srch_d[fi * 4], bq = srch_d[fi * 4 + 1], c = srch_d[fi * 4 + 2];
+  const uint8_t* img = frames + (size_t)b * seq_stride;
+  const uint8_t* pbytes = patch + fi * kPatchStride;
+  SearchResult r = search_core_mfma<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a, bq, c, s_pl, s_tpl);
+  const bool fell_back = r.code < 0;
+  if (fell_back) r = search_core_v0(img, width, pbytes, sb, a, bq, c);
+  if ((threadIdx.x & 63) == 0) {
+    int* o = srch_res + ((size_t)b * N + k) * 8;
+    o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | (fell_back ? 4 : 0);
     meas_score[(size_t)b * N + k] = r.score;
   }
 }
@@ -750,7 +1039,8 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
                                                      const double* __restrict__ centre, const double* __restrict__ puinv,
                                                      int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
   const int i = blockIdx.x;
-  __shared__ unsigned s_win[kWinRows * kWinPitchDw];
+  __shared__ __attribute__((aligned(16))) unsigned s_win[VARIANT == 2 ? 3 * kMfPlaneDw : kWinRows * kWinPitchDw];
+  __shared__ unsigned s_tpl[VARIANT == 2 ? kMfTplDw : 1];
   const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
   const double a = puinv[i * 3], b = puinv[i * 3 + 1], c = puinv[i * 3 + 2];
   const SearchBounds sb = search_bounds(ce, a, b, c, width, height);
@@ -758,6 +1048,7 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
   SearchResult r;
   r.code = -1;
   if (VARIANT == 1) r = search_core_v1<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win);
+  if (VARIANT == 2) r = search_core_mfma<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win, s_tpl);
   if (r.code < 0) r = search_core_v0(img, width, patches + (size_t)i * 121, sb, a, b, c);
   if ((threadIdx.x & 63) == 0) {
     ok[i] = r.ok;
@@ -783,6 +1074,9 @@ int launch_search(sl2_engine* e) {
       hipLaunchKernelGGL(k_search_packed, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
                          e->srch_i, e->srch_d, e->sel_idx, e->pack_first, e->pack_count, e->n_packs, e->srch_res,
                          e->meas_score, e->N, e->nsel_max, e->B);
+    else if (e->root->search_variant == 3)
+      hipLaunchKernelGGL(k_search_mfma, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
+                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
     else if (e->root->search_variant == 0)
       hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
                          e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
@@ -810,7 +1104,7 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
                                            int variant) {
   using namespace sl2;
   if (!images || !patches || !centre || !puinv || !ok || !uv || !score || count < 0 || nimages <= 0) return SL2_ERR_INVALID;
-  if (variant != 0 && variant != 1) return SL2_ERR_INVALID;
+  if (variant < 0 || variant > 2) return SL2_ERR_INVALID;
   if (count == 0) return SL2_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device (the engine has no CPU fallback)"); return SL2_ERR_NO_DEVICE; }
@@ -835,6 +1129,8 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
   SL2_HIP(hipMemcpy(d_pu, puinv, sizeof(double) * 3 * count, hipMemcpyHostToDevice));
   if (variant == 0)
     hipLaunchKernelGGL(k_search_batch<0>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
+  else if (variant == 2)
+    hipLaunchKernelGGL(k_search_batch<2>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   else
     hipLaunchKernelGGL(k_search_batch<1>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   SL2_HIP(hipGetLastError());

@@ -86,8 +86,9 @@ def _search_cases(rng, n, W, H):
     return (np.stack(images), np.array(idx, np.int32), np.stack(patches), np.array(centres), np.array(puinv))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_elliptical_search_batch_matches_oracle_exactly(variant):
+    """variant 0 = baseline kernel, 1 = LDS column walk, 2 = int8 matrix-core walk (the engine's default search core)."""
     rng = np.random.default_rng(102)
     W, H = 160, 120
     images, idx, patches, centres, puinv = _search_cases(rng, 160, W, H)
@@ -135,7 +136,8 @@ def test_elliptical_search_windows_larger_than_the_tile_are_walked_in_blocks():
     images, idx, patches = np.stack(images), np.array(idx, np.int32), np.stack(patches)
     centres, puinv = np.array(centres), np.array(puinv)
     n = len(idx)
-    for variant in (1, 0):
+    wants = [oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t]) for t in range(n)]
+    for variant in (2, 1, 0):
         ok = np.zeros(n, np.int32)
         uv = np.full((n, 2), -7, np.int32)
         score = np.zeros(n)
@@ -143,12 +145,54 @@ def test_elliptical_search_windows_larger_than_the_tile_are_walked_in_blocks():
                                                            _lib.dp(centres), _lib.dp(puinv), n, _lib.ip(ok), _lib.ip(uv),
                                                            _lib.dp(score), variant))
         for t in range(n):
-            want = oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t])
+            want = wants[t]
             assert bool(ok[t]) == want["ok"], "variant %d case %d ok" % (variant, t)
             assert score[t] == want["corr"], "variant %d case %d score %r vs %r" % (variant, t, score[t], want["corr"])
             if want["corr"] < 1e6:
                 assert (uv[t, 0], uv[t, 1]) == (want["u"], want["v"]), "variant %d case %d uv" % (variant, t)
         assert ok.sum() >= 10
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_near_ties_inside_the_fp32_guard_band_are_decided_like_the_reference(variant):
+    """Adversarial for the FP32 ranking of the fast search cores: two (or three) copies of the template inside the ellipse
+    that differ from it in k and k + 1 pixels by one grey level.  Their reference scores are ~1e-6 .. 4e-6 apart - at or
+    below the FP32 ranking error - so the rank alone could invert them; the guard band must send such searches to the
+    exact FP64 path and the answer must still be the reference's (position, score and the last-wins tie rule)."""
+    rng = np.random.default_rng(2024)
+    W, H = 160, 120
+    images, idx, patches, centres, puinv = [], [], [], [], []
+    for t in range(120):
+        img = (128 + 12 * rng.standard_normal((H, W))).clip(0, 255).astype(np.uint8)
+        patch = (128 + 45 * rng.standard_normal((11, 11))).clip(1, 254).astype(np.uint8)
+        cx, cy = int(rng.integers(40, W - 40)), int(rng.integers(40, H - 40))
+        spots = [(cx - 14, cy - 3), (cx + 13, cy + 2)] + ([(cx, cy + 14)] if t % 3 == 0 else [])
+        k0 = int(rng.integers(0, 4))
+        for si, (x, y) in enumerate(spots):
+            q = patch.astype(np.int32).copy()
+            nflip = k0 + (si if t % 4 else 0)           # t % 4 == 0: EXACT ties (identical copies): last in scan order wins
+            for _ in range(nflip):
+                q[rng.integers(0, 11), rng.integers(0, 11)] += int(rng.choice([-1, 1]))
+            img[y - 5:y + 6, x - 5:x + 6] = q.clip(0, 255).astype(np.uint8)
+        a, b, c = oa.sinv_from_S(np.array([[90.0, 5.0], [5.0, 70.0]]))       # half-widths ~28 x 25: all copies inside
+        images.append(img); idx.append(t); patches.append(patch.reshape(121)); centres.append([cx + 0.2, cy - 0.3]); puinv.append([a, b, c])
+    images, idx, patches = np.stack(images), np.array(idx, np.int32), np.stack(patches)
+    centres, puinv = np.array(centres), np.array(puinv)
+    n = len(idx)
+    ok = np.zeros(n, np.int32)
+    uv = np.full((n, 2), -7, np.int32)
+    score = np.zeros(n)
+    _lib.check(_lib.load().sl2_elliptical_search_batch(0, _lib.u8p(images), n, W, H, _lib.ip(idx), _lib.u8p(patches),
+                                                       _lib.dp(centres), _lib.dp(puinv), n, _lib.ip(ok), _lib.ip(uv),
+                                                       _lib.dp(score), variant))
+    close = 0
+    for t in range(n):
+        want = oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t])
+        assert want["ok"] and bool(ok[t]), t
+        assert (uv[t, 0], uv[t, 1]) == (want["u"], want["v"]), "case %d: %s vs %s" % (t, uv[t], (want["u"], want["v"]))
+        assert score[t] == want["corr"], t
+        close += want["corr"] < 2e-5
+    assert close >= 100          # the constructed copies really are the winners
 
 
 def test_device_renderer_matches_host_bytes():

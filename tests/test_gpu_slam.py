@@ -64,9 +64,9 @@ def test_seams_one_frame():
         assert rel_fro(e.total_covariance(b), Po) < TOL_P
 
 
-@pytest.mark.parametrize("n_features,n_frames,batch,variant", [(20, 40, 3, 2), (20, 40, 3, 1), (20, 12, 2, 0), (100, 12, 2, 2)])
+@pytest.mark.parametrize("n_features,n_frames,batch,variant", [(20, 40, 3, 3), (20, 40, 3, 2), (20, 40, 3, 1), (20, 12, 2, 0), (100, 12, 2, 3), (100, 12, 2, 2)])
 def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
-    """variant: search kernel (2 packed column walk = default, 1 one feature per wave, 0 baseline)."""
+    """variant: search kernel (3 int8 matrix-core walk, 2 packed column walk, 1 column walk with one feature per wave, 0 baseline)."""
     pr = Pair(n_features, n_frames, batch=batch)
     pr.engine.set_search_variant(variant)
     traj_o = np.zeros((batch, n_frames, 3))

@@ -156,6 +156,7 @@ struct sl2_engine {
   int* srch_i = nullptr;      // [B][N][8]  per-feature search window: ucentre, vcentre, urelstart, nu, vrelstart, nv, hw, hh
   double* srch_d = nullptr;   // [B][N][4]  PuInv (a, b, c), pad
   int* srch_res = nullptr;    // [B][N][8]  per selected position: code, u, v, S1, S2, X, ncand, pad
+  int* srch_sel = nullptr;    // [B][N][16] per selected position k (written by k_select): slot f, the 7 window ints of srch_i, then PuInv (a, b, c) as 3 doubles, pad - one 64-byte line, so that the search kernel needs ONE round trip for it
   int* pack_first = nullptr;  // [B][N]  work list of the packed search: first selected position of pack p
   int* pack_count = nullptr;  // [B][N]  ... and number of features in it
   int* n_packs = nullptr;     // [B]

@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
                                                 const int* __restrict__ n_slots, const double* __restrict__ xp_org,
                                                 int* __restrict__ sel_idx, int* __restrict__ n_sel, int* __restrict__ n_vis,
                                                 double* __restrict__ last_r, const int* __restrict__ srch_i,
+                                                const double* __restrict__ srch_d, int* __restrict__ srch_sel,
                                                 int* __restrict__ pack_first, int* __restrict__ pack_count,
                                                 int* __restrict__ n_packs, int N, int n_want) {
   extern __shared__ double s_dyn[];
@@ -212,8 +213,17 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     if (rank < limit) {
       sel_idx[(size_t)b * N + rank] = i;
       f_flags[(size_t)b * N + i] |= FF_SELECTED;
-      s_nu[rank] = srch_i[((size_t)b * N + i) * 8 + 3];
-      s_nv[rank] = srch_i[((size_t)b * N + i) * 8 + 5];
+      const int* si = srch_i + ((size_t)b * N + i) * 8;
+      s_nu[rank] = si[3];
+      s_nv[rank] = si[5];
+      // the selected position's search record in ONE 64-byte line: slot, window, PuInv (what the search kernel reads)
+      int* rec = srch_sel + ((size_t)b * N + rank) * 16;
+      rec[0] = i;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) rec[1 + q] = si[q];
+      const double* sd = srch_d + ((size_t)b * N + i) * 4;
+      double* recd = (double*)(rec + 8);
+      recd[0] = sd[0]; recd[1] = sd[1]; recd[2] = sd[2];
     }
   }
   __syncthreads();
@@ -426,7 +436,7 @@ int launch_select(sl2_engine* e, int n) {
   if (n > e->nsel_max) n = e->nsel_max;
   const size_t shm = (size_t)e->N * (sizeof(double) + 3 * sizeof(int));
   hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
-                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->pack_first, e->pack_count, e->n_packs, e->N, n);
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->pack_first, e->pack_count, e->n_packs, e->N, n);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

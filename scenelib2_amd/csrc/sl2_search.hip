@@ -363,6 +363,13 @@ __device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict
 // and byte e of A always meet lane group g, byte e of B, and both operands are built from (g, e) -> (template row
 // 2p + (g >> 1), window byte 16 (g & 1) + e).
 // ---------------------------------------------------------------------------
+#ifdef SL2_SEARCH_TRACE
+__device__ long long* g_search_trace = nullptr;     // development only: 8 cycle stamps per workgroup
+#define STR(slot) do { if (g_search_trace && threadIdx.x == 0) g_search_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STR(slot) do { } while (0)
+#endif
+
 constexpr int kMfPitchDw = 12;                 // 48-byte rows: 32 candidate columns + 10 + pad, 16-byte aligned
 constexpr int kMfRows = 28;                    // 16 candidate rows + 10 + the partner row of template row 10
 constexpr int kMfPlaneDw = kMfRows * kMfPitchDw;
@@ -379,12 +386,14 @@ __device__ __forceinline__ unsigned mf_sq_pairs(unsigned packed_u16x2) {   // (x
   return r;
 }
 
-// 16 bytes of padded template row `row` starting at byte `off` (1..32) of its 48-byte LDS row
+// 16 bytes of padded template row `row` starting at byte `off` (1..32) of its 48-byte LDS row: five aligned dwords and
+// four v_alignbyte.  (gfx950 runs in unaligned-access mode and a single ds_read_b128 at a byte address works - the
+// compiler emits it for an align-1 copy - but it is slow: the kernel took 0.150 ms with it against 0.119 ms this way.)
 __device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int off) {
+  mf_v4i r;
   const unsigned* p = s_T + row * kMfPitchDw + (off >> 2);
   const int sh = off & 3;
   const unsigned q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
-  mf_v4i r;
   r.x = (int)__builtin_amdgcn_alignbyte(q1, q0, sh);
   r.y = (int)__builtin_amdgcn_alignbyte(q2, q1, sh);
   r.z = (int)__builtin_amdgcn_alignbyte(q3, q2, sh);
@@ -392,193 +401,180 @@ __device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int of
   return r;
 }
 
-// band staging: 27 rows x 12 dwords of the frame -> three byte planes (g - 128, high and low byte of g^2, each - 128).
-// Loads are unconditional (row and dword indices are clamped into the band, so nothing outside the window is touched)
-// and all in flight before the first one is consumed.
-__device__ __forceinline__ void mf_stage_band(const uint8_t* __restrict__ image, int img_lo, int width, int x0, int y0,
-                                              int rows_needed, int bytes_needed, unsigned* s_I, unsigned* s_H, unsigned* s_L,
-                                              int k, int rsub) {
-  unsigned val[7];
-  int osh[7];
+// ---- band staging: rows_needed (<= 26) rows x ndw (<= 11) dwords of the frame -> three byte planes (g - 128, high and
+// low byte of g^2, each - 128).  Split into "issue the loads" and "consume them", so that the engine kernel can have the
+// next feature's window in flight while it works on the current one.  The band's dwords are dealt out to the lanes
+// densely (lane -> (row, dword) by a division by the band's own width), so a typical 24 x 7-dword window takes three
+// passes, not seven; loads are plain dword loads at byte addresses (unaligned-access mode), and the last dword of a row
+// is fetched from four bytes before the row's end and shifted, so that nothing beyond the window is ever touched.
+constexpr int kMfPasses = 5;                   // ceil(26 * 11 / 64)
+struct MfBand { int base, rows_needed, bytes_needed, ndw; float rcp; };
+__device__ __forceinline__ MfBand mf_band(const SearchBounds& sb, int nu_all, int nv_all, int up, int vt, int width) {
+  MfBand bd;
+  bd.base = (sb.vcentre + sb.vrelstart + 16 * vt - 5) * width + (sb.ucentre + sb.urelstart + 16 * up - 5);   // < 2^31
+  bd.rows_needed = min(nv_all - 16 * vt, 16) + 10;          // <= 26
+  bd.bytes_needed = min(nu_all - 16 * up, 32) + 10;          // 11 .. 42
+  bd.ndw = (bd.bytes_needed + 3) >> 2;                       // 3 .. 11
+  bd.rcp = __builtin_amdgcn_rcpf((float)bd.ndw);
+  return bd;
+}
+// lane's (row, dword) of pass ps; false when the lane has nothing to do in that pass
+__device__ __forceinline__ bool mf_band_slot(const MfBand& bd, int ps, int lane, int* r, int* k) {
+  const int idx = ps * 64 + lane;
+  const int rr = (int)(((float)idx + 0.5f) * bd.rcp);        // idx / ndw: (idx + 1/2) / ndw is >= 0.04 away from an integer
+  *r = rr;
+  *k = idx - mul24(rr, bd.ndw);
+  return rr < bd.rows_needed;
+}
+__device__ __forceinline__ void mf_band_loads(const uint8_t* __restrict__ image, int width, const MfBand bd, int lane,
+                                              unsigned (&val)[kMfPasses]) {
 #pragma unroll
-  for (int ps = 0; ps < 7; ++ps) {
-    const int r = min(4 * ps + rsub, rows_needed - 1);
-    const int off = (y0 + r) * width + x0;                  // byte offset in the frame (< 2^31)
-    const int o = (img_lo + off) & 3;
-    const int need = (o + bytes_needed + 3) >> 2;           // <= 12 dwords hold the row's bytes
-    val[ps] = *(const unsigned*)(image + (off - o) + 4 * min(k, need - 1));
-    osh[ps] = o;
+  for (int ps = 0; ps < kMfPasses; ++ps) {
+    if (ps * 64 < bd.rows_needed * bd.ndw) {                // wave-uniform
+      int r, k;
+      unsigned v = 0;
+      if (mf_band_slot(bd, ps, lane, &r, &k)) {
+        const int pos = min(4 * k, bd.bytes_needed - 4);
+        __builtin_memcpy(&v, image + (unsigned)(bd.base + mul24(r, width) + pos), 4);
+      }
+      val[ps] = v;
+    }
   }
+}
+__device__ __forceinline__ void mf_band_store(const unsigned (&val)[kMfPasses], const MfBand bd, unsigned* s_I, unsigned* s_H,
+                                              unsigned* s_L, int lane) {
 #pragma unroll
-  for (int ps = 0; ps < 7; ++ps) {
-    const unsigned nxt = (unsigned)__shfl_down((int)val[ps], 1, 64);
-    const unsigned d = __builtin_amdgcn_alignbyte(nxt, val[ps], osh[ps]);
-    const unsigned lo = d & 0x00ff00ffu, hi = (d >> 8) & 0x00ff00ffu;
-    const unsigned sqlo = mf_sq_pairs(lo), sqhi = mf_sq_pairs(hi);
-    const unsigned Hd = ((sqlo >> 8) & 0x00ff00ffu) | (sqhi & 0xff00ff00u);
-    const unsigned Ld = (sqlo & 0x00ff00ffu) | ((sqhi << 8) & 0xff00ff00u);
-    if (k < kMfPitchDw) {
-      const int idx = (4 * ps + rsub) * kMfPitchDw + k;
-      s_I[idx] = d ^ 0x80808080u;
-      s_H[idx] = Hd ^ 0x80808080u;
-      s_L[idx] = Ld ^ 0x80808080u;
+  for (int ps = 0; ps < kMfPasses; ++ps) {
+    if (ps * 64 < bd.rows_needed * bd.ndw) {
+      int r, k;
+      if (mf_band_slot(bd, ps, lane, &r, &k)) {
+        const int pos = min(4 * k, bd.bytes_needed - 4);
+        const unsigned d = val[ps] >> (8 * (4 * k - pos));
+        const unsigned lo = d & 0x00ff00ffu, hi = (d >> 8) & 0x00ff00ffu;
+        const unsigned sqlo = mf_sq_pairs(lo), sqhi = mf_sq_pairs(hi);
+        const unsigned Hd = ((sqlo >> 8) & 0x00ff00ffu) | (sqhi & 0xff00ff00u);
+        const unsigned Ld = (sqlo & 0x00ff00ffu) | ((sqhi << 8) & 0xff00ff00u);
+        const int idx = mul24(r, kMfPitchDw) + k;
+        s_I[idx] = d ^ 0x80808080u;
+        s_H[idx] = Hd ^ 0x80808080u;
+        s_L[idx] = Ld ^ 0x80808080u;
+      }
     }
   }
 }
 
-template <bool DEFER>
-__device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width,
-                                                         const unsigned* __restrict__ tpl, const uint8_t* __restrict__ patch,
-                                                         const SearchBounds sb, double a, double b, double c,
-                                                         unsigned* s_pl, unsigned* s_T) {
-  const int lane = threadIdx.x & 63;
-  const int nu_all = sb.urelfinish - sb.urelstart + 1;
-  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
-  SearchResult res;
-  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
-  res.S1 = res.S2 = res.X = 0;
-  if (nu_all <= 0 || nv_all <= 0) return res;
-
-  // ---- padded template rows in LDS: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones.
-  // Every dword is written once, with its final value (no separate zero pass).
-  int Sg0, Sg0sq;
-  bool patch_ok;
-  if (tpl) {     // packed template (33 dwords: row r = bytes 0..10, byte 11 = 0; then sum g0, sum g0^2, sigma flag)
-    for (int i = lane; i < kMfTplDw; i += 64) {
-      const int r = i / kMfPitchDw, cc = i - r * kMfPitchDw;
-      unsigned val = 0u;
-      if (cc >= 4 && cc <= 6) {
-        if (r < 11) {
-          val = tpl[3 * r + cc - 4] ^ 0x80808080u;
-          if (cc == 6) val &= 0x00ffffffu;
-        } else if (r == 12) {
-          val = (cc == 6) ? 0x00010101u : 0x01010101u;
-        }
-      }
-      s_T[i] = val;
-    }
-    Sg0 = (int)tpl[33]; Sg0sq = (int)tpl[34];
-    patch_ok = tpl[35] != 0;
-  } else {
-    unsigned tv = 0;
-    if (lane < 33) {
-      const int r = lane / 3, d = lane - 3 * r;
-      for (int kk = 0; kk < 4; ++kk) {
-        const int col = 4 * d + kk;
-        const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
-        tv |= byte << (8 * kk);
-      }
-    }
-    unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
-    for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-    Sg0 = (int)s1; Sg0sq = (int)s2;
-    const double g0bar = (double)Sg0 / 121.0;
-    const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
-    const double sigmag0 = sqrt(varg0);
-    patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
-    for (int i = lane; i < kMfTplDw; i += 64) s_T[i] = 0u;
-    __syncthreads();
-    if (lane < 33) {
-      const int r = lane / 3, d = lane - 3 * r;
-      unsigned val = tv ^ 0x80808080u;
-      if (d == 2) val &= 0x00ffffffu;
-      s_T[r * kMfPitchDw + 4 + d] = val;
-    }
-    if (lane < 3) s_T[12 * kMfPitchDw + 4 + lane] = (lane == 2) ? 0x00010101u : 0x01010101u;
+// padded template rows in LDS: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones.
+// mf_tpl_init writes everything that does not depend on the template (once per wavefront), mf_tpl_store the 33 data
+// dwords: tv = the packed template dword of lanes 0..32 (row lane / 3, bytes 4 (lane % 3) .., byte 11 = 0).  The two
+// touch disjoint dwords, so no barrier is needed between them.
+__device__ __forceinline__ void mf_tpl_init(unsigned* s_T, int lane) {
+  for (int i = lane; i < kMfTplDw; i += 64) {
+    const int r = i / kMfPitchDw, cc = i - r * kMfPitchDw;
+    const bool mid = cc >= 4 && cc <= 6;
+    if (!(mid && r < 11)) s_T[i] = (mid && r == 12) ? (cc == 6 ? 0x00010101u : 0x01010101u) : 0u;
   }
-  const int D0 = 121 * Sg0sq - Sg0 * Sg0;
-  const float d0f = (float)D0;
+}
+__device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned* s_T, int lane) {
+  if (lane < 33) {
+    const int r = lane / 3, d = lane - 3 * r;
+    unsigned val = tv ^ 0x80808080u;
+    if (d == 2) val &= 0x00ffffffu;
+    s_T[r * kMfPitchDw + 4 + d] = val;
+  }
+}
 
-  const int j = lane & 15, g = lane >> 4;
+// running state of one search: per lane the best and second-best FP32 rank, the integer sums of the best, counters
+struct MfState {
+  float best_q, second_q;
+  int best_idx, best_S1, best_S2, best_X, need_exact, ncand;
+  __device__ __forceinline__ void reset() {
+    best_q = -3.0e38f; second_q = -3.0e38f; best_idx = -1; best_S1 = best_S2 = best_X = 0; need_exact = 0; ncand = 0;
+  }
+};
+
+// the (up to two) 16 x 16 candidate tiles of the band in LDS: 24 MFMAs each, then the lane's four candidates per tile
+__device__ __forceinline__ void mf_band_tiles(const unsigned* s_I, const unsigned* s_H, const unsigned* s_L, const unsigned* s_T,
+                                              int up, int vt, int TU, int nu_all, int nv_all, int urelstart, int vrelstart,
+                                              double a, double b2, double c, int Sg0, float d0f, bool patch_ok, int j, int g,
+                                              MfState& st) {
   const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
-  const int img_lo = (int)((size_t)image & 3);
-
-  unsigned* s_I = s_pl;
-  unsigned* s_H = s_pl + kMfPlaneDw;
-  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
-
-  float best_q = -3.0e38f, second_q = -3.0e38f;
-  int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
-  int need_exact = 0;
-  int ncand_lane = 0;
-  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
-  const double au0 = 2 * b;                                // in_ellipse: ((a u) u) + (((2 b) u) v) + ((c v) v) < 9
-
-  for (int vt = 0; vt < TV; ++vt) {
-    const int rows_needed = min(nv_all - 16 * vt, 16) + 10;            // <= 26
-    for (int up = 0; up < TU; up += 2) {
-      if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
-      mf_stage_band(image, img_lo, width, sb.ucentre + sb.urelstart + 16 * up - 5, sb.vcentre + sb.vrelstart + 16 * vt - 5,
-                    rows_needed, min(nu_all - 16 * up, 32) + 10, s_I, s_H, s_L, j, g);
-      __syncthreads();
-      const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
-      for (int ut = up; ut < min(up + 2, TU); ++ut) {
-        mf_v4i accX = {0, 0, 0, 0}, acc1 = accX, accH = accX, accL = accX;
-        if (patch_ok) {                      // (a flat template: every candidate is skipped, they are only counted)
-          const int abase = j * (kMfPitchDw * 4) + 16 * ((ut - up) + (g & 1)) + (g >> 1) * (kMfPitchDw * 4);
+  const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+  for (int ut = up; ut < min(up + 2, TU); ++ut) {
+    mf_v4i accX = {0, 0, 0, 0}, acc1 = accX, accH = accX, accL = accX;
+    if (patch_ok) {                      // (a flat template: every candidate is skipped, they are only counted)
+      const int abase = j * (kMfPitchDw * 4) + 16 * ((ut - up) + (g & 1)) + (g >> 1) * (kMfPitchDw * 4);
 #pragma unroll 2
-          for (int p = 0; p < 6; ++p) {
-            const int aoff = abase + 2 * p * (kMfPitchDw * 4);            // multiple of 16
-            const mf_v4i aI = *(const mf_v4i*)((const char*)s_I + aoff);
-            const mf_v4i aH = *(const mf_v4i*)((const char*)s_H + aoff);
-            const mf_v4i aL = *(const mf_v4i*)((const char*)s_L + aoff);
-            const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
-            mf_v4i bo = b_ones;
-            if (p == 5 && (g >> 1)) bo = mf_v4i{0, 0, 0, 0};               // template row 11 does not exist
-            accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, accX, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, acc1, 0, 0, 0);
-            accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, accH, 0, 0, 0);
-            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, accL, 0, 0, 0);
-          }
-        }
-        // ---- the lane's four candidates: column ui, rows 16 vt + 4 g + reg ----
-        const int ui = 16 * ut + j;
-        const double du = (double)(sb.urelstart + ui);
-        const double e_uu = a * du * du, e_u = au0 * du;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int vi = 16 * vt + 4 * g + reg;
-          const double dv = (double)(sb.vrelstart + vi);
-          const bool cand = ui < nu_all && vi < nv_all && (e_uu + e_u * dv + c * dv * dv < kNoSigma * kNoSigma);
-          if (cand) {
-            ++ncand_lane;
-            const int s1p = acc1[reg];
-            const int S1 = s1p + 15488;
-            const int S2 = ((accH[reg] + 15488) << 8) + accL[reg] + 15488;
-            const int X = accX[reg] + 128 * s1p + 128 * Sg0;
-            const int D1 = mul24(121, S2) - mul24(S1, S1);
-            if (D1 == 1464100) need_exact = 1;                 // sigma1 == 10 boundary: decided in FP64 only
-            if (D1 > 1464100 && patch_ok) {
-              const int Nc = mul24(121, X) - mul24(Sg0, S1);
-              const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
-              if (q > best_q) {
-                second_q = best_q;
-                best_q = q; best_idx = ui * nv_all + vi; best_S1 = S1; best_S2 = S2; best_X = X;
-              } else if (q > second_q) {
-                second_q = q;
-              }
-            }
-          }
-        }
+      for (int p = 0; p < 6; ++p) {
+        const int aoff = abase + 2 * p * (kMfPitchDw * 4);            // multiple of 16
+        const mf_v4i aI = *(const mf_v4i*)((const char*)s_I + aoff);
+        const mf_v4i aH = *(const mf_v4i*)((const char*)s_H + aoff);
+        const mf_v4i aL = *(const mf_v4i*)((const char*)s_L + aoff);
+        const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
+        mf_v4i bo = b_ones;
+        if (p == 5 && (g >> 1)) bo = mf_v4i{0, 0, 0, 0};               // template row 11 does not exist
+        accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, accX, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, acc1, 0, 0, 0);
+        accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, accH, 0, 0, 0);
+        accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, accL, 0, 0, 0);
       }
     }
+    // ---- the lane's four candidates: column ui, rows 16 vt + 4 g + reg.  Ellipse membership is the reference's
+    // expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9 with the u-only factors hoisted (same values, same order).
+    // Straight-line code with selects: the per-candidate branches cost more (scalar traffic, issue bubbles) than the
+    // arithmetic they skip.
+    const int ui = 16 * ut + j;
+    const double du = (double)(urelstart + ui);
+    const double e_uu = a * du * du, e_u = b2 * du;
+    const int idx0 = mul24(ui, nv_all) + 16 * vt + 4 * g;
+    const bool col_ok = ui < nu_all;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int vi = 16 * vt + 4 * g + reg;
+      const double dv = (double)(vrelstart + vi);
+      const bool cand = col_ok && vi < nv_all && (e_uu + e_u * dv + c * dv * dv < kNoSigma * kNoSigma);
+      const int s1p = acc1[reg];
+      const int S1 = s1p + 15488;
+      const int S2 = ((accH[reg] + 15488) << 8) + accL[reg] + 15488;
+      const int X = accX[reg] + 128 * s1p + 128 * Sg0;
+      const int D1 = mul24(121, S2) - mul24(S1, S1);
+      const int Nc = mul24(121, X) - mul24(Sg0, S1);
+      const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
+      st.ncand += cand ? 1 : 0;
+      st.need_exact |= (cand && D1 == 1464100) ? 1 : 0;          // sigma1 == 10 boundary: decided in FP64 only
+      const float qq = (cand && D1 > 1464100 && patch_ok) ? q : -3.0e38f;
+      const bool better = qq > st.best_q;
+      st.second_q = better ? st.best_q : fmaxf(st.second_q, qq);
+      st.best_q = better ? qq : st.best_q;
+      st.best_idx = better ? idx0 + reg : st.best_idx;
+      st.best_S1 = better ? S1 : st.best_S1;
+      st.best_S2 = better ? S2 : st.best_S2;
+      st.best_X = better ? X : st.best_X;
+    }
   }
-  int ncand = ncand_lane;
+}
+
+// wave-wide decision (as variant 1): code 1 = unique near-best candidate, its sums handed on; -1 = exact path needed
+template <bool DEFER>
+__device__ __forceinline__ SearchResult mf_decide(const MfState& st, const SearchBounds& sb, int nv_all, int Sg0, int Sg0sq,
+                                                  bool patch_ok) {
+  SearchResult res;
+  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.score = 1000000.0;
+  res.S1 = res.S2 = res.X = 0;
+  int ncand = st.ncand;
   for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
   res.ncand = ncand;
   if (!patch_ok) return res;
-  // ---- decide (as variant 1) ----
-  float gmax = best_q;
+  float gmax = st.best_q;
   for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
   const float thr = gmax - 4.0e-6f;
-  const bool lane_amb = (second_q >= thr) && (best_idx >= 0);
-  const bool lane_near = (best_idx >= 0) && (best_q >= thr);
+  const bool lane_amb = (st.second_q >= thr) && (st.best_idx >= 0);
+  const bool lane_near = (st.best_idx >= 0) && (st.best_q >= thr);
   const unsigned long long near_mask = __ballot(lane_near);
-  if (__any(need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
+  if (__any(st.need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
   if (near_mask == 0ull) return res;
   const int wl = __ffsll((long long)near_mask) - 1;
-  const int w_idx = __shfl(best_idx, wl, 64);
-  res.S1 = __shfl(best_S1, wl, 64); res.S2 = __shfl(best_S2, wl, 64); res.X = __shfl(best_X, wl, 64);
+  const int w_idx = __shfl(st.best_idx, wl, 64);
+  res.S1 = __shfl(st.best_S1, wl, 64); res.S2 = __shfl(st.best_S2, wl, 64); res.X = __shfl(st.best_X, wl, 64);
   res.found = 1;
   res.u = sb.ucentre + sb.urelstart + w_idx / nv_all;
   res.v = sb.vcentre + sb.vrelstart + w_idx % nv_all;
@@ -592,6 +588,61 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
   res.score = corr;
   res.ok = !(corr > kCorrThresh2) ? 1 : 0;
   return res;
+}
+
+// One search, one wavefront, nothing in flight across calls: the stateless batch API (templates as raw 121 bytes).
+__device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width,
+                                                         const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
+                                                         double b, double c, unsigned* s_pl, unsigned* s_T) {
+  const int lane = threadIdx.x & 63;
+  const int nu_all = sb.urelfinish - sb.urelstart + 1;
+  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
+  if (nu_all <= 0 || nv_all <= 0) {
+    SearchResult res;
+    res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
+    res.S1 = res.S2 = res.X = 0;
+    return res;
+  }
+  unsigned tv = 0;
+  if (lane < 33) {
+    const int r = lane / 3, d = lane - 3 * r;
+    for (int kk = 0; kk < 4; ++kk) {
+      const int col = 4 * d + kk;
+      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
+      tv |= byte << (8 * kk);
+    }
+  }
+  unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  const int Sg0 = (int)s1, Sg0sq = (int)s2;
+  // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
+  const double g0bar = (double)Sg0 / 121.0;
+  const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
+  const double sigmag0 = sqrt(varg0);
+  const bool patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
+  const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+  mf_tpl_init(s_T, lane);
+  mf_tpl_store(tv, s_T, lane);
+
+  const int j = lane & 15, g = lane >> 4;
+  unsigned* s_I = s_pl;
+  unsigned* s_H = s_pl + kMfPlaneDw;
+  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
+  MfState st;
+  st.reset();
+  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+  for (int vt = 0; vt < TV; ++vt)
+    for (int up = 0; up < TU; up += 2) {
+      if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
+      const MfBand bd = mf_band(sb, nu_all, nv_all, up, vt, width);
+      unsigned val[kMfPasses];
+      mf_band_loads(image, width, bd, lane, val);
+      mf_band_store(val, bd, s_I, s_H, s_L, lane);
+      __syncthreads();
+      mf_band_tiles(s_I, s_H, s_L, s_T, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, Sg0, d0f, patch_ok,
+                    j, g, st);
+    }
+  return mf_decide<false>(st, sb, nv_all, Sg0, Sg0sq, patch_ok);
 }
 
 // ---------------------------------------------------------------------------
@@ -630,37 +681,116 @@ __global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frame
   }
 }
 
-// Variant 3 engine kernel: one wavefront per (sequence, selected position), XCD-mapped like k_search.  Held to the
-// register budget of SL2_MF_WAVES wavefronts per SIMD: the kernel is a chain of short latency-bound phases per feature,
-// and it is the number of features in flight that hides them.
+// Variant 3 engine kernel.  One wavefront works through kMfChunk consecutive selected positions of one sequence
+// (XCD-mapped like k_search: a sequence's frame stays in one XCD's L2).  A feature's search is a chain of dependent
+// memory round trips - record, template + window, LDS - that takes ~18 000 cycles for ~3 000 cycles of issue, so the
+// loop is software-pipelined: the four 64-byte records of the chunk come with one coalesced load (lane = dword), and
+// while feature i is in the matrix cores and being scored, the template and the first window band of feature i + 1 are
+// already in flight (eight VGPRs).  Held to the register budget of SL2_MF_WAVES wavefronts per SIMD.
+constexpr int kMfChunk = 4;
 #ifndef SL2_MF_WAVES
-#define SL2_MF_WAVES 5
+#define SL2_MF_WAVES 4
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
 k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, const uint8_t* __restrict__ patch,
-              const int* __restrict__ srch_i, const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
-              const int* __restrict__ n_sel, int* __restrict__ srch_res, double* __restrict__ meas_score, int N, int nsel_max,
-              int B) {
-  int b, k;
-  if (!xcd_map(nsel_max, B, &b, &k)) return;
-  if (k >= n_sel[b]) return;
+              const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
+              double* __restrict__ meas_score, int N, int nchunks, int B) {
+  int b, ch;
+  if (!xcd_map(nchunks, B, &b, &ch)) return;
+  STR(0);
   __shared__ __attribute__((aligned(16))) unsigned s_pl[3 * kMfPlaneDw];
-  __shared__ unsigned s_tpl[kMfTplDw];
-  const int f = sel_idx[(size_t)b * N + k];
-  const size_t fi = (size_t)b * N + f;
-  const SearchBounds sb = bounds_from_desc(srch_i + fi * 8);
-  const double a = srch_d[fi * 4], bq = srch_d[fi * 4 + 1], c = srch_d[fi * 4 + 2];
+  __shared__ unsigned s_T[kMfTplDw];
+  const int lane = threadIdx.x;
+  const int k0 = ch * kMfChunk;
+  const int nsel = n_sel[b];
+  if (k0 >= nsel) return;
+  const int nf = min(kMfChunk, nsel - k0);
   const uint8_t* img = frames + (size_t)b * seq_stride;
-  const uint8_t* pbytes = patch + fi * kPatchStride;
-  SearchResult r = search_core_mfma<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a, bq, c, s_pl, s_tpl);
-  const bool fell_back = r.code < 0;
-  if (fell_back) r = search_core_v0(img, width, pbytes, sb, a, bq, c);
-  if ((threadIdx.x & 63) == 0) {
-    int* o = srch_res + ((size_t)b * N + k) * 8;
-    o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
-    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | (fell_back ? 4 : 0);
-    meas_score[(size_t)b * N + k] = r.score;
+  const int j = lane & 15, g = lane >> 4;
+  unsigned* s_I = s_pl;
+  unsigned* s_H = s_pl + kMfPlaneDw;
+  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
+
+  // the record k_select wrote for selected position k (one 64-byte line; uniform address: scalar loads)
+  struct Rec { int f, nu_all, nv_all; SearchBounds sb; double a, b, c; };
+  auto record = [&](int i) {
+    const int* rec = srch_sel + ((size_t)b * N + k0 + i) * 16;
+    Rec r;
+    r.f = rec[0];
+    r.sb.ucentre = rec[1]; r.sb.vcentre = rec[2]; r.sb.urelstart = rec[3]; r.nu_all = rec[4];
+    r.sb.vrelstart = rec[5]; r.nv_all = rec[6]; r.sb.halfwidth = rec[7]; r.sb.halfheight = 0;
+    r.sb.urelfinish = r.sb.urelstart + r.nu_all - 1; r.sb.vrelfinish = r.sb.vrelstart + r.nv_all - 1;
+    const double* recd = (const double*)(rec + 8);
+    r.a = recd[0]; r.b = recd[1]; r.c = recd[2];
+    return r;
+  };
+
+  mf_tpl_init(s_T, lane);
+  const int tslot = (lane < 33) ? (lane / 3) * kMfPitchDw + 4 + lane % 3 : 0;      // where this lane's template dword goes
+  const unsigned tmask = (lane % 3 == 2) ? 0x00ffffffu : 0xffffffffu;
+  unsigned pf_val[kMfPasses];
+  unsigned pf_tv = 0;
+  Rec rc = record(0);
+  {
+    if (rc.nu_all > 0 && rc.nv_all > 0) mf_band_loads(img, width, mf_band(rc.sb, rc.nu_all, rc.nv_all, 0, 0, width), lane, pf_val);
+    const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rc.f) * kPatchStride + kPatchPackedOffset);
+    pf_tv = tpl[min(lane, 35)];
   }
+  STR(1);
+  for (int i = 0; i < nf; ++i) {
+    // the next position's record: scalar loads issued here, consumed after the barrier below (clamped index: the last
+    // iteration re-reads its own record instead of branching)
+    const Rec rn = record(min(i + 1, nf - 1));
+    const int nu_all = rc.nu_all, nv_all = rc.nv_all;
+    const bool geom_ok = nu_all > 0 && nv_all > 0;
+    const unsigned tv = pf_tv;
+    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 33), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
+    const bool patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
+    const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+    if (i > 0) __syncthreads();                       // feature i - 1 is done with the LDS
+    if (geom_ok) {
+      if (lane < 33) s_T[tslot] = (tv ^ 0x80808080u) & tmask;
+      mf_band_store(pf_val, mf_band(rc.sb, nu_all, nv_all, 0, 0, width), s_I, s_H, s_L, lane);
+    }
+    __syncthreads();
+    if (i + 1 < nf) {                                 // next feature's template and first band: in flight from here on
+      if (rn.nu_all > 0 && rn.nv_all > 0)
+        mf_band_loads(img, width, mf_band(rn.sb, rn.nu_all, rn.nv_all, 0, 0, width), lane, pf_val);
+      const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rn.f) * kPatchStride + kPatchPackedOffset);
+      pf_tv = tpl[min(lane, 35)];
+    }
+    MfState st;
+    st.reset();
+    SearchResult r;
+    r.code = 0; r.ok = 0; r.found = 0; r.u = 0; r.v = 0; r.ncand = 0; r.score = 1000000.0; r.S1 = r.S2 = r.X = 0;
+    if (geom_ok) {
+      const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+      mf_band_tiles(s_I, s_H, s_L, s_T, 0, 0, TU, nu_all, nv_all, rc.sb.urelstart, rc.sb.vrelstart, rc.a, 2 * rc.b, rc.c, Sg0, d0f,
+                    patch_ok, j, g, st);
+      for (int vt = 0; vt < TV; ++vt)                 // the other bands of a large window: staged synchronously
+        for (int up = (vt == 0 ? 2 : 0); up < TU; up += 2) {
+          __syncthreads();
+          const MfBand bd = mf_band(rc.sb, nu_all, nv_all, up, vt, width);
+          unsigned val[kMfPasses];
+          mf_band_loads(img, width, bd, lane, val);
+          mf_band_store(val, bd, s_I, s_H, s_L, lane);
+          __syncthreads();
+          mf_band_tiles(s_I, s_H, s_L, s_T, up, vt, TU, nu_all, nv_all, rc.sb.urelstart, rc.sb.vrelstart, rc.a, 2 * rc.b, rc.c,
+                        Sg0, d0f, patch_ok, j, g, st);
+        }
+      r = mf_decide<true>(st, rc.sb, nv_all, Sg0, Sg0sq, patch_ok);
+    }
+    const bool fell_back = r.code < 0;
+    if (fell_back) r = search_core_v0(img, width, patch + ((size_t)b * N + rc.f) * kPatchStride, rc.sb, rc.a, rc.b, rc.c);
+    if (lane == 0) {
+      int* o = srch_res + ((size_t)b * N + k0 + i) * 8;
+      o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+      o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | (fell_back ? 4 : 0);
+      meas_score[(size_t)b * N + k0 + i] = r.score;
+    }
+    rc = rn;
+  }
+  STR(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -692,13 +822,6 @@ __device__ __forceinline__ int seg_reduce_sum(int val, int gid, int lane) {
   }
   return val;
 }
-
-#ifdef SL2_SEARCH_TRACE
-__device__ long long* g_search_trace = nullptr;     // development only: 8 cycle stamps per workgroup
-#define STR(slot) do { if (g_search_trace && threadIdx.x == 0) g_search_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define STR(slot) do { } while (0)
-#endif
 
 __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
                                                       const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
@@ -1048,7 +1171,7 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
   SearchResult r;
   r.code = -1;
   if (VARIANT == 1) r = search_core_v1<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win);
-  if (VARIANT == 2) r = search_core_mfma<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win, s_tpl);
+  if (VARIANT == 2) r = search_core_mfma(img, width, patches + (size_t)i * 121, sb, a, b, c, s_win, s_tpl);
   if (r.code < 0) r = search_core_v0(img, width, patches + (size_t)i * 121, sb, a, b, c);
   if ((threadIdx.x & 63) == 0) {
     ok[i] = r.ok;
@@ -1074,9 +1197,11 @@ int launch_search(sl2_engine* e) {
       hipLaunchKernelGGL(k_search_packed, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
                          e->srch_i, e->srch_d, e->sel_idx, e->pack_first, e->pack_count, e->n_packs, e->srch_res,
                          e->meas_score, e->N, e->nsel_max, e->B);
-    else if (e->root->search_variant == 3)
-      hipLaunchKernelGGL(k_search_mfma, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
-                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
+    else if (e->root->search_variant == 3) {
+      const int nchunks = (e->nsel_max + kMfChunk - 1) / kMfChunk;
+      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+                         e->cam.width, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score, e->N, nchunks, e->B);
+    }
     else if (e->root->search_variant == 0)
       hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
                          e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);

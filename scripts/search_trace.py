@@ -1,4 +1,4 @@
-"""Development aid: phase cycle stamps inside k_search_packed (SL2_SEARCH_TRACE build:
+"""Development aid: phase cycle stamps inside k_search_mfma (SL2_SEARCH_VARIANT=3, default) or k_search_packed (=2) (SL2_SEARCH_TRACE build:
    make -C scenelib2_amd/csrc trace ; SL2_LIB_PATH=scenelib2_amd/libscenelib2_amd_trace.so python scripts/search_trace.py)."""
 import ctypes as C
 import os
@@ -14,9 +14,10 @@ from scenelib2_amd import _lib  # noqa: E402
 
 def main():
     B, N = 1024, 100
-    eng, step, keep = build_engine(B, N, 320, 240)
+    warm = int(os.environ.get("SL2_TRACE_WARM", "30"))      # past the start-up transient of the search windows
+    eng, step, keep = build_engine(B, N, 320, 240, n_render=warm + 3)
     L = eng.L
-    for it in range(3):
+    for it in range(warm):
         step(it)
     eng.synchronize()
     nblk = 110000                      # >= xcd_grid(N, B)
@@ -24,7 +25,7 @@ def main():
     buf.upload(np.zeros(nblk * 8, dtype=np.int64))
     L.sl2_debug_search_trace.argtypes = [C.c_void_p]
     assert L.sl2_debug_search_trace(C.c_void_p(buf.ptr)) == 0
-    step(3)
+    step(warm)
     eng.synchronize()
     tr = buf.download((nblk, 8), np.int64)
     act = tr[:, 6] != 0
@@ -32,7 +33,11 @@ def main():
     print("active waves:", int(act.sum()))
     d = np.diff(t[:, :7], axis=1)
     tot = (t[:, 6] - t[:, 0]).mean()
-    for i, nme in enumerate(["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]):
+    names = ["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]
+    if os.environ.get("SL2_SEARCH_VARIANT", "3") == "3":     # k_search_mfma
+        names = ["n_sel + descriptors", "template -> LDS (issue)", "band staging + barrier", "B operands + MFMA", "scoring",
+                 "decision + result"]
+    for i, nme in enumerate(names):
         print("%-24s mean %8.0f cycles  (%4.1f %%)" % (nme, d[:, i].mean(), 100 * d[:, i].mean() / tot))
     print("total per wave mean %.0f cycles, p95 %.0f" % (tot, np.percentile(t[:, 6] - t[:, 0], 95)))
     print("kernel span %.0f cycles" % (tr[act][:, 6].max() - tr[act][:, 0].min()))

@@ -132,7 +132,7 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
  * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
  * enable_mapping != 0 runs the feature-initialisation tail (monoslam.cpp:152-170: AutoInitialiseFeature behind the
  * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) for the shipped max_features_to_init_at_once = 1 and up to
- * 128 particles; other settings are rejected with SL2_ERR_INVALID.  Status bit 2 = a sequence could not reserve a
+ * 128 particles; other settings are rejected with SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not reserve a
  * label because max_features is exhausted. */
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
                     int save_trajectory, int enable_mapping);
@@ -222,8 +222,13 @@ int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, 
 /* FileGrabber + FrameGrabber for a batch: dirs[s] is the frame directory of sequence s.  A producer thread decodes
  * (sl2_read_image: PGM or PNG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of
  * every sequence asynchronously on `stream` into one of two device buffers and returns it for
- * sl2_go_one_step(frames_on_device = 1).  The returned pointer stays valid until the next-but-one call on the same
- * stream.  SL2_ERR_CAPACITY = the shortest sequence is exhausted (sl2_ingest_frame_count). */
+ * sl2_go_one_step(frames_on_device = 1).  The returned pointer stays valid until the next-but-one call.
+ * Stream contract: the copy is ordered only with work on `stream`.  Pass the stream the engine steps on (the one given
+ * to sl2_create; with an engine-owned stream create the engine on a stream of yours): the copy of frame k + 2 then queues
+ * behind the step on frame k that still reads the same buffer, and the step on frame k queues behind its copy.  With a
+ * different stream the caller must provide both orderings (events), or synchronise.
+ * A decode failure is reported by the call whose frame could not be produced, not by earlier ones.
+ * SL2_ERR_CAPACITY = the shortest sequence is exhausted (sl2_ingest_frame_count). */
 typedef struct sl2_ingest sl2_ingest;
 int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, int device, int depth, sl2_ingest** out);
 int sl2_ingest_frame_count(const sl2_ingest* g);
@@ -268,9 +273,13 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
  * fully initialised feature with that label existed and was removed (partially initialised ones are removed by the engine's
  * own sell-by / conversion logic only).  The label is not reused.  Synchronises. */
 int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels, int32_t* deleted);
-/* Feature::attempted_/successful_measurements (test hook for delete_bad_features). */
-int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful);
-/* Non-zero bits: 1 = NaN/Inf seen in the state (e.g. the omega == 0 hazard, Q10). */
+/* Per-sequence status bits (sticky).  SL2_STATUS_NONFINITE: NaN / Inf seen in the state (e.g. the omega == 0 hazard, Q10).
+ * SL2_STATUS_LABELS_EXHAUSTED: feature initialisation wanted a new label but all max_features label slots of the sequence
+ * have been handed out over its lifetime (a deleted feature's slot is not reused; the reference's next_free_label_ is
+ * unbounded): the sequence keeps tracking its map but initialises no further features.  Callers that run with
+ * enable_mapping must poll this (the MonoSLAM adapters do, and raise). */
+#define SL2_STATUS_NONFINITE 1
+#define SL2_STATUS_LABELS_EXHAUSTED 2
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
 
 /* ------------------------------------------------------------------- profiling */
@@ -313,19 +322,6 @@ int sl2_dev_malloc(int device, size_t bytes, void** out);
 int sl2_dev_free(int device, void* p);
 int sl2_dev_upload(int device, void* dst_dev, const void* src_host, size_t bytes);
 int sl2_dev_download(int device, void* dst_host, const void* src_dev, size_t bytes);
-
-/* ------------------------------------------------------------ debug / test hooks */
-/* FP64 epilogue of correlate2_warning (improc.cpp:99-133) evaluated ON THE DEVICE
- * for `count` tuples of the five integer sums: checks IEEE div/sqrt parity. */
-int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* score, double* sd0, double* sd1);
-/* C[M][N] = sum_k XT[k][m] * YT[k][n] on the FP64 MFMA tile path used by the EKF
- * kernels (k-major operands): XT [K][ldx], YT [K][ldy], C [M][ldc].  Host pointers. */
-int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const double* YT, int ldy, int M, int N, int K,
-                      double* C, int ldc);
-
-/* Micro-benchmarks that calibrate the roofline peaks on the box: which = 0 FP64 MFMA
- * TFLOP/s (4 independent accumulators), 1 = dependent chain, 2 = streaming copy GB/s. */
-int sl2_debug_microbench(int device, int which, double* result);
 
 #ifdef __cplusplus
 }

@@ -69,11 +69,15 @@ EXPORTED_SYMBOLS = [
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
-    "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_set_feature_counters", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
+    "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
-    "sl2_dev_download", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench",
+    "sl2_dev_download",
 ]
+# test hooks and micro-benchmarks (include/scenelib2_amd_testing.h): exported by libscenelib2_amd_test.so ONLY
+TEST_SYMBOLS = ["sl2_set_feature_counters", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench"]
+TEST_LIB_PATH = os.path.join(_HERE, "libscenelib2_amd_test.so")
+_testlib = None
 
 _lib = None
 
@@ -93,6 +97,25 @@ def ip(a):
 
 def u8p(a):
     return a.ctypes.data_as(c_u8p)
+
+
+def load_testing():
+    """The TEST build of the library (same sources + -DSL2_TESTING): only the hooks of include/scenelib2_amd_testing.h are
+    bound here.  A hook that takes an engine accepts engines created through load() (same structures, one HIP runtime)."""
+    global _testlib
+    if _testlib is not None:
+        return _testlib
+    load()      # the product library first: it pins the HIP runtime both share
+    if not os.path.exists(TEST_LIB_PATH):
+        raise ImportError("scenelib2_amd: %s not built (make -C scenelib2_amd/csrc)" % TEST_LIB_PATH)
+    T = C.CDLL(TEST_LIB_PATH)
+    T.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    T.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
+    T.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
+    T.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]
+    T.sl2_last_error.restype = C.c_char_p
+    _testlib = T
+    return T
 
 
 def load():
@@ -149,7 +172,6 @@ def load():
     L.sl2_get_feature_patch.argtypes = [vp, C.c_int, C.c_int, c_u8p]
     L.sl2_delete_features.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip]
     L.sl2_get_position_log.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.POINTER(C.c_int)]
-    L.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.sl2_get_status_flags.argtypes = [vp, C.c_int, C.c_int, c_ip]
     L.sl2_set_profiling.argtypes = [vp, C.c_int]
     L.sl2_set_profile_focus.argtypes = [vp, C.c_char_p]
@@ -164,9 +186,6 @@ def load():
     L.sl2_dev_free.argtypes = [C.c_int, vp]
     L.sl2_dev_upload.argtypes = [C.c_int, vp, vp, C.c_size_t]
     L.sl2_dev_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
-    L.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
-    L.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
-    L.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]
     _lib = L
     return L
 

@@ -1378,6 +1378,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       }
 }
 
+#ifdef SL2_TESTING
 // ---------------------------------------------------------------------------
 // Debug GEMM on the same fragment conventions (tests the MFMA layout):
 // C[m][n] = sum_k XT[k][m] YT[k][n], one wave per 32x32 tile.
@@ -1401,8 +1402,9 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
     for (int jt = 0; jt < 2; ++jt)
       for (int r = 0; r < 4; ++r) C[(size_t)(i0 + 16 * it + hi + 4 * r) * ldc + j0 + 16 * jt + lo] = acc[it][jt][r];
 }
+#endif  // SL2_TESTING
 
-int launch_update(sl2_engine* e) {
+static int launch_update_range(sl2_engine* e) {
   const int B = e->B;
   {
     LaunchScope ls(e, "k_compact");
@@ -1501,8 +1503,36 @@ int launch_update(sl2_engine* e) {
   return SL2_OK;
 }
 
+// The update of the whole batch, or chunk by chunk: with SL2_UPDATE_CHUNK = C (sequences) the four-kernel chain runs on C
+// sequences at a time and every chunk uses the SAME At / St / Vt workspace, so that the intermediates (1.55 MB per
+// sequence at 100 features) are produced and consumed inside the 256 MiB Infinity Cache instead of going through HBM.
+int launch_update(sl2_engine* e) {
+  const int chunk = e->root->update_chunk;
+  if (chunk <= 0 || chunk >= e->B) return launch_update_range(e);
+  const int B = e->B;
+  const size_t N = e->N, ld = e->ld;
+  struct Saved { double *x, *P, *f_Hx, *f_Hy, *f_nu, *f_R, *LinvT; int *sel_idx, *n_sel, *meas_ok, *succ_idx, *m_count; } sv =
+      {e->x, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R, e->LinvT, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count};
+  int rc = SL2_OK;
+  for (int c0 = 0; c0 < B && rc == SL2_OK; c0 += chunk) {
+    const size_t f = c0;
+    e->B = (c0 + chunk <= B) ? chunk : B - c0;
+    e->x = sv.x + f * ld; e->P = sv.P + f * ld * ld; e->f_Hx = sv.f_Hx + f * N * 14; e->f_Hy = sv.f_Hy + f * N * 6;
+    e->f_nu = sv.f_nu + f * N * 2; e->f_R = sv.f_R + f * N; e->LinvT = sv.LinvT + f * (size_t)e->nblk_max * 1024;
+    e->sel_idx = sv.sel_idx + f * N; e->n_sel = sv.n_sel + f; e->meas_ok = sv.meas_ok + f * N; e->succ_idx = sv.succ_idx + f * N;
+    e->m_count = sv.m_count + f;
+    rc = launch_update_range(e);
+  }
+  e->B = B;
+  e->x = sv.x; e->P = sv.P; e->f_Hx = sv.f_Hx; e->f_Hy = sv.f_Hy; e->f_nu = sv.f_nu; e->f_R = sv.f_R; e->LinvT = sv.LinvT;
+  e->sel_idx = sv.sel_idx; e->n_sel = sv.n_sel; e->meas_ok = sv.meas_ok; e->succ_idx = sv.succ_idx; e->m_count = sv.m_count;
+  return rc;
+}
+
 }  // namespace sl2
 
+#ifdef SL2_TESTING   // everything below is test / calibration code: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)
+#include "../../include/scenelib2_amd_testing.h"
 extern "C" int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const double* YT, int ldy, int M, int N, int K,
                                  double* C, int ldc) {
   using namespace sl2;
@@ -1655,3 +1685,4 @@ extern "C" int sl2_debug_microbench(int device, int which, double* result) {
   hipEventDestroy(e0); hipEventDestroy(e1);
   return SL2_OK;
 }
+#endif  // SL2_TESTING

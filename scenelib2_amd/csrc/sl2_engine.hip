@@ -118,6 +118,9 @@ static int fetch_vec(std::vector<T>& v, const T* dev, size_t off, size_t n) {
 
 }  // namespace sl2
 
+#ifdef SL2_TESTING
+#include "../../include/scenelib2_amd_testing.h"
+#endif
 using namespace sl2;
 
 // Build the group objects: shallow copies of the root whose per-sequence pointers start at
@@ -170,12 +173,13 @@ static int fork_groups(sl2_engine* e) {
   for (sl2_engine* g : e->groups) SL2_HIP(hipStreamWaitEvent(g->stream, e->fork_event, 0));
   return SL2_OK;
 }
-// ... and the root stream after the groups (join).  Only needed when the caller owns the root
-// stream and may queue its own work behind ours; with an engine-owned stream the groups free-run
-// from step to step and every host-visible call synchronises all of them.
+// ... and the root stream after the groups (join).
 static int join_groups(sl2_engine* e) {
   if (e->groups.size() == 1 && e->groups[0]->stream == e->stream) return SL2_OK;
-  if (e->own_stream) return SL2_OK;
+  // Always: the next thing queued on the root stream may be the host-frame copy into frames_buf (bind_frames), an
+  // ingest copy into a device batch, or the caller's own work - all of which must come after the groups' kernels that
+  // still read the previous frame.  (An engine-owned stream used to skip this: a plain C caller stepping with host
+  // frames and groups > 1 then raced the copy against the previous step's search.)
   for (sl2_engine* g : e->groups) {
     if (!g->fork_event) SL2_HIP(hipEventCreateWithFlags(&g->fork_event, hipEventDisableTiming));
     SL2_HIP(hipEventRecord(g->fork_event, g->stream));
@@ -263,6 +267,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   SL2_HIP(hipSetDevice(device));
   sl2_engine* e = new sl2_engine();
   e->device = device;
+  e->root = e;
+  // everything below runs inside `build`: on any failure the partially built engine (stream, allocations) is released
+  auto build = [&]() -> int {
   if (stream) { e->stream = (hipStream_t)stream; e->own_stream = false; }
   else { SL2_HIP(hipStreamCreate(&e->stream)); e->own_stream = true; }
   e->cam.width = cam->width; e->cam.height = cam->height; e->cam.fku = cam->fku; e->cam.fkv = cam->fkv;
@@ -343,6 +350,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
   if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);
+  if (const char* v = getenv("SL2_UPDATE_CHUNK")) e->update_chunk = atoi(v);
   {
     int G = 1;
     const char* env = getenv("SL2_GROUPS");
@@ -350,6 +358,10 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
     int rc2 = build_groups(e, G);
     if (rc2 != SL2_OK) return rc2;
   }
+  return SL2_OK;
+  };
+  rc = build();
+  if (rc != SL2_OK) { sl2_destroy(e); return rc; }
   *out = e;
   return SL2_OK;
 }
@@ -550,7 +562,7 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   int rc = for_each_group(e, [=](sl2_engine* g) { return launch_finalize(g, save_trajectory); });
-  e->steps_done += 1;
+  if (rc == SL2_OK) e->steps_done += 1;
   return rc;
 }
 
@@ -611,9 +623,13 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       hipGraph_t graph = nullptr;
       SL2_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
       rc = issue();
-      const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
-      if (rc != SL2_OK) { if (graph) hipGraphDestroy(graph); return rc; }
-      SL2_HIP(ce);
+      const hipError_t ce = hipStreamEndCapture(e->stream, &graph);     // always: a stream left capturing is unusable
+      if (rc != SL2_OK || ce != hipSuccess) {
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();                                        // clear the sticky capture error
+        if (rc != SL2_OK) return rc;
+        SL2_HIP(ce);
+      }
       SL2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       hipGraphDestroy(graph);
       if (e->step_graphs.size() >= 8) { hipGraphExecDestroy(e->step_graphs.front().exec); e->step_graphs.erase(e->step_graphs.begin()); }
@@ -624,8 +640,8 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   } else {
     rc = issue();
   }
-  e->steps_done += 1;
   if (rc != SL2_OK) return rc;
+  e->steps_done += 1;
   if (e->profiling && e->pending.size() > 8192) return e->fold_events();
   return SL2_OK;
 }
@@ -867,6 +883,7 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
   return SL2_OK;
 }
 
+#ifdef SL2_TESTING   // test hook: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful) {
   if (!range_ok(e, seq, 1) || label < 0 || label >= e->N) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
@@ -875,6 +892,7 @@ int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, i
   SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + label, &successful, sizeof(int), hipMemcpyHostToDevice));
   return SL2_OK;
 }
+#endif  // SL2_TESTING
 
 // mark_feature_by_lab + delete_feature for one feature per sequence (monoslam.cpp:743-812): the slot is retired
 // (inactive, deselected, its label never reused) and its rows / columns of P are zeroed, which is what removing them from
@@ -1017,6 +1035,7 @@ int sl2_dev_download(int device, void* dst_host, const void* src_dev, size_t byt
   return SL2_OK;
 }
 
+#ifdef SL2_TESTING   // test hook: libscenelib2_amd_test.so only
 int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* score, double* sd0, double* sd1) {
   if (!sums5 || !score || !sd0 || !sd1 || count <= 0) return SL2_ERR_INVALID;
   int rc = check_device();
@@ -1038,5 +1057,6 @@ int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* sco
   hipFree(ds); hipFree(dsc); hipFree(d0); hipFree(d1);
   return SL2_OK;
 }
+#endif  // SL2_TESTING
 
 }  // extern "C"

@@ -341,10 +341,16 @@ int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, in
   for (int i = 0; i < depth; ++i) {
     if (hipHostMalloc((void**)&g->host[i], batch, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) {
       set_error("sl2_ingest_open: pinned allocation failed");
+      sl2_ingest_close(g);
       return SL2_ERR_HIP;
     }
   }
-  for (int i = 0; i < 2; ++i) SL2_HIP(hipMalloc((void**)&g->dev[i], batch));
+  for (int i = 0; i < 2; ++i)
+    if (hipMalloc((void**)&g->dev[i], batch) != hipSuccess) {
+      set_error("sl2_ingest_open: device allocation failed");
+      sl2_ingest_close(g);
+      return SL2_ERR_HIP;
+    }
   g->producer = std::thread([g] { g->run(); });
   *out = g;
   return SL2_OK;
@@ -371,8 +377,9 @@ int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_
   }
   {
     std::unique_lock<std::mutex> lk(g->mu);
+    // a decode failure further ahead does not fail THIS frame if its batch is already decoded
     g->cv.wait(lk, [&] { return g->failed || g->state[slot] == 1; });
-    if (g->failed) { set_error(g->fail_msg.c_str()); return SL2_ERR_INVALID; }
+    if (g->state[slot] != 1) { set_error(g->fail_msg.c_str()); return SL2_ERR_INVALID; }
   }
   const size_t batch = (size_t)g->nseq * g->width * g->height;
   uint8_t* dst = g->dev[g->flip];

@@ -1228,24 +1228,43 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
                                            const double* puinv, int count, int32_t* ok, int32_t* uv, double* score,
                                            int variant) {
   using namespace sl2;
-  if (!images || !patches || !centre || !puinv || !ok || !uv || !score || count < 0 || nimages <= 0) return SL2_ERR_INVALID;
+  if (!images || !image_index || !patches || !centre || !puinv || !ok || !uv || !score || count < 0 || nimages <= 0) {
+    set_error("sl2_elliptical_search_batch: null pointer or bad count");
+    return SL2_ERR_INVALID;
+  }
   if (variant < 0 || variant > 2) return SL2_ERR_INVALID;
+  if (width < kBoxSize || height < kBoxSize) { set_error("sl2_elliptical_search_batch: image smaller than the 11x11 patch"); return SL2_ERR_INVALID; }
+  for (int i = 0; i < count; ++i)
+    if (image_index[i] < 0 || image_index[i] >= nimages) {
+      set_error("sl2_elliptical_search_batch: image_index out of range");
+      return SL2_ERR_INVALID;
+    }
   if (count == 0) return SL2_OK;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device (the engine has no CPU fallback)"); return SL2_ERR_NO_DEVICE; }
   SL2_HIP(hipSetDevice(device));
+  // device temporaries, released on every exit path
+  struct Temps {
+    std::vector<void*> p;
+    ~Temps() { for (void* q : p) if (q) (void)hipFree(q); }
+    int alloc(void** out, size_t bytes) {
+      *out = nullptr;
+      const hipError_t e = hipMalloc(out, bytes);
+      if (e == hipSuccess) p.push_back(*out);
+      return e == hipSuccess ? SL2_OK : SL2_ERR_HIP;
+    }
+  } tmp;
   uint8_t *d_img = nullptr, *d_pat = nullptr;
   int *d_idx = nullptr, *d_ok = nullptr, *d_uv = nullptr;
   double *d_ce = nullptr, *d_pu = nullptr, *d_sc = nullptr;
   const size_t img_bytes = (size_t)nimages * width * height;
-  SL2_HIP(hipMalloc(&d_img, img_bytes));
-  SL2_HIP(hipMalloc(&d_pat, (size_t)count * 121 + 16));
-  SL2_HIP(hipMalloc(&d_idx, sizeof(int) * count));
-  SL2_HIP(hipMalloc(&d_ok, sizeof(int) * count));
-  SL2_HIP(hipMalloc(&d_uv, sizeof(int) * 2 * count));
-  SL2_HIP(hipMalloc(&d_ce, sizeof(double) * 2 * count));
-  SL2_HIP(hipMalloc(&d_pu, sizeof(double) * 3 * count));
-  SL2_HIP(hipMalloc(&d_sc, sizeof(double) * count));
+  if (tmp.alloc((void**)&d_img, img_bytes) || tmp.alloc((void**)&d_pat, (size_t)count * 121 + 16) ||
+      tmp.alloc((void**)&d_idx, sizeof(int) * count) || tmp.alloc((void**)&d_ok, sizeof(int) * count) ||
+      tmp.alloc((void**)&d_uv, sizeof(int) * 2 * count) || tmp.alloc((void**)&d_ce, sizeof(double) * 2 * count) ||
+      tmp.alloc((void**)&d_pu, sizeof(double) * 3 * count) || tmp.alloc((void**)&d_sc, sizeof(double) * count)) {
+    set_error("sl2_elliptical_search_batch: device allocation failed");
+    return SL2_ERR_HIP;
+  }
   SL2_HIP(hipMemcpy(d_img, images, img_bytes, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pat, patches, (size_t)count * 121, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_idx, image_index, sizeof(int) * count, hipMemcpyHostToDevice));
@@ -1263,6 +1282,5 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
   SL2_HIP(hipMemcpy(ok, d_ok, sizeof(int) * count, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(uv, d_uv, sizeof(int) * 2 * count, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(score, d_sc, sizeof(double) * count, hipMemcpyDeviceToHost));
-  hipFree(d_img); hipFree(d_pat); hipFree(d_idx); hipFree(d_ok); hipFree(d_uv); hipFree(d_ce); hipFree(d_pu); hipFree(d_sc);
   return SL2_OK;
 }

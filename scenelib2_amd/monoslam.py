@@ -199,7 +199,8 @@ class Engine:
         return out.reshape(-1)[: nseq * cnt.value * 3].reshape(nseq, cnt.value, 3).copy()
 
     def set_feature_counters(self, seq, label, attempted, successful):
-        _lib.check(self.L.sl2_set_feature_counters(self.h, seq, label, attempted, successful))
+        # test hook: lives in the TEST build of the library only (include/scenelib2_amd_testing.h)
+        _lib.check(_lib.load_testing().sl2_set_feature_counters(self.h, seq, label, attempted, successful))
 
     def delete_features(self, labels, seq0=0):
         """mark_feature_by_lab + delete_feature, one label per sequence (-1: none); returns the per-sequence bool."""
@@ -321,6 +322,11 @@ class MonoSLAM:
         if f.size != self._engine.frame_bytes:
             raise ValueError("frame must be %d x %d 8-bit single channel" % (self.camera_["width"], self.camera_["height"]))
         self._engine.go_one_step(f.reshape(1, -1), save_trajectory, enable_mapping)
+        # the reference's next_free_label_ is unbounded; the engine has max_features label slots over a sequence's
+        # lifetime: running out must not pass silently (SL2_STATUS_LABELS_EXHAUSTED, set by the feature initialisation)
+        if enable_mapping and int(self._engine.status_flags()[0]) & 2:
+            raise RuntimeError("MonoSLAM: all %d feature label slots have been used (max_features); mapping has stopped "
+                               "initialising features - create the engine with a larger max_features" % self._max_features)
         return True  # the reference always returns true (monoslam.cpp:179)
 
     @property

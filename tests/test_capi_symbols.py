@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
 
 
+def test_product_library_exports_only_the_documented_surface():
+    """Test hooks and micro-benchmarks live in libscenelib2_amd_test.so (include/scenelib2_amd_testing.h), not in the
+    product library: its exported sl2_* symbols are exactly the header's."""
+    import subprocess
+    from scenelib2_amd import _lib
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return sorted(set(re.findall(r"\b(sl2_[a-z0-9_]+)$", out, flags=re.M)))
+    prod = exported(_lib.LIB_PATH)
+    assert prod == _declared(), sorted(set(prod) ^ set(_declared()))
+    assert not [n for n in prod if n.startswith("sl2_debug") or n in _lib.TEST_SYMBOLS]
+    text = open(os.path.join(ROOT, "include", "scenelib2_amd_testing.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    hooks = sorted(set(re.findall(r"\b(sl2_[a-z0-9_]+)\s*\(", text)))
+    assert hooks == sorted(_lib.TEST_SYMBOLS)
+    test = exported(_lib.TEST_LIB_PATH)
+    assert set(hooks) <= set(test) and set(prod) <= set(test)
+
+
 def test_struct_layouts_match_header():
     from scenelib2_amd import _lib
     assert C.sizeof(_lib.sl2_camera) == 56          # 2 x i32, 5 x f64, i32 (+pad)

@@ -26,7 +26,7 @@ def test_device_fp64_score_epilogue_is_bit_exact():
     score = np.zeros(n)
     sd0 = np.zeros(n)
     sd1 = np.zeros(n)
-    _lib.check(_lib.load().sl2_debug_ncc_score(0, _lib.ip(sums), n, _lib.dp(score), _lib.dp(sd0), _lib.dp(sd1)))
+    _lib.check(_lib.load_testing().sl2_debug_ncc_score(0, _lib.ip(sums), n, _lib.dp(score), _lib.dp(sd0), _lib.dp(sd1)))
     L = oa.lib()
     # host evaluation of the same expression through the oracle's correlate2_warning
     bad = 0
@@ -44,7 +44,7 @@ def test_fp64_mfma_fragment_layout():
     XT = np.ascontiguousarray(rng.normal(size=(K, M)))
     YT = np.ascontiguousarray(rng.normal(size=(K, N)) + np.arange(N)[None, :] * 0.01)
     Cm = np.zeros((M, N))
-    _lib.check(_lib.load().sl2_debug_gemm_kt(0, _lib.dp(XT), M, _lib.dp(YT), N, M, N, K, _lib.dp(Cm), N))
+    _lib.check(_lib.load_testing().sl2_debug_gemm_kt(0, _lib.dp(XT), M, _lib.dp(YT), N, M, N, K, _lib.dp(Cm), N))
     want = XT.T @ YT
     assert np.allclose(Cm, want, rtol=1e-13, atol=1e-13), np.abs(Cm - want).max()
     # identity check with an asymmetric B
@@ -52,7 +52,7 @@ def test_fp64_mfma_fragment_layout():
     I[np.arange(4), np.arange(4)] = 1.0
     B = np.arange(4 * 32, dtype=np.float64).reshape(4, 32)
     Cm = np.zeros((32, 32))
-    _lib.check(_lib.load().sl2_debug_gemm_kt(0, _lib.dp(np.ascontiguousarray(I)), 32, _lib.dp(B), 32, 32, 32, 4, _lib.dp(Cm), 32))
+    _lib.check(_lib.load_testing().sl2_debug_gemm_kt(0, _lib.dp(np.ascontiguousarray(I)), 32, _lib.dp(B), 32, 32, 32, 4, _lib.dp(Cm), 32))
     assert np.array_equal(Cm[:4], B) and not Cm[4:].any()
 
 

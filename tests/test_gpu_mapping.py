@@ -171,3 +171,35 @@ def test_engine_matches_committed_mapping_golden():
         assert np.array_equal(eng.feature_patch(0, f["label"]), s.feature_patch(i)), f["label"]
     with pytest.raises(_lib.Sl2Error):
         eng.feature_patch(0, 31)                     # label never handed out
+
+
+def test_label_slots_run_out_loudly():
+    """More lifetime initialisations than label slots: the reference's next_free_label_ is unbounded, the engine has
+    max_features slots per sequence and does not reuse a deleted feature's slot.  Running out must be visible: the status
+    bit SL2_STATUS_LABELS_EXHAUSTED on the C ABI, an exception from the MonoSLAM adapter - and until that frame the engine
+    must have followed the oracle exactly."""
+    from scenelib2_amd import Engine, MonoSLAM
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60)
+    nslots = spec.n_features + 2                      # room for two initialisations only
+    eng = Engine(cam, params, 1, nslots)
+    eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
+    eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
+    s = oracle_for(cam, params, spec, templates, oa)
+    exhausted_at = None
+    for k in range(1, 61):
+        eng.go_one_step(frames[k][None], enable_mapping=True)
+        s.go_one_step(frames[k], False, True)
+        if int(eng.status_flags()[0]) & 2:
+            exhausted_at = k
+            break
+        assert eng.partial_feature(0)["info"]["initialised"] == s.mapping_info()["initialised"], k
+        assert np.abs(eng.total_state(0) - s.total_state()).max() < 1e-9, k
+    assert exhausted_at is not None and s.mapping_info()["initialised"] == 3      # the oracle got its third label
+    assert not int(eng.status_flags()[0]) & 1
+    # the adapter raises instead of going on silently
+    m = MonoSLAM(max_features=nslots).InitFromValues(cam, params, spec.xv0, spec.Pxx0)
+    for i in range(spec.n_features):
+        m.AddNewKnownFeature(spec.feat_y[i], spec.xp_org()[i], templates[i])
+    with pytest.raises(RuntimeError, match="label slots"):
+        for k in range(1, 61):
+            m.GoOneStep(frames[k], False, True)

@@ -144,6 +144,27 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  *   Kalman::KalmanFilterUpdate(monoslam)+normalise_state kalman.cpp:72-119, monoslam.cpp:616-637
  *   delete_bad_features + symmetrise                     monoslam.cpp:141-150
  */
+/* MonoSLAM::InitialiseFeature(frame) (monoslam.cpp:1211-1235; the "initialise manual feature" button of
+ * examples/MonoSlamSceneLib1.cpp:191-192, after a mouse click set uu_ / vv_): for every sequence s with uv[2 s] >= 0 a
+ * partially initialised feature is created at pixel (uu_, vv_) = (uv[2 s], uv[2 s + 1]) of that sequence's frame - the
+ * 11 x 11 patch copied from the frame, the semi-infinite line from the current pose, number_of_particles depth hypotheses
+ * - exactly as the feature-initialisation tail of sl2_go_one_step creates one.  Later steps match and convert it
+ * (MatchPartiallyInitialisedFeatures runs in every step from now on, like monoslam.cpp:167).  uv: host [batch][2].
+ * created: host [batch], may be NULL (the call then stays asynchronous); 1 = a feature was created.  It is NOT created -
+ * and the reference would have created it - when the sequence already has a partially initialised feature (this engine
+ * carries one at a time, the shipped max_features_to_init_at_once = 1), when the patch would leave the frame (the
+ * reference reads out of bounds), or when the label slots are exhausted (SL2_STATUS_LABELS_EXHAUSTED). */
+int sl2_initialise_feature(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, const int32_t* uv,
+                           int32_t* created);
+/* MonoSLAM::InitialiseAutoFeature(frame) (monoslam.cpp:1535-1541, the "initialise auto feature" button): AutoInitialiseFeature
+ * with zero control input for every sequence - FindNonOverlappingRegion (consumes the sequence's drand48 stream), the
+ * Shi-Tomasi detector, the 20000 score threshold, then the creation above - without the speed and visible-feature gates
+ * of GoOneStep.  created as above. */
+int sl2_initialise_auto_feature(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int32_t* created);
+/* MonoSLAM::SavePatch (monoslam.cpp:1551-1572): writes Feature::patch_ of the feature with this label (the reference saves
+ * the marked feature to "patch.png").  ".pgm" writes a binary PGM, any other name an 8-bit greyscale PNG.  Synchronises. */
+int sl2_save_patch(sl2_engine* e, int seq, int label, const char* path);
+
 /* Split the batch into `groups` contiguous sequence groups, each stepped on its own HIP stream
  * (latency-bound kernels of one group overlap throughput-bound kernels of another).  Default 1
  * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024); env SL2_GROUPS overrides. */

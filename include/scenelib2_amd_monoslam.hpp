@@ -200,6 +200,43 @@ class MonoSLAM {
     return done != 0;
   }
 
+  // MonoSLAM::InitialiseFeature(frame) (monoslam.cpp:1211-1235): a partially initialised feature at the selected pixel
+  // (uu_, vv_).  False where the reference would have created one but this engine cannot (see sl2_initialise_feature).
+  bool InitialiseFeature(const Frame& frame) {
+    const int32_t uv[2] = {uu_, vv_};
+    int32_t created = 0;
+    check(sl2_initialise_feature(eng_, frame.data, (size_t)frame.cols * frame.rows, frame.on_device ? 1 : 0, uv, &created),
+          "sl2_initialise_feature");
+    refresh_public_members();
+    return created != 0;
+  }
+  // MonoSLAM::InitialiseAutoFeature(frame) (monoslam.cpp:1535-1541)
+  bool InitialiseAutoFeature(const Frame& frame) {
+    int32_t created = 0;
+    check(sl2_initialise_auto_feature(eng_, frame.data, (size_t)frame.cols * frame.rows, frame.on_device ? 1 : 0, &created),
+          "sl2_initialise_auto_feature");
+    refresh_public_members();
+    return created != 0;
+  }
+  // MonoSLAM::mark_feature_by_lab (monoslam.cpp:743-768)
+  void mark_feature_by_lab(int lab) {
+    if (lab != -1) {
+      bool found = false;
+      for (const auto& f : feature_list_) found = found || f->label_ == lab;
+      if (!found) return;
+    }
+    marked_feature_label_ = lab;
+  }
+  // MonoSLAM::SavePatch (monoslam.cpp:1551-1572): the marked feature's template to "patch.png" in the working directory
+  bool SavePatch(const char* path = "patch.png") {
+    if (marked_feature_label_ == -1) return false;
+    bool found = false;
+    for (const auto& f : feature_list_) found = found || f->label_ == marked_feature_label_;
+    if (!found) return false;
+    check(sl2_save_patch(eng_, 0, marked_feature_label_, path), "sl2_save_patch");
+    return true;
+  }
+
   // MonoSLAM::print_robot_state (monoslam.cpp: "[Robot state]" xv_, "[Robot covariance]" Pxx_)
   void print_robot_state(FILE* out = stdout) const {
     std::fprintf(out, "[Robot state]\n");

@@ -238,6 +238,16 @@ void orc_set_feature_counters(void* h, int idx, int attempted, int successful) {
   f->attempted = attempted; f->successful = successful;
 }
 
+// MonoSLAM::InitialiseFeature at (uu_, vv_) = (u, v) (monoslam.cpp:1211-1235: what the "initialise manual feature" button of
+// examples/MonoSlamSceneLib1.cpp:191-192 calls after a mouse click set uu_ / vv_) and InitialiseAutoFeature (:1535-1541)
+void orc_initialise_feature(void* h, const uint8_t* frame, int u, int v) {
+  MonoSLAM* m = (MonoSLAM*)h;
+  m->uu = u; m->vv = v;
+  m->location_selected_flag = true;
+  m->InitialiseFeature(frame);
+}
+void orc_initialise_auto_feature(void* h, const uint8_t* frame) { ((MonoSLAM*)h)->AutoInitialiseFeature(frame); }
+
 // ---- stateless functions ------------------------------------------------------
 double orc_correlate2_warning(int x0, int y0, int x0lim, int y0lim, int x1, int y1, const uint8_t* p0, int w0,
                               const uint8_t* p1, int w1, double* sd0, double* sd1) {

@@ -64,7 +64,7 @@ class sl2_feature_info(C.Structure):
 EXPORTED_SYMBOLS = [
     "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
-    "sl2_go_one_step", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
+    "sl2_go_one_step", "sl2_initialise_feature", "sl2_initialise_auto_feature", "sl2_save_patch", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
@@ -170,6 +170,9 @@ def load():
     L.sl2_get_selection.argtypes = [vp, C.c_int, c_ip, C.c_int, c_ip]
     L.sl2_get_trajectory.argtypes = [vp, C.c_int, c_dp, C.c_int, C.POINTER(C.c_int)]
     L.sl2_get_feature_patch.argtypes = [vp, C.c_int, C.c_int, c_u8p]
+    L.sl2_initialise_feature.argtypes = [vp, vp, C.c_size_t, C.c_int, c_ip, c_ip]
+    L.sl2_initialise_auto_feature.argtypes = [vp, vp, C.c_size_t, C.c_int, c_ip]
+    L.sl2_save_patch.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]
     L.sl2_delete_features.argtypes = [vp, C.c_int, C.c_int, c_ip, c_ip]
     L.sl2_get_position_log.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.POINTER(C.c_int)]
     L.sl2_get_status_flags.argtypes = [vp, C.c_int, C.c_int, c_ip]

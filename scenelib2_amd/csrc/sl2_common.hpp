@@ -130,6 +130,7 @@ struct sl2_engine {
   double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
   int* owner_map = nullptr;              // [B][H][W] which particle ellipse scores a position (kOwnerFree between searches)
   bool mapping_used = false;
+  int* init_uv = nullptr;                // [B][2] pixel selections of sl2_initialise_feature (allocated on first use)
   // ---- whole-step HIP graphs (small batches are launch-bound: ~12 kernels per step) ----
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
   bool graph_mode = false;
@@ -227,5 +228,8 @@ int launch_search(sl2_engine* e);
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);
+int launch_manual_init(sl2_engine* e, const int* d_uv);
+int launch_auto_init(sl2_engine* e);
+int write_grey_image(const char* path, const uint8_t* px, int w, int h);   // sl2_ingest.hip (PGM / PNG)
 
 }  // namespace sl2

@@ -388,7 +388,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel, e->pack_first, e->pack_count, e->n_packs,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -566,31 +566,81 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory) {
   return rc;
 }
 
-int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int save_trajectory,
-                    int enable_mapping) {
-  if (!e) return SL2_ERR_INVALID;
-  SL2_HIP(hipSetDevice(e->device));
-  if (enable_mapping && !e->mapping_used) {
-    // feature initialisation: what this engine supports is the shipped configuration
-    if (e->prm.max_features_to_init_at_once != 1 || e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
-      set_error("enable_mapping: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 128");
-      return SL2_ERR_INVALID;
-    }
-    if (e->groups.size() > 1) { set_error("enable_mapping: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
-    e->mapping_used = true;
+static void drop_step_graphs_of(sl2_engine* e) {
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  e->step_graphs.clear();
+}
+
+// Feature initialisation is in use from now on (enable_mapping, or one of the two "initialise feature" entry points): checks
+// what this engine supports and allocates the per-pixel maps of the multi-ellipse search.
+static int enable_feature_initialisation(sl2_engine* e) {
+  if (e->mapping_used) return SL2_OK;
+  // what this engine supports is the shipped configuration (data/SceneLib2.cfg:62 max_features_to_init_at_once = 1)
+  if (e->prm.max_features_to_init_at_once != 1 || e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
+    set_error("feature initialisation: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 128");
+    return SL2_ERR_INVALID;
   }
-  int rc;
-  if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
-  const int nsel = e->prm.number_of_features_to_select;
-  // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
-  // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
-  const bool tail = e->mapping_used;
-  if (tail && !e->score_map) {
+  if (e->groups.size() > 1) { set_error("feature initialisation: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
+  if (!e->score_map) {
     const size_t px = (size_t)e->B * e->cam.width * e->cam.height;
     SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));
     SL2_HIP(hipMalloc((void**)&e->owner_map, sizeof(int) * px));
     SL2_HIP(hipMemsetAsync(e->owner_map, 0x7f, sizeof(int) * px, e->stream));   // 0x7f7f7f7f: above every particle index
   }
+  e->mapping_used = true;
+  return SL2_OK;
+}
+
+static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, const int32_t* uv,
+                             int32_t* created) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  int rc;
+  if ((rc = enable_feature_initialisation(e)) != SL2_OK) return rc;
+  if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
+  sl2_engine* g = e->groups.empty() ? e : e->groups[0];
+  g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
+  g->score_map = e->score_map; g->owner_map = e->owner_map;
+  if (uv) {
+    if (!e->init_uv) SL2_HIP(hipMalloc((void**)&e->init_uv, sizeof(int) * 2 * e->B));
+    SL2_HIP(hipMemcpyAsync(e->init_uv, uv, sizeof(int) * 2 * e->B, hipMemcpyHostToDevice, e->stream));
+    // (pageable source: the copy has been staged by the time the call returns)
+    rc = launch_manual_init(g, e->init_uv);
+  } else {
+    rc = launch_auto_init(g);
+  }
+  if (rc != SL2_OK) return rc;
+  drop_step_graphs_of(e);     // captured steps were recorded without the feature-initialisation tail
+  if (created) {
+    { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+    std::vector<int> pi((size_t)e->B * kPartInts);
+    SL2_HIP(hipMemcpy(pi.data(), e->part_i, sizeof(int) * pi.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < e->B; ++b) created[b] = pi[(size_t)b * kPartInts + kPartCreated];
+  }
+  return SL2_OK;
+}
+
+int sl2_initialise_feature(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, const int32_t* uv,
+                           int32_t* created) {
+  if (!uv) return SL2_ERR_INVALID;
+  return initialise_common(e, frames, seq_stride, frames_on_device, uv, created);
+}
+
+int sl2_initialise_auto_feature(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int32_t* created) {
+  return initialise_common(e, frames, seq_stride, frames_on_device, nullptr, created);
+}
+
+int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device, int save_trajectory,
+                    int enable_mapping) {
+  if (!e) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  int rc;
+  if (enable_mapping && !e->mapping_used && (rc = enable_feature_initialisation(e)) != SL2_OK) return rc;
+  if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
+  const int nsel = e->prm.number_of_features_to_select;
+  // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
+  // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
+  const bool tail = e->mapping_used;
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
@@ -843,6 +893,16 @@ int sl2_get_feature_patch(sl2_engine* e, int seq, int label, uint8_t* patch121) 
   if (!(flags & FF_USED)) { set_error("sl2_get_feature_patch: no feature with this label"); return SL2_ERR_INVALID; }
   SL2_HIP(hipMemcpy(patch121, e->patch + ((size_t)seq * e->N + label) * kPatchStride, SL2_PATCH_BYTES, hipMemcpyDeviceToHost));
   return SL2_OK;
+}
+
+// MonoSLAM::SavePatch (monoslam.cpp:1551-1572): cv::imwrite("patch.png", patch_) of the marked feature.  The file type
+// follows the extension like cv::imwrite: ".pgm" = binary PGM, anything else = 8-bit greyscale PNG (stored with zlib).
+int sl2_save_patch(sl2_engine* e, int seq, int label, const char* path) {
+  if (!path) return SL2_ERR_INVALID;
+  uint8_t patch[SL2_PATCH_BYTES];
+  int rc = sl2_get_feature_patch(e, seq, label, patch);
+  if (rc != SL2_OK) return rc;
+  return write_grey_image(path, patch, SL2_PATCH_SIZE, SL2_PATCH_SIZE);
 }
 
 int sl2_get_trajectory(sl2_engine* e, int seq, double* out, int capacity, int* count) {

@@ -262,6 +262,51 @@ struct sl2_ingest {
   }
 };
 
+namespace sl2 {
+
+// 8-bit greyscale image writer for sl2_save_patch (cv::imwrite's role at monoslam.cpp:1570): binary PGM for ".pgm",
+// otherwise PNG (colour type 0, one zlib stream, filter 0 on every scan line - readable by any PNG decoder, and by
+// sl2_read_image above).
+int write_grey_image(const char* path, const uint8_t* px, int w, int h) {
+  const size_t len = strlen(path);
+  FILE* f = fopen(path, "wb");
+  if (!f) { set_error(std::string("cannot write ") + path); return SL2_ERR_INVALID; }
+  bool ok = true;
+  if (len >= 4 && strcmp(path + len - 4, ".pgm") == 0) {
+    ok = fprintf(f, "P5\n%d %d\n255\n", w, h) > 0 && fwrite(px, 1, (size_t)w * h, f) == (size_t)w * h;
+  } else {
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    auto chunk = [&](const char* type, const uint8_t* data, uint32_t n) {
+      uint8_t hdr[8];
+      be32(hdr, n);
+      memcpy(hdr + 4, type, 4);
+      uint32_t crc = crc32(0L, hdr + 4, 4);
+      if (n) crc = crc32(crc, data, n);
+      uint8_t tail[4];
+      be32(tail, crc);
+      ok = ok && fwrite(hdr, 1, 8, f) == 8 && (n == 0 || fwrite(data, 1, n, f) == n) && fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    ok = fwrite(sig, 1, 8, f) == 8;
+    uint8_t ihdr[13];
+    be32(ihdr, (uint32_t)w); be32(ihdr + 4, (uint32_t)h);
+    ihdr[8] = 8; ihdr[9] = 0; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    std::vector<uint8_t> raw((size_t)h * (w + 1));
+    for (int r = 0; r < h; ++r) { raw[(size_t)r * (w + 1)] = 0; memcpy(&raw[(size_t)r * (w + 1) + 1], px + (size_t)r * w, w); }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(zlen);
+    ok = ok && compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), Z_BEST_SPEED) == Z_OK;
+    chunk("IDAT", z.data(), (uint32_t)zlen);
+    chunk("IEND", nullptr, 0);
+  }
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) { set_error(std::string("write failed: ") + path); return SL2_ERR_INVALID; }
+  return SL2_OK;
+}
+
+}  // namespace sl2
+
 extern "C" {
 
 int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count) {

@@ -22,6 +22,7 @@ namespace sl2 {
 
 struct MapParams {
   int enable_mapping, save_trajectory;
+  int force;      // InitialiseAutoFeature (monoslam.cpp:1535-1541): no speed gate, no visible-feature count
   int keep_visible, n_particles, min_particles, erase_after;
   double min_lambda, max_lambda, sd_ratio, prune_threshold, dt;
 };
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
     const double vx = (xb[0] - prev_r[b * 3 + 0]) / mp.dt, vy = (xb[1] - prev_r[b * 3 + 1]) / mp.dt,
                  vz = (xb[2] - prev_r[b * 3 + 2]) / mp.dt;
     const double speed = sqrt(vx * vx + vy * vy + vz * vz);
-    if (speed > 0.2 && mp.enable_mapping && n_vis[b] < mp.keep_visible && !pi[kPartActive]) {
+    if ((mp.force || (speed > 0.2 && mp.enable_mapping && n_vis[b] < mp.keep_visible)) && !pi[kPartActive]) {
       if (ns >= N) {
         status[b] |= 2;            // the map is full: cannot reserve a label (capacity chosen at sl2_create)
       } else {
@@ -532,9 +533,73 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   }
 }
 
+// MonoSLAM::InitialiseFeature at a caller-chosen pixel (monoslam.cpp:1211-1235; the GUI sets uu_ / vv_ by mouse click):
+// per sequence, publish the selection for k_map_create exactly as k_map_region + k_map_detect would have.
+__global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, const int* __restrict__ n_slots, int* __restrict__ part_i,
+                                                   double* __restrict__ part_d, int* __restrict__ status, int N, int width,
+                                                   int height, int B) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  int* pi = part_i + (size_t)b * kPartInts;
+  pi[kPartRegionValid] = 0;
+  pi[kPartCreated] = 0;
+  const int u = uv[2 * b], v = uv[2 * b + 1];
+  if (u < 0) return;                                                   // this sequence is left alone
+  if (u < 5 || v < 5 || u > width - 6 || v > height - 6) return;       // the 11 x 11 patch must lie inside the frame
+  if (pi[kPartActive]) return;                                         // one partially initialised feature at a time
+  if (n_slots[b] >= N) { status[b] |= 2; return; }
+  pi[kPartUU] = u; pi[kPartVV] = v;
+  pi[kPartRegionValid] = 1;
+  part_d[(size_t)b * kPartDoubles + 2] = 1.0e300;                      // no score threshold on a manual selection
+}
+
+static MapParams map_params(const sl2_engine* e, int enable_mapping, int save_trajectory, int force) {
+  MapParams mp;
+  mp.enable_mapping = enable_mapping; mp.save_trajectory = save_trajectory; mp.force = force;
+  mp.keep_visible = e->prm.number_of_features_to_keep_visible;
+  mp.n_particles = e->prm.number_of_particles;
+  mp.min_particles = e->prm.min_number_of_particles;
+  mp.erase_after = e->prm.erase_partially_init_feature_after_this_many_attempts;
+  mp.min_lambda = e->prm.min_lambda; mp.max_lambda = e->prm.max_lambda;
+  mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
+  mp.dt = e->prm.delta_t;
+  return mp;
+}
+
+static int launch_create(sl2_engine* e, const MapParams& mp) {
+  LaunchScope ls(e, "k_map_create");
+  hipLaunchKernelGGL(k_map_create, dim3(e->B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch,
+                     e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->part_i, e->part_d,
+                     e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+// InitialiseFeature(frame) with (uu_, vv_) = uv[b] (device array [B][2]; u < 0 = skip the sequence)
+int launch_manual_init(sl2_engine* e, const int* d_uv) {
+  const MapParams mp = map_params(e, 1, 0, 1);
+  hipLaunchKernelGGL(k_map_manual, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, d_uv, e->n_slots, e->part_i, e->part_d, e->status,
+                     e->N, e->cam.width, e->cam.height, e->B);
+  SL2_HIP(hipGetLastError());
+  return launch_create(e, mp);
+}
+
+// InitialiseAutoFeature(frame) = AutoInitialiseFeature(frame, 0) (monoslam.cpp:1535-1541, 823-865): region, detector, creation
+int launch_auto_init(sl2_engine* e) {
+  const MapParams mp = map_params(e, 1, 0, 1);
+  hipLaunchKernelGGL(k_map_region, dim3(e->B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
+                     e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
+  SL2_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_map_detect, dim3(e->B), dim3(kDetThreads), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width,
+                     e->cam.height, e->part_i, e->part_d);
+  SL2_HIP(hipGetLastError());
+  return launch_create(e, mp);
+}
+
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   const int B = e->B;
   MapParams mp;
+  mp.force = 0;
   mp.enable_mapping = enable_mapping; mp.save_trajectory = save_trajectory;
   mp.keep_visible = e->prm.number_of_features_to_keep_visible;
   mp.n_particles = e->prm.number_of_particles;

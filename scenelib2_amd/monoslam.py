@@ -12,6 +12,8 @@ All numerical work happens in the HIP library; nothing here computes SLAM math.
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -209,6 +211,25 @@ class Engine:
         _lib.check(self.L.sl2_delete_features(self.h, int(seq0), lab.size, _lib.ip(lab), _lib.ip(done)))
         return done.astype(bool)
 
+    def initialise_feature(self, frames, uv, on_device=False, seq_stride=0):
+        """MonoSLAM::InitialiseFeature at (uu_, vv_) = uv[s] for every sequence (u < 0: skip); returns created [batch]."""
+        ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
+        sel = np.ascontiguousarray(uv, dtype=np.int32).reshape(self.batch, 2)
+        created = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(self.L.sl2_initialise_feature(self.h, ptr, stride, dev, _lib.ip(sel), _lib.ip(created)))
+        return created.astype(bool)
+
+    def initialise_auto_feature(self, frames, on_device=False, seq_stride=0):
+        """MonoSLAM::InitialiseAutoFeature for every sequence; returns created [batch]."""
+        ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
+        created = np.zeros(self.batch, dtype=np.int32)
+        _lib.check(self.L.sl2_initialise_auto_feature(self.h, ptr, stride, dev, _lib.ip(created)))
+        return created.astype(bool)
+
+    def save_patch(self, seq, label, path):
+        """MonoSLAM::SavePatch: Feature::patch_ of the feature with this label as PNG (or PGM by extension)."""
+        _lib.check(self.L.sl2_save_patch(self.h, int(seq), int(label), os.fsencode(path)))
+
     def feature_patch(self, seq, label):
         """Feature::patch_ of the feature with this label (11x11 uint8)."""
         out = np.zeros((11, 11), dtype=np.uint8)
@@ -289,6 +310,9 @@ class MonoSLAM:
         self._engine = None
         self._patches = {}
         self.camera_ = None
+        self.uu_, self.vv_ = 0, 0                   # image selection (set by the GUI's mouse handler in the reference)
+        self.location_selected_flag_ = False
+        self.marked_feature_label_ = -1             # monoslam.h:171
 
     # MonoSLAM::Init(config_path) — monoslam.cpp:1574-1969
     def Init(self, config_path, template_dirs=()):
@@ -328,6 +352,45 @@ class MonoSLAM:
             raise RuntimeError("MonoSLAM: all %d feature label slots have been used (max_features); mapping has stopped "
                                "initialising features - create the engine with a larger max_features" % self._max_features)
         return True  # the reference always returns true (monoslam.cpp:179)
+
+    def _frame(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        if f.size != self._engine.frame_bytes:
+            raise ValueError("frame must be %d x %d 8-bit single channel" % (self.camera_["width"], self.camera_["height"]))
+        return f.reshape(1, -1)
+
+    # MonoSLAM::InitialiseFeature(frame) at (uu_, vv_) — monoslam.cpp:1211-1235
+    def InitialiseFeature(self, frame):
+        return bool(self._engine.initialise_feature(self._frame(frame), [[self.uu_, self.vv_]])[0])
+
+    # MonoSLAM::InitialiseAutoFeature(frame) — monoslam.cpp:1535-1541
+    def InitialiseAutoFeature(self, frame):
+        created = bool(self._engine.initialise_auto_feature(self._frame(frame))[0])
+        info = self._engine.partial_feature(0)["info"]
+        self.uu_, self.vv_ = info["uu"], info["vv"]
+        self.location_selected_flag_ = bool(info.get("location_selected", created))
+        return created
+
+    # MonoSLAM::mark_feature_by_lab — monoslam.cpp:743-768
+    def mark_feature_by_lab(self, lab):
+        if lab == -1 or any(f.label_ == lab for f in self.feature_list_):
+            self.marked_feature_label_ = lab
+
+    # MonoSLAM::delete_feature — monoslam.cpp:770-812
+    def delete_feature(self):
+        if self.marked_feature_label_ == -1:
+            return False
+        done = bool(self._engine.delete_features([self.marked_feature_label_])[0])
+        if done:
+            self.marked_feature_label_ = -1
+        return done
+
+    # MonoSLAM::SavePatch — monoslam.cpp:1551-1572 (writes "patch.png" in the working directory)
+    def SavePatch(self, path="patch.png"):
+        if self.marked_feature_label_ == -1 or not any(f.label_ == self.marked_feature_label_ for f in self.feature_list_):
+            return False
+        self._engine.save_patch(0, self.marked_feature_label_, path)
+        return True
 
     @property
     def xv_(self):

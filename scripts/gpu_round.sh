@@ -27,7 +27,7 @@ bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -c 4000 $OUT/bench.json; tail -5 $OUT/bench.err ;;
 prof)
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
   find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done ;;
 pmc)
   # separate passes (PMC only with --kernel-trace; never with sys/runtime traces)

@@ -84,6 +84,8 @@ def _declare(L):
     L.orc_motion_model.argtypes = [c_dp, C.c_double, c_dp, c_dp, c_dp]
     L.orc_dqnorm_by_dq.argtypes = [c_dp, c_dp]
     L.orc_measurement_model.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
+    L.orc_initialise_feature.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
+    L.orc_initialise_auto_feature.argtypes = [C.c_void_p, c_u8p]
     L.orc_run_sequences.restype = C.c_double
     L.orc_run_sequences.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(c_u8p), C.c_int, C.c_size_t,
                                     C.c_int, c_dp]
@@ -136,8 +138,6 @@ def ref_lib():
         _declare(L)
         L.ref_create_from_cfg.restype = C.c_void_p
         L.ref_create_from_cfg.argtypes = [C.c_char_p]
-        L.ref_initialise_feature.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
-        L.ref_initialise_auto_feature.argtypes = [C.c_void_p, c_u8p]
         L.ref_save_patch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_u8p]
         L.ref_save_patch.restype = C.c_int
         L.ref_sinv_from_S4.argtypes = [c_dp, c_dp, c_dp]
@@ -305,6 +305,15 @@ class OracleSLAM:
     def set_feature_counters(self, idx, attempted, successful):
         self.L.orc_set_feature_counters(self.h, idx, attempted, successful)
 
+    # MonoSLAM::InitialiseFeature at (uu_, vv_) = (u, v) / InitialiseAutoFeature (monoslam.cpp:1211-1235, 1535-1541)
+    def initialise_feature(self, frame, u, v):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        self.L.orc_initialise_feature(self.h, _u8(f), int(u), int(v))
+
+    def initialise_auto_feature(self, frame):
+        f = np.ascontiguousarray(frame, dtype=np.uint8)
+        self.L.orc_initialise_auto_feature(self.h, _u8(f))
+
 
 class RefSLAM(OracleSLAM):
     """One MonoSLAM object of the REFERENCE ITSELF (oracle/_ref/libref.so): same interface as OracleSLAM."""
@@ -320,14 +329,6 @@ class RefSLAM(OracleSLAM):
 
     def diag(self):
         raise NotImplementedError("the reference keeps no counters")
-
-    def initialise_feature(self, frame, u, v):
-        f = np.ascontiguousarray(frame, dtype=np.uint8)
-        self.L.ref_initialise_feature(self.h, _u8(f), int(u), int(v))
-
-    def initialise_auto_feature(self, frame):
-        f = np.ascontiguousarray(frame, dtype=np.uint8)
-        self.L.ref_initialise_auto_feature(self.h, _u8(f))
 
     def save_patch(self, label, directory):
         p = np.zeros(121, dtype=np.uint8)

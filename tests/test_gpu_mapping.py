@@ -203,3 +203,71 @@ def test_label_slots_run_out_loudly():
     with pytest.raises(RuntimeError, match="label slots"):
         for k in range(1, 61):
             m.GoOneStep(frames[k], False, True)
+
+
+@pytest.mark.parametrize("mode", ["manual", "auto"])
+def test_initialise_feature_buttons_match_the_oracle(mode, tmp_path):
+    """sl2_initialise_feature / sl2_initialise_auto_feature / sl2_save_patch = MonoSLAM::InitialiseFeature at (uu_, vv_),
+    InitialiseAutoFeature and SavePatch (monoslam.cpp:1211-1235, 1535-1541, 1551-1572; the three buttons of
+    examples/MonoSlamSceneLib1.cpp:191-205), called between frames, followed by ordinary steps with enable_mapping = 0
+    (MatchPartiallyInitialisedFeatures still runs, :167).  The oracle is pinned on exactly this scenario against the
+    reference's own code (tests/test_oracle_vs_ref.py::test_manual_and_auto_initialisation_buttons).  Two sequences in the
+    batch: the second is left alone (u < 0) in manual mode."""
+    from scenelib2_amd import Engine
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=30)
+    B = 2
+    eng = Engine(cam, params, B, 32)
+    eng.set_vehicle_state(np.tile(spec.xv0, (B, 1)), np.tile(spec.Pxx0, (B, 1, 1)))
+    eng.add_known_features(np.tile(spec.feat_y, (B, 1, 1)), np.tile(spec.xp_org(), (B, 1, 1)), np.tile(templates, (B, 1, 1, 1)))
+    oracles = [oracle_for(cam, params, spec, templates, oa) for _ in range(B)]
+    for k in range(1, 7):
+        eng.go_one_step(np.tile(frames[k], (B, 1, 1)))
+        for s in oracles:
+            s.go_one_step(frames[k], False, False)
+    fb = np.tile(frames[6], (B, 1, 1))
+    if mode == "manual":
+        created = eng.initialise_feature(fb, [[171, 97], [-1, -1]])
+        oracles[0].initialise_feature(frames[6], 171, 97)
+        assert list(created) == [True, False]
+        assert np.array_equal(eng.feature_patch(0, spec.n_features), frames[6][97 - 5:97 + 6, 171 - 5:171 + 6])
+        # a second manual initialisation while one is in flight is refused (one partial feature at a time), loudly
+        assert list(eng.initialise_feature(fb, [[60, 60], [-1, -1]])) == [False, False]
+        # and a patch that would leave the frame is refused instead of read out of bounds
+        assert list(eng.initialise_feature(fb, [[-1, -1], [2, 100]])) == [False, False]
+    else:
+        created = eng.initialise_auto_feature(fb)
+        for s in oracles:
+            s.initialise_auto_feature(frames[6])
+        assert list(created) == [bool(s.mapping_info()["n_partial"]) for s in oracles]
+        assert created.any()
+    for b, s in enumerate(oracles):
+        info, got = s.mapping_info(), eng.partial_feature(b)["info"]
+        assert got["n_partial"] == info["n_partial"], b
+        if info["n_partial"]:
+            assert (got["uu"], got["vv"]) == (info["uu"], info["vv"])
+        assert np.abs(eng.total_state(b) - s.total_state()).max() < 1e-9
+        assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-8
+    for k in range(7, 23):
+        eng.go_one_step(np.tile(frames[k], (B, 1, 1)))
+        for b, s in enumerate(oracles):
+            s.go_one_step(frames[k], False, False)
+            info, got = s.mapping_info(), eng.partial_feature(b)
+            assert [got["info"][key] for key in ("n_partial", "converted", "deleted")] == \
+                   [info[key] for key in ("n_partial", "converted", "deleted")], (k, b)
+            x0, x1 = s.total_state(), eng.total_state(b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
+            assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-8, (k, b)
+            if info["n_partial"]:
+                po = s.partial_feature(0)
+                assert got["pf"]["n_particles"] == po["n_particles"] and got["pf"]["attempts"] == po["attempts"]
+                assert np.array_equal(got["pf"]["particles"][:, 0], po["particles"][:, 0])
+    # SavePatch: PNG (read back with the engine's own decoder) and PGM
+    from scenelib2_amd import ingest
+    lab = eng.features(0)[2]["label"]
+    for name in ("patch.png", "patch.pgm"):
+        path = str(tmp_path / name)
+        eng.save_patch(0, lab, path)
+        img = ingest.read_image(path)
+        assert img.shape == (11, 11) and np.array_equal(img, oracles[0].feature_patch(2))
+    with pytest.raises(_lib.Sl2Error):
+        eng.save_patch(0, 31, str(tmp_path / "none.png"))       # label never handed out

@@ -446,3 +446,53 @@ def test_reference_init_on_the_shipped_cfg(tmp_path):
         zr = np.array([r.feature(i)["z"] for i in range(4)])
         sel = np.array([r.feature(i)["success"] for i in range(4)])
         assert np.array_equal(zr[sel], gold["z"][k][sel])
+
+
+def test_manual_and_auto_initialisation_buttons():
+    """The three buttons of examples/MonoSlamSceneLib1.cpp:191-205 outside GoOneStep: InitialiseFeature at a clicked pixel
+    (monoslam.cpp:1211-1235), InitialiseAutoFeature (:1535-1541) and SavePatch (:1551-1572), then ordinary frames with
+    enable_mapping = false (MatchPartiallyInitialisedFeatures still runs, :167)."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=30)
+    def fresh(cls):
+        s = cls(cam, params["delta_t"], params["number_of_features_to_select"])
+        s.set_mapping_params(params)
+        s.set_state(spec.xv0, spec.Pxx0)
+        for i in range(spec.n_features):
+            s.add_known_feature(spec.feat_y[i], spec.xp_org()[i], templates[i])
+        return s
+    for mode in ("manual", "auto"):
+        o, r = fresh(oa.OracleSLAM), fresh(oa.RefSLAM)
+        for k in range(1, 7):
+            for s in (o, r):
+                s.go_one_step(frames[k], False, False)
+        for s in (o, r):
+            if mode == "manual":
+                s.initialise_feature(frames[6], 171, 97)
+            else:
+                s.initialise_auto_feature(frames[6])
+        assert o.mapping_info()["n_partial"] == r.mapping_info()["n_partial"] == 1
+        if mode == "manual":
+            assert o.mapping_info()["n_partial"] == 1
+            assert np.array_equal(r.feature_patch(r.num_features - 1), frames[6][97 - 5:97 + 6, 171 - 5:171 + 6])
+        else:
+            io, ir = o.mapping_info(), r.mapping_info()
+            assert (io["uu"], io["vv"], io["location_selected"]) == (ir["uu"], ir["vv"], ir["location_selected"])
+        compare(o, r, tol=1e-12, what=mode + " created")
+        assert np.array_equal(o.feature_kinds(), r.feature_kinds())
+        for k in range(7, 23):
+            for s in (o, r):
+                s.go_one_step(frames[k], False, False)
+            assert np.array_equal(o.feature_kinds(), r.feature_kinds()), (mode, k)
+            compare(o, r, tol=1e-11, what="%s frame %d" % (mode, k))
+            if o.mapping_info()["n_partial"]:
+                po, pr = o.partial_feature(0), r.partial_feature(0)
+                assert (po["n_particles"], po["attempts"], po["making"]) == (pr["n_particles"], pr["attempts"], pr["making"])
+                assert np.array_equal(po["particles"][:, 0], pr["particles"][:, 0])
+                assert rel_err(po["particles"][:, 1], pr["particles"][:, 1]) <= 1e-9
+    # SavePatch: the marked feature's 11x11 template, as cv::imwrite receives it
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        lab = r.feature(2)["label"]
+        ok, patch = r.save_patch(lab, td)
+        assert ok and np.array_equal(patch, o.feature_patch(2)) and os.path.exists(os.path.join(td, "patch.png"))
+        ok, _ = r.save_patch(4242, td)          # no such label: mark_feature_by_lab leaves the mark, SavePatch saves that one

@@ -483,6 +483,35 @@ __device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned* s_T, int lan
   }
 }
 
+// wave-wide reductions on the VALU cross-lane path (six DPP operations and a readlane, no LDS round trips): four xor /
+// mirror steps inside each row of 16 lanes, then row_bcast15 / row_bcast31 carry the partial results up to lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int mf_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += mf_dpp_i<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
+  v += mf_dpp_i<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
+  v += mf_dpp_i<0x141, 0xf>(v);       // row_half_mirror
+  v += mf_dpp_i<0x140, 0xf>(v);       // row_mirror: every lane of a row holds the row's sum
+  v += mf_dpp_i<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3
+  v += mf_dpp_i<0x143, 0xc>(v);       // row_bcast31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float x) {
+  auto step = [](float v, int o) { return fmaxf(v, __int_as_float(o)); };
+  // identity of max for the lanes a bcast does not reach: the lane's own value (old = v is not expressible with a
+  // template on the value, so the masked rows are re-maxed with themselves)
+  int v = __float_as_int(x);
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false)));
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false)));
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false)));
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)));
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)));
+  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)));
+  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
+}
+
 // running state of one search: per lane the best and second-best FP32 rank, the integer sums of the best, counters
 struct MfState {
   float best_q, second_q;
@@ -499,6 +528,7 @@ __device__ __forceinline__ void mf_band_tiles(const unsigned* s_I, const unsigne
                                               MfState& st) {
   const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
   const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+  const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
   for (int ut = up; ut < min(up + 2, TU); ++ut) {
     mf_v4i accX = {0, 0, 0, 0}, acc1 = accX, accH = accX, accL = accX;
     if (patch_ok) {                      // (a flat template: every candidate is skipped, they are only counted)
@@ -510,8 +540,7 @@ __device__ __forceinline__ void mf_band_tiles(const unsigned* s_I, const unsigne
         const mf_v4i aH = *(const mf_v4i*)((const char*)s_H + aoff);
         const mf_v4i aL = *(const mf_v4i*)((const char*)s_L + aoff);
         const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
-        mf_v4i bo = b_ones;
-        if (p == 5 && (g >> 1)) bo = mf_v4i{0, 0, 0, 0};               // template row 11 does not exist
+        const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
         accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, accX, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, acc1, 0, 0, 0);
         accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, accH, 0, 0, 0);
@@ -543,7 +572,7 @@ __device__ __forceinline__ void mf_band_tiles(const unsigned* s_I, const unsigne
       st.need_exact |= (cand && D1 == 1464100) ? 1 : 0;          // sigma1 == 10 boundary: decided in FP64 only
       const float qq = (cand && D1 > 1464100 && patch_ok) ? q : -3.0e38f;
       const bool better = qq > st.best_q;
-      st.second_q = better ? st.best_q : fmaxf(st.second_q, qq);
+      st.second_q = __builtin_amdgcn_fmed3f(st.best_q, st.second_q, qq);    // second of {best, second, new}
       st.best_q = better ? qq : st.best_q;
       st.best_idx = better ? idx0 + reg : st.best_idx;
       st.best_S1 = better ? S1 : st.best_S1;
@@ -560,12 +589,9 @@ __device__ __forceinline__ SearchResult mf_decide(const MfState& st, const Searc
   SearchResult res;
   res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.score = 1000000.0;
   res.S1 = res.S2 = res.X = 0;
-  int ncand = st.ncand;
-  for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
-  res.ncand = ncand;
+  res.ncand = wave_sum_i32(st.ncand);
   if (!patch_ok) return res;
-  float gmax = st.best_q;
-  for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+  const float gmax = wave_max_f32(st.best_q);
   const float thr = gmax - 4.0e-6f;
   const bool lane_amb = (st.second_q >= thr) && (st.best_idx >= 0);
   const bool lane_near = (st.best_idx >= 0) && (st.best_q >= thr);

@@ -37,6 +37,17 @@ pmc)
     ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
   done
   python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
+c4|c5)
+  # BASELINE configs[3] / configs[4] per GPU: bench line, rocprofv3 kernel stats, FETCH / WRITE passes
+  if [ $st = c4 ]; then SHAPE="--width 640 --height 480 --features 200 --batch 1024 --steps 20 --warmup 10"; else SHAPE="--width 1280 --height 720 --features 500 --batch 512 --steps 10 --warmup 6"; fi
+  timeout 1200 python bench.py $SHAPE > $OUT/bench_$st.json 2> $OUT/bench_$st.err; echo "bench $st exit $?"; tail -c 600 $OUT/bench_$st.json
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof_$st -o bench -- python $OLDPWD/bench.py $SHAPE --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_$st.json 2> $OLDPWD/$OUT/prof_$st.err ); echo "prof $st exit $?"
+  i=0
+  for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/${st}/pmc_$i -o bench -- python $OLDPWD/bench.py $SHAPE --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/${st}_pmc_$i.json 2> $OLDPWD/$OUT/${st}_pmc_$i.err ); echo "pmc $st group $i exit $?"
+  done
+  python scripts/summarize_pmc.py $OUT/$st $OUT/${st}_pmc_traffic.json > $OUT/${st}_pmc_summary.txt 2>&1; grep -E "k_syrk|k_build|k_fwd|k_chol|k_search_mfma" $OUT/${st}_pmc_summary.txt | head -20 ;;
 esac
 done
 ls -la $OUT | head -30

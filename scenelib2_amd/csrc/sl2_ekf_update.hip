@@ -166,7 +166,15 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
           if (i < ld) {
             double py[3];
 #pragma unroll
+#ifdef SL2_PROBE_UPPER   // timing probe only (wrong results): what the pass costs when it fetches one triangle of P
+#if SL2_PROBE_UPPER == 1
+            for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : 0.0;
+#else       // correct values through the symmetric element (uncoalesced)
+            for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : Pb[(size_t)i * ld + pos + c];
+#endif
+#else
             for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+#endif
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
               double acc = 0.0;
@@ -175,7 +183,9 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
 #pragma unroll
               for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
               if (i == ld - 1) acc = f_nu[fi * 2 + r];
+#if !defined(SL2_PROBE_UPPER) || SL2_PROBE_UPPER != 3
               Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
+#endif
               sAt[(2 * jj + r) * ld + i] = acc;
             }
           }
@@ -199,7 +209,11 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
             if (t == k) acc += Rn;
             v = acc;
           }
+#if !defined(SL2_PROBE_UPPER) || SL2_PROBE_UPPER != 4
           Sb[(size_t)k * mld + t] = v;
+#else
+          if (v == 12345.678) Sb[(size_t)k * mld + t] = v;
+#endif
         }
       }
     }
@@ -1226,7 +1240,10 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   if (!xcd_map(ntl * (ntl + 1) / 2, B, &b, &t)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
-  const int mp = (2 * cnt + kSyrkKC - 1) / kSyrkKC * kSyrkKC;   // rows >= 2 cnt of Vt are zero up to the 32-multiple
+  const int mp = (2 * cnt + kSyrkKC - 1) / kSyrkKC * kSyrkKC;   // rows >= 2 cnt of Vt are zero up to the 16-multiple
+  // k-steps (of 4 rows) of the LAST chunk that hold measurements: with m = 198 the 13th chunk has 6 live rows of 16,
+  // and the two k-steps of zeros were 3 % of the launch's matrix instructions
+  const int nks_last = (2 * cnt - (mp - kSyrkKC) + 3) >> 2;
   int tj = 0;
   while (t > tj) { t -= tj + 1; ++tj; }
   const int ti = t;  // ti <= tj
@@ -1274,26 +1291,32 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   // HBM round trip under load); chunks alternate between the register sets r0 / r1.
   Stage r1 = r0;
   if (nchunk > 1) r1 = stage_load(1);
-  auto chunk_mfma = [&](int buf) {
+  // The two diagonal 32x32 blocks of a diagonal tile are symmetric: their lower-left 16x16 quarter is not computed, the
+  // epilogue writes it as the transpose of the upper-right one (interior blocks only: the innovation row / column of the
+  // last block keeps the general path).
+  const bool interior = (i0 + 32 < ld && j0 + 32 < ld);
+  const bool diagw = (ti == tj) && (wi == wj) && interior;
+  auto chunk_mfma = [&](int buf, int nks) {
     // k-row 4 ks + hi has the parity of hi: its first / second 16 columns sit at sw / sw ^ 16
     const int sw = (hi & 1) << 4;
     const double* pa = &sAB[buf][0][hi * 64 + wi + lo];
     const double* pb = &sAB[buf][1][hi * 64 + wj + lo];
 #pragma unroll
     for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
-      const double a0 = pa[ks * 256 + sw], a1 = pa[ks * 256 + (sw ^ 16)];
-      const double b0 = pb[ks * 256 + sw], b1 = pb[ks * 256 + (sw ^ 16)];
-      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+      if (ks < nks) {
+        const double a0 = pa[ks * 256 + sw], a1 = pa[ks * 256 + (sw ^ 16)];
+        const double b0 = pb[ks * 256 + sw], b1 = pb[ks * 256 + (sw ^ 16)];
+        acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+        acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+        if (!diagw) acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+        acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+      }
     }
   };
   // The P tile of an interior block is fetched in one burst right after the K loop.  (Fetching it under the MFMAs of the
   // last chunk gained 2 % at three workgroups per CU, but holds 32 more registers through the loop: with the 32 KB LDS
   // layout the kernel is better off at 74 registers and more workgroups per CU, 0.535 vs 0.552 ms.  Peeling the last
   // chunk out of the loop made the compiler copy the prefetch registers and wait for every load on the spot: 1.40 ms.)
-  const bool interior = (i0 + 32 < ld && j0 + 32 < ld);
   double pold[2][2][4];
   auto fetch_tile = [&]() {
     const double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;
@@ -1310,13 +1333,13 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
     stage_store(0, r0);
     __syncthreads();
     if (ch + 2 < nchunk) r0 = stage_load(ch + 2);
-    if (!idle) chunk_mfma(0);
+    if (!idle) chunk_mfma(0, (ch + 1 >= nchunk) ? nks_last : kSyrkKC / 4);
     if (ch + 1 >= nchunk) break;
     // odd chunk: registers r1 -> buffer 1
     stage_store(1, r1);
     __syncthreads();
     if (ch + 3 < nchunk) r1 = stage_load(ch + 3);
-    if (!idle) chunk_mfma(1);
+    if (!idle) chunk_mfma(1, (ch + 2 >= nchunk) ? nks_last : kSyrkKC / 4);
     // a buffer is rewritten two chunks after it was read, with a barrier in between: one barrier per chunk suffices
   }
   const int lastbuf = (nchunk - 1) & 1;
@@ -1333,11 +1356,12 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          if (diagw && it == 1 && jt == 0) continue;            // written below as the transpose of quarter (0, 1)
           const double pn = pold[it][jt][r] - acc[it][jt][r];
           prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt] = pn;
           acc[it][jt][r] = pn;
         }
-    if (mirror) {
+    if (mirror || diagw) {
       // The mirror block goes through LDS so that its stores are row segments of 128 bytes like the direct ones (written
       // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
       // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past
@@ -1349,6 +1373,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
       for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
+          if (diagw && !(it == 0 && jt == 1)) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) sM[lo * 17 + 4 * r + hi] = acc[it][jt][r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1575,6 +1600,18 @@ __global__ void __launch_bounds__(256) k_ubench_mfma(double* out, int iters) {
 __global__ void __launch_bounds__(256) k_ubench_copy(const double4* __restrict__ src, double4* __restrict__ dst, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+__global__ void __launch_bounds__(256) k_ubench_write(double4* __restrict__ dst, size_t n) {
+  const double4 v = {1.0, 2.0, 3.0, 4.0};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+__global__ void __launch_bounds__(256) k_ubench_read(const double4* __restrict__ src, double* __restrict__ out, size_t n) {
+  double s = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double4 v = src[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  if (s == 12345.678) out[0] = s;
+}
 }  // namespace sl2
 
 namespace sl2 {
@@ -1619,7 +1656,8 @@ __global__ void __launch_bounds__(256) k_ubench_mix(double* out, int iters) {
 
 // which: 0 = FP64 MFMA TFLOP/s with 4 independent accumulators per wave, 2 blocks of 4 waves per CU
 //        1 = same with 1 accumulator (dependent chain), 2 = streaming copy GB/s (read+write bytes),
-//        3 = 8 accumulators, 4 blocks per CU, 4 = FP64 VALU FMA TFLOP/s
+//        3 = 8 accumulators, 4 blocks per CU, 4 = FP64 VALU FMA TFLOP/s, 5 = MFMA + VALU mixed,
+//        6 = streaming write GB/s, 7 = streaming read GB/s
 extern "C" int sl2_debug_microbench(int device, int which, double* result) {
   using namespace sl2;
   if (!result) return SL2_ERR_INVALID;
@@ -1674,12 +1712,14 @@ extern "C" int sl2_debug_microbench(int device, int which, double* result) {
     SL2_HIP(hipMemset(s, 1, bytes));
     for (int rep = 0; rep < 3; ++rep) {
       SL2_HIP(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(k_ubench_copy, dim3(256 * 8), dim3(256), 0, 0, s, t, bytes / sizeof(double4));
+      if (which == 6) hipLaunchKernelGGL(k_ubench_write, dim3(256 * 8), dim3(256), 0, 0, t, bytes / sizeof(double4));
+      else if (which == 7) hipLaunchKernelGGL(k_ubench_read, dim3(256 * 8), dim3(256), 0, 0, s, (double*)t, bytes / sizeof(double4));
+      else hipLaunchKernelGGL(k_ubench_copy, dim3(256 * 8), dim3(256), 0, 0, s, t, bytes / sizeof(double4));
       SL2_HIP(hipEventRecord(e1, 0));
       SL2_HIP(hipEventSynchronize(e1));
     }
     SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *result = 2.0 * bytes / (ms * 1e-3) / 1e9;
+    *result = ((which == 6 || which == 7) ? 1.0 : 2.0) * bytes / (ms * 1e-3) / 1e9;
     hipFree(s); hipFree(t);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);

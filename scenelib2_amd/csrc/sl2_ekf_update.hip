@@ -166,8 +166,8 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
           if (i < ld) {
             double py[3];
 #pragma unroll
-#ifdef SL2_PROBE_UPPER   // timing probe only (wrong results): what the pass costs when it fetches one triangle of P
-#if SL2_PROBE_UPPER == 1
+#if defined(SL2_PROBE_UPPER) && SL2_PROBE_UPPER <= 2   // timing probes: the pass when it fetches one triangle of P
+#if SL2_PROBE_UPPER == 1   // (wrong results)
             for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : 0.0;
 #else       // correct values through the symmetric element (uncoalesced)
             for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : Pb[(size_t)i * ld + pos + c];
@@ -1361,7 +1361,11 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
           prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt] = pn;
           acc[it][jt][r] = pn;
         }
+#if defined(SL2_PROBE_UPPER) && SL2_PROBE_UPPER == 5   // timing probe: no mirror block (the lower triangle goes stale)
+    if (diagw) {
+#else
     if (mirror || diagw) {
+#endif
       // The mirror block goes through LDS so that its stores are row segments of 128 bytes like the direct ones (written
       // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
       // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past

@@ -115,34 +115,41 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
+    # stdout carries exactly ONE line, the JSON record.  Libraries write there too (gloo announces its connections, RCCL prints a
+    # version banner through C stdio, buffered until exit): file descriptor 1 is pointed at stderr for the whole run and the
+    # record goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch  # first: one shared HIP runtime (scenelib2_amd/_lib.py)
     import torch.distributed as dist
     from scenelib2_amd import Engine, _lib, sharding, synth
 
     rank, world, local_rank = sharding.env_rank_world()
-    if world > 1:
-        # RCCL ("nccl" on ROCm).  SL2_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU on a
-        # single-GPU box to exercise this multi-rank code path (collectives then run on host tensors).
-        backend = os.environ.get("SL2_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
-        # gloo's C++ side announces its connections on stdout: keep stdout for the one JSON line
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group(backend)
-            dist.barrier()
-        finally:
-            os.dup2(saved, 1)
-            os.close(saved)
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if world > torch.cuda.device_count() and os.environ.get("SL2_BENCH_BACKEND") != "gloo":
         raise SystemExit("bench.py: %d ranks but %d HIP device(s): one rank per GPU" % (world, torch.cuda.device_count()))
+    # the rank's device is chosen BEFORE the process group exists: RCCL binds its communicator to the device it is told
+    # (device_id) - left to guess, every rank of a fresh process sits on device 0 and the first collective sees duplicates
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     tdev = torch.device("cuda", dev)
-    if world > 1 and dist.get_backend() != "nccl":
-        tdev = None
+    # SL2_BENCH_FORCE_DIST=1: create the process group even for a single rank (tests: the RCCL path - communicator bound to the
+    # device, barrier, reductions and all-gather on device tensors - on a one-GPU box)
+    use_dist = world > 1 or os.environ.get("SL2_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        # RCCL ("nccl" on ROCm).  SL2_BENCH_BACKEND=gloo is a test hook: it lets two ranks share one GPU on a
+        # single-GPU box to exercise this multi-rank code path (collectives then run on host tensors).
+        backend = os.environ.get("SL2_BENCH_BACKEND") or "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend, device_id=tdev)
+            dist.barrier(device_ids=[dev])
+        else:
+            dist.init_process_group(backend)
+            dist.barrier()
+        if dist.get_backend() != "nccl":
+            tdev = None
 
     def barrier():
         # RCCL needs to know which device this rank drives (otherwise it guesses from the rank and warns)
@@ -220,17 +227,17 @@ def main():
         eng.reset_kernel_times()
 
     # ---- timed region: exactly K steps ----
-    if world > 1:
+    if use_dist:
         barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(Wm, Wm + K):
         step(k)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, tdev if world > 1 else None)
+    elapsed = sharding.max_over_ranks(elapsed, tdev if use_dist else None)
 
     ktimes = eng.kernel_times() if not args.no_profile else {}
     eng.set_profiling(0)
@@ -247,12 +254,12 @@ def main():
         eng.synchronize()
         breakdown = eng.kernel_times()
         eng.set_profiling(0)
-    total_frames = sharding.sum_over_ranks(B * K, tdev if world > 1 else None)
+    total_frames = sharding.sum_over_ranks(B * K, tdev if use_dist else None)
     value = total_frames / elapsed
 
     # ---- gather of the small results (RCCL all-gather; outside the timed region) ----
     t_g = time.perf_counter()
-    all_xv = sharding.gather_states(xv_final, tdev if world > 1 else None)
+    all_xv = sharding.gather_states(xv_final, tdev if use_dist else None)
     gather_ms = (time.perf_counter() - t_g) * 1e3
     status_bad = int(eng.status_flags().any())
 
@@ -421,9 +428,8 @@ def main():
             "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,
             "gathered_states": int(all_xv.shape[0]),
         }
-        print(json.dumps(out))
-        sys.stdout.flush()
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if use_dist:
         barrier()
         dist.destroy_process_group()
     return out

@@ -51,3 +51,21 @@ def test_bench_self_spawns_ranks():
     assert d["n_gpus"] == 2 and d["gathered_states"] == 32 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert d["cpu_baseline"] is None                      # rank 0 at N = 1 only
+
+
+def test_bench_rccl_path_single_rank():
+    """The collectives of the multi-GPU bench over RCCL itself (backend "nccl"), as far as a one-GPU box allows: a launcher-style
+    environment with WORLD_SIZE = 1 and SL2_BENCH_FORCE_DIST=1 creates the process group bound to the rank's device, and the
+    barrier, the MAX / SUM reductions and the all-gather run on device tensors."""
+    env = dict(os.environ)
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29731",
+               SL2_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SL2_BENCH_BACKEND", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--batch", "16",
+                          "--cpu-sample", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["gathered_states"] == 16
+    assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]

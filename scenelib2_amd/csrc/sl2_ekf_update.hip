@@ -24,29 +24,6 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
 }
 
 // ---------------------------------------------------------------------------
-// k_compact: successful measurements in selected_feature_list_ order
-// (construct_total_measurement_stuff, monoslam.cpp:548-572).
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_compact(const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
-                                                const int* __restrict__ meas_ok, int* __restrict__ succ_idx,
-                                                int* __restrict__ m_count, int N) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int ns = n_sel[b];
-  int base = 0;
-  for (int k0 = 0; k0 < ns; k0 += 64) {
-    const int k = k0 + lane;
-    const int flag = (k < ns) ? (meas_ok[(size_t)b * N + k] != 0) : 0;
-    const unsigned long long mask = __ballot(flag);
-    if (flag) {
-      const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
-      succ_idx[(size_t)b * N + pos] = sel_idx[(size_t)b * N + k];
-    }
-    base += __popcll(mask);
-  }
-  if (lane == 0) m_count[b] = base;
-}
-
-// ---------------------------------------------------------------------------
 // k_build_A: At[a][i] = (P H^T)[i][a], a = 2j+r for the j-th successful feature.
 // Column ld-1 carries the innovation nu (so that L^-1 nu and W nu fall out of the
 // same substitution / SYRK).  Rows of padding up to a multiple of 32 are zeroed.
@@ -1433,17 +1410,29 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
 }
 #endif  // SL2_TESTING
 
+#ifdef SL2_PROBE_UPPER
+__global__ void __launch_bounds__(64) k_dummy(int* m_count, int mode) {
+  if (mode == 7 && threadIdx.x == 0) m_count[blockIdx.x] = m_count[blockIdx.x];   // 6: empty kernel, 7: touches m_count
+}
+#endif
 static int launch_update_range(sl2_engine* e) {
-  const int B = e->B;
-  {
-    LaunchScope ls(e, "k_compact");
-    hipLaunchKernelGGL(k_compact, dim3(B), dim3(64), 0, e->stream, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count, e->N);
-    SL2_HIP(hipGetLastError());
-  }
+  const int B = e->B;     // (succ_idx / m_count, the successful measurements in selection order, come from k_search_score)
+#ifdef SL2_PROBE_UPPER
+  const int dmask = getenv("SL2_DUMMY_MASK") ? atoi(getenv("SL2_DUMMY_MASK")) : 1;
+#define SL2_DUMMY(bit) do { if (dmask & (bit)) { LaunchScope ls(e, "k_dummy"); hipLaunchKernelGGL(k_dummy, dim3(B), dim3(64), 0, e->stream, e->m_count, SL2_PROBE_UPPER); } } while (0)
+#else
+#define SL2_DUMMY(bit) do { } while (0)
+#endif
+  SL2_DUMMY(1);
   if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
     // workgroups per sequence: enough to put ~512 on the chip
-    int nsplit = B >= 512 ? 1 : (512 + B - 1) / B;
+    // (~3000 workgroups in all, also at large batches: with ONE workgroup per sequence batch 1024 is exactly one round of four
+    // workgroups per CU, and the launch then took 0.35 or 0.44 ms depending on which kernel ran before it - measured with an
+    // empty kernel in front, profiles/r02_probes.txt; three per sequence re-balance as they finish: 0.348 either way)
+    int nsplit = (3072 + B - 1) / B;
+    if (const char* v = getenv("SL2_BUILD_SPLIT")) nsplit = atoi(v);     // experiments
+    if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;
     if (e->ld <= 1024) {
@@ -1472,6 +1461,7 @@ static int launch_update_range(sl2_engine* e) {
       SL2_HIP(hipGetLastError());
     }
   }
+  SL2_DUMMY(2);
   if (e->nblk_max > kFusedMaxBlocks && e->root->chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
     LaunchScope ls(e, "k_chol_fused");
     launch_chol_panels(e, B);
@@ -1508,6 +1498,7 @@ static int launch_update_range(sl2_engine* e) {
       }
     }
   }
+  SL2_DUMMY(4);
   {
     LaunchScope ls(e, "k_fwdsub", true);
     bool done = false;
@@ -1522,6 +1513,7 @@ static int launch_update_range(sl2_engine* e) {
                          e->m_count, e->ld, e->mld, e->nblk_max, B);
     SL2_HIP(hipGetLastError());
   }
+  SL2_DUMMY(8);
   {
     LaunchScope ls(e, "k_syrk", true);
     const int nt = e->ld / 64;

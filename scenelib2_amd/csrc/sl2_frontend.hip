@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
                                                 double* __restrict__ last_r, const int* __restrict__ srch_i,
                                                 const double* __restrict__ srch_d, int* __restrict__ srch_sel,
                                                 int* __restrict__ pack_first, int* __restrict__ pack_count,
-                                                int* __restrict__ n_packs, int N, int n_want) {
+                                                int* __restrict__ n_packs, int N, int n_want, int make_packs) {
   extern __shared__ double s_dyn[];
   double* s_score = s_dyn;                 // [N]
   int* s_vis = (int*)(s_dyn + N);          // [N]
@@ -234,7 +234,8 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
   // The greedy segmentation is a chain, but the length of the pack that STARTS at k depends on k alone: every
   // thread computes it for its k (<= 8 look-ahead reads), then one thread follows the chain (~25 hops).  (Walked
   // feature by feature by one thread - in LDS or on the scalar unit - this phase was half of the kernel.)
-  for (int k = tid; k < limit; k += blockDim.x) {
+  // (only the packed column-walk variant of the search reads the pack lists)
+  for (int k = tid; make_packs && k < limit; k += blockDim.x) {
     int cnt = 0;
     if (s_nu[k] > kPackMaxNu || s_nv[k] > kPackMaxNv) {
       cnt = 1;
@@ -252,7 +253,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     s_vis[k] = cnt;          // s_vis (the ranks) is free again
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && make_packs) {
     int np = 0, k = 0;
     while (k < limit) {
       const int cnt = s_vis[k];
@@ -436,7 +437,8 @@ int launch_select(sl2_engine* e, int n) {
   if (n > e->nsel_max) n = e->nsel_max;
   const size_t shm = (size_t)e->N * (sizeof(double) + 3 * sizeof(int));
   hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
-                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->pack_first, e->pack_count, e->n_packs, e->N, n);
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->pack_first, e->pack_count, e->n_packs, e->N, n,
+                     e->root->search_variant == 2 ? 1 : 0);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

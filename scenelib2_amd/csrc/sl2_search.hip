@@ -720,17 +720,17 @@ constexpr int kMfChunk = 4;
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
 k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, const uint8_t* __restrict__ patch,
               const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
-              double* __restrict__ meas_score, int N, int nchunks, int B) {
+              double* __restrict__ meas_score, int N, int nchunks, int B, int chunk) {
   int b, ch;
   if (!xcd_map(nchunks, B, &b, &ch)) return;
   STR(0);
   __shared__ __attribute__((aligned(16))) unsigned s_pl[3 * kMfPlaneDw];
   __shared__ unsigned s_T[kMfTplDw];
   const int lane = threadIdx.x;
-  const int k0 = ch * kMfChunk;
+  const int k0 = ch * chunk;
   const int nsel = n_sel[b];
   if (k0 >= nsel) return;
-  const int nf = min(kMfChunk, nsel - k0);
+  const int nf = min(chunk, nsel - k0);
   const uint8_t* img = frames + (size_t)b * seq_stride;
   const int j = lane & 15, g = lane >> 4;
   unsigned* s_I = s_pl;
@@ -1130,54 +1130,83 @@ __global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict_
   STR(6);
 }
 
-__global__ void __launch_bounds__(64) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
-                                                     const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
-                                                     const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
-                                                     int* __restrict__ f_flags, double* __restrict__ f_z,
-                                                     double* __restrict__ f_nu, int* __restrict__ attempted,
-                                                     int* __restrict__ successful, int* __restrict__ meas_ok,
-                                                     double* __restrict__ meas_score, double* __restrict__ work, int N) {
-  const int b = blockIdx.y;
-  const int k = blockIdx.x * 64 + threadIdx.x;
+// One workgroup per sequence, one thread per selected position.  Besides the deferred FP64 scores and the reference's
+// bookkeeping it compacts the successful measurements in selected_feature_list_ order (construct_total_measurement_stuff,
+// monoslam.cpp:548-572: succ_idx / m_count, what the EKF update reads) and leaves the step's work counters - a launch
+// of its own for the compaction and a memset + atomics for the counters were 10 us of a single-sequence step.
+__global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
+                                                       const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
+                                                       const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
+                                                       int* __restrict__ f_flags, double* __restrict__ f_z,
+                                                       double* __restrict__ f_nu, int* __restrict__ attempted,
+                                                       int* __restrict__ successful, int* __restrict__ meas_ok,
+                                                       double* __restrict__ meas_score, double* __restrict__ work,
+                                                       int* __restrict__ succ_idx, int* __restrict__ m_count, int N) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
+  __shared__ int s_wcnt[16];
+  __shared__ double s_red[16][4];
+  const int ns = n_sel[b];
   double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0;
-  if (k < n_sel[b]) {
-    const int f = sel_idx[(size_t)b * N + k];
-    const size_t fi = (size_t)b * N + f;
-    const int* o = srch_res + ((size_t)b * N + k) * 8;
-    const int code = o[0];
-    int ok = (o[7] & 2) ? 1 : 0;
-    double score = meas_score[(size_t)b * N + k];
-    if (code == 1) {   // deferred: the only candidate that can win; reference FP64 score + thresholds
-      const unsigned* packed = (const unsigned*)(patch + fi * kPatchStride + kPatchPackedOffset);
-      double sd0, sd1;
-      score = ncc_score((int)packed[33], o[3], o[5], (int)packed[34], o[4], &sd0, &sd1);
-      ok = (!(sd0 < kCorrelationSigmaThreshold) && !(sd1 < kCorrelationSigmaThreshold) && !(score > kCorrThresh2)) ? 1 : 0;
-      meas_score[(size_t)b * N + k] = score;
+  int base = 0;
+  for (int k0 = 0; k0 < ns; k0 += (int)blockDim.x) {
+    const int k = k0 + tid;
+    int ok = 0, f = 0;
+    if (k < ns) {
+      f = sel_idx[(size_t)b * N + k];
+      const size_t fi = (size_t)b * N + f;
+      const int* o = srch_res + ((size_t)b * N + k) * 8;
+      const int code = o[0];
+      ok = (o[7] & 2) ? 1 : 0;
+      double score = meas_score[(size_t)b * N + k];
+      if (code == 1) {   // deferred: the only candidate that can win; reference FP64 score + thresholds
+        const unsigned* packed = (const unsigned*)(patch + fi * kPatchStride + kPatchPackedOffset);
+        double sd0, sd1;
+        score = ncc_score((int)packed[33], o[3], o[5], (int)packed[34], o[4], &sd0, &sd1);
+        ok = (!(sd0 < kCorrelationSigmaThreshold) && !(sd1 < kCorrelationSigmaThreshold) && !(score > kCorrThresh2)) ? 1 : 0;
+        meas_score[(size_t)b * N + k] = score;
+      }
+      meas_ok[(size_t)b * N + k] = ok;
+      int fl = f_flags[fi];
+      attempted[fi] += 1;
+      if (ok) {
+        successful[fi] += 1;
+        const double h0 = f_h[fi * 2], h1 = f_h[fi * 2 + 1];
+        f_z[fi * 2] = (double)o[1]; f_z[fi * 2 + 1] = (double)o[2];
+        f_nu[fi * 2] = (double)o[1] - h0; f_nu[fi * 2 + 1] = (double)o[2] - h1;   // func_nui
+        fl |= FF_SUCCESS;
+      } else {
+        fl &= ~FF_SUCCESS;
+      }
+      f_flags[fi] = fl;
+      const int* si = srch_i + fi * 8;
+      w_win += (double)(2 * si[6] + 11) * (double)(2 * si[7] + 11);
+      w_n += 1.0; w_cand += (double)o[6]; w_fb += (o[7] & 4) ? 1.0 : 0.0;
     }
-    meas_ok[(size_t)b * N + k] = ok;
-    int fl = f_flags[fi];
-    attempted[fi] += 1;
-    if (ok) {
-      successful[fi] += 1;
-      const double h0 = f_h[fi * 2], h1 = f_h[fi * 2 + 1];
-      f_z[fi * 2] = (double)o[1]; f_z[fi * 2 + 1] = (double)o[2];
-      f_nu[fi * 2] = (double)o[1] - h0; f_nu[fi * 2 + 1] = (double)o[2] - h1;   // func_nui
-      fl |= FF_SUCCESS;
-    } else {
-      fl &= ~FF_SUCCESS;
+    // order-preserving compaction of the successes of this round of positions
+    const unsigned long long mask = __ballot(ok != 0);
+    if (lane == 0) s_wcnt[wave] = __popcll(mask);
+    __syncthreads();
+    int off = base, total = 0;
+    for (int w = 0; w < nwave; ++w) {
+      const int c = s_wcnt[w];
+      if (w < wave) off += c;
+      total += c;
     }
-    f_flags[fi] = fl;
-    const int* si = srch_i + fi * 8;
-    w_win = (double)(2 * si[6] + 11) * (double)(2 * si[7] + 11);
-    w_n = 1.0; w_cand = (double)o[6]; w_fb = (o[7] & 4) ? 1.0 : 0.0;
+    if (ok) succ_idx[(size_t)b * N + off + __popcll(mask & ((1ull << lane) - 1ull))] = f;
+    base += total;
+    __syncthreads();
   }
+  if (tid == 0) m_count[b] = base;
   for (int off = 32; off > 0; off >>= 1) {
     w_win += __shfl_xor(w_win, off, 64); w_n += __shfl_xor(w_n, off, 64);
     w_cand += __shfl_xor(w_cand, off, 64); w_fb += __shfl_xor(w_fb, off, 64);
   }
-  if (threadIdx.x == 0 && w_n > 0.0) {
-    atomicAdd(&work[b * 4 + 0], w_win); atomicAdd(&work[b * 4 + 1], w_n);
-    atomicAdd(&work[b * 4 + 2], w_cand); atomicAdd(&work[b * 4 + 3], w_fb);
+  if (lane == 0) { s_red[wave][0] = w_win; s_red[wave][1] = w_n; s_red[wave][2] = w_cand; s_red[wave][3] = w_fb; }
+  __syncthreads();
+  if (tid < 4) {
+    double acc = 0.0;
+    for (int w = 0; w < nwave; ++w) acc += s_red[w][tid];
+    work[b * 4 + tid] = acc;
   }
 }
 
@@ -1215,7 +1244,6 @@ namespace sl2 {
 #endif
 
 int launch_search(sl2_engine* e) {
-  SL2_HIP(hipMemsetAsync(e->work, 0, sizeof(double) * 4 * e->B, e->stream));
   {
     LaunchScope ls(e, "k_search", true);
     dim3 grid(xcd_grid(e->nsel_max, e->B));
@@ -1224,9 +1252,13 @@ int launch_search(sl2_engine* e) {
                          e->srch_i, e->srch_d, e->sel_idx, e->pack_first, e->pack_count, e->n_packs, e->srch_res,
                          e->meas_score, e->N, e->nsel_max, e->B);
     else if (e->root->search_variant == 3) {
-      const int nchunks = (e->nsel_max + kMfChunk - 1) / kMfChunk;
+      // positions per wavefront: kMfChunk when the batch fills the chip's wave slots (4096 at four per SIMD), fewer at
+      // small batches - the positions of a wavefront run one after the other (18 us for four at batch 1)
+      int chunk = (int)(((long long)e->B * e->nsel_max + 4095) / 4096);
+      chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
+      const int nchunks = (e->nsel_max + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
-                         e->cam.width, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score, e->N, nchunks, e->B);
+                         e->cam.width, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score, e->N, nchunks, e->B, chunk);
     }
     else if (e->root->search_variant == 0)
       hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
@@ -1238,10 +1270,11 @@ int launch_search(sl2_engine* e) {
   }
   {
     LaunchScope ls(e, "k_search_score");
-    dim3 grid((e->nsel_max + 63) / 64, e->B);
-    hipLaunchKernelGGL(k_search_score, grid, dim3(64), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
+    int threads = (e->nsel_max + 63) / 64 * 64;
+    if (threads > 1024) threads = 1024;
+    hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
-                       e->N);
+                       e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

@@ -132,8 +132,8 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
  * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
  * enable_mapping != 0 runs the feature-initialisation tail (monoslam.cpp:152-170: AutoInitialiseFeature behind the
  * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) for the shipped max_features_to_init_at_once = 1 and up to
- * 128 particles; other settings are rejected with SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not reserve a
- * label because max_features is exhausted. */
+ * 128 particles; other settings are rejected with SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not take a
+ * new feature because all max_features slots hold live features. */
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
                     int save_trajectory, int enable_mapping);
 
@@ -292,13 +292,15 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
 /* MonoSLAM::mark_feature_by_lab(label) + delete_feature() (monoslam.cpp:743-812) for one feature per sequence:
  * labels [nseq], -1 = leave that sequence alone.  deleted [nseq] (may be NULL) receives the reference's bool: 1 if a live,
  * fully initialised feature with that label existed and was removed (partially initialised ones are removed by the engine's
- * own sell-by / conversion logic only).  The label is not reused.  Synchronises. */
+ * own sell-by / conversion logic only).  The label is never reused (its slot may be).  Synchronises. */
 int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels, int32_t* deleted);
 /* Per-sequence status bits (sticky).  SL2_STATUS_NONFINITE: NaN / Inf seen in the state (e.g. the omega == 0 hazard, Q10).
- * SL2_STATUS_LABELS_EXHAUSTED: feature initialisation wanted a new label but all max_features label slots of the sequence
- * have been handed out over its lifetime (a deleted feature's slot is not reused; the reference's next_free_label_ is
- * unbounded): the sequence keeps tracking its map but initialises no further features.  Callers that run with
- * enable_mapping must poll this (the MonoSLAM adapters do, and raise). */
+ * SL2_STATUS_LABELS_EXHAUSTED: feature initialisation wanted a new feature but every one of the sequence's max_features slots
+ * holds a LIVE feature (the reference's feature_list_ is unbounded).  Deleted features do not count: their slots are squeezed
+ * out, in feature_list_ order, when a sequence runs out of slots, and labels (Feature::label_ = next_free_label_++) are kept
+ * apart from slots and never reused - a sequence may hand out any number of labels over its lifetime.  When the bit is set the
+ * sequence keeps tracking its map but initialises no further features.  Callers that run with enable_mapping must poll
+ * this (the MonoSLAM adapters do, and raise). */
 #define SL2_STATUS_NONFINITE 1
 #define SL2_STATUS_LABELS_EXHAUSTED 2
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);

@@ -170,11 +170,11 @@ class MonoSLAM {
                           enable_mapping ? 1 : 0),
           "sl2_go_one_step");
     refresh_public_members();
-    if (enable_mapping) {   // next_free_label_ is unbounded in the reference; here the label slots are finite: never silently
+    if (enable_mapping) {   // feature_list_ is unbounded in the reference; here at most max_features LIVE features: never silently
       int32_t flags = 0;
       check(sl2_get_status_flags(eng_, 0, 1, &flags), "sl2_get_status_flags");
       if (flags & SL2_STATUS_LABELS_EXHAUSTED)
-        throw std::runtime_error("MonoSLAM::GoOneStep: every feature label slot has been used (max_features): mapping can "
+        throw std::runtime_error("MonoSLAM::GoOneStep: all max_features feature slots hold live features: mapping can "
                                  "initialise no further features; construct MonoSLAM with a larger max_features");
     }
     return true;

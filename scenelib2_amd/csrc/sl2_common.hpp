@@ -105,7 +105,9 @@ struct sl2_engine {
   int* patch_sums = nullptr;  // [B][N][2]      (sum g0, sum g0^2) of each template
   double* xp_org = nullptr;   // [B][N][8]      xp_org_ (7 used)
   int* f_flags = nullptr;     // [B][N]
-  int* n_slots = nullptr;     // [B]            slots used so far == next_free_label_
+  int* n_slots = nullptr;     // [B]            slots in use (live, reserved or retired features), list order = slot order
+  int* f_label = nullptr;     // [B][N]         Feature::label_ of the slot (slots are compacted when they run out, labels never reused)
+  int* next_label = nullptr;  // [B]            next_free_label_
   int* attempted = nullptr;   // [B][N]
   int* successful = nullptr;  // [B][N]
   double* traj = nullptr;     // [B][kTrajCapacity][3]
@@ -230,6 +232,7 @@ int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);
 int launch_manual_init(sl2_engine* e, const int* d_uv);
 int launch_auto_init(sl2_engine* e);
+int launch_compact_slots(sl2_engine* e);     // sl2_mapping.hip: retired slots squeezed out when a sequence has none left
 int write_grey_image(const char* path, const uint8_t* px, int w, int h);   // sl2_ingest.hip (PGM / PNG)
 
 }  // namespace sl2

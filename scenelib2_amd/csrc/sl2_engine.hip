@@ -16,12 +16,14 @@ void set_error(const std::string& s) { g_err = s; }
 
 __global__ void k_add_features(double* __restrict__ x, double* __restrict__ xp_org, uint8_t* __restrict__ patch,
                                int* __restrict__ patch_sums, int* __restrict__ f_flags, int* __restrict__ n_slots,
-                               int* __restrict__ attempted, int* __restrict__ successful, const double* __restrict__ y_in,
+                               int* __restrict__ attempted, int* __restrict__ successful, int* __restrict__ f_label,
+                               int* __restrict__ next_label, const double* __restrict__ y_in,
                                const double* __restrict__ xp_in, const uint8_t* __restrict__ patch_in, int seq0, int nfeat,
                                int N, int ld) {
   // one block per sequence, threads over features
   const int s = blockIdx.x, b = seq0 + s;
   const int base = n_slots[b];
+  const int base_label = next_label[b];
   for (int f = threadIdx.x; f < nfeat; f += blockDim.x) {
     const int slot = base + f;
     const size_t fi = (size_t)b * N + slot;
@@ -57,9 +59,10 @@ __global__ void k_add_features(double* __restrict__ x, double* __restrict__ xp_o
     patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
     f_flags[fi] = FF_ACTIVE | FF_USED;
     attempted[fi] = 0; successful[fi] = 0;
+    f_label[fi] = base_label + f;                 // label_ = next_free_label_++ (monoslam.cpp:1306-1307)
   }
   __syncthreads();
-  if (threadIdx.x == 0) n_slots[b] = base + nfeat;
+  if (threadIdx.x == 0) { n_slots[b] = base + nfeat; next_label[b] = base_label + nfeat; }
 }
 
 __global__ void k_set_feature_cov(double* __restrict__ P, const double* __restrict__ Pyy, int seq0, int nfeat, int ld) {
@@ -146,6 +149,7 @@ static int build_groups(sl2_engine* e, int G) {
     const size_t f = first;
     g->x = e->x + f * ld; g->P = e->P + f * ld * ld; g->patch = e->patch + f * N * kPatchStride;
     g->patch_sums = e->patch_sums + f * N * 2; g->xp_org = e->xp_org + f * N * 8; g->f_flags = e->f_flags + f * N;
+    g->f_label = e->f_label + f * N; g->next_label = e->next_label + f;
     g->n_slots = e->n_slots + f; g->attempted = e->attempted + f * N; g->successful = e->successful + f * N;
     g->traj = e->traj + f * kTrajCapacity * 3; g->traj_count = e->traj_count + f; g->last_r = e->last_r + f * 3;
     g->status = e->status + f; g->pos_log = e->pos_log + f * kTrajCapacity * 3; g->pos_count = e->pos_count + f;
@@ -298,6 +302,8 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->xp_org, B * N * 8));
   A(dmalloc(&e->f_flags, B * N));
   A(dmalloc(&e->n_slots, B));
+  A(dmalloc(&e->f_label, B * N));
+  A(dmalloc(&e->next_label, B));
   A(dmalloc(&e->attempted, B * N));
   A(dmalloc(&e->successful, B * N));
   A(dmalloc(&e->traj, B * kTrajCapacity * 3));
@@ -388,7 +394,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel, e->pack_first, e->pack_count, e->n_packs,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
@@ -472,7 +478,7 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
   SL2_HIP(hipMemcpyAsync(dxp, xp_org, sizeof(double) * 7 * cnt, hipMemcpyHostToDevice, e->stream));
   SL2_HIP(hipMemcpyAsync(dp, patches, 121 * cnt, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_add_features, dim3(nseq), dim3(64), 0, e->stream, e->x, e->xp_org, e->patch, e->patch_sums, e->f_flags,
-                     e->n_slots, e->attempted, e->successful, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
+                     e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
   SL2_HIP(hipGetLastError());
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   hipFree(dy); hipFree(dxp); hipFree(dp);
@@ -714,7 +720,7 @@ int sl2_set_graph_mode(sl2_engine* e, int enabled) {
 
 struct HostSeq {
   std::vector<double> x, P;
-  std::vector<int> flags;
+  std::vector<int> flags, labels;
   int n_slots = 0;
   int part[kPartInts] = {0};
 };
@@ -726,12 +732,30 @@ static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
   SL2_HIP(hipMemcpy(hs.part, e->part_i + (size_t)seq * kPartInts, sizeof(int) * kPartInts, hipMemcpyDeviceToHost));
   hs.flags.resize(e->N);
   SL2_HIP(hipMemcpy(hs.flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  hs.labels.resize(e->N);
+  SL2_HIP(hipMemcpy(hs.labels.data(), e->f_label + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
   hs.x.resize(e->ld);
   SL2_HIP(hipMemcpy(hs.x.data(), e->x + (size_t)seq * e->ld, sizeof(double) * e->ld, hipMemcpyDeviceToHost));
   if (want_P) {
     hs.P.resize((size_t)e->ld * e->ld);
     SL2_HIP(hipMemcpy(hs.P.data(), e->P + (size_t)seq * e->ld * e->ld, sizeof(double) * e->ld * e->ld, hipMemcpyDeviceToHost));
   }
+  return SL2_OK;
+}
+
+// Slot that holds the feature with this label (labels are handed out once, next_free_label_++; slots are squeezed when a
+// sequence runs out of them, so slot != label in general): -1 if there is none.  Synchronises.
+static int slot_of_label(sl2_engine* e, int seq, int label, int* slot) {
+  *slot = -1;
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  int ns = 0;
+  SL2_HIP(hipMemcpy(&ns, e->n_slots + seq, sizeof(int), hipMemcpyDeviceToHost));
+  if (ns <= 0) return SL2_OK;
+  std::vector<int> lab(ns), fl(ns);
+  SL2_HIP(hipMemcpy(lab.data(), e->f_label + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(fl.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
+  for (int f = 0; f < ns; ++f)
+    if ((fl[f] & FF_USED) && lab[f] == label) { *slot = f; break; }
   return SL2_OK;
 }
 
@@ -816,7 +840,7 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
     if (n >= capacity) return SL2_ERR_CAPACITY;
     sl2_feature_info& fi = out[n++];
     memset(&fi, 0, sizeof(fi));
-    fi.label = f;
+    fi.label = hs.labels[f];
     fi.active = active ? 1 : 0;
     fi.selected_flag = (fl & FF_SELECTED) ? 1 : 0;
     fi.successful_measurement_flag = (fl & FF_SUCCESS) ? 1 : 0;
@@ -849,6 +873,8 @@ int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, 
   SL2_HIP(hipMemcpy(pi, e->part_i + (size_t)seq * kPartInts, sizeof(pi), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(pd, e->part_d + (size_t)seq * kPartDoubles, sizeof(pd), hipMemcpyDeviceToHost));
   for (int k = 0; k < kPartInts; ++k) ints[k] = pi[k];
+  if (pi[kPartActive] && pi[kPartLabel] >= 0 && pi[kPartLabel] < e->N)     // the record holds the SLOT: report the label
+    SL2_HIP(hipMemcpy(&ints[kPartLabel], e->f_label + (size_t)seq * e->N + pi[kPartLabel], sizeof(int), hipMemcpyDeviceToHost));
   dbl[0] = pd[0]; dbl[1] = pd[1];
   std::vector<double> y(6, 0.0);
   if (pi[kPartActive]) SL2_HIP(hipMemcpy(y.data(), e->x + (size_t)seq * e->ld + e->ppos, sizeof(double) * 6, hipMemcpyDeviceToHost));
@@ -874,24 +900,24 @@ int sl2_get_selection(sl2_engine* e, int seq, int32_t* labels, int capacity, int
   if (ns > capacity) return SL2_ERR_CAPACITY;
   // delete_feature() deselects the feature it removes (monoslam.cpp:800-801): features deleted at
   // the end of the step no longer appear in selected_feature_list_
-  std::vector<int> sel(ns > 0 ? ns : 1), flags(e->N);
+  std::vector<int> sel(ns > 0 ? ns : 1), flags(e->N), lab(e->N);
   if (ns > 0) SL2_HIP(hipMemcpy(sel.data(), e->sel_idx + (size_t)seq * e->N, sizeof(int) * ns, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(lab.data(), e->f_label + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
   int kept = 0;
   for (int k = 0; k < ns; ++k)
-    if (flags[sel[k]] & FF_ACTIVE) labels[kept++] = sel[k];
+    if (sel[k] >= 0 && (flags[sel[k]] & FF_ACTIVE)) labels[kept++] = lab[sel[k]];
   counters[0] = nv; counters[1] = kept; counters[2] = 2 * mc;
   return SL2_OK;
 }
 
 int sl2_get_feature_patch(sl2_engine* e, int seq, int label, uint8_t* patch121) {
-  if (!range_ok(e, seq, 1) || !patch121 || label < 0 || label >= e->N) return SL2_ERR_INVALID;
+  if (!range_ok(e, seq, 1) || !patch121 || label < 0) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  int flags = 0;
-  SL2_HIP(hipMemcpy(&flags, e->f_flags + (size_t)seq * e->N + label, sizeof(int), hipMemcpyDeviceToHost));
-  if (!(flags & FF_USED)) { set_error("sl2_get_feature_patch: no feature with this label"); return SL2_ERR_INVALID; }
-  SL2_HIP(hipMemcpy(patch121, e->patch + ((size_t)seq * e->N + label) * kPatchStride, SL2_PATCH_BYTES, hipMemcpyDeviceToHost));
+  int slot = -1;
+  { int _rc = slot_of_label(e, seq, label, &slot); if (_rc != SL2_OK) return _rc; }
+  if (slot < 0) { set_error("sl2_get_feature_patch: no feature with this label"); return SL2_ERR_INVALID; }
+  SL2_HIP(hipMemcpy(patch121, e->patch + ((size_t)seq * e->N + slot) * kPatchStride, SL2_PATCH_BYTES, hipMemcpyDeviceToHost));
   return SL2_OK;
 }
 
@@ -945,11 +971,13 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
 
 #ifdef SL2_TESTING   // test hook: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful) {
-  if (!range_ok(e, seq, 1) || label < 0 || label >= e->N) return SL2_ERR_INVALID;
+  if (!range_ok(e, seq, 1) || label < 0) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  SL2_HIP(hipMemcpy(e->attempted + (size_t)seq * e->N + label, &attempted, sizeof(int), hipMemcpyHostToDevice));
-  SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + label, &successful, sizeof(int), hipMemcpyHostToDevice));
+  int slot = -1;
+  { int _rc = slot_of_label(e, seq, label, &slot); if (_rc != SL2_OK) return _rc; }
+  if (slot < 0) return SL2_ERR_INVALID;
+  SL2_HIP(hipMemcpy(e->attempted + (size_t)seq * e->N + slot, &attempted, sizeof(int), hipMemcpyHostToDevice));
+  SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + slot, &successful, sizeof(int), hipMemcpyHostToDevice));
   return SL2_OK;
 }
 #endif  // SL2_TESTING
@@ -957,19 +985,26 @@ int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, i
 // mark_feature_by_lab + delete_feature for one feature per sequence (monoslam.cpp:743-812): the slot is retired
 // (inactive, deselected, its label never reused) and its rows / columns of P are zeroed, which is what removing them from
 // the total state amounts to in this layout (k_finalize does the same for delete_bad_features).
-__global__ void __launch_bounds__(256) k_delete_feature(double* __restrict__ P, int* __restrict__ f_flags, const int* __restrict__ labels,
+__global__ void __launch_bounds__(256) k_delete_feature(double* __restrict__ P, int* __restrict__ f_flags, const int* __restrict__ f_label,
+                                                        const int* __restrict__ n_slots, const int* __restrict__ labels,
                                                         int* __restrict__ done, int N, int ld) {
   const int b = blockIdx.x;
   const int lab = labels[b];
-  if (lab < 0 || lab >= N) { if (threadIdx.x == 0) done[b] = 0; return; }
-  const size_t fi = (size_t)b * N + lab;
-  const int fl = f_flags[fi];
-  const bool ok = (fl & FF_ACTIVE) && !(fl & FF_PARTIAL);
+  __shared__ int s_slot;
+  if (threadIdx.x == 0) s_slot = -1;
   __syncthreads();
-  if (threadIdx.x == 0) { done[b] = ok ? 1 : 0; if (ok) f_flags[fi] = FF_USED; }
+  if (lab >= 0)
+    for (int f = threadIdx.x; f < n_slots[b]; f += blockDim.x) {
+      const int fl = f_flags[(size_t)b * N + f];
+      if ((fl & FF_ACTIVE) && !(fl & FF_PARTIAL) && f_label[(size_t)b * N + f] == lab) s_slot = f;    // labels are unique
+    }
+  __syncthreads();
+  const int slot = s_slot;
+  const bool ok = slot >= 0;
+  if (threadIdx.x == 0) { done[b] = ok ? 1 : 0; if (ok) f_flags[(size_t)b * N + slot] = FF_USED; }
   if (!ok) return;
   double* Pb = P + (size_t)b * ld * ld;
-  const int pos = 13 + 3 * lab;
+  const int pos = 13 + 3 * slot;
   for (int j = threadIdx.x; j < ld; j += blockDim.x)
     for (int r = 0; r < 3; ++r) {
       Pb[(size_t)(pos + r) * ld + j] = 0.0;
@@ -987,7 +1022,8 @@ int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels
   hipError_t err = hipMemcpy(d_lab, labels, sizeof(int) * nseq, hipMemcpyHostToDevice);
   if (err == hipSuccess) {
     hipLaunchKernelGGL(k_delete_feature, dim3(nseq), dim3(256), 0, e->stream, e->P + (size_t)seq0 * e->ld * e->ld,
-                       e->f_flags + (size_t)seq0 * e->N, d_lab, d_done, e->N, e->ld);
+                       e->f_flags + (size_t)seq0 * e->N, e->f_label + (size_t)seq0 * e->N, e->n_slots + seq0, d_lab, d_done,
+                       e->N, e->ld);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = hipStreamSynchronize(e->stream);

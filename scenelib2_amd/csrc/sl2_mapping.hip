@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
                                                    size_t seq_stride, uint8_t* __restrict__ patch, int* __restrict__ patch_sums,
                                                    double* __restrict__ xp_org, int* __restrict__ f_flags, int* __restrict__ n_slots,
                                                    int* __restrict__ attempted, int* __restrict__ successful,
+                                                   int* __restrict__ f_label, int* __restrict__ next_label,
                                                    int* __restrict__ part_i, double* __restrict__ part_d,
                                                    double* __restrict__ particles, double* __restrict__ last_r, CameraParams cam,
                                                    MapParams mp, int N, int ld, int ppos) {
@@ -152,6 +153,7 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
   double* pd = part_d + (size_t)b * kPartDoubles;
   if (!pi[kPartRegionValid]) return;
   if (!(pd[2] > 20000)) return;        // SUITABLE_PATCH_SCORE_THRESHOLD (:837, 850-858)
+  // (`label` below is the SLOT the feature takes - the end of the list; its Feature::label_ comes from next_label)
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
   const int label = n_slots[b];
@@ -203,6 +205,8 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     xp_org[fi * 8 + 7] = 0.0;
     f_flags[fi] = FF_USED | FF_PARTIAL;
     attempted[fi] = 0; successful[fi] = 0;
+    f_label[fi] = next_label[b];           // label_ = next_free_label_++ (monoslam.cpp:1306-1307)
+    next_label[b] += 1;
     n_slots[b] = label + 1;
     // template: copy_into_patch (:1240-1251) + the packed form the search kernels read
     const uint8_t* img = frames + (size_t)b * seq_stride;
@@ -533,6 +537,151 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   }
 }
 
+// ---------------------------------------------------------------------------
+// k_map_compact_slots: one workgroup per sequence; does nothing unless the sequence has used all N slots and some of them
+// are retired (features deleted by delete_bad_features, the sell-by date of a partial feature or sl2_delete_features keep
+// their slot with zeroed rows / columns of P).  The reference erases such features from feature_list_ and its
+// next_free_label_ is unbounded: here the live features are squeezed down to the front of the slot range IN LIST ORDER
+// (so every "in feature_list_ order" rule - selection ties, the deletion walk, the total state layout - is untouched) and
+// the freed slots at the end take the next initialisations.  Labels live in f_label and are never reused.  Everything
+// indexed by slot moves: the feature's entries of x, its rows and columns of P, template, counters, flags, the per-frame
+// scratch the accessors read, and the slot numbers held by the selection lists and the partial feature's record.
+// ---------------------------------------------------------------------------
+struct SlotArrays {
+  double *x, *P, *xp_org, *f_h, *f_Hx, *f_Hy, *f_R, *f_S, *f_score, *f_z, *f_nu, *srch_d;
+  uint8_t* patch;
+  int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *n_sel, *m_count, *n_slots, *part_i;
+};
+template <typename T>
+__device__ __forceinline__ void slot_move(T* base, int per, int dst, int src, int tid, int nthreads) {
+  for (int k = tid; k < per; k += nthreads) base[(size_t)dst * per + k] = base[(size_t)src * per + k];
+}
+__global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, int ld, int ppos) {
+  extern __shared__ int s_map[];        // [N] new slot -> old slot, then [N] old slot -> new slot (-1: retired)
+  int* s_src = s_map;
+  int* s_new = s_map + N;
+  __shared__ int s_live;
+  const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int ns = a.n_slots[b];
+  if (ns < N) return;                                            // slots left: nothing to do
+  int* flags = a.f_flags + (size_t)b * N;
+  if (tid == 0) {
+    int nl = 0;
+    for (int f = 0; f < ns; ++f) {
+      const bool keep = (flags[f] & (FF_ACTIVE | FF_PARTIAL)) != 0;
+      s_new[f] = keep ? nl : -1;
+      if (keep) s_src[nl++] = f;
+    }
+    s_live = nl;
+  }
+  __syncthreads();
+  const int nl = s_live;
+  if (nl == ns) return;                                          // genuinely full
+  const size_t o = (size_t)b * N;
+  // ---- per-slot records: in increasing new slot (src >= dst, every earlier move wrote below dst); a barrier per slot
+  // because the source of one move can be the destination of the next
+  for (int d = 0; d < nl; ++d) {
+    const int f = s_src[d];
+    if (f != d) {
+      slot_move(a.patch + o * kPatchStride, kPatchStride, d, f, tid, nt);
+      slot_move(a.patch_sums + o * 2, 2, d, f, tid, nt);
+      slot_move(a.xp_org + o * 8, 8, d, f, tid, nt);
+      slot_move(a.f_flags + o, 1, d, f, tid, nt);
+      slot_move(a.attempted + o, 1, d, f, tid, nt);
+      slot_move(a.successful + o, 1, d, f, tid, nt);
+      slot_move(a.f_label + o, 1, d, f, tid, nt);
+      slot_move(a.f_h + o * 2, 2, d, f, tid, nt);
+      slot_move(a.f_Hx + o * 14, 14, d, f, tid, nt);
+      slot_move(a.f_Hy + o * 6, 6, d, f, tid, nt);
+      slot_move(a.f_R + o, 1, d, f, tid, nt);
+      slot_move(a.f_S + o * 4, 4, d, f, tid, nt);
+      slot_move(a.f_score + o, 1, d, f, tid, nt);
+      slot_move(a.f_z + o * 2, 2, d, f, tid, nt);
+      slot_move(a.f_nu + o * 2, 2, d, f, tid, nt);
+      slot_move(a.srch_i + o * 8, 8, d, f, tid, nt);
+      slot_move(a.srch_d + o * 4, 4, d, f, tid, nt);
+      slot_move(a.x + (size_t)b * ld + 13, 3, d, f, tid, nt);
+    }
+    __syncthreads();
+  }
+  for (int f = nl + tid; f < ns; f += nt) {                      // the freed slots: unused again
+    flags[f] = 0;
+    a.attempted[o + f] = 0; a.successful[o + f] = 0;
+    for (int k = 0; k < 3; ++k) a.x[(size_t)b * ld + 13 + 3 * f + k] = 0.0;
+  }
+  // slot numbers held elsewhere
+  for (int k = tid; k < a.n_sel[b]; k += nt) { const int f = a.sel_idx[o + k]; a.sel_idx[o + k] = (f >= 0 && f < ns) ? s_new[f] : -1; }
+  for (int k = tid; k < a.m_count[b]; k += nt) { const int f = a.succ_idx[o + k]; a.succ_idx[o + k] = (f >= 0 && f < ns) ? s_new[f] : -1; }
+  if (tid == 0) {
+    int* pi = a.part_i + (size_t)b * kPartInts;
+    if (pi[kPartActive] && pi[kPartLabel] >= 0 && pi[kPartLabel] < ns) pi[kPartLabel] = s_new[pi[kPartLabel]];
+  }
+  // ---- P: new index i <- old index src(i); pose rows and the partial feature's six rows / the innovation row stay where
+  // they are, the vacated feature rows / columns become zero.  Row by row in increasing i: src(i) >= i, so a source row is
+  // never one already rewritten; within a row all reads complete (barrier) before the writes.
+  double* Pb = a.P + (size_t)b * ld * ld;
+  auto src_index = [&](int i) -> int {
+    if (i < 13 || i >= 13 + 3 * N) return i;
+    const int d = (i - 13) / 3, c = (i - 13) % 3;
+    return d < nl ? 13 + 3 * s_src[d] + c : -1;
+  };
+  const int n_end = 13 + 3 * ns;                                  // (ns == N here: every feature row is visited)
+  constexpr int kMaxCols = 8;                                     // columns per thread: ld <= 2048
+  for (int i = 13; i < ld; ++i) {
+    const int si = src_index(i);
+    double v[kMaxCols];
+#pragma unroll
+    for (int q = 0; q < kMaxCols; ++q) {
+      const int j = tid + q * nt;
+      v[q] = 0.0;
+      if (j < ld) {
+        const int sj = src_index(j);
+        if (si >= 0 && sj >= 0) v[q] = Pb[(size_t)si * ld + sj];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMaxCols; ++q) {
+      const int j = tid + q * nt;
+      if (j < ld) Pb[(size_t)i * ld + j] = v[q];
+    }
+    // (no second barrier: the next row reads row src(i + 1) >= i + 1, never the row just written)
+  }
+  // the pose rows: only their feature columns move
+  for (int i = 0; i < 13; ++i) {
+    double v[kMaxCols];
+#pragma unroll
+    for (int q = 0; q < kMaxCols; ++q) {
+      const int j = tid + q * nt;
+      v[q] = 0.0;
+      if (j < ld) { const int sj = src_index(j); if (sj >= 0) v[q] = Pb[(size_t)i * ld + sj]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kMaxCols; ++q) {
+      const int j = tid + q * nt;
+      if (j < ld) Pb[(size_t)i * ld + j] = v[q];
+    }
+    __syncthreads();
+  }
+  (void)n_end;
+  if (tid == 0) a.n_slots[b] = nl;
+}
+
+int launch_compact_slots(sl2_engine* e) {
+  if ((size_t)e->ld > 8 * 256) return SL2_OK;                     // (maps beyond 2048 states: slots are not squeezed)
+  LaunchScope ls(e, "k_map_compact_slots");
+  SlotArrays a;
+  a.x = e->x; a.P = e->P; a.xp_org = e->xp_org; a.f_h = e->f_h; a.f_Hx = e->f_Hx; a.f_Hy = e->f_Hy; a.f_R = e->f_R; a.f_S = e->f_S;
+  a.f_score = e->f_score; a.f_z = e->f_z; a.f_nu = e->f_nu; a.srch_d = e->srch_d; a.patch = e->patch; a.patch_sums = e->patch_sums;
+  a.f_flags = e->f_flags; a.attempted = e->attempted; a.successful = e->successful; a.f_label = e->f_label; a.srch_i = e->srch_i;
+  a.sel_idx = e->sel_idx; a.succ_idx = e->succ_idx; a.n_sel = e->n_sel; a.m_count = e->m_count; a.n_slots = e->n_slots;
+  a.part_i = e->part_i;
+  hipLaunchKernelGGL(k_map_compact_slots, dim3(e->B), dim3(256), sizeof(int) * 2 * e->N, e->stream, a, e->N, e->ld, e->ppos);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
 // MonoSLAM::InitialiseFeature at a caller-chosen pixel (monoslam.cpp:1211-1235; the GUI sets uu_ / vv_ by mouse click):
 // per sequence, publish the selection for k_map_create exactly as k_map_region + k_map_detect would have.
 __global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, const int* __restrict__ n_slots, int* __restrict__ part_i,
@@ -569,7 +718,7 @@ static MapParams map_params(const sl2_engine* e, int enable_mapping, int save_tr
 static int launch_create(sl2_engine* e, const MapParams& mp) {
   LaunchScope ls(e, "k_map_create");
   hipLaunchKernelGGL(k_map_create, dim3(e->B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch,
-                     e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->part_i, e->part_d,
+                     e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
                      e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
@@ -578,6 +727,7 @@ static int launch_create(sl2_engine* e, const MapParams& mp) {
 // InitialiseFeature(frame) with (uu_, vv_) = uv[b] (device array [B][2]; u < 0 = skip the sequence)
 int launch_manual_init(sl2_engine* e, const int* d_uv) {
   const MapParams mp = map_params(e, 1, 0, 1);
+  { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
   hipLaunchKernelGGL(k_map_manual, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, d_uv, e->n_slots, e->part_i, e->part_d, e->status,
                      e->N, e->cam.width, e->cam.height, e->B);
   SL2_HIP(hipGetLastError());
@@ -587,6 +737,7 @@ int launch_manual_init(sl2_engine* e, const int* d_uv) {
 // InitialiseAutoFeature(frame) = AutoInitialiseFeature(frame, 0) (monoslam.cpp:1535-1541, 823-865): region, detector, creation
 int launch_auto_init(sl2_engine* e) {
   const MapParams mp = map_params(e, 1, 0, 1);
+  { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
   hipLaunchKernelGGL(k_map_region, dim3(e->B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
                      e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
   SL2_HIP(hipGetLastError());
@@ -610,6 +761,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.dt = e->prm.delta_t;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
+  if (enable_mapping) { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
   {
     LaunchScope ls(e, "k_map_region");
     hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
@@ -624,8 +776,8 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   {
     LaunchScope ls(e, "k_map_create");
     hipLaunchKernelGGL(k_map_create, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch, e->patch_sums,
-                       e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->part_i, e->part_d, e->particles,
-                       e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+                       e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
+                       e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }
   {

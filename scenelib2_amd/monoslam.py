@@ -346,10 +346,10 @@ class MonoSLAM:
         if f.size != self._engine.frame_bytes:
             raise ValueError("frame must be %d x %d 8-bit single channel" % (self.camera_["width"], self.camera_["height"]))
         self._engine.go_one_step(f.reshape(1, -1), save_trajectory, enable_mapping)
-        # the reference's next_free_label_ is unbounded; the engine has max_features label slots over a sequence's
-        # lifetime: running out must not pass silently (SL2_STATUS_LABELS_EXHAUSTED, set by the feature initialisation)
+        # the reference's feature_list_ is unbounded; the engine holds at most max_features LIVE features per sequence
+        # (deleted ones give their slots back): a full map must not pass silently (SL2_STATUS_LABELS_EXHAUSTED)
         if enable_mapping and int(self._engine.status_flags()[0]) & 2:
-            raise RuntimeError("MonoSLAM: all %d feature label slots have been used (max_features); mapping has stopped "
+            raise RuntimeError("MonoSLAM: all %d feature slots hold live features (max_features); mapping has stopped "
                                "initialising features - create the engine with a larger max_features" % self._max_features)
         return True  # the reference always returns true (monoslam.cpp:179)
 

@@ -173,34 +173,82 @@ def test_engine_matches_committed_mapping_golden():
         eng.feature_patch(0, 31)                     # label never handed out
 
 
-def test_label_slots_run_out_loudly():
-    """More lifetime initialisations than label slots: the reference's next_free_label_ is unbounded, the engine has
-    max_features slots per sequence and does not reuse a deleted feature's slot.  Running out must be visible: the status
-    bit SL2_STATUS_LABELS_EXHAUSTED on the C ABI, an exception from the MonoSLAM adapter - and until that frame the engine
-    must have followed the oracle exactly."""
+def test_slots_are_squeezed_and_labels_stay_the_references():
+    """More lifetime initialisations than feature slots.  The reference erases deleted features from feature_list_ and hands
+    out labels without bound; the engine keeps a deleted feature's slot until the sequence runs out of slots, then squeezes
+    the live features to the front IN LIST ORDER (k_map_compact_slots) and goes on.  The two soak sequences hand out 44 and
+    43 labels with at most 18 features alive: with 20 slots the engine must stay on the reference's events, values, labels
+    and counters throughout."""
+    from scenelib2_amd import Engine
+    n = 160
+    seqs = [make_mapping_sequence(seed=sd, n_frames=n, v_amp=va) for sd, va in ((7, 0.45), (31, 0.35))]
+    cam, params = seqs[0][0], seqs[0][1]
+    oracles = [oracle_for(cam, params, q[2], q[4], oa) for q in seqs]
+    eng = Engine(cam, params, 2, 20)
+    eng.set_vehicle_state(np.stack([q[2].xv0 for q in seqs]), np.stack([q[2].Pxx0 for q in seqs]))
+    eng.add_known_features(np.stack([q[2].feat_y for q in seqs]), np.stack([q[2].xp_org() for q in seqs]),
+                           np.stack([q[4] for q in seqs]))
+    for k in range(1, n + 1):
+        eng.go_one_step(np.stack([q[3][k] for q in seqs]), save_trajectory=True, enable_mapping=True)
+        for b, s in enumerate(oracles):
+            s.go_one_step(seqs[b][3][k], True, True)
+            info, got = s.mapping_info(), eng.partial_feature(b)["info"]
+            assert [got[key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
+                   [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], (k, b)
+            pf = s.partial_feature(0)
+            if pf is not None:
+                assert eng.partial_feature(b)["pf"]["label"] == pf["label"], (k, b)
+            if k % 4 == 0 or k == n:
+                x0, x1 = s.total_state(), eng.total_state(b)
+                assert x0.size == x1.size, (k, b)
+                assert np.abs(x0 - x1).max() < 1e-8, (k, b, np.abs(x0 - x1).max())
+                feats = eng.features(b)
+                assert [f["label"] for f in feats] == [s.feature(i)["label"] for i in range(s.num_features)], (k, b)
+                assert [(f["attempted"], f["successful"]) for f in feats] == \
+                       [(s.feature(i)["attempted"], s.feature(i)["successful"]) for i in range(s.num_features)], (k, b)
+    for b, s in enumerate(oracles):
+        assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-7
+        assert np.abs(eng.trajectory(b) - s.trajectory()).max() < 1e-8
+        feats = eng.features(b)
+        assert max(f["label"] for f in feats) >= 20                    # labels went past the slot count: slots were reused
+        for i, f in enumerate(feats):                                  # templates moved with their features
+            if f["state_size"] == 3:
+                assert np.array_equal(eng.feature_patch(b, f["label"]), s.feature_patch(i)), (b, f["label"])
+    assert sum(s.mapping_info()["initialised"] for s in oracles) >= 70
+    assert not eng.status_flags().any()
+    # manual deletion by label after the slots have moved
+    lab = [f["label"] for f in eng.features(0) if f["state_size"] == 3][-1]
+    assert eng.delete_features([lab, -1]).tolist() == [1, 0]
+    assert lab not in [f["label"] for f in eng.features(0)]
+
+
+def test_a_full_map_is_loud():
+    """Every slot holds a live feature: the next initialisation cannot take place.  That must be visible - the status bit
+    SL2_STATUS_LABELS_EXHAUSTED on the C ABI, an exception from the MonoSLAM adapter - never a silent stop of mapping."""
     from scenelib2_amd import Engine, MonoSLAM
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60)
-    nslots = spec.n_features + 2                      # room for two initialisations only
+    nslots = spec.n_features                          # no room for a single initialisation
     eng = Engine(cam, params, 1, nslots)
     eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
     eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
     s = oracle_for(cam, params, spec, templates, oa)
-    exhausted_at = None
+    full_at = None
     for k in range(1, 61):
         eng.go_one_step(frames[k][None], enable_mapping=True)
         s.go_one_step(frames[k], False, True)
         if int(eng.status_flags()[0]) & 2:
-            exhausted_at = k
+            full_at = k
             break
-        assert eng.partial_feature(0)["info"]["initialised"] == s.mapping_info()["initialised"], k
         assert np.abs(eng.total_state(0) - s.total_state()).max() < 1e-9, k
-    assert exhausted_at is not None and s.mapping_info()["initialised"] == 3      # the oracle got its third label
+    # (raised at the first frame whose speed gate / visible-feature count call for an initialisation: before the region
+    # search that may still find nothing - the oracle has initialised at most one feature by then)
+    assert full_at is not None and s.mapping_info()["initialised"] <= 1
     assert not int(eng.status_flags()[0]) & 1
     # the adapter raises instead of going on silently
     m = MonoSLAM(max_features=nslots).InitFromValues(cam, params, spec.xv0, spec.Pxx0)
     for i in range(spec.n_features):
         m.AddNewKnownFeature(spec.feat_y[i], spec.xp_org()[i], templates[i])
-    with pytest.raises(RuntimeError, match="label slots"):
+    with pytest.raises(RuntimeError):
         for k in range(1, 61):
             m.GoOneStep(frames[k], False, True)
 

@@ -137,7 +137,6 @@ struct sl2_engine {
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
   bool graph_mode = false;
   std::vector<StepGraph> step_graphs;
-  int update_chunk = 0;       // > 0: the EKF update runs on this many sequences at a time through one shared At / St / Vt workspace (Infinity-Cache resident)
   int search_variant = 3;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk, 3 = int8 matrix-core walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----

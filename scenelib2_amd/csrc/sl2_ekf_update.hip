@@ -143,15 +143,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
           if (i < ld) {
             double py[3];
 #pragma unroll
-#if defined(SL2_PROBE_UPPER) && SL2_PROBE_UPPER <= 2   // timing probes: the pass when it fetches one triangle of P
-#if SL2_PROBE_UPPER == 1   // (wrong results)
-            for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : 0.0;
-#else       // correct values through the symmetric element (uncoalesced)
-            for (int c = 0; c < 3; ++c) py[c] = (i >= pos) ? Pb[(size_t)(pos + c) * ld + i] : Pb[(size_t)i * ld + pos + c];
-#endif
-#else
             for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
-#endif
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
               double acc = 0.0;
@@ -160,9 +152,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
 #pragma unroll
               for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
               if (i == ld - 1) acc = f_nu[fi * 2 + r];
-#if !defined(SL2_PROBE_UPPER) || SL2_PROBE_UPPER != 3
               Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
-#endif
               sAt[(2 * jj + r) * ld + i] = acc;
             }
           }
@@ -186,11 +176,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
             if (t == k) acc += Rn;
             v = acc;
           }
-#if !defined(SL2_PROBE_UPPER) || SL2_PROBE_UPPER != 4
           Sb[(size_t)k * mld + t] = v;
-#else
-          if (v == 12345.678) Sb[(size_t)k * mld + t] = v;
-#endif
         }
       }
     }
@@ -1338,11 +1324,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
           prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt] = pn;
           acc[it][jt][r] = pn;
         }
-#if defined(SL2_PROBE_UPPER) && SL2_PROBE_UPPER == 5   // timing probe: no mirror block (the lower triangle goes stale)
-    if (diagw) {
-#else
     if (mirror || diagw) {
-#endif
       // The mirror block goes through LDS so that its stores are row segments of 128 bytes like the direct ones (written
       // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
       // 0.07 ms of the 0.58 ms launch).  The staging buffer that the LAST chunk did not use is free: every wave is past
@@ -1410,20 +1392,8 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
 }
 #endif  // SL2_TESTING
 
-#ifdef SL2_PROBE_UPPER
-__global__ void __launch_bounds__(64) k_dummy(int* m_count, int mode) {
-  if (mode == 7 && threadIdx.x == 0) m_count[blockIdx.x] = m_count[blockIdx.x];   // 6: empty kernel, 7: touches m_count
-}
-#endif
 static int launch_update_range(sl2_engine* e) {
   const int B = e->B;     // (succ_idx / m_count, the successful measurements in selection order, come from k_search_score)
-#ifdef SL2_PROBE_UPPER
-  const int dmask = getenv("SL2_DUMMY_MASK") ? atoi(getenv("SL2_DUMMY_MASK")) : 1;
-#define SL2_DUMMY(bit) do { if (dmask & (bit)) { LaunchScope ls(e, "k_dummy"); hipLaunchKernelGGL(k_dummy, dim3(B), dim3(64), 0, e->stream, e->m_count, SL2_PROBE_UPPER); } } while (0)
-#else
-#define SL2_DUMMY(bit) do { } while (0)
-#endif
-  SL2_DUMMY(1);
   if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
     // workgroups per sequence: enough to put ~512 on the chip
@@ -1461,7 +1431,6 @@ static int launch_update_range(sl2_engine* e) {
       SL2_HIP(hipGetLastError());
     }
   }
-  SL2_DUMMY(2);
   if (e->nblk_max > kFusedMaxBlocks && e->root->chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
     LaunchScope ls(e, "k_chol_fused");
     launch_chol_panels(e, B);
@@ -1498,7 +1467,6 @@ static int launch_update_range(sl2_engine* e) {
       }
     }
   }
-  SL2_DUMMY(4);
   {
     LaunchScope ls(e, "k_fwdsub", true);
     bool done = false;
@@ -1513,7 +1481,6 @@ static int launch_update_range(sl2_engine* e) {
                          e->m_count, e->ld, e->mld, e->nblk_max, B);
     SL2_HIP(hipGetLastError());
   }
-  SL2_DUMMY(8);
   {
     LaunchScope ls(e, "k_syrk", true);
     const int nt = e->ld / 64;
@@ -1524,31 +1491,7 @@ static int launch_update_range(sl2_engine* e) {
   return SL2_OK;
 }
 
-// The update of the whole batch, or chunk by chunk: with SL2_UPDATE_CHUNK = C (sequences) the four-kernel chain runs on C
-// sequences at a time and every chunk uses the SAME At / St / Vt workspace, so that the intermediates (1.55 MB per
-// sequence at 100 features) are produced and consumed inside the 256 MiB Infinity Cache instead of going through HBM.
-int launch_update(sl2_engine* e) {
-  const int chunk = e->root->update_chunk;
-  if (chunk <= 0 || chunk >= e->B) return launch_update_range(e);
-  const int B = e->B;
-  const size_t N = e->N, ld = e->ld;
-  struct Saved { double *x, *P, *f_Hx, *f_Hy, *f_nu, *f_R, *LinvT; int *sel_idx, *n_sel, *meas_ok, *succ_idx, *m_count; } sv =
-      {e->x, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R, e->LinvT, e->sel_idx, e->n_sel, e->meas_ok, e->succ_idx, e->m_count};
-  int rc = SL2_OK;
-  for (int c0 = 0; c0 < B && rc == SL2_OK; c0 += chunk) {
-    const size_t f = c0;
-    e->B = (c0 + chunk <= B) ? chunk : B - c0;
-    e->x = sv.x + f * ld; e->P = sv.P + f * ld * ld; e->f_Hx = sv.f_Hx + f * N * 14; e->f_Hy = sv.f_Hy + f * N * 6;
-    e->f_nu = sv.f_nu + f * N * 2; e->f_R = sv.f_R + f * N; e->LinvT = sv.LinvT + f * (size_t)e->nblk_max * 1024;
-    e->sel_idx = sv.sel_idx + f * N; e->n_sel = sv.n_sel + f; e->meas_ok = sv.meas_ok + f * N; e->succ_idx = sv.succ_idx + f * N;
-    e->m_count = sv.m_count + f;
-    rc = launch_update_range(e);
-  }
-  e->B = B;
-  e->x = sv.x; e->P = sv.P; e->f_Hx = sv.f_Hx; e->f_Hy = sv.f_Hy; e->f_nu = sv.f_nu; e->f_R = sv.f_R; e->LinvT = sv.LinvT;
-  e->sel_idx = sv.sel_idx; e->n_sel = sv.n_sel; e->meas_ok = sv.meas_ok; e->succ_idx = sv.succ_idx; e->m_count = sv.m_count;
-  return rc;
-}
+int launch_update(sl2_engine* e) { return launch_update_range(e); }
 
 }  // namespace sl2
 

@@ -356,7 +356,6 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
   if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);
-  if (const char* v = getenv("SL2_UPDATE_CHUNK")) e->update_chunk = atoi(v);
   {
     int G = 1;
     const char* env = getenv("SL2_GROUPS");

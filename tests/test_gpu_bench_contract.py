@@ -69,3 +69,20 @@ def test_bench_rccl_path_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["gathered_states"] == 16
     assert abs(d["value"] - 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`.  Two ranks on the one-GPU box through the gloo hook; stdout must carry
+    exactly the one JSON record of rank 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["SL2_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29741", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                          "--warmup", "2", "--batch", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["gathered_states"] == 32 and d["steps"] == 3 and d["warmup"] == 2
+    assert abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]

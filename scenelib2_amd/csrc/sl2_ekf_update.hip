@@ -1397,10 +1397,11 @@ static int launch_update_range(sl2_engine* e) {
   if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
     LaunchScope ls(e, "k_build_A", true);
     // workgroups per sequence: enough to put ~512 on the chip
-    // (~3000 workgroups in all, also at large batches: with ONE workgroup per sequence batch 1024 is exactly one round of four
-    // workgroups per CU, and the launch then took 0.35 or 0.44 ms depending on which kernel ran before it - measured with an
-    // empty kernel in front, profiles/r02_probes.txt; three per sequence re-balance as they finish: 0.348 either way)
-    int nsplit = (3072 + B - 1) / B;
+    // One workgroup per sequence from batch 1024 on (one exact round of four per CU at 1024; it needs the launch in front
+    // of it - k_search_score - to consist of single-wave workgroups, see launch_search: 0.33-0.35 ms on every box tried;
+    // three workgroups per sequence are indifferent to what ran before but take 0.346-0.377 depending on the box).  Smaller
+    // batches: ~3000 workgroups in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
+    int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
     if (const char* v = getenv("SL2_BUILD_SPLIT")) nsplit = atoi(v);     // experiments
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;

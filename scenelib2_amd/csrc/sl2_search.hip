@@ -1270,8 +1270,15 @@ int launch_search(sl2_engine* e) {
   }
   {
     LaunchScope ls(e, "k_search_score");
+    // One wavefront per sequence at large batches, one thread per position at small ones (latency).  The block shape matters
+    // to the NEXT launch: k_build_AS at batch 1024 is exactly one round of four 5-wave workgroups per CU, and it runs 0.33-0.35 ms
+    // behind a kernel of 1024 single-wave workgroups but 0.41-0.44 ms behind one of 1024 two-wave workgroups (the hardware
+    // dispatcher's placement; measured on four boxes with this kernel at 64 / 128 threads and with an empty kernel in
+    // between, profiles/r02_probes.txt).
     int threads = (e->nsel_max + 63) / 64 * 64;
     if (threads > 1024) threads = 1024;
+    if (e->B >= 256) threads = 64;
+    if (const char* v = getenv("SL2_SCORE_THREADS")) threads = atoi(v);      // experiments
     hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
                        e->succ_idx, e->m_count, e->N);

@@ -31,16 +31,17 @@ def main():
     act = tr[:, 6] != 0
     t = tr[act].astype(np.float64)
     print("active waves:", int(act.sum()))
-    d = np.diff(t[:, :7], axis=1)
     tot = (t[:, 6] - t[:, 0]).mean()
-    names = ["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]
-    if os.environ.get("SL2_SEARCH_VARIANT", "3") == "3":     # k_search_mfma
-        names = ["n_sel + descriptors", "template -> LDS (issue)", "band staging + barrier", "B operands + MFMA", "scoring",
-                 "decision + result"]
-    for i, nme in enumerate(names):
-        print("%-24s mean %8.0f cycles  (%4.1f %%)" % (nme, d[:, i].mean(), 100 * d[:, i].mean() / tot))
+    if os.environ.get("SL2_SEARCH_VARIANT", "3") == "3":     # k_search_mfma stamps: 0 = entry, 1 = first loads issued, 6 = exit
+        print("entry -> first template / band loads issued  mean %8.0f cycles" % (t[:, 1] - t[:, 0]).mean())
+        print("pipelined loop over the wavefront's positions mean %8.0f cycles" % (t[:, 6] - t[:, 1]).mean())
+    else:
+        d = np.diff(t[:, :7], axis=1)
+        names = ["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]
+        for i, nme in enumerate(names):
+            print("%-24s mean %8.0f cycles  (%4.1f %%)" % (nme, d[:, i].mean(), 100 * d[:, i].mean() / tot))
     print("total per wave mean %.0f cycles, p95 %.0f" % (tot, np.percentile(t[:, 6] - t[:, 0], 95)))
-    print("kernel span %.0f cycles" % (tr[act][:, 6].max() - tr[act][:, 0].min()))
+    print("launch span %.0f cycles" % (t[:, 6].max() - t[:, 0].min()))
 
 
 if __name__ == "__main__":

@@ -750,21 +750,22 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       }
       __builtin_amdgcn_s_setprio(0);
     } else {
-      // tiles below the diagonal: (J+1, J) to M0, the others dealt M1, M2, M0, M1, ...
-      if (mw == 0 && more) {
-        const Tile32 t = tile_left_update(Sb, mld, J, J + 1, J, lo, hi);
-        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, t);
-      }
-      for (int I = J + 2 + (mw + 2) % 3; I < nblk; I += 3) {
-        const Tile32 t = tile_left_update(Sb, mld, J, I, J, lo, hi);
-        tile_store(Sb, mld, o, I * 32, lo, hi, t);
-      }
-      // ... and the next diagonal tile as far as finished columns go; parked in LDS in fragment order (registers held
-      // across the barrier and the panel solve spilled)
-      if (mw == 0 && more) {
-        const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
+      // The column's update tasks - tile (J+1, J), the next diagonal tile (J+1, J+1) as far as finished columns go, then the
+      // tiles (J+2, J) ... - are dealt M0, M1, M2, M0, ...: every task costs J tile products, so this is what balances the
+      // three waves.  (M0 used to take (J+1, J) AND the next diagonal tile on top of its share of the others: 3 / 1 / 1 tasks
+      // at J = 2, 2 / 0 / 0 at J = 5, and its 40-60 k cycles were the column's critical path next to 20-30 k for M1 / M2.)
+      // The next diagonal tile is parked in LDS in fragment order (held in registers across the barrier and the panel solve
+      // it spilled); M0 picks it up in P3.
+      for (int q = mw; more && q < nblk - J; q += 3) {     // (the last column has no tile below it)
+        if (q == 1) {
+          const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) sNext[q * 64 + lane_j] = dn.f[q >> 3][(q >> 2) & 1][q & 3];
+          for (int k = 0; k < 16; ++k) sNext[k * 64 + lane_j] = dn.f[k >> 3][(k >> 2) & 1][k & 3];
+        } else {
+          const int I = (q == 0) ? J + 1 : J + q;
+          const Tile32 t = tile_left_update(Sb, mld, J, I, J, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
+        }
       }
     }
     TRL(2);

@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
     TRL(2);
     __syncthreads();                       // X2: L_JJ^-1 is in LDS, every tile of column J is updated
     // ---- P3 ----
-    if (!isD) {
+    {
       if (mw == 0 && more) {
         const Tile32 l = tile_panel(sLinv, Sb, mld, o, (J + 1) * 32, lo, hi);
         tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, l);
@@ -786,10 +786,13 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 #pragma unroll
         for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
       }
-      for (int I = J + 2 + (mw + 2) % 3; I < nblk; I += 3) {
-        const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
-        tile_store(Sb, mld, o, I * 32, lo, hi, t);
-      }
+      // the other panel tiles: M1, M2 and the D wave (idle in this phase) in turn; M0 keeps to the chain above
+      const int turn = isD ? 2 : mw - 1;            // M0: -1
+      if (turn >= 0)
+        for (int I = J + 2 + turn; I < nblk; I += 3) {
+          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
+          tile_store(Sb, mld, o, I * 32, lo, hi, t);
+        }
     }
     TRL(3);
     if (more) __syncthreads();             // X3: column J of L is complete, the next diagonal tile is in LDS

@@ -319,3 +319,46 @@ def test_initialise_feature_buttons_match_the_oracle(mode, tmp_path):
         assert img.shape == (11, 11) and np.array_equal(img, oracles[0].feature_patch(2))
     with pytest.raises(_lib.Sl2Error):
         eng.save_patch(0, 31, str(tmp_path / "none.png"))       # label never handed out
+
+
+def test_slot_squeeze_at_100_features_moves_state_covariance_and_templates_exactly():
+    """k_map_compact_slots at the headline map size (100 features, 320 state columns: more than one column per thread in the
+    in-place permutation of P): a full map loses scattered features, then InitialiseFeature needs a slot.  The squeeze must
+    leave the total state, the total covariance, the labels, counters and templates of the surviving features BIT FOR BIT
+    what the accessors reported before it (they skip retired slots), and the filter must carry on like the oracle's."""
+    from slam_helpers import Pair
+    pr = Pair(100, 6, batch=2, feature_sigma=0.004)
+    eng = pr.engine
+    for k in range(3):
+        pr.step_both(k)
+    gone = [[3, 97], [41, 42], [99, 0], [57, -1]]          # one label per sequence and call; -1: leave that sequence alone
+    for a, b in gone:
+        done = eng.delete_features([a, b])
+        assert list(done) == [True, b >= 0]
+        assert pr.oracles[0].delete_feature(a)
+        if b >= 0:
+            assert pr.oracles[1].delete_feature(b)
+    before = [(eng.total_state(b), eng.total_covariance(b), eng.features(b)) for b in range(2)]
+    tpl_before = [{f["label"]: eng.feature_patch(b, f["label"]) for f in before[b][2]} for b in range(2)]
+    frames = pr.frame_batch(2)
+    created = eng.initialise_feature(frames, [[160, 120], [150, 110]])
+    assert list(created) == [True, True]                   # every slot was in use: the squeeze made room
+    assert not eng.status_flags().any()
+    for b in range(2):
+        x0, P0, f0 = before[b]
+        x1, P1, f1 = eng.total_state(b), eng.total_covariance(b), eng.features(b)
+        n = x0.size
+        assert x1.size == n + 6 and np.array_equal(x1[:n], x0)
+        assert np.array_equal(P1[:n, :n], P0)
+        assert [f["label"] for f in f1[:-1]] == [f["label"] for f in f0] and f1[-1]["label"] == 100 and f1[-1]["state_size"] == 6
+        assert [(f["attempted"], f["successful"]) for f in f1[:-1]] == [(f["attempted"], f["successful"]) for f in f0]
+        for f in f0:
+            assert np.array_equal(eng.feature_patch(b, f["label"]), tpl_before[b][f["label"]])
+        pr.oracles[b].initialise_feature(pr.frames[b][2], 160 if b == 0 else 150, 120 if b == 0 else 110)
+    for k in range(3, 6):
+        eng.go_one_step(pr.frame_batch(k))
+        for b in range(2):
+            pr.oracles[b].go_one_step(pr.frames[b][k], False, False)
+            x0, x1 = pr.oracles[b].total_state(), eng.total_state(b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
+            assert rel_fro(eng.total_covariance(b), pr.oracles[b].total_covariance()) < 1e-8, (k, b)

@@ -756,13 +756,17 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       // at J = 2, 2 / 0 / 0 at J = 5, and its 40-60 k cycles were the column's critical path next to 20-30 k for M1 / M2.)
       // The next diagonal tile is parked in LDS in fragment order (held in registers across the barrier and the panel solve
       // it spilled); M0 picks it up in P3.
-      for (int q = mw; more && q < nblk - J; q += 3) {     // (the last column has no tile below it)
-        if (q == 1) {
+      if (more) {                                   // (the last column has no tile below it)
+        if (mw == 0) {                              // task 0
+          const Tile32 t = tile_left_update(Sb, mld, J, J + 1, J, lo, hi);
+          tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, t);
+        }
+        if (mw == 1) {                              // task 1
           const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
 #pragma unroll
           for (int k = 0; k < 16; ++k) sNext[k * 64 + lane_j] = dn.f[k >> 3][(k >> 2) & 1][k & 3];
-        } else {
-          const int I = (q == 0) ? J + 1 : J + q;
+        }
+        for (int I = J + 2 + (mw + 1) % 3; I < nblk; I += 3) {    // tasks 2, 3, 4, ...: M2, M0, M1, ...
           const Tile32 t = tile_left_update(Sb, mld, J, I, J, lo, hi);
           tile_store(Sb, mld, o, I * 32, lo, hi, t);
         }

@@ -1224,9 +1224,10 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
   const double* Vb = Vt + (size_t)b * mld * ld;
   double* Pb = P + (size_t)b * ld * ld;
-  // LDS: [buffer][A | B][16 k-rows x 64 columns], 32 KB, so that FIVE workgroups share a CU (the 80-double row pitch of
-  // the first version cost 40 KB = three: with m = 200 a tile has only 13 chunks, and a third of its life is prologue
-  // and epilogue, which only other resident workgroups can cover).  Instead of padding, the odd k-rows swap their two
+  // LDS: [buffer][A | B][16 k-rows x 64 columns], 32 KB (the 80-double row pitch of the first version cost 40 KB = three
+  // workgroups per CU: with m = 200 a tile has only 13 chunks, and a third of its life is prologue and epilogue, which
+  // only other resident workgroups can cover).  Registers: 76 + 32 accumulator = 108 -> FOUR workgroups per CU; forcing
+  // five (__launch_bounds__(256, 5): 94 registers, no spills) measured 0.507 against 0.498 ms, so four it stays.  Instead of padding, the odd k-rows swap their two
   // 16-column halves within each 32-column group (column ^ 16): the two k-rows read by one 32-lane group still land on
   // disjoint banks.
   __shared__ double sAB[2][2][kSyrkKC * 64];
@@ -1286,7 +1287,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   };
   // The P tile of an interior block is fetched in one burst right after the K loop.  (Fetching it under the MFMAs of the
   // last chunk gained 2 % at three workgroups per CU, but holds 32 more registers through the loop: with the 32 KB LDS
-  // layout the kernel is better off at 74 registers and more workgroups per CU, 0.535 vs 0.552 ms.  Peeling the last
+  // layout the kernel is better off without the 32 extra registers, 0.535 vs 0.552 ms.  Peeling the last
   // chunk out of the loop made the compiler copy the prefetch registers and wait for every load on the spot: 1.40 ms.)
   double pold[2][2][4];
   auto fetch_tile = [&]() {

@@ -301,13 +301,39 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   const int ns = n_slots[b];
   const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * ns;
   const bool updated = (n_sel[b] > 0) && (m_count[b] > 0);
+  // Everything this kernel reads that does not depend on its own results is requested NOW, in one round trip: the vehicle
+  // block, this thread's strip columns (rows 3..6), its feature's flags and counters.  (Phase by phase the kernel was a
+  // chain of six dependent round trips: 16 us for a single sequence.)
+  constexpr int kStripCols = 6;                       // strip columns per thread: blockDim.x * 6 >= 768 > any n_used - 13 here
+  double pre_P[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + q * (int)blockDim.x;
+    pre_P[q] = (e < 169) ? Pb[(size_t)(e / 13) * ld + (e % 13)] : 0.0;
+  }
+  const bool strip_in_regs = updated && (n_used - 13 <= kStripCols * (int)blockDim.x);
+  double pre_v[kStripCols][4];
+  if (strip_in_regs) {
+#pragma unroll
+    for (int q = 0; q < kStripCols; ++q) {
+      const int j = 13 + tid + q * (int)blockDim.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pre_v[q][k] = (j < n_used) ? Pb[(size_t)(3 + k) * ld + j] : 0.0;
+    }
+  }
+  int pre_fl = 0, pre_att = 0, pre_suc = 0;
+  if (tid < ns) { const size_t fi = (size_t)b * N + tid; pre_fl = f_flags[fi]; pre_att = attempted[fi]; pre_suc = successful[fi]; }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int e = tid + q * (int)blockDim.x;
+    if (e < 169) s_P[e] = pre_P[q];
+  }
   if (updated) {
     if (tid == 0) {
       double q[4] = {xb[3], xb[4], xb[5], xb[6]}, Nn[16];
       dqnorm_by_dq(q, Nn);
       for (int i = 0; i < 16; ++i) s_N[i] = Nn[i];
     }
-    for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
     __syncthreads();
     // T = Jn * Pxx
     for (int e = tid; e < 169; e += blockDim.x) {
@@ -331,22 +357,40 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
       s_P[e] = v;
     }
     // strip
-    for (int j = 13 + tid; j < n_used; j += blockDim.x) {
-      double v[4], w[4];
-      for (int k = 0; k < 4; ++k) v[k] = Pb[(size_t)(3 + k) * ld + j];
-      for (int a = 0; a < 4; ++a) {
-        double acc = 0.0;
-        for (int k = 0; k < 4; ++k) acc += s_N[a * 4 + k] * v[k];
-        w[a] = acc;
+    if (strip_in_regs) {
+#pragma unroll
+      for (int q = 0; q < kStripCols; ++q) {
+        const int j = 13 + tid + q * (int)blockDim.x;
+        if (j < n_used) {
+          double w[4];
+          for (int a = 0; a < 4; ++a) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) acc += s_N[a * 4 + k] * pre_v[q][k];
+            w[a] = acc;
+          }
+          for (int a = 0; a < 4; ++a) {
+            Pb[(size_t)(3 + a) * ld + j] = w[a];
+            Pb[(size_t)j * ld + 3 + a] = w[a];
+          }
+        }
       }
-      for (int a = 0; a < 4; ++a) {
-        Pb[(size_t)(3 + a) * ld + j] = w[a];
-        Pb[(size_t)j * ld + 3 + a] = w[a];
+    } else {
+      for (int j = 13 + tid; j < n_used; j += blockDim.x) {
+        double v[4], w[4];
+        for (int k = 0; k < 4; ++k) v[k] = Pb[(size_t)(3 + k) * ld + j];
+        for (int a = 0; a < 4; ++a) {
+          double acc = 0.0;
+          for (int k = 0; k < 4; ++k) acc += s_N[a * 4 + k] * v[k];
+          w[a] = acc;
+        }
+        for (int a = 0; a < 4; ++a) {
+          Pb[(size_t)(3 + a) * ld + j] = w[a];
+          Pb[(size_t)j * ld + 3 + a] = w[a];
+        }
       }
     }
     __syncthreads();
   } else {
-    for (int e = tid; e < 169; e += blockDim.x) s_P[e] = Pb[(size_t)(e / 13) * ld + (e % 13)];
     __syncthreads();
   }
   // (2) deletion bookkeeping.  The scheduling test is per feature (all threads); the list walk with its
@@ -354,9 +398,10 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   // cost one memory round trip per feature: 50 us of this kernel's 60).
   for (int i = tid; i < ns; i += blockDim.x) {
     const size_t fi = (size_t)b * N + i;
-    int fl = f_flags[fi];
+    const bool first = i == tid;                                  // this thread's first feature came with the prefetch
+    int fl = first ? pre_fl : f_flags[fi];
     if (fl & FF_ACTIVE) {
-      const int att = attempted[fi], suc = successful[fi];
+      const int att = first ? pre_att : attempted[fi], suc = first ? pre_suc : successful[fi];
       if (att >= min_attempts && double(suc) / double(att) < match_fraction) { fl |= FF_SCHEDULED; f_flags[fi] = fl; }
     }
     s_del[N + i] = fl;      // second half of the dynamic LDS: this frame's flags

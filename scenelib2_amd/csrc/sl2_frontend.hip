@@ -323,6 +323,14 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   }
   int pre_fl = 0, pre_att = 0, pre_suc = 0;
   if (tid < ns) { const size_t fi = (size_t)b * N + tid; pre_fl = f_flags[fi]; pre_att = attempted[fi]; pre_suc = successful[fi]; }
+  // ... and what thread 0 needs for the trajectory push and the log at the very end (xv is not changed by this kernel, Q9)
+  double pre_x[13], pre_lr[3];
+  int pre_tc = 0, pre_pc = 0;
+  if (tid == 0) {
+    for (int k = 0; k < 13; ++k) pre_x[k] = xb[k];
+    for (int k = 0; k < 3; ++k) pre_lr[k] = last_r[b * 3 + k];
+    pre_tc = traj_count[b]; pre_pc = pos_count[b];
+  }
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int e = tid + q * (int)blockDim.x;
@@ -330,7 +338,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   }
   if (updated) {
     if (tid == 0) {
-      double q[4] = {xb[3], xb[4], xb[5], xb[6]}, Nn[16];
+      double q[4] = {pre_x[3], pre_x[4], pre_x[5], pre_x[6]}, Nn[16];
       dqnorm_by_dq(q, Nn);
       for (int i = 0; i < 16; ++i) s_N[i] = Nn[i];
     }
@@ -407,20 +415,28 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
     s_del[N + i] = fl;      // second half of the dynamic LDS: this frame's flags
   }
   __syncthreads();
-  if (tid == 0) {
-    int nd = 0;
-    bool skip_next = false;
-    for (int i = 0; i < ns; ++i) {
-      const int fl = s_del[N + i];
-      if (!(fl & FF_ACTIVE)) continue;
-      if (skip_next) { skip_next = false; continue; }
-      if (fl & FF_SCHEDULED) {
-        f_flags[(size_t)b * N + i] = FF_USED;  // inactive, deselected
-        s_del[nd++] = i;
-        skip_next = true;
+  // The reference walks feature_list_ and, after erasing a feature, skips the one that follows it (Q27: the iterator is
+  // advanced before vector::erase): among the ACTIVE features in list order, del(k) = scheduled(k) && !del(k - 1) - in a
+  // run of consecutive scheduled features the 1st, 3rd, 5th ... go.  Every thread decides its own feature from the length
+  // of the scheduled run that ends just before it (runs are a few features at most); walked by one thread over LDS the
+  // list cost 6 us of a single-sequence step.
+  if (tid == 0) s_ndel = 0;
+  __syncthreads();
+  for (int i = tid; i < ns; i += blockDim.x) {
+    const int fl = s_del[N + i];
+    if ((fl & FF_ACTIVE) && (fl & FF_SCHEDULED)) {
+      int run = 0;                                   // scheduled active features directly before i (inactive slots do not count)
+      for (int j = i - 1; j >= 0; --j) {
+        const int fj = s_del[N + j];
+        if (!(fj & FF_ACTIVE)) continue;
+        if (!(fj & FF_SCHEDULED)) break;
+        ++run;
+      }
+      if ((run & 1) == 0) {
+        f_flags[(size_t)b * N + i] = FF_USED;        // inactive, deselected
+        s_del[atomicAdd(&s_ndel, 1)] = i;            // (the order of the list does not matter: rows / columns are zeroed)
       }
     }
-    s_ndel = nd;
   }
   __syncthreads();
   for (int d = 0; d < s_ndel; ++d) {
@@ -438,16 +454,16 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   }
   if (tid == 0) {
     if (save_trajectory) {
-      const int c = traj_count[b];
+      const int c = pre_tc;
       double* t = traj + ((size_t)b * kTrajCapacity + (c % kTrajCapacity)) * 3;
-      for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
+      for (int k = 0; k < 3; ++k) t[k] = pre_lr[k];
       traj_count[b] = c + 1;
     }
-    const int log_slot = pos_count[b] % kTrajCapacity;   // device-side step counter: the launch carries no per-step argument
-    pos_count[b] += 1;
-    for (int k = 0; k < 3; ++k) pos_log[((size_t)b * kTrajCapacity + log_slot) * 3 + k] = xb[k];
+    const int log_slot = pre_pc % kTrajCapacity;   // device-side step counter: the launch carries no per-step argument
+    pos_count[b] = pre_pc + 1;
+    for (int k = 0; k < 3; ++k) pos_log[((size_t)b * kTrajCapacity + log_slot) * 3 + k] = pre_x[k];
     bool bad = false;
-    for (int k = 0; k < 13; ++k) bad = bad || !isfinite(xb[k]) || !isfinite(s_P[k * 13 + k]);   // (Q10 poisons Pxx first)
+    for (int k = 0; k < 13; ++k) bad = bad || !isfinite(pre_x[k]) || !isfinite(s_P[k * 13 + k]);   // (Q10 poisons Pxx first)
     if (bad) status[b] |= 1;
   }
 }

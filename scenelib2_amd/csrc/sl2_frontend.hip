@@ -172,11 +172,19 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
   const int ns = n_slots[b];
   if (tid == 0) { s_nvis = 0; s_zero_rank = 0x7fffffff; s_last = -1; }
   __syncthreads();
-  for (int i = tid; i < ns; i += blockDim.x) {
-    const int fl = f_flags[(size_t)b * N + i];
-    s_score[i] = f_score[(size_t)b * N + i];
-    s_vis[i] = (fl & FF_VISIBLE) ? 1 : 0;
-    if (fl & FF_ACTIVE) atomicMax(&s_last, i);
+  // (wave-level reductions, one LDS atomic per wavefront: a hundred threads hitting one LDS word one after the other cost
+  // 2.5 us each time at batch 1)
+  for (int i0 = 0; i0 < ns; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    int last = -1;
+    if (i < ns) {
+      const int fl = f_flags[(size_t)b * N + i];
+      s_score[i] = f_score[(size_t)b * N + i];
+      s_vis[i] = (fl & FF_VISIBLE) ? 1 : 0;
+      if (fl & FF_ACTIVE) last = i;
+    }
+    for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+    if ((tid & 63) == 0 && last >= 0) atomicMax(&s_last, last);
   }
   __syncthreads();
   FTR(1, 1);
@@ -189,18 +197,27 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
     else if (s_score[i] != s_score[i]) s_score[i] = -0.5;
   }
   __syncthreads();
-  for (int i = tid; i < ns; i += blockDim.x) {
-    if (!s_vis[i]) continue;
-    const double si = s_score[i];
-    int rank = 0;
+  for (int i0 = 0; i0 < ns; i0 += blockDim.x) {
+    const int i = i0 + tid;
+    const bool vis = i < ns && s_vis[i];
+    int zero_rank = 0x7fffffff;
+    if (vis) {
+      const double si = s_score[i];
+      int rank = 0;
 #pragma unroll 8
-    for (int j = 0; j < ns; ++j) {
-      const double sj = s_score[j];
-      rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+      for (int j = 0; j < ns; ++j) {
+        const double sj = s_score[j];
+        rank += (sj > si || (sj == si && j < i)) ? 1 : 0;
+      }
+      s_vis[i] = 1 + rank;  // store rank+1
+      if (si == 0.0) zero_rank = rank;
     }
-    s_vis[i] = 1 + rank;  // store rank+1
-    atomicAdd(&s_nvis, 1);
-    if (si == 0.0) atomicMin(&s_zero_rank, rank);
+    const int nv = __popcll(__ballot(vis));
+    for (int off = 32; off > 0; off >>= 1) zero_rank = min(zero_rank, __shfl_xor(zero_rank, off, 64));
+    if ((tid & 63) == 0) {
+      if (nv) atomicAdd(&s_nvis, nv);
+      if (zero_rank != 0x7fffffff) atomicMin(&s_zero_rank, zero_rank);
+    }
   }
   __syncthreads();
   FTR(1, 2);

@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from chol_trace import build_engine  # noqa: E402
 from scenelib2_amd import _lib  # noqa: E402
 
-B = 1024
+B = int(os.environ.get("TRACE_B", "1024"))
 eng, step, keep = build_engine(B, 100, 320, 240)
 for it in range(3):
     step(it)

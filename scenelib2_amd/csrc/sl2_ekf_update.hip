@@ -1011,7 +1011,131 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
 #undef SL2_TILE_PTR
 }
 
+// ---------------------------------------------------------------------------
+// k_fwdsub_ksplit: the forward substitution for SMALL batches, where k_fwdsub_lds is a chain, not a throughput problem:
+// there one wavefront walks all (J + 1) tile products of every block row of its 16 columns one after the other - 23
+// dependent 16-MFMA steps, 26 us for a single sequence.  Here a four-wave workgroup owns ONE 16-column strip: the solved
+// block rows live in LDS (the B fragments of every wave), the J products of block row J are dealt to the four waves,
+// their partial sums meet in LDS, and wave 0 applies the inverted diagonal block.  Same sums in a different association
+// (four partial sums): tolerance parity like every other variant.  Up to kKsMaxBlocks 32-blocks.
+// ---------------------------------------------------------------------------
+constexpr int kKsMaxBlocks = 8;
+__global__ void __launch_bounds__(256) k_fwdsub_ksplit(const double* __restrict__ At, double* __restrict__ Vt,
+                                                       const double* __restrict__ St, const double* __restrict__ LinvT,
+                                                       const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B) {
+  int b, ct;
+  if (!xcd_map(ld / 16, B, &b, &ct)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int nblk = (2 * cnt + 31) / 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int i0 = ct * 16;
+  const double* Ab = At + (size_t)b * mld * ld;
+  double* Vb = Vt + (size_t)b * mld * ld;
+  const double* Sb = St + (size_t)b * mld * mld;
+  const double* Lb = LinvT + (size_t)b * nblk_max * 1024;
+  __shared__ double sV[kKsMaxBlocks][32 * 16];      // solved block rows: [row][column]
+  __shared__ double sPart[4][32 * 16];              // the waves' partial sums of the current block row
+  // Operand prefetch (registers): the L tile of the wave's NEXT product - its (J, K) pairs are known in advance: K = wave,
+  // wave + 4, ... < J for J = wave + 1, wave + 2, ... -, and for wave 0 the next block row of At and the inverted diagonal
+  // block of the current one: nothing on the chain waits for a memory round trip it could have started earlier.
+  auto load_l = [&](int J, int K, double (&a0)[8], double (&a1)[8]) {
+    const double* lt = Sb + (size_t)(K * 32 + hi) * mld + J * 32 + lo;       // L[J][K], k-major: [contraction][row of J]
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) { a0[s8] = lt[(size_t)(4 * s8) * mld]; a1[s8] = lt[(size_t)(4 * s8) * mld + 16]; }
+  };
+  auto load_linv = [&](int J, double (&l0)[4], double (&l1)[8]) {
+    const double* li = Lb + (size_t)J * 1024 + hi * 32 + lo;                 // LinvT[p][k]: [contraction][row]
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) { if (s8 < 4) l0[s8] = li[4 * s8 * 32]; l1[s8] = li[4 * s8 * 32 + 16]; }
+  };
+  v4d at[2];
+  double li0[4], li1[8];
+  double pa0[8], pa1[8];
+  int pJ = wave + 1, pK = wave;                       // the wave's next (J, K)
+  if (pJ < nblk) load_l(pJ, pK, pa0, pa1);
+  if (wave == 0) {
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) at[jt][r] = Ab[(size_t)(16 * jt + hi + 4 * r) * ld + i0 + lo];
+    load_linv(0, li0, li1);
+  }
+  for (int J = 0; J < nblk; ++J) {
+    // ---- the products of this block row: K = wave, wave + 4, ...
+    v4d acc[2];
+    acc[0] = (v4d){0, 0, 0, 0};
+    acc[1] = (v4d){0, 0, 0, 0};
+    for (int K = wave; K < J; K += 4) {
+      double a0[8], a1[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) { a0[s8] = pa0[s8]; a1[s8] = pa1[s8]; }
+      // next pair: same block row while K + 4 < J, else the first product of the next block row that has one for this wave
+      if (K + 4 < J) { pJ = J; pK = K + 4; } else { pJ = J + 1; pK = wave; }
+      if (pJ < nblk) load_l(pJ, pK, pa0, pa1);
+      const double* vk = &sV[K][hi * 16 + lo];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const double bv = vk[4 * s8 * 16];
+        acc[0] = mfma_f64(a0[s8], bv, acc[0]);
+        acc[1] = mfma_f64(a1[s8], bv, acc[1]);
+      }
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sPart[wave][(16 * jt + hi + 4 * r) * 16 + lo] = acc[jt][r];
+    __syncthreads();
+    // ---- wave 0: rhs = At[J] - sum of the partial sums; V[J] = Linv_JJ rhs
+    if (wave == 0) {
+      v4d rhs[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int e = (16 * jt + hi + 4 * r) * 16 + lo;
+          rhs[jt][r] = at[jt][r] - (((sPart[0][e] + sPart[1][e]) + sPart[2][e]) + sPart[3][e]);
+        }
+      double l0[4], l1[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) { if (s8 < 4) l0[s8] = li0[s8]; l1[s8] = li1[s8]; }
+      if (J + 1 < nblk) {          // the next block row of At and its inverted diagonal block travel under this product
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) at[jt][r] = Ab[(size_t)((J + 1) * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo];
+        load_linv(J + 1, li0, li1);
+      }
+      v4d out[2];
+      out[0] = (v4d){0, 0, 0, 0};
+      out[1] = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+        const double bv = rhs[s8 >> 2][s8 & 3];
+        if (s8 < 4) out[0] = mfma_f64(l0[s8], bv, out[0]);          // Linv lower triangular: rows 0..15 need p < 16
+        out[1] = mfma_f64(l1[s8], bv, out[1]);
+      }
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * jt + hi + 4 * r;
+          sV[J][row * 16 + lo] = out[jt][r];
+          Vb[(size_t)(J * 32 + row) * ld + i0 + lo] = out[jt][r];
+        }
+    }
+    __syncthreads();
+  }
+}
+
 static bool launch_fwdsub_lds(sl2_engine* e, int B) {
+  // small batches: the chain-shortening kernel (one 16-column strip per workgroup, products dealt to its four waves)
+  if (e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !getenv("SL2_NO_KSPLIT")) {
+    hipLaunchKernelGGL(k_fwdsub_ksplit, dim3(xcd_grid(e->ld / 16, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                       e->m_count, e->ld, e->mld, e->nblk_max, B);
+    return true;
+  }
   const dim3 grid(xcd_grid(e->ld / 64, B)), block(256);
 #define SL2_FWD_CASE(NBV)                                                                                           \
   case NBV:                                                                                                         \

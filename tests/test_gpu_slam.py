@@ -317,6 +317,28 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_features", [5, 24, 60, 100])
+def test_both_substitution_kernels_on_small_batches(n_features, monkeypatch):
+    """Up to eight sequences the forward substitution runs in k_fwdsub_ksplit (a block row's products dealt to four waves), larger
+    batches in k_fwdsub_lds; SL2_NO_KSPLIT (read at launch) forces the latter.  Both must stay on the oracle at every block
+    count from one to seven, and agree with each other to rounding."""
+    states = []
+    for no_ksplit in (False, True):
+        if no_ksplit:
+            monkeypatch.setenv("SL2_NO_KSPLIT", "1")
+        else:
+            monkeypatch.delenv("SL2_NO_KSPLIT", raising=False)
+        pr = Pair(n_features, 4, batch=2, feature_sigma=0.004)
+        for k in range(4):
+            pr.step_both(k)
+            pr.compare_state(1e-9, 1e-8)
+        states.append([pr.engine.total_covariance(b) for b in range(2)])
+    monkeypatch.delenv("SL2_NO_KSPLIT", raising=False)
+    for b in range(2):
+        assert np.linalg.norm(states[0][b] - states[1][b]) <= 1e-10 * np.linalg.norm(states[1][b])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mapping", [False, True])
 def test_graph_replay_is_bit_identical(mapping):
     """sl2_set_graph_mode: the captured step replayed from two alternating device frame buffers (what the ingest

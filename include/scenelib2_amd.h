@@ -298,7 +298,8 @@ int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels
  * SL2_STATUS_LABELS_EXHAUSTED: feature initialisation wanted a new feature but every one of the sequence's max_features slots
  * holds a LIVE feature (the reference's feature_list_ is unbounded).  Deleted features do not count: their slots are squeezed
  * out, in feature_list_ order, when a sequence runs out of slots, and labels (Feature::label_ = next_free_label_++) are kept
- * apart from slots and never reused - a sequence may hand out any number of labels over its lifetime.  When the bit is set the
+ * apart from slots and never reused - a sequence may hand out any number of labels over its lifetime (maps of more than 2048
+ * state columns - max_features > 676 - keep retired slots: there the bit also rises when the slots run out).  When the bit is set the
  * sequence keeps tracking its map but initialises no further features.  Callers that run with enable_mapping must poll
  * this (the MonoSLAM adapters do, and raise). */
 #define SL2_STATUS_NONFINITE 1

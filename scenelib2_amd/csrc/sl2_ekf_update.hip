@@ -1329,7 +1329,18 @@ static void launch_fwdsub_grouped(sl2_engine* e, int B) {
 // ---------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
-                                              const int* __restrict__ m_count, int ld, int mld, int B) {
+                                              const int* __restrict__ m_count, int ld, int mld, int B
+#ifdef SL2_CHOL_TRACE
+                                              , long long* trace
+#endif
+                                              ) {
+#ifdef SL2_CHOL_TRACE   // development builds: entry / exit cycle stamps of wave 0 (scripts/syrk_clock.py)
+  struct Stamp {
+    long long* p;
+    __device__ Stamp(long long* q) : p(q) { if (p && threadIdx.x == 0) p[2 * blockIdx.x] = (long long)__builtin_readcyclecounter(); }
+    __device__ ~Stamp() { if (p && threadIdx.x == 0) p[2 * blockIdx.x + 1] = (long long)__builtin_readcyclecounter(); }
+  } stamp(trace);
+#endif
   int b, t;
   const int ntl = ld / 64;
   if (!xcd_map(ntl * (ntl + 1) / 2, B, &b, &t)) return;
@@ -1618,8 +1629,13 @@ static int launch_update_range(sl2_engine* e) {
   {
     LaunchScope ls(e, "k_syrk", true);
     const int nt = e->ld / 64;
+#ifdef SL2_CHOL_TRACE
+    hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count,
+                       e->ld, e->mld, B, (long long*)e->root->chol_trace);
+#else
     hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count,
                        e->ld, e->mld, B);
+#endif
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

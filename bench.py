@@ -299,7 +299,10 @@ def main():
                             frac=ach / FP64_MFMA_PEAK_TF, traffic=None, algorithmic_flops_per_launch=flops[dom],
                             avg_launch_ms=dur * 1e3,
                             measured_ceiling={"fp64_mfma_microbench_TFLOPs": 47.8, "fp64_valu_fma_microbench_TFLOPs": 54.1,
-                                              "source": "profiles/r01_microbench.txt (scripts/microbench.py on this box type)"})
+                                              "source": "profiles/r01_microbench.txt (scripts/microbench.py on this box type)",
+                                              # separate measurement, not of this run: cycle stamps of every k_syrk workgroup
+                                              "clock_under_k_syrk_GHz": 1.57, "fp64_mfma_peak_at_that_clock_TFLOPs": 51.5,
+                                              "clock_source": "profiles/r02_probes.txt item 17 (scripts/syrk_clock.py, batch 1024 x 100 features); `peak` above is the 2.4 GHz spec"})
             elif dom in hbm_bytes:
                 dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
                 ach = hbm_bytes[dom] / dur / 1e9

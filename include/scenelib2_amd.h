@@ -114,7 +114,9 @@ int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double*
  * Feature ctor feature.cpp:108-149), batched: `nfeat` features appended to each of
  * sequences [seq0, seq0+nseq).  y [nseq][nfeat][3], xp_org [nseq][nfeat][7],
  * patches [nseq][nfeat][121] = the 11x11 8-bit template the reference would
- * cv::imread from `identifier`. */
+ * cv::imread from `identifier`.  Labels continue from next_free_label_; a sequence that lacks free slots first gets the slots
+ * of its deleted features back (see SL2_STATUS_LABELS_EXHAUSTED below); SL2_ERR_CAPACITY if it still holds more than
+ * max_features - nfeat live features. */
 int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const double* y, const double* xp_org,
                            const uint8_t* patches);
 

@@ -231,7 +231,7 @@ int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);
 int launch_manual_init(sl2_engine* e, const int* d_uv);
 int launch_auto_init(sl2_engine* e);
-int launch_compact_slots(sl2_engine* e);     // sl2_mapping.hip: retired slots squeezed out when a sequence has none left
+int launch_compact_slots(sl2_engine* e, int need);   // sl2_mapping.hip: retired slots squeezed out when a sequence lacks room for `need` more features
 int write_grey_image(const char* path, const uint8_t* px, int w, int h);   // sl2_ingest.hip (PGM / PNG)
 
 }  // namespace sl2

@@ -465,6 +465,17 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   std::vector<int> slots(nseq);
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
+  bool lacking = false;
+  for (int s = 0; s < nseq; ++s) lacking = lacking || slots[s] + nfeat > e->N;
+  if (lacking) {        // slots of deleted features are given back first (the reference's feature_list_ simply shrinks)
+    sl2_engine* g = e->groups.empty() ? e : e->groups[0];
+    if (e->groups.size() <= 1) {
+      int rc = launch_compact_slots(g, nfeat);
+      if (rc != SL2_OK) return rc;
+      { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+      SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
+    }
+  }
   for (int s = 0; s < nseq; ++s)
     if (slots[s] + nfeat > e->N) { set_error("sl2_add_known_features: feature capacity exceeded"); return SL2_ERR_CAPACITY; }
   double *dy = nullptr, *dxp = nullptr;

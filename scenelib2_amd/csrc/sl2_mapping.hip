@@ -556,14 +556,14 @@ template <typename T>
 __device__ __forceinline__ void slot_move(T* base, int per, int dst, int src, int tid, int nthreads) {
   for (int k = tid; k < per; k += nthreads) base[(size_t)dst * per + k] = base[(size_t)src * per + k];
 }
-__global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, int ld, int ppos) {
+__global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, int ld, int ppos, int need) {
   extern __shared__ int s_map[];        // [N] new slot -> old slot, then [N] old slot -> new slot (-1: retired)
   int* s_src = s_map;
   int* s_new = s_map + N;
   __shared__ int s_live;
   const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
   const int ns = a.n_slots[b];
-  if (ns < N) return;                                            // slots left: nothing to do
+  if (ns + need <= N) return;                                    // room for what is about to be added: nothing to do
   int* flags = a.f_flags + (size_t)b * N;
   if (tid == 0) {
     int nl = 0;
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
   }
   __syncthreads();
   const int nl = s_live;
-  if (nl == ns) return;                                          // genuinely full
+  if (nl == ns) return;                                          // no retired slot to give back
   const size_t o = (size_t)b * N;
   // ---- per-slot records: in increasing new slot (src >= dst, every earlier move wrote below dst); a barrier per slot
   // because the source of one move can be the destination of the next
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
     const int d = (i - 13) / 3, c = (i - 13) % 3;
     return d < nl ? 13 + 3 * s_src[d] + c : -1;
   };
-  const int n_end = 13 + 3 * ns;                                  // (ns == N here: every feature row is visited)
+  const int n_end = 13 + 3 * ns;                                  // (rows of never-used slots beyond ns are zero and stay zero)
   constexpr int kMaxCols = 8;                                     // columns per thread: ld <= 2048
   for (int i = 13; i < ld; ++i) {
     const int si = src_index(i);
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
   if (tid == 0) a.n_slots[b] = nl;
 }
 
-int launch_compact_slots(sl2_engine* e) {
+int launch_compact_slots(sl2_engine* e, int need) {
   if ((size_t)e->ld > 8 * 256) return SL2_OK;                     // (maps beyond 2048 states: slots are not squeezed)
   LaunchScope ls(e, "k_map_compact_slots");
   SlotArrays a;
@@ -677,7 +677,7 @@ int launch_compact_slots(sl2_engine* e) {
   a.f_flags = e->f_flags; a.attempted = e->attempted; a.successful = e->successful; a.f_label = e->f_label; a.srch_i = e->srch_i;
   a.sel_idx = e->sel_idx; a.succ_idx = e->succ_idx; a.n_sel = e->n_sel; a.m_count = e->m_count; a.n_slots = e->n_slots;
   a.part_i = e->part_i;
-  hipLaunchKernelGGL(k_map_compact_slots, dim3(e->B), dim3(256), sizeof(int) * 2 * e->N, e->stream, a, e->N, e->ld, e->ppos);
+  hipLaunchKernelGGL(k_map_compact_slots, dim3(e->B), dim3(256), sizeof(int) * 2 * e->N, e->stream, a, e->N, e->ld, e->ppos, need);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }
@@ -727,7 +727,7 @@ static int launch_create(sl2_engine* e, const MapParams& mp) {
 // InitialiseFeature(frame) with (uu_, vv_) = uv[b] (device array [B][2]; u < 0 = skip the sequence)
 int launch_manual_init(sl2_engine* e, const int* d_uv) {
   const MapParams mp = map_params(e, 1, 0, 1);
-  { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
+  { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   hipLaunchKernelGGL(k_map_manual, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, d_uv, e->n_slots, e->part_i, e->part_d, e->status,
                      e->N, e->cam.width, e->cam.height, e->B);
   SL2_HIP(hipGetLastError());
@@ -737,7 +737,7 @@ int launch_manual_init(sl2_engine* e, const int* d_uv) {
 // InitialiseAutoFeature(frame) = AutoInitialiseFeature(frame, 0) (monoslam.cpp:1535-1541, 823-865): region, detector, creation
 int launch_auto_init(sl2_engine* e) {
   const MapParams mp = map_params(e, 1, 0, 1);
-  { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
+  { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   hipLaunchKernelGGL(k_map_region, dim3(e->B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
                      e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
   SL2_HIP(hipGetLastError());
@@ -761,7 +761,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.dt = e->prm.delta_t;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
-  if (enable_mapping) { int rc = launch_compact_slots(e); if (rc != SL2_OK) return rc; }
+  if (enable_mapping) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   {
     LaunchScope ls(e, "k_map_region");
     hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,

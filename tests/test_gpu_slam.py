@@ -503,6 +503,33 @@ def test_manual_delete_feature_matches_mark_and_delete():
     assert int(pr.engine.total_state_sizes(0, 1)[0]) == 13 + 3 * 15
 
 
+def test_known_features_added_after_deletions_reuse_the_slots():
+    """AddNewKnownFeature on a map whose slots are all taken but some of whose features have been deleted: the retired slots are
+    squeezed out first (the reference's feature_list_ just shrinks and grows), the new features get the next labels, and the
+    filter carries on like the oracle's."""
+    pr = Pair(16, 6, batch=2, feature_sigma=0.003, max_features=16)
+    for k in range(2):
+        pr.step_both(k)
+    for lab in (3, 9, 10):
+        assert list(pr.engine.delete_features([lab, lab])) == [True, True]
+        for o in pr.oracles:
+            assert o.delete_feature(lab)
+    # two new known features per sequence: copies of two deleted ones under new labels
+    for b in range(2):
+        sp = pr.specs[b]
+        ys, tp = sp.feat_y[[3, 9]], pr.templates[b][[3, 9]]
+        pr.engine.add_known_features(ys[None], np.tile(sp.poses[0], (1, 2, 1)), tp[None], seq0=b)
+        for i in range(2):
+            pr.oracles[b].add_known_feature(ys[i], sp.poses[0], tp[i])
+    assert [f["label"] for f in pr.engine.features(0)] == [i for i in range(16) if i not in (3, 9, 10)] + [16, 17]
+    pr.compare_state(TOL_X, TOL_P)
+    with pytest.raises(Exception):
+        pr.engine.add_known_features(pr.specs[0].feat_y[None, :2], np.tile(pr.specs[0].poses[0], (1, 2, 1)), pr.templates[0][None, :2], seq0=0)   # 15 + 2 > 16
+    for k in range(2, 6):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+
+
 def test_create_step_destroy_does_not_leak_device_memory():
     """sl2_destroy gives back everything sl2_create and the first steps allocated (state, work buffers, lazily created
     mapping maps, events, streams): free device memory after twenty engines equals free memory after the first one."""

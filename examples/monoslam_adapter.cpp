@@ -2,7 +2,7 @@
 // adapter (include/scenelib2_amd_monoslam.hpp) instead of SceneLib2::MonoSLAM: Init(cfg), GetFrame, GoOneStep, then the
 // members GraphicTool would draw.  No Pangolin window: the per-frame read-out is printed / dumped instead.
 //
-//   monoslam_adapter --cfg scene.cfg --frames frame_dir [--mapping] [--dump out.txt]
+//   monoslam_adapter --cfg scene.cfg --frames frame_dir [--mapping | --seams] [--dump out.txt]
 //
 // The dump lists, one value per line: total_state_size_, the total state (construct_total_state), then per feature in
 // feature_list_ order: label_, fully_initialised_flag_, attempted_, successful_, position_in_total_state_vector_, Pyy_
@@ -13,14 +13,15 @@
 
 int main(int argc, char** argv) {
   std::string cfg, frames_dir, dump;
-  bool enable_mapping = false;
+  bool enable_mapping = false, seams = false;    // --seams: the step through the reference's individual members instead of GoOneStep
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--cfg" && i + 1 < argc) cfg = argv[++i];
     else if (a == "--frames" && i + 1 < argc) frames_dir = argv[++i];
     else if (a == "--dump" && i + 1 < argc) dump = argv[++i];
     else if (a == "--mapping") enable_mapping = true;
-    else { fprintf(stderr, "usage: %s --cfg scene.cfg --frames dir [--mapping] [--dump file]\n", argv[0]); return 2; }
+    else if (a == "--seams") seams = true;
+    else { fprintf(stderr, "usage: %s --cfg scene.cfg --frames dir [--mapping | --seams] [--dump file]\n", argv[0]); return 2; }
   }
   if (cfg.empty() || frames_dir.empty()) { fprintf(stderr, "need --cfg and --frames\n"); return 2; }
   try {
@@ -42,7 +43,15 @@ int main(int argc, char** argv) {
       size_t stride = 0;
       if (sl2_ingest_next(grab, nullptr, &frame.data, &stride) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
       frame.cols = slam.camera_->width_; frame.rows = slam.camera_->height_; frame.on_device = true;
-      slam.GoOneStep(frame, save_trajectory, enable_mapping);
+      if (!seams) {
+        slam.GoOneStep(frame, save_trajectory, enable_mapping);
+      } else {                                                          // monoslam.cpp:118-177 call by call (no mapping tail)
+        SceneLib2Amd::Kalman kalman;
+        kalman.KalmanFilterPredict(&slam);
+        slam.auto_select_n_features(slam.kNumberOfFeaturesToSelect_);
+        if (slam.make_measurements(frame) > 0) kalman.KalmanFilterUpdate(&slam);
+        slam.finish_step(save_trajectory);
+      }
       if (frame_id % 10 == 9 || frame_id + 1 == n) {
         int measured = 0;
         for (const SceneLib2Amd::Feature* f : slam.selected_feature_list_) measured += f->successful_measurement_flag_ ? 1 : 0;

@@ -180,6 +180,34 @@ class MonoSLAM {
     return true;
   }
 
+  // The seams of GoOneStep, callable one by one like the reference's public members (monoslam.cpp:118-177; kalman.h:51-52
+  // through the Kalman struct below).  With enable_mapping = false, predict -> auto_select_n_features ->
+  // make_measurements -> update -> finish_step is GoOneStep.
+  int auto_select_n_features(int n) {                                   // monoslam.cpp:187-254 (+ the measurement predictions)
+    check(sl2_auto_select_n_features(eng_, n), "sl2_auto_select_n_features");
+    refresh_public_members();
+    return (int)selected_feature_list_.size();
+  }
+  int make_measurements(const Frame& image) {                           // monoslam.cpp:336-359
+    if (!image.data || image.cols != camera_->width_ || image.rows != camera_->height_)
+      throw std::runtime_error("MonoSLAM::make_measurements: frame does not match the camera");
+    check(sl2_make_measurements(eng_, image.data, (size_t)image.cols * image.rows, image.on_device ? 1 : 0), "sl2_make_measurements");
+    refresh_public_members();
+    return successful_measurement_vector_size_;
+  }
+  // normalise_state + delete_bad_features + the symmetrisation + the trajectory_store_ push (monoslam.cpp:137-177) in one
+  // call: the engine does them in one kernel
+  void finish_step(bool save_trajectory) {
+    check(sl2_finish_step(eng_, save_trajectory ? 1 : 0), "sl2_finish_step");
+    refresh_public_members();
+  }
+  void kalman_filter_predict() { check(sl2_kalman_filter_predict(eng_), "sl2_kalman_filter_predict"); refresh_public_members(); }
+  void kalman_filter_update() { check(sl2_kalman_filter_update(eng_), "sl2_kalman_filter_update"); refresh_public_members(); }
+  Feature* find_feature_lab(int lab) {                                  // monoslam.cpp:719-741
+    for (const auto& f : feature_list_) if (f->label_ == lab) return f.get();
+    return nullptr;
+  }
+
   // construct_total_state / construct_total_covariance (monoslam.cpp:501-546)
   void construct_total_state(std::vector<double>& V) {
     V.assign(total_state_size_, 0.0);
@@ -400,6 +428,14 @@ class MonoSLAM {
 
   int max_features_, device_;
   sl2_engine* eng_ = nullptr;
+};
+
+// Kalman (kalman.h:51-52): the reference's filter object works on the MonoSLAM it is handed; so does this one.
+struct Kalman {
+  void KalmanFilterPredict(MonoSLAM* monoslam, const std::array<double, 3>& /*u: the constant-velocity model takes no control*/ = {}) {
+    monoslam->kalman_filter_predict();                                  // kalman.cpp:50-69
+  }
+  void KalmanFilterUpdate(MonoSLAM* monoslam) { monoslam->kalman_filter_update(); }   // kalman.cpp:72-119
 };
 
 }  // namespace SceneLib2Amd

@@ -64,7 +64,7 @@ def test_headless_example_matches_oracle(tmp_path, mapping):
         assert s.mapping_info()["initialised"] >= 2
 
 
-@pytest.mark.parametrize("mapping", [False, True])
+@pytest.mark.parametrize("mapping", [False, True, "seams"])
 def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mapping):
     """examples/monoslam_adapter.cpp: the reference example's loop written against include/scenelib2_amd_monoslam.hpp
     (Init / GoOneStep / xv_, feature_list_, selected_feature_list_, trajectory_store_ ...).  Its read-out must be what the
@@ -75,7 +75,9 @@ def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mappin
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=20)
     cfg, fd = _write_scene(str(tmp_path), cam, params, spec, frames, templates)
     dump = os.path.join(str(tmp_path), "members.txt")
-    cmd = [exe, "--cfg", cfg, "--frames", fd, "--dump", dump] + (["--mapping"] if mapping else [])
+    seams = mapping == "seams"      # the step through Kalman::KalmanFilterPredict / auto_select_n_features / make_measurements / ...
+    mapping = bool(mapping) and not seams
+    cmd = [exe, "--cfg", cfg, "--frames", fd, "--dump", dump] + (["--mapping"] if mapping else []) + (["--seams"] if seams else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "%d known features" % spec.n_features in out.stdout

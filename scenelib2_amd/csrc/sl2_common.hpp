@@ -137,6 +137,9 @@ struct sl2_engine {
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
   bool graph_mode = false;
   std::vector<StepGraph> step_graphs;
+  int build_split = 0;        // development switches, read from the environment once at sl2_create (SL2_BUILD_SPLIT,
+  int score_threads = 0;      // SL2_SCORE_THREADS, SL2_NO_KSPLIT): 0 = the engine's own choice
+  int no_ksplit = 0;
   int search_variant = 3;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk, 3 = int8 matrix-core walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----

@@ -1131,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_fwdsub_ksplit(const double* __restrict_
 
 static bool launch_fwdsub_lds(sl2_engine* e, int B) {
   // small batches: the chain-shortening kernel (one 16-column strip per workgroup, products dealt to its four waves)
-  if (e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !getenv("SL2_NO_KSPLIT")) {
+  if (e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !e->root->no_ksplit) {
     hipLaunchKernelGGL(k_fwdsub_ksplit, dim3(xcd_grid(e->ld / 16, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                        e->m_count, e->ld, e->mld, e->nblk_max, B);
     return true;
@@ -1546,7 +1546,7 @@ static int launch_update_range(sl2_engine* e) {
     // three workgroups per sequence are indifferent to what ran before but take 0.346-0.377 depending on the box).  Smaller
     // batches: ~3000 workgroups in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
     int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
-    if (const char* v = getenv("SL2_BUILD_SPLIT")) nsplit = atoi(v);     // experiments
+    if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (SL2_BUILD_SPLIT)
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;

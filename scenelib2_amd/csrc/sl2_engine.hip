@@ -356,6 +356,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
   if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);
+  if (const char* v = getenv("SL2_BUILD_SPLIT")) e->build_split = atoi(v);
+  if (const char* v = getenv("SL2_SCORE_THREADS")) e->score_threads = atoi(v);
+  if (getenv("SL2_NO_KSPLIT")) e->no_ksplit = 1;
   {
     int G = 1;
     const char* env = getenv("SL2_GROUPS");

@@ -1278,7 +1278,7 @@ int launch_search(sl2_engine* e) {
     int threads = (e->nsel_max + 63) / 64 * 64;
     if (threads > 1024) threads = 1024;
     if (e->B >= 256) threads = 64;
-    if (const char* v = getenv("SL2_SCORE_THREADS")) threads = atoi(v);      // experiments
+    if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
     hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
                        e->succ_idx, e->m_count, e->N);

@@ -320,7 +320,7 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
 @pytest.mark.parametrize("n_features", [5, 24, 60, 100])
 def test_both_substitution_kernels_on_small_batches(n_features, monkeypatch):
     """Up to eight sequences the forward substitution runs in k_fwdsub_ksplit (a block row's products dealt to four waves), larger
-    batches in k_fwdsub_lds; SL2_NO_KSPLIT (read at launch) forces the latter.  Both must stay on the oracle at every block
+    batches in k_fwdsub_lds; SL2_NO_KSPLIT (read when the engine is created) forces the latter.  Both must stay on the oracle at every block
     count from one to seven, and agree with each other to rounding."""
     states = []
     for no_ksplit in (False, True):

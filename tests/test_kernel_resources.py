@@ -1,0 +1,58 @@
+"""Register budgets of the hot kernels, checked at build time (hipcc cross-compiles without a GPU).
+
+Occupancy on gfx950 is decided by the unified register file: 512 / registers wavefronts per SIMD (in steps of 8
+registers).  A change that pushes a kernel over its budget - or makes the compiler spill - does not fail any parity test,
+it only shows up as a slower launch on the GPU box (round 2: a loop-carried index in k_chol_left cost six spilled
+registers and 3 % of the launch).  This test reads the kernel descriptors of the device assembly."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "scenelib2_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# kernel name fragment -> (file, extra flags, max total registers (arch + accumulator), wavefronts per SIMD that buys,
+#                         scalar registers the compiler may park in vector lanes)
+BUDGET = {
+    "k_syrkEPKd": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 128, 4, 0),
+    "k_fwdsub_ldsILi7E": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 168, 3, 0),
+    "k_chol_left": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 128, 4, 0),
+    "k_build_ASILi1ELi4E": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 80, 6, 0),
+    "k_search_mfma": ("sl2_search.hip", ["-ffp-contract=off"], 128, 4, 16),      # (eleven today: the records of two positions in flight)
+}
+
+
+def _assembly(src, flags, tmp_path):
+    out = os.path.join(str(tmp_path), src + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-Wno-unused-value", "-Wno-unused-result",
+           "--cuda-device-only", "-S", os.path.join(CSRC, src), "-o", out] + flags
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return open(out).read()
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_hot_kernels_stay_inside_their_register_budgets(tmp_path):
+    texts = {}
+    for frag, (src, flags, max_regs, waves, max_sspill) in BUDGET.items():
+        if src not in texts:
+            texts[src] = _assembly(src, flags, tmp_path)
+        t = texts[src]
+        m = re.search(r"\.name:\s+(\S*%s\S*)\n(.*?)\.wavefront_size" % re.escape(frag), t, re.S)
+        assert m, "kernel %s not found in %s" % (frag, src)
+        meta = m.group(2)
+        # the fields of one kernel descriptor follow its .name in any order up to the next kernel: take the enclosing block
+        start = t.rfind("- .agpr_count", 0, m.start())
+        end = t.find("- .agpr_count", m.end())
+        block = t[start:end if end > 0 else len(t)]
+        vg = int(re.search(r"\.vgpr_count:\s+(\d+)", block).group(1))
+        spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", block).group(1))
+        sspills = int(re.search(r"\.sgpr_spill_count:\s+(\d+)", block).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", block).group(1))
+        assert spills == 0 and scratch == 0, "%s spills (%d vector registers, %d bytes of scratch)" % (frag, spills, scratch)
+        assert sspills <= max_sspill, "%s spills %d scalar registers (allowed %d)" % (frag, sspills, max_sspill)
+        assert vg <= max_regs, "%s uses %d registers, budget %d (= %d wavefronts per SIMD)" % (frag, vg, max_regs, waves)
+        assert 512 // ((vg + 7) // 8 * 8) >= waves

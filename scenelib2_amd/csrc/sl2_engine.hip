@@ -516,7 +516,7 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
 }
 
 int sl2_set_search_variant(sl2_engine* e, int variant) {
-  if (!e || variant < 0 || variant > 3) return SL2_ERR_INVALID;
+  if (!e || variant < 0 || variant > 4) return SL2_ERR_INVALID;
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   e->step_graphs.clear();
   e->search_variant = variant;

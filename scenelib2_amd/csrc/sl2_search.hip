@@ -820,6 +820,428 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
 }
 
 // ---------------------------------------------------------------------------
+// Variant 4 ("lean matrix-core walk", production from round 3): the arithmetic of variant 3 - the same int8 Toeplitz
+// products, the same operand layout, the same FP32 rank + exact FP64 decision - re-costed for vector-instruction issue,
+// which is what bounds this kernel (round 2: 551 vector instructions per searched feature, matrix pipes 23 % busy):
+//   * the window band is staged in 16-byte pieces (one global_load_dwordx4 and three ds_write_b128 per lane: a 26 x 26
+//     byte band is ONE pass of 52 lanes instead of three passes of dwords), the byte planes come out of v_perm_b32;
+//   * the Toeplitz operand of the ones matrix is loaded once per wavefront, the six template operands once per feature
+//     (not per tile);
+//   * the offsets of the signed operands are never taken out per candidate: variance and covariance are shift
+//     invariant, so D1 = 121 w + s1 (-30976 - s1) + K and Nc = 121 x + (15488 - sum g0) s1 straight from the
+//     accumulators (s1 = sum(g - 128), w = 256 H' + L', x = the raw cross term); only the winner's sums are converted;
+//   * candidate counts and the sigma == 10 flag live in scalar registers (popcount / or of compare masks), the
+//     per-row terms of the ellipse expression are formed once per band, and the winning lane stores its own record.
+// ---------------------------------------------------------------------------
+constexpr int kM4Pitch = 48;                     // bytes per LDS row: three 16-byte pieces (32 candidate columns + 10)
+constexpr int kM4Rows = 28;                      // 16 candidate rows + 10 + the partner row of template row 10
+constexpr int kM4Plane = kM4Rows * kM4Pitch;     // bytes per plane
+typedef unsigned m4_u4 __attribute__((ext_vector_type(4)));
+
+struct M4Band { int base, rows_needed, nchunk, ntask; unsigned mul; };
+__device__ __forceinline__ M4Band m4_band(int ucentre, int vcentre, int urelstart, int vrelstart, int nu_all, int nv_all, int up,
+                                          int vt, int width) {
+  M4Band bd;
+  bd.base = (vcentre + vrelstart + 16 * vt - 5) * width + (ucentre + urelstart + 16 * up - 5);   // < 2^31
+  bd.rows_needed = min(nv_all - 16 * vt, 16) + 10;             // <= 26
+  const int bytes_needed = min(nu_all - 16 * up, 32) + 10;     // 11 .. 42
+  bd.nchunk = (bytes_needed + 15) >> 4;                        // 1 .. 3
+  bd.ntask = bd.rows_needed * bd.nchunk;                       // <= 78
+  bd.mul = bd.nchunk == 1 ? 128u : (bd.nchunk == 2 ? 64u : 43u);   // (idx * mul) >> 7 == idx / nchunk for idx < 128
+  return bd;
+}
+// the band's 16-byte pieces in flight: two passes of 64 lanes; lds = byte offset of the piece inside a plane, -1 = this
+// lane has no piece in that pass, bit 30 = the piece runs past the end of the frame (see m4_band_fix)
+struct M4Pf { m4_u4 v[2]; int lds[2]; };
+__device__ __forceinline__ bool m4_band_loads(const uint8_t* __restrict__ img, int width, int frame_bytes, const M4Band bd,
+                                              int lane, M4Pf& pf) {
+  bool over = false;
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (ps * 64 < bd.ntask) {                                  // wave-uniform
+      if (ps) asm volatile("" ::: "memory");                   // (a real branch: the second pass is the exception, not to be speculated)
+      const int idx = ps * 64 + lane;
+      const int row = (int)(((unsigned)idx * bd.mul) >> 7);
+      const int chunk = idx - mul24(row, bd.nchunk);
+      const bool valid = idx < bd.ntask;
+      const int off = bd.base + mul24(row, width) + 16 * chunk;
+      // A piece may reach up to 37 bytes beyond its window row; inside the frame that is harmless (the bytes land in
+      // columns no candidate uses), but the last image row must not be over-read: the address is clamped and the piece is
+      // re-read byte by byte by m4_band_fix (windows that touch the last image row only).
+      const bool ov = valid && off > frame_bytes - 16;
+      over |= ov;
+      __builtin_memcpy(&pf.v[ps], img + min(off, frame_bytes - 16), 16);
+      pf.lds[ps] = valid ? ((mul24(row, kM4Pitch) + 16 * chunk) | (ov ? 0x40000000 : 0)) : -1;
+    }
+  }
+  return __any(over);
+}
+// a piece that would run past the end of the frame, read byte by byte (bytes beyond the frame are zero: they belong to
+// columns no candidate uses)
+__device__ __noinline__ m4_u4 m4_piece_bytes(const uint8_t* __restrict__ img, int off, int frame_bytes) {
+  unsigned w[4] = {0u, 0u, 0u, 0u};
+  for (int e = 0; e < 16; ++e)
+    if (off + e < frame_bytes) w[e >> 2] |= (unsigned)img[off + e] << (8 * (e & 3));
+  m4_u4 r;
+  r.x = w[0]; r.y = w[1]; r.z = w[2]; r.w = w[3];
+  return r;
+}
+__device__ __forceinline__ void m4_band_fix(const uint8_t* __restrict__ img, int width, int frame_bytes, const M4Band bd, int lane,
+                                            M4Pf& pf) {
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (ps * 64 < bd.ntask && pf.lds[ps] >= 0 && (pf.lds[ps] & 0x40000000)) {
+      const int idx = ps * 64 + lane;
+      const int row = (int)(((unsigned)idx * bd.mul) >> 7);
+      const int chunk = idx - row * bd.nchunk;
+      pf.v[ps] = m4_piece_bytes(img, bd.base + row * width + 16 * chunk, frame_bytes);
+      pf.lds[ps] &= ~0x40000000;
+    }
+  }
+}
+// four pixels -> the three signed byte planes (g - 128, high and low byte of g^2, each - 128)
+__device__ __forceinline__ void m4_planes(unsigned d, unsigned& I, unsigned& H, unsigned& L) {
+  const unsigned lo = d & 0x00ff00ffu;                                  // pixels 0, 2 as 16-bit lanes
+  const unsigned hi = __builtin_amdgcn_perm(0u, d, 0x0c030c01u);        // pixels 1, 3
+  const unsigned sqlo = mf_sq_pairs(lo), sqhi = mf_sq_pairs(hi);
+  H = __builtin_amdgcn_perm(sqhi, sqlo, 0x07030501u) ^ 0x80808080u;
+  L = __builtin_amdgcn_perm(sqhi, sqlo, 0x06020400u) ^ 0x80808080u;
+  I = d ^ 0x80808080u;
+}
+__device__ __forceinline__ void m4_band_store(const M4Pf& pf, const M4Band bd, char* s_pl) {
+#pragma unroll
+  for (int ps = 0; ps < 2; ++ps) {
+    if (ps * 64 < bd.ntask && pf.lds[ps] >= 0) {
+      m4_u4 I, H, L;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned iq, hq, lq;
+        m4_planes(pf.v[ps][q], iq, hq, lq);
+        I[q] = iq; H[q] = hq; L[q] = lq;
+      }
+      char* p = s_pl + pf.lds[ps];
+      *(m4_u4*)p = I;
+      *(m4_u4*)(p + kM4Plane) = H;
+      *(m4_u4*)(p + 2 * kM4Plane) = L;
+    }
+  }
+}
+
+// wave-wide maximum in seven instructions: v_max_f32 with the DPP modifier (the compiler spells each of these steps as
+// v_mov + v_mov_dpp + two canonicalising v_max: 27 instructions).  Two wait states between a VALU write and the DPP read.
+__device__ __forceinline__ float m4_wave_max(float x) {
+  asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// per-lane state of one search (raw accumulator values of the best candidate) ...
+struct M4State {
+  float best_q, second_q;
+  int best_key, best_S1, best_w, best_x;
+  __device__ __forceinline__ void reset() { best_q = -3.0e38f; second_q = -3.0e38f; best_key = 0; best_S1 = best_w = best_x = 0; }
+};
+// ... and its wave-uniform part
+struct M4Uni { int ncand; unsigned long long nx; };
+
+// Lane predicates as 64-bit masks in scalar registers.  The compiler keeps a predicate that is both selected on and
+// counted (popcount of a ballot) as a 0 / 1 vector register and re-compares it - two more vector instructions per use, in
+// a kernel bound by vector issue - so the compares and selects of the scoring loop are spelled out: a compare writes an
+// SGPR pair, masks are combined and counted on the scalar unit, v_cndmask takes the pair.
+typedef unsigned long long m4_mask;
+__device__ __forceinline__ m4_mask m4_gt_i32(int s_a, int v_b) { m4_mask m; asm("v_cmp_gt_i32_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }   // a > b
+__device__ __forceinline__ m4_mask m4_lt_i32(int s_a, int v_b) { m4_mask m; asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }   // a < b
+__device__ __forceinline__ m4_mask m4_eq_i32(int s_a, int v_b) { m4_mask m; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }
+__device__ __forceinline__ m4_mask m4_gt_f64(double s_a, double v_b) { m4_mask m; asm("v_cmp_gt_f64_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }   // a > b
+__device__ __forceinline__ m4_mask m4_gt_f32(float v_a, float v_b) { m4_mask m; asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v_a), "v"(v_b)); return m; }   // a > b
+__device__ __forceinline__ int m4_sel(m4_mask m, int t, int f) { int r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
+__device__ __forceinline__ float m4_self(m4_mask m, float t, float f) { float r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
+
+// the (up to two) 16 x 16 candidate tiles of the band in LDS
+__device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* s_T, const mf_v4i b_ones, const mf_v4i b_ones_last,
+                                              int up, int vt, int TU, int nu_all, int nv_all, int urelstart, int vrelstart,
+                                              double a, double b2, double c, int kS, float d0f, bool patch_ok, int j, int g,
+                                              M4State& st, M4Uni& un) {
+  const int vi0 = 16 * vt + 4 * g;
+  const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
+  for (int ut = up; ut < min(up + 2, TU); ++ut) {
+    // ellipse membership: the reference's expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9, same values, same order
+    const int ui = 16 * ut + j;
+    const double du = (double)(urelstart + ui);
+    const double e_uu = a * du * du, e_u = b2 * du;
+    const m4_mask m_col = m4_gt_i32(nu_all, ui);
+    m4_mask m_cand[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      int vi = vi0 + reg;
+      asm volatile("" : "+v"(vi));        // (keeps the per-row terms out of registers across the matrix-core section)
+      const double dv = (double)(vrelstart + vi);
+      m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & m4_gt_f64(kNoSigma * kNoSigma, e_uu + e_u * dv + c * dv * dv);
+      un.ncand += __popcll(m_cand[reg]);
+    }
+    if (!patch_ok) continue;             // (a flat template: every candidate is skipped, they are only counted)
+    mf_v4i accX, acc1, accH, accL;
+    const mf_v4i zero = {0, 0, 0, 0};
+    const char* ap = s_pl + j * kM4Pitch + 16 * ((ut - up) + (g & 1)) + (g >> 1) * kM4Pitch;
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+      const mf_v4i aI = *(const mf_v4i*)(ap + 2 * p * kM4Pitch);
+      const mf_v4i aH = *(const mf_v4i*)(ap + 2 * p * kM4Pitch + kM4Plane);
+      const mf_v4i aL = *(const mf_v4i*)(ap + 2 * p * kM4Pitch + 2 * kM4Plane);
+      const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
+      const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
+      accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, p ? accX : zero, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, p ? acc1 : zero, 0, 0, 0);
+      accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, p ? accH : zero, 0, 0, 0);
+      accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? accL : zero, 0, 0, 0);
+    }
+    const int key0 = (ui << 16) | vi0;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int s1 = acc1[reg];                                  // sum (g - 128)
+      const int S1 = s1 + 15488;                                 // sum g
+      const int w = (accH[reg] << 8) + accL[reg];                // sum g^2 - 15488 * 257
+      const int D1 = mul24(121, w) - (mul24(S1, S1) - 481630336);   // 121 sum g^2 - (sum g)^2, exact
+      const int Nc = mul24(121, accX[reg]) + mul24(kS, s1);      // 121 sum g0 g - sum g0 sum g, exact (shift invariant)
+      const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
+      un.nx |= m_cand[reg] & m4_eq_i32(1464100, D1);             // sigma1 == 10 boundary: decided in FP64 only
+      const float qq = m4_self(m_cand[reg] & m4_lt_i32(1464100, D1), q, -3.0e38f);
+      const m4_mask better = m4_gt_f32(qq, st.best_q);
+      st.second_q = __builtin_amdgcn_fmed3f(st.best_q, st.second_q, qq);    // second of {best, second, new}
+      st.best_q = m4_self(better, qq, st.best_q);
+      st.best_key = m4_sel(better, key0 + reg, st.best_key);
+      st.best_S1 = m4_sel(better, S1, st.best_S1);
+      st.best_w = m4_sel(better, w, st.best_w);
+      st.best_x = m4_sel(better, accX[reg], st.best_x);
+    }
+  }
+}
+
+// One search, one wavefront, nothing in flight across calls: the stateless batch API (templates as raw 121 bytes).
+__device__ __forceinline__ SearchResult search_core_m4(const uint8_t* __restrict__ image, int width, int frame_bytes,
+                                                       const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
+                                                       double b, double c, char* s_pl, unsigned* s_T) {
+  const int lane = threadIdx.x & 63;
+  const int nu_all = sb.urelfinish - sb.urelstart + 1;
+  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
+  SearchResult res;
+  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
+  res.S1 = res.S2 = res.X = 0;
+  if (nu_all <= 0 || nv_all <= 0) return res;
+  unsigned tv = 0;
+  if (lane < 33) {
+    const int r = lane / 3, d = lane - 3 * r;
+    for (int kk = 0; kk < 4; ++kk) {
+      const int col = 4 * d + kk;
+      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
+      tv |= byte << (8 * kk);
+    }
+  }
+  unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
+  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+  const int Sg0 = (int)s1, Sg0sq = (int)s2;
+  // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
+  const double g0bar = (double)Sg0 / 121.0;
+  const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
+  const double sigmag0 = sqrt(varg0);
+  const bool patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
+  const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+  mf_tpl_init(s_T, lane);
+  mf_tpl_store(tv, s_T, lane);
+  const int j = lane & 15, g = lane >> 4;
+  const int boff = 16 + 16 * (g & 1) - j;
+  const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+  const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
+  M4State st;
+  st.reset();
+  M4Uni un;
+  un.ncand = 0; un.nx = 0ull;
+  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+  for (int vt = 0; vt < TV; ++vt)
+    for (int up = 0; up < TU; up += 2) {
+      if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
+      const M4Band bd = m4_band(sb.ucentre, sb.vcentre, sb.urelstart, sb.vrelstart, nu_all, nv_all, up, vt, width);
+      M4Pf pf;
+      if (m4_band_loads(image, width, frame_bytes, bd, lane, pf)) m4_band_fix(image, width, frame_bytes, bd, lane, pf);
+      m4_band_store(pf, bd, s_pl);
+      __syncthreads();
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, 15488 - Sg0,
+                    d0f, patch_ok, j, g, st, un);
+    }
+  res.ncand = un.ncand;
+  if (!patch_ok) return res;
+  const float gmax = m4_wave_max(st.best_q);
+  if (!(gmax > -1.0e38f)) { if (un.nx) res.code = -1; return res; }       // nothing passed the sigma test
+  const float thr = gmax - 4.0e-6f;
+  const unsigned long long near_mask = __ballot(st.best_q >= thr);
+  if (un.nx != 0ull || __any(st.second_q >= thr) || __popcll(near_mask) > 1) { res.code = -1; return res; }
+  const int wl = __ffsll((long long)near_mask) - 1;
+  const int key = __shfl(st.best_key, wl, 64), wS1 = __shfl(st.best_S1, wl, 64), ww = __shfl(st.best_w, wl, 64),
+            wx = __shfl(st.best_x, wl, 64);
+  res.S1 = wS1; res.S2 = ww + 15488 * 257; res.X = wx + 128 * (wS1 - 15488) + 128 * Sg0;
+  res.found = 1;
+  res.u = sb.ucentre + sb.urelstart + (key >> 16);
+  res.v = sb.vcentre + sb.vrelstart + (key & 0xffff);
+  double sd0, sd1;
+  const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
+  if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {   // cannot happen (D1 > bound), kept exact
+    res.found = 0; res.u = res.v = 0;
+    return res;
+  }
+  res.score = corr;
+  res.ok = !(corr > kCorrThresh2) ? 1 : 0;
+  return res;
+}
+
+// Variant 4 engine kernel: the work split and the software pipeline of k_search_mfma (one wavefront walks `chunk`
+// consecutive selected positions of one sequence, XCD-mapped; the next position's template and first band are in flight
+// while the current one is in the matrix cores).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
+k_search_m4(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int frame_bytes, const uint8_t* __restrict__ patch,
+            const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
+            double* __restrict__ meas_score, int N, int nchunks, int B, int chunk) {
+  int b, ch;
+  if (!xcd_map(nchunks, B, &b, &ch)) return;
+  STR(0);
+  __shared__ __attribute__((aligned(16))) char s_pl[3 * kM4Plane];
+  __shared__ unsigned s_T[kMfTplDw];
+  const int lane = threadIdx.x;
+  const int k0 = ch * chunk;
+  const int nsel = n_sel[b];
+  if (k0 >= nsel) return;
+  const int nf = min(chunk, nsel - k0);
+  const uint8_t* img = frames + (size_t)b * seq_stride;
+  const int j = lane & 15, g = lane >> 4;
+
+  // the record k_select wrote for selected position k (one 64-byte line; uniform address: scalar loads).  The window
+  // integers are fetched one position ahead (the prefetch needs them), PuInv when its position is worked on.
+  struct Rec { int f, uc, vc, us, nu, vs, nv; };
+  auto record = [&](int i) {
+    const int* rec = srch_sel + ((size_t)b * N + k0 + i) * 16;
+    Rec r;
+    r.f = rec[0]; r.uc = rec[1]; r.vc = rec[2]; r.us = rec[3]; r.nu = rec[4]; r.vs = rec[5]; r.nv = rec[6];
+    return r;
+  };
+
+  mf_tpl_init(s_T, lane);
+  const int tslot = (lane < 33) ? (lane / 3) * kMfPitchDw + 4 + lane % 3 : 0;      // where this lane's template dword goes
+  const unsigned tmask = (lane % 3 == 2) ? 0x00ffffffu : 0xffffffffu;
+  M4Pf pf;
+  pf.lds[0] = pf.lds[1] = -1;
+  bool pf_over = false;
+  unsigned pf_tv = 0;
+  Rec rc = record(0);
+  {
+    if (rc.nu > 0 && rc.nv > 0)
+      pf_over = m4_band_loads(img, width, frame_bytes, m4_band(rc.uc, rc.vc, rc.us, rc.vs, rc.nu, rc.nv, 0, 0, width), lane, pf);
+    const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rc.f) * kPatchStride + kPatchPackedOffset);
+    pf_tv = tpl[min(lane, 35)];
+  }
+  // operands of the ones matrix: they depend on the lane alone
+  __syncthreads();
+  const int boff = 16 + 16 * (g & 1) - j;
+  const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+  const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
+  STR(1);
+  for (int i = 0; i < nf; ++i) {
+    // the next position's record: scalar loads issued here, consumed after the barrier below (clamped index: the last
+    // iteration re-reads its own record instead of branching)
+    const Rec rn = record(min(i + 1, nf - 1));
+    const double* recd = (const double*)(srch_sel + ((size_t)b * N + k0 + i) * 16 + 8);
+    const double pa = recd[0], pb = recd[1], pc = recd[2];
+    const int nu_all = rc.nu, nv_all = rc.nv;
+    const bool geom_ok = nu_all > 0 && nv_all > 0;
+    const unsigned tv = pf_tv;
+    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 33), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
+    const bool patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
+    const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+    if (i > 0) __syncthreads();                       // feature i - 1 is done with the LDS
+    if (geom_ok) {
+      if (lane < 33) s_T[tslot] = (tv ^ 0x80808080u) & tmask;
+      const M4Band bd0 = m4_band(rc.uc, rc.vc, rc.us, rc.vs, nu_all, nv_all, 0, 0, width);
+      if (pf_over) m4_band_fix(img, width, frame_bytes, bd0, lane, pf);
+      m4_band_store(pf, bd0, s_pl);
+    }
+    __syncthreads();
+    pf_over = false;
+    if (i + 1 < nf) {                                 // next feature's template and first band: in flight from here on
+      if (rn.nu > 0 && rn.nv > 0)
+        pf_over = m4_band_loads(img, width, frame_bytes, m4_band(rn.uc, rn.vc, rn.us, rn.vs, rn.nu, rn.nv, 0, 0, width), lane, pf);
+      const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rn.f) * kPatchStride + kPatchPackedOffset);
+      pf_tv = tpl[min(lane, 35)];
+    }
+    int* o = srch_res + ((size_t)b * N + k0 + i) * 8;
+    M4State st;
+    st.reset();
+    M4Uni un;
+    un.ncand = 0; un.nx = 0ull;
+    int code = 0;
+    if (geom_ok) {
+      const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+      const int kS = 15488 - Sg0;
+      const double b2 = 2 * pb;
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, 0, 0, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kS, d0f, patch_ok, j, g,
+                    st, un);
+      for (int vt = 0; vt < TV; ++vt)                 // the other bands of a large window: staged synchronously
+        for (int up = (vt == 0 ? 2 : 0); up < TU; up += 2) {
+          __syncthreads();
+          const M4Band bd = m4_band(rc.uc, rc.vc, rc.us, rc.vs, nu_all, nv_all, up, vt, width);
+          M4Pf p2;
+          if (m4_band_loads(img, width, frame_bytes, bd, lane, p2)) m4_band_fix(img, width, frame_bytes, bd, lane, p2);
+          m4_band_store(p2, bd, s_pl);
+          __syncthreads();
+          m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kS, d0f, patch_ok,
+                        j, g, st, un);
+        }
+      // ---- decision (as variants 1 and 3): a unique near-best candidate goes on to k_search_score with its exact sums
+      if (patch_ok) {
+        const float gmax = m4_wave_max(st.best_q);
+        if (gmax > -1.0e38f) {
+          const float thr = gmax - 4.0e-6f;
+          const bool near = st.best_q >= thr;
+          const unsigned long long near_mask = __ballot(near);
+          if (un.nx != 0ull || __any(st.second_q >= thr) || __popcll(near_mask) > 1) code = -1;
+          else {
+            code = 1;
+            if (near) {                               // the one lane that holds the only possible winner stores its record
+              int4 o0, o1;
+              o0.x = 1; o0.y = rc.uc + rc.us + (st.best_key >> 16); o0.z = rc.vc + rc.vs + (st.best_key & 0xffff); o0.w = st.best_S1;
+              o1.x = st.best_w + 15488 * 257; o1.y = st.best_x + 128 * st.best_S1 + 128 * (Sg0 - 15488); o1.z = un.ncand; o1.w = 1;
+              *(int4*)o = o0; *(int4*)(o + 4) = o1;     // (k_search_score writes this position's score)
+            }
+          }
+        } else if (un.nx != 0ull) code = -1;
+      }
+    }
+    if (code < 0) {
+      SearchBounds sb;
+      sb.ucentre = rc.uc; sb.vcentre = rc.vc; sb.urelstart = rc.us; sb.urelfinish = rc.us + nu_all - 1;
+      sb.vrelstart = rc.vs; sb.vrelfinish = rc.vs + nv_all - 1; sb.halfwidth = sb.halfheight = 0;
+      const double* recd2 = (const double*)(srch_sel + ((size_t)b * N + k0 + i) * 16 + 8);     // (rare path: fetched again)
+      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + rc.f) * kPatchStride, sb, recd2[0], recd2[1], recd2[2]);
+      if (lane == 0) {
+        o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
+        meas_score[(size_t)b * N + k0 + i] = r.score;
+      }
+    } else if (code == 0 && lane == 0) {              // nothing found (or nothing to search)
+      int4 o0, o1;
+      o0.x = 0; o0.y = 0; o0.z = 0; o0.w = 0; o1.x = 0; o1.y = 0; o1.z = un.ncand; o1.w = 0;
+      *(int4*)o = o0; *(int4*)(o + 4) = o1;
+      meas_score[(size_t)b * N + k0 + i] = 1000000.0;
+    }
+    rc = rn;
+  }
+  STR(6);
+}
+
+// ---------------------------------------------------------------------------
 // Variant 2 ("packed column walk", production): same arithmetic as variant 1, but one
 // wavefront serves SEVERAL features at once.  With 3-sigma ellipses of ~15 columns a single
 // feature keeps a quarter of the lanes busy and pays the 10-row warm-up of the sliding
@@ -1217,8 +1639,8 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
                                                      const double* __restrict__ centre, const double* __restrict__ puinv,
                                                      int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
   const int i = blockIdx.x;
-  __shared__ __attribute__((aligned(16))) unsigned s_win[VARIANT == 2 ? 3 * kMfPlaneDw : kWinRows * kWinPitchDw];
-  __shared__ unsigned s_tpl[VARIANT == 2 ? kMfTplDw : 1];
+  __shared__ __attribute__((aligned(16))) unsigned s_win[VARIANT == 3 ? 3 * kM4Plane / 4 : (VARIANT == 2 ? 3 * kMfPlaneDw : kWinRows * kWinPitchDw)];
+  __shared__ unsigned s_tpl[VARIANT >= 2 ? kMfTplDw : 1];
   const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
   const double a = puinv[i * 3], b = puinv[i * 3 + 1], c = puinv[i * 3 + 2];
   const SearchBounds sb = search_bounds(ce, a, b, c, width, height);
@@ -1227,6 +1649,7 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
   r.code = -1;
   if (VARIANT == 1) r = search_core_v1<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win);
   if (VARIANT == 2) r = search_core_mfma(img, width, patches + (size_t)i * 121, sb, a, b, c, s_win, s_tpl);
+  if (VARIANT == 3) r = search_core_m4(img, width, width * height, patches + (size_t)i * 121, sb, a, b, c, (char*)s_win, s_tpl);
   if (r.code < 0) r = search_core_v0(img, width, patches + (size_t)i * 121, sb, a, b, c);
   if ((threadIdx.x & 63) == 0) {
     ok[i] = r.ok;
@@ -1259,6 +1682,14 @@ int launch_search(sl2_engine* e) {
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score, e->N, nchunks, e->B, chunk);
+    }
+    else if (e->root->search_variant == 4) {
+      int chunk = (int)(((long long)e->B * e->nsel_max + 4095) / 4096);
+      chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
+      const int nchunks = (e->nsel_max + chunk - 1) / chunk;
+      hipLaunchKernelGGL(k_search_m4, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+                         e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,
+                         e->N, nchunks, e->B, chunk);
     }
     else if (e->root->search_variant == 0)
       hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
@@ -1298,7 +1729,7 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
     set_error("sl2_elliptical_search_batch: null pointer or bad count");
     return SL2_ERR_INVALID;
   }
-  if (variant < 0 || variant > 2) return SL2_ERR_INVALID;
+  if (variant < 0 || variant > 3) return SL2_ERR_INVALID;
   if (width < kBoxSize || height < kBoxSize) { set_error("sl2_elliptical_search_batch: image smaller than the 11x11 patch"); return SL2_ERR_INVALID; }
   for (int i = 0; i < count; ++i)
     if (image_index[i] < 0 || image_index[i] >= nimages) {
@@ -1339,6 +1770,8 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
   SL2_HIP(hipMemcpy(d_pu, puinv, sizeof(double) * 3 * count, hipMemcpyHostToDevice));
   if (variant == 0)
     hipLaunchKernelGGL(k_search_batch<0>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
+  else if (variant == 3)
+    hipLaunchKernelGGL(k_search_batch<3>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   else if (variant == 2)
     hipLaunchKernelGGL(k_search_batch<2>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   else

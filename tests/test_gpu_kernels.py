@@ -86,9 +86,9 @@ def _search_cases(rng, n, W, H):
     return (np.stack(images), np.array(idx, np.int32), np.stack(patches), np.array(centres), np.array(puinv))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_elliptical_search_batch_matches_oracle_exactly(variant):
-    """variant 0 = baseline kernel, 1 = LDS column walk, 2 = int8 matrix-core walk (the engine's default search core)."""
+    """variant 0 = baseline kernel, 1 = LDS column walk, 2 = round-2 int8 matrix-core walk, 3 = lean matrix-core walk (the engine's default search core)."""
     rng = np.random.default_rng(102)
     W, H = 160, 120
     images, idx, patches, centres, puinv = _search_cases(rng, 160, W, H)
@@ -137,7 +137,7 @@ def test_elliptical_search_windows_larger_than_the_tile_are_walked_in_blocks():
     centres, puinv = np.array(centres), np.array(puinv)
     n = len(idx)
     wants = [oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t]) for t in range(n)]
-    for variant in (2, 1, 0):
+    for variant in (3, 2, 1, 0):
         ok = np.zeros(n, np.int32)
         uv = np.full((n, 2), -7, np.int32)
         score = np.zeros(n)
@@ -153,7 +153,7 @@ def test_elliptical_search_windows_larger_than_the_tile_are_walked_in_blocks():
         assert ok.sum() >= 10
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_near_ties_inside_the_fp32_guard_band_are_decided_like_the_reference(variant):
     """Adversarial for the FP32 ranking of the fast search cores: two (or three) copies of the template inside the ellipse
     that differ from it in k and k + 1 pixels by one grey level.  Their reference scores are ~1e-6 .. 4e-6 apart - at or
@@ -193,6 +193,48 @@ def test_near_ties_inside_the_fp32_guard_band_are_decided_like_the_reference(var
         assert score[t] == want["corr"], t
         close += want["corr"] < 2e-5
     assert close >= 100          # the constructed copies really are the winners
+
+
+@pytest.mark.parametrize("variant", [3, 2, 0])
+def test_search_windows_in_the_last_rows_of_the_last_image_do_not_read_past_it(variant):
+    """Windows clamped into the bottom-right corner: the 16-byte staging pieces of the lean matrix-core walk would reach
+    past the end of the frame there (the last image of the batch ends the allocation), so they are re-read byte by byte;
+    the sigma == 10 boundary block sits in the corner of some images too.  Results must be the reference's."""
+    rng = np.random.default_rng(31)
+    W, H = 96, 64
+    tex = synth.make_texture(size=512)
+    images, idx, patches, centres, puinv = [], [], [], [], []
+    for t in range(48):
+        oy, ox = int(rng.integers(0, 512 - H)), int(rng.integers(0, 512 - W))
+        img = tex[oy:oy + H, ox:ox + W].copy()
+        cx, cy = W - 6 - int(rng.integers(0, 6)), H - 6 - int(rng.integers(0, 4))
+        patch = img[cy - 5:cy + 6, cx - 5:cx + 6].copy()
+        if t % 6 == 5:                                                   # a window whose sigma is exactly 10 in the very corner
+            vals = np.array([60] * 21 + [61] * 50 + [81] * 50, dtype=np.uint8)
+            img[H - 11:, W - 11:] = rng.permutation(vals).reshape(11, 11)
+        s0, s1 = rng.uniform(4, 120, 2)
+        r = rng.uniform(-0.6, 0.6) * np.sqrt(s0 * s1)
+        a, b, c = oa.sinv_from_S(np.array([[s0, r], [r, s1]]))
+        ce = np.array([cx + rng.uniform(-3, 8), cy + rng.uniform(-3, 8)])     # often beyond the border: clamped
+        images.append(img); idx.append(t); patches.append(patch.reshape(121)); centres.append(ce); puinv.append([a, b, c])
+    images, idx, patches = np.stack(images), np.array(idx, np.int32), np.stack(patches)
+    centres, puinv = np.array(centres), np.array(puinv)
+    n = len(idx)
+    ok = np.zeros(n, np.int32)
+    uv = np.full((n, 2), -7, np.int32)
+    score = np.zeros(n)
+    _lib.check(_lib.load().sl2_elliptical_search_batch(0, _lib.u8p(images), n, W, H, _lib.ip(idx), _lib.u8p(patches),
+                                                       _lib.dp(centres), _lib.dp(puinv), n, _lib.ip(ok), _lib.ip(uv),
+                                                       _lib.dp(score), variant))
+    found = 0
+    for t in range(n):
+        want = oa.elliptical_search(images[t], patches[t], centres[t], *puinv[t])
+        assert bool(ok[t]) == want["ok"], "case %d ok" % t
+        assert score[t] == want["corr"], "case %d score %r vs %r" % (t, score[t], want["corr"])
+        if want["corr"] < 1e6:
+            assert (uv[t, 0], uv[t, 1]) == (want["u"], want["v"]), "case %d uv" % t
+            found += 1
+    assert found >= 30
 
 
 def test_device_renderer_matches_host_bytes():

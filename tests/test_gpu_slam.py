@@ -64,9 +64,9 @@ def test_seams_one_frame():
         assert rel_fro(e.total_covariance(b), Po) < TOL_P
 
 
-@pytest.mark.parametrize("n_features,n_frames,batch,variant", [(20, 40, 3, 3), (20, 40, 3, 2), (20, 40, 3, 1), (20, 12, 2, 0), (100, 12, 2, 3), (100, 12, 2, 2)])
+@pytest.mark.parametrize("n_features,n_frames,batch,variant", [(20, 40, 3, 4), (20, 40, 3, 3), (20, 40, 3, 2), (20, 40, 3, 1), (20, 12, 2, 0), (100, 12, 2, 4), (100, 12, 2, 3), (100, 12, 2, 2)])
 def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
-    """variant: search kernel (3 int8 matrix-core walk, 2 packed column walk, 1 column walk with one feature per wave, 0 baseline)."""
+    """variant: search kernel (4 lean int8 matrix-core walk = default, 3 round-2 matrix-core walk, 2 packed column walk, 1 column walk with one feature per wave, 0 baseline)."""
     pr = Pair(n_features, n_frames, batch=batch)
     pr.engine.set_search_variant(variant)
     traj_o = np.zeros((batch, n_frames, 3))
@@ -86,6 +86,74 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
     for b in range(batch):     # trajectory_store_ keeps the reference's stale-scratch semantics (Q12)
         assert np.array_equal(pr.engine.trajectory(b), pr.oracles[b].trajectory())
     assert not pr.engine.status_flags().any()
+
+
+def _sigma_ten_block():
+    """An 11x11 block whose population sigma is EXACTLY 10 (121 * sum g^2 - (sum g)^2 == 1464100): the boundary of the
+    reference's `sdimage < 10` test (monoslam.cpp:458-461), which the fast search cores hand to the exact FP64 path."""
+    vals = np.array([60] * 21 + [61] * 50 + [81] * 50, dtype=np.int64)
+    assert 121 * (vals ** 2).sum() - vals.sum() ** 2 == 1464100
+    return np.random.default_rng(5).permutation(vals).reshape(11, 11).astype(np.uint8)
+
+
+@pytest.mark.parametrize("variant", [4, 3])
+def test_engine_search_kernel_on_adversarial_frames(variant):
+    """The ENGINE's pipelined search kernel (sl2_go_one_step -> k_search_m4 / k_search_mfma: packed template records, first
+    band prefetched, later bands staged in the loop) on crafted frames, against the oracle: around the last measured
+    position of every feature the frame gets, in turn, two copies of the template that differ by k and k + 1 one-level
+    pixel flips (scores inside the FP32 guard band), two identical copies (exact tie: the last in scan order wins), a
+    flat patch of image (every candidate fails the sigma test), and a block whose sigma is exactly 10.  The first frames
+    have 3-sigma windows of several bands, some clamped by the border.  The exact fallback must have run (and still
+    everything - measurements, counters, state, covariance - equals the reference's)."""
+    rng = np.random.default_rng(77)
+    B, N, F = 4, 24, 7
+    pr = Pair(N, F, batch=B)
+    pr.engine.set_search_variant(variant)
+    H, W = pr.cam["height"], pr.cam["width"]
+    ten = _sigma_ten_block()
+    fallbacks, multi_band, clamped, pasted = 0, 0, 0, 0
+    for k in range(F):
+        if k >= 1:
+            for b in range(B):
+                img = np.array(pr.frames[b][k], dtype=np.uint8).reshape(H, W).copy()
+                for i in range(N):
+                    fo = pr.oracles[b].feature(i)
+                    zx, zy = int(fo["z"][0]), int(fo["z"][1])
+                    if not fo["success"] or not (12 <= zx < W - 12 and 6 <= zy < H - 6):
+                        continue
+                    tpl = pr.templates[b][i].reshape(11, 11).astype(np.int32)
+                    kind = (i + k) % 5
+                    spots = [(zx - 6, zy), (zx + 6, zy)]
+                    if kind == 4:
+                        continue                                   # the rendered frame as it is
+                    pasted += 1
+                    for si, (x, y) in enumerate(spots):
+                        if kind == 0 or kind == 1:
+                            q = tpl.copy()
+                            nflip = 0 if kind == 1 else int(rng.integers(0, 3)) + si
+                            for _ in range(nflip):
+                                q[rng.integers(0, 11), rng.integers(0, 11)] += int(rng.choice([-1, 1]))
+                            img[y - 5:y + 6, x - 5:x + 6] = q.clip(0, 255).astype(np.uint8)
+                        elif kind == 2:
+                            img[y - 5:y + 6, x - 5:x + 6] = 97   # flat: sigma 0
+                        elif kind == 3 and si == 0:
+                            img[y - 5:y + 6, x - 5:x + 6] = ten
+                pr.frames[b][k] = img.reshape(pr.frames[b][k].shape)
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+        w = pr.engine.step_work()
+        fallbacks += int(w["search_fallbacks"])
+        for b in range(B):
+            for i in range(N):
+                S = pr.oracles[b].feature(i)["S"]
+                if 3.0 * np.sqrt(S[0, 0]) >= 16 or 3.0 * np.sqrt(S[1, 1]) >= 8:
+                    multi_band += 1
+                h = pr.oracles[b].feature(i)["h"]
+                if min(h[0], W - 1 - h[0]) < 3.0 * np.sqrt(S[0, 0]) + 5 or min(h[1], H - 1 - h[1]) < 3.0 * np.sqrt(S[1, 1]) + 5:
+                    clamped += 1
+    assert pasted > 100
+    assert fallbacks > 20, "the exact fallback of the fast search core never ran: the crafted frames missed their purpose"
+    assert multi_band > 50 and clamped > 0
 
 
 def test_uncertain_map_dense_covariance():

@@ -109,6 +109,45 @@ def workload_name(B, W, H, N, world):
     return "custom: " + shape
 
 
+def per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render, tdev, world, nseq=2, nframes=8):
+    """A rank's leg of the parity check in a multi-GPU run: the first `nseq` sequences of this rank's shard, the first
+    `nframes` frames, against oracle/_ref/libref.so (the oracle restatement when that library is absent), on the same
+    bytes the GPU consumed.  All ranks call this (it ends in two collectives); returns the job-wide summary."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as oa
+    use_ref = oa.ref_available()
+    if use_ref:
+        try:
+            oa.ref_lib()
+        except Exception:
+            use_ref = False
+    nseq = max(1, min(nseq, B))
+    n_state = 13 + 3 * N
+    nframes = max(2, min(n_render - 1, nframes if N <= 100 else int(nframes * (313.0 / n_state) ** 3 + 0.5) or 2))
+    allf = np.stack([d_frames.download((nseq, H, W), np.uint8, offset=k * B * fb) for k in range(nframes + 1)])
+    slams = []
+    for b in range(nseq):
+        s = oa.RefSLAM(cam, params["delta_t"], N) if use_ref else oa.OracleSLAM(cam, params["delta_t"], N)
+        s.set_state(specs[b].xv0, specs[b].Pxx0)
+        xo = specs[b].xp_org()
+        for i in range(N):
+            s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
+        if args.feature_sigma > 0.0:
+            for i in range(N):
+                s.set_feature_Pyy(i, np.eye(3) * args.feature_sigma ** 2)
+        slams.append(s)
+    _, traj = oa.run_sequences(slams, [np.ascontiguousarray(allf[1:, b]) for b in range(nseq)], nthreads=nseq, L=slams[0].L)
+    log = eng.position_log(0, nseq, capacity=n_render)[:, :nframes]
+    sq = float(((log - traj) ** 2).sum(axis=2).mean())
+    worst_rmse = sharding.max_over_ranks(float(np.sqrt(sq)), tdev)
+    worst_abs = sharding.max_over_ranks(float(np.abs(log - traj).max()), tdev)
+    checked = sharding.sum_over_ranks(1, tdev)
+    return dict(traj_rmse_vs_oracle=worst_rmse, position_maxabs=worst_abs, ranks_checked=int(checked), n_gpus=world,
+                checker="reference build (oracle/_ref/libref.so)" if use_ref else "oracle",
+                sequences=nseq, frames=nframes,
+                note="every rank: the first %d sequences of its own shard x %d frames; worst over ranks" % (nseq, nframes))
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -203,8 +242,10 @@ def main():
     # ---- warm-up ----  (its last steps, when there are enough, carry a bracket on EVERY launch: they tell which kernel
     # dominates, so that the timed region brackets only that one and the search kernel - each bracket is two event markers
     # on the stream, and bracketing the four large kernels cost 1-3 % of the step)
-    MAJOR = ("k_syrk", "k_fwdsub", "k_build_A", "k_search")
-    focus = "k_syrk,k_search"
+    # profiling scopes carry the kernel symbols (they join with rocprofv3's kernel_stats.csv on the name)
+    MAJOR = ("k_syrk", "k_fwdsub_lds", "k_fwdsub_ksplit", "k_fwd_gemm", "k_build_AS", "k_chol_left", "k_chol_syrk", "k_search_mfma")
+    SEARCH = "k_search_mfma"
+    focus = "k_syrk," + SEARCH
     n_probe = 3 if (not args.no_profile and Wm >= 6) else 0
     for k in range(Wm - n_probe):
         step(k)
@@ -219,7 +260,7 @@ def main():
         eng.set_profiling(0)
         cand = {n: probe[n]["total_ms"] for n in MAJOR if n in probe}
         if cand:
-            focus = max(cand, key=cand.get) + ",k_search"
+            focus = max(cand, key=cand.get) + "," + SEARCH
     eng.synchronize()
     if not args.no_profile:
         eng.set_profile_focus(focus)
@@ -263,6 +304,13 @@ def main():
     gather_ms = (time.perf_counter() - t_g) * 1e3
     status_bad = int(eng.status_flags().any())
 
+    # ---- N > 1: every rank checks a small sample of ITS OWN sequences against the reference build (values, not shapes);
+    # rank 0 reports the worst deviation and how many ranks took part
+    rank_parity = None
+    if world > 1 and args.cpu_sample != 0:
+        rank_parity = per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render,
+                                      tdev if use_dist else None, world)
+
     out = None
     if rank == 0:
         # ---- roofline of the dominant kernel + the search kernel ----
@@ -278,20 +326,24 @@ def main():
             dom = max(ktimes.items(), key=lambda kv: kv[1]["total_ms"])[0]
             # algorithmic FLOPs per launch over the rank's batch (executed formulation)
             flops = {"k_syrk": work["sum_nnm"],                  # P -= V V^T on the symmetric half: n^2 m
-                     "k_fwdsub": work["sum_nmm"],                # V = A L^-T: n m^2
-                     "k_build_S": 20.0 * work["sum_m2"]}
-            # k_build_A (A = P H^T and S = H A + R in one pass) streams: the measured features' rows of P (1.5 m n
+                     "k_fwdsub_lds": work["sum_nmm"],            # V = A L^-T: n m^2
+                     "k_fwdsub_ksplit": work["sum_nmm"],
+                     "k_chol_left": work["sum_m3"] / 3.0}        # S = L L^T (one launch per batch up to 16 blocks)
+            # k_build_AS (A = P H^T and S = H A + R in one pass) streams: the measured features' rows of P (1.5 m n
             # doubles) + the 7 pose rows, writes A (m n) and the lower blocks of S (m^2 / 2)
-            hbm_bytes = {"k_build_A": 8.0 * (2.5 * work["sum_nm"] + 0.5 * work["sum_m2"])}
-            chol = work["sum_m3"] / 3.0
-            n_chol_launch = sum(ktimes[n]["launches"] for n in ("k_chol_diag", "k_chol_panel", "k_chol_trail") if n in ktimes)
-            bsearch = work["window_bytes"] + (121.0 + 64.0) * work["searched"]   # SURVEY §8(d) B_search, summed over the batch
-            if "k_search" in ktimes:
-                dur = ktimes["k_search"]["total_ms"] / ktimes["k_search"]["launches"] * 1e-3
+            hbm_bytes = {"k_build_AS": 8.0 * (2.5 * work["sum_nm"] + 0.5 * work["sum_m2"])}
+            bsearch = work["window_bytes"] + (121.0 + 64.0) * work["searched"]   # SURVEY 8(d) B_search, summed over the batch
+            if SEARCH in ktimes:
+                dur = ktimes[SEARCH]["total_ms"] / ktimes[SEARCH]["launches"] * 1e-3
                 ach = bsearch / dur / 1e9
-                roof_search = dict(kernel="k_search", bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                # the formulation's own matrix-core floor: 24 v_mfma_i32_16x16x64_i8 (16 cycles each) per 16 x 16 candidate
+                # tile, over the chip's 1024 matrix pipes at the 2.4 GHz spec clock
+                mfma_floor_us = work["search_tiles"] * 24.0 * 16.0 / (256 * 4) / 2.4e9 * 1e6
+                roof_search = dict(kernel=SEARCH, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                                    frac=ach / HBM_PEAK_GBS, traffic=None, algorithmic_bytes_per_launch=bsearch,
-                                   avg_launch_ms=dur * 1e3, candidates_per_launch=work["candidates"])
+                                   avg_launch_ms=dur * 1e3, candidates_per_launch=work["candidates"],
+                                   tiles_per_launch=work["search_tiles"], mfma_floor_us=mfma_floor_us,
+                                   valu_insts_per_search=None)
             if dom in flops:
                 dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
                 ach = flops[dom] / dur / 1e12
@@ -308,36 +360,32 @@ def main():
                 ach = hbm_bytes[dom] / dur / 1e9
                 roof = dict(kernel=dom, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                             traffic=None, algorithmic_bytes_per_launch=hbm_bytes[dom], avg_launch_ms=dur * 1e3)
-            elif dom == "k_search":
+            elif dom == SEARCH:
                 roof = roof_search
-            elif dom.startswith("k_chol"):
-                dur_all = sum(ktimes[n]["total_ms"] for n in ("k_chol_diag", "k_chol_panel", "k_chol_trail") if n in ktimes) / K * 1e-3
-                ach = chol / dur_all / 1e12
-                roof = dict(kernel="k_chol_*", bound="mfma", achieved=ach, peak=FP64_MFMA_PEAK_TF, unit="TFLOP/s",
-                            frac=ach / FP64_MFMA_PEAK_TF, traffic=None, algorithmic_flops_per_launch=chol,
-                            avg_launch_ms=dur_all * 1e3, launches=n_chol_launch / K)
             else:
                 dur = ktimes[dom]["total_ms"] / ktimes[dom]["launches"] * 1e-3
                 roof = dict(kernel=dom, bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None,
                             traffic=None, avg_launch_ms=dur * 1e3)
 
-        # HBM traffic from the committed PMC pass of this same command (profiles/pmc_traffic.json; rocprofv3
-        # cannot be nested inside this process), corrected as MI355X_MICROARCH.md prescribes
+        # HBM traffic (and the search kernel's instruction count) from the committed PMC passes of this same command
+        # (profiles/pmc_traffic.json; rocprofv3 cannot be nested inside this process), corrected as MI355X_MICROARCH.md
+        # prescribes; only when the file was measured on this shape
         try:
             pmc_file = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             pmc = pmc_file["kernels"]
-            pmc_meta = pmc_file.get("meta", {"shape": [1024, 320, 240, 100], "git": "b0a562c (round 1, v12)"})
-            for rf in (roof, roof_search):
-                if rf and rf.get("kernel"):
-                    # the profiling scope name is a prefix of the kernel symbol (k_fwdsub -> k_fwdsub_lds, ...)
-                    cands = [kn for kn in pmc if kn.startswith(rf["kernel"])]
-                    key = max(cands, key=lambda kn: pmc[kn].get("hbm_bytes", 0)) if cands else None
-                    if key and pmc_meta.get("shape") == [B, W, H, N]:
-                        rf["traffic"] = pmc[key]["hbm_bytes"]
+            pmc_meta = pmc_file.get("meta", {})
+            if pmc_meta.get("shape") == [B, W, H, N]:
+                for rf in (roof, roof_search):
+                    key = rf.get("kernel", "").split("@")[0] if rf else None
+                    if key and key in pmc:
+                        rf["traffic"] = pmc[key].get("hbm_bytes")
                         rf["traffic_measured_in_run"] = False
                         rf["traffic_source"] = ("profiles/pmc_traffic.json: separate rocprofv3 --pmc passes of this command "
                                                 "(FETCH_SIZE / WRITE_SIZE corrected as MI355X_MICROARCH.md prescribes, bytes per "
                                                 "launch), library git %s" % pmc_meta.get("git", "unknown"))
+                if roof_search and SEARCH in pmc and pmc[SEARCH].get("valu_insts") and work["searched"] > 0:
+                    roof_search["valu_insts_per_search"] = pmc[SEARCH]["valu_insts"] / pmc[SEARCH].get("searched", work["searched"])
+                    roof_search["valu_insts_source"] = "profiles/pmc_traffic.json: SQ_INSTS_VALU per launch (wave instructions, MFMAs included) / searches per launch"
         except Exception:
             pass
 
@@ -425,7 +473,7 @@ def main():
             # roofline = the dominant kernel of the step; roofline_search = the NCC search kernel the north star names
             # (HBM roofline + its VALU-issue roofline); the same object is repeated under roofline["search"]
             "roofline": (dict(roof, search=roof_search) if roof is not None and roof_search is not None and roof is not roof_search else roof),
-            "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity,
+            "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity if parity is not None else rank_parity,
             "kernels": per_kernel,
             "work_per_step": {k: v for k, v in work.items()},
             "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,

@@ -169,20 +169,25 @@ int sl2_save_patch(sl2_engine* e, int seq, int label, const char* path);
 
 /* Split the batch into `groups` contiguous sequence groups, each stepped on its own HIP stream
  * (latency-bound kernels of one group overlap throughput-bound kernels of another).  Default 1
- * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024); env SL2_GROUPS overrides. */
+ * (measured on MI355X: no gain from 2, a loss from 4+ at batch 1024).  The library never reads the environment: the
+ * SL2_* development switches exist in the TEST build (libscenelib2_amd_test.so) only. */
 int sl2_set_groups(sl2_engine* e, int groups);
 /* Whole-step HIP graphs: when enabled, sl2_go_one_step with device-resident frames captures its launches once per
  * (frame buffer, flags) and replays the graph (at batch 1 the step is launch-bound: ~12 kernels).  Off by default;
  * ignored while per-kernel profiling is on or with more than one sequence group. */
 int sl2_set_graph_mode(sl2_engine* e, int enabled);
-/* Which search kernel sl2_make_measurements / sl2_go_one_step use: 2 = packed column walk (default),
- * 1 = column walk with one feature per wavefront, 0 = baseline.  Identical results. */
+/* Which search kernel sl2_make_measurements / sl2_go_one_step use: 1 = int8 matrix-core walk (k_search_mfma, default),
+ * 0 = the exact kernel with one candidate per lane (k_search_exact, the cross-check).  Identical results, bit for bit. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
- * chol_variant 1 = one-launch left-looking Cholesky (default, <= 12 blocks of 32), 2 = one-launch right-looking,
+ * chol_variant 1 = one-launch left-looking Cholesky (k_chol_left; default), 2 = one-launch right-looking (k_chol_fused4),
  *              0 = three launches per block column;
- * fwd_variant  1 = forward substitution with L streamed through LDS and the solved rows in registers (default,
- *              <= 8 blocks), 0 = operands re-read from memory.  Larger systems always take variant 0. */
+ * fwd_variant  1 = forward substitution with L streamed through LDS and the solved rows in registers (k_fwdsub_lds;
+ *              default), 0 = operands re-read from memory (k_fwdsub).
+ * Only the defaults (1, 1) are compiled into this library; the superseded variants live in the TEST build
+ * (libscenelib2_amd_test.so, include/scenelib2_amd_testing.h), where this call selects them - here anything else
+ * returns SL2_ERR_INVALID.  Systems of more than 16 blocks are factored panel-wise (k_chol_left + k_fwdsub_lds +
+ * k_chol_syrk per 128 columns) and substituted in groups of eight block rows (k_fwd_gemm + k_fwdsub_lds) either way. */
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);
@@ -195,8 +200,9 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory);
  * width x height).  patches [count][121]; centre [count][2]; puinv [count][3] =
  * (PuInv(0,0), PuInv(0,1), PuInv(1,1)).  Outputs: ok[count] (the bool return),
  * uv[count][2] (left untouched where no candidate qualified, Q4), score[count]
- * (corrmax).  All pointers are HOST pointers; variant 1 = production kernel (LDS column walk),
- * variant 0 = the simple baseline kernel kept for cross-checking (identical results). */
+ * (corrmax).  All pointers are HOST pointers; variant 1 = production search core (int8 matrix-core walk, the one
+ * k_search_mfma runs), variant 0 = the exact kernel kept for cross-checking (identical results); anything else is
+ * SL2_ERR_INVALID. */
 int sl2_elliptical_search_batch(int device, const uint8_t* images, int nimages, int width, int height,
                                 const int32_t* image_index, const uint8_t* patches, const double* centre,
                                 const double* puinv, int count, int32_t* ok, int32_t* uv, double* score,
@@ -314,7 +320,7 @@ int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
  * events on the engine's stream (8 events per step); enabled = 2: every kernel launch is; sl2_get_kernel_times returns accumulated milliseconds and
  * launch counts per kernel name since the last reset. */
 int sl2_set_profiling(sl2_engine* e, int enabled);
-/* Level 1 brackets only the kernels named here (comma separated scope names, e.g. "k_syrk,k_search"; NULL or "" = the
+/* Level 1 brackets only the kernels named here (comma separated scope names, e.g. "k_syrk,k_search_mfma"; NULL or "" = the
  * four large ones): every bracket is two event markers on the stream, and four of them cost 1-3 % of a step. */
 int sl2_set_profile_focus(sl2_engine* e, const char* names);
 int sl2_reset_kernel_times(sl2_engine* e);
@@ -325,8 +331,10 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
  * out[1] = number of searched features, out[2] = in-ellipse candidates,
  * out[3] = sum over sequences of m (measurement rows), out[4] = sum of m^2,
  * out[5] = sum of m^3, out[6] = sum of n (state size) , out[7] = sum n*m, out[8] = sum n*n*m, out[9] = sum n*m*m,
- * out[10] = searches that took the exact fallback kernel path */
-int sl2_get_step_work(sl2_engine* e, double out[11]);
+ * out[10] = searches that took the exact fallback kernel path,
+ * out[11] = 16 x 16 candidate tiles of the search windows, sum_f ceil(nu / 16) ceil(nv / 16): the matrix-core work of
+ * k_search_mfma (24 v_mfma_i32_16x16x64_i8 per tile) */
+int sl2_get_step_work(sl2_engine* e, double out[12]);
 
 /* ------------------------------------------------------------- synthetic input */
 

@@ -99,34 +99,8 @@ def u8p(a):
     return a.ctypes.data_as(c_u8p)
 
 
-def load_testing():
-    """The TEST build of the library (same sources + -DSL2_TESTING): only the hooks of include/scenelib2_amd_testing.h are
-    bound here.  A hook that takes an engine accepts engines created through load() (same structures, one HIP runtime)."""
-    global _testlib
-    if _testlib is not None:
-        return _testlib
-    load()      # the product library first: it pins the HIP runtime both share
-    if not os.path.exists(TEST_LIB_PATH):
-        raise ImportError("scenelib2_amd: %s not built (make -C scenelib2_amd/csrc)" % TEST_LIB_PATH)
-    T = C.CDLL(TEST_LIB_PATH)
-    T.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
-    T.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
-    T.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
-    T.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]
-    T.sl2_last_error.restype = C.c_char_p
-    _testlib = T
-    return T
-
-
-def load():
-    """Load the native library (fails loudly if it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError("scenelib2_amd: native library %s not built (run __graft_entry__.build() or "
-                          "`make -C scenelib2_amd/csrc`); there is no CPU fallback" % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+def _bind(L):
+    """argtypes / restypes of every entry point of include/scenelib2_amd.h."""
     L.sl2_last_error.restype = C.c_char_p
     L.sl2_device_count.restype = C.c_int
     L.sl2_create.argtypes = [C.POINTER(sl2_camera), C.POINTER(sl2_params), C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
@@ -189,13 +163,46 @@ def load():
     L.sl2_dev_free.argtypes = [C.c_int, vp]
     L.sl2_dev_upload.argtypes = [C.c_int, vp, vp, C.c_size_t]
     L.sl2_dev_download.argtypes = [C.c_int, vp, vp, C.c_size_t]
-    _lib = L
     return L
 
 
-def check(rc):
+def load_testing():
+    """The TEST build of the library (same sources + -DSL2_TESTING): every entry point of the product library plus the
+    hooks of include/scenelib2_amd_testing.h and the superseded / experimental kernel variants (sl2_set_update_variant,
+    sl2_set_search_variant beyond the defaults, the SL2_* environment switches).  An Engine may be created on it
+    (Engine(..., lib=load_testing())); a hook that takes an engine also accepts engines created through load() (same
+    structures, one HIP runtime)."""
+    global _testlib
+    if _testlib is not None:
+        return _testlib
+    load()      # the product library first: it pins the HIP runtime both share
+    if not os.path.exists(TEST_LIB_PATH):
+        raise ImportError("scenelib2_amd: %s not built (make -C scenelib2_amd/csrc)" % TEST_LIB_PATH)
+    T = _bind(C.CDLL(TEST_LIB_PATH))
+    T.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    T.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
+    T.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
+    T.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]
+    _testlib = T
+    return T
+
+
+def load():
+    """Load the native library (fails loudly if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("scenelib2_amd: native library %s not built (run __graft_entry__.build() or "
+                          "`make -C scenelib2_amd/csrc`); there is no CPU fallback" % LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc, L=None):
+    """Raise on a non-zero status; L = the library whose call returned rc (its sl2_last_error holds the message)."""
     if rc != SL2_OK:
-        raise Sl2Error(rc, load().sl2_last_error().decode("utf-8", "replace"))
+        raise Sl2Error(rc, (L or load()).sl2_last_error().decode("utf-8", "replace"))
 
 
 def device_count():

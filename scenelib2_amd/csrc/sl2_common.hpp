@@ -47,13 +47,13 @@ constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2
 constexpr int kPartInts = 16, kPartDoubles = 4;   // per-sequence record of the partial feature (part_i / part_d)
 enum : int { kPartActive = 0, kPartLabel, kPartAttempts, kPartNp, kPartMaking, kPartUU, kPartVV, kPartRegionValid,
              kPartRegion /* 4 ints */, kPartInitialised = 12, kPartConverted, kPartDeleted, kPartCreated };
+constexpr int kWorkDoubles = 5;     // per-sequence work counters of a step (work[]): window bytes, searches, candidates, exact
+                                    // fallbacks, 16 x 16 candidate tiles of the matrix-core search
 constexpr int kCholBlock = 32;       // block size of the blocked Cholesky / forward substitution
 constexpr int kPatchStride = 288;    // bytes per stored template: 121 raw bytes (+7 pad), then at byte
                                      // 128 the packed form: 33 dwords (11 rows x 12 bytes, byte 11 = 0),
                                      // sum g0, sum g0^2, flag (patch sigma >= 10), pad
 constexpr int kPatchPackedOffset = 128;
-constexpr int kPackMaxNu = 51, kPackMaxNv = 54;   // largest search window the LDS column-walk kernels take
-constexpr int kPackMaxRows = 160;                 // LDS window rows per packed wavefront
 
 // XCD-aware block -> (sequence, tile) mapping.  MI355X dispatches workgroup L to XCD L % 8 and
 // every XCD has its own 4 MB L2; all tiles of one sequence share that sequence's operands
@@ -137,10 +137,10 @@ struct sl2_engine {
   struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
   bool graph_mode = false;
   std::vector<StepGraph> step_graphs;
-  int build_split = 0;        // development switches, read from the environment once at sl2_create (SL2_BUILD_SPLIT,
-  int score_threads = 0;      // SL2_SCORE_THREADS, SL2_NO_KSPLIT): 0 = the engine's own choice
+  int build_split = 0;        // development switches (TEST build only: SL2_BUILD_SPLIT, SL2_SCORE_THREADS, SL2_NO_KSPLIT read
+  int score_threads = 0;      // once at sl2_create): 0 = the engine's own choice
   int no_ksplit = 0;
-  int search_variant = 3;     // 0 = baseline kernel, 1 = LDS column walk (one feature per wave), 2 = packed column walk, 3 = int8 matrix-core walk (default)
+  int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]
@@ -158,14 +158,11 @@ struct sl2_engine {
   double* meas_score = nullptr;  // [B][N]
   int* succ_idx = nullptr;    // [B][N]   successful feature slots in selection order
   int* m_count = nullptr;     // [B]      number of successful features (m = 2 * m_count)
-  double* work = nullptr;     // [B][4]   window bytes, searched, candidates, exact-fallback searches
+  double* work = nullptr;     // [B][kWorkDoubles]   window bytes, searched, candidates, exact-fallback searches, candidate tiles
   int* srch_i = nullptr;      // [B][N][8]  per-feature search window: ucentre, vcentre, urelstart, nu, vrelstart, nv, hw, hh
   double* srch_d = nullptr;   // [B][N][4]  PuInv (a, b, c), pad
   int* srch_res = nullptr;    // [B][N][8]  per selected position: code, u, v, S1, S2, X, ncand, pad
   int* srch_sel = nullptr;    // [B][N][16] per selected position k (written by k_select): slot f, the 7 window ints of srch_i, then PuInv (a, b, c) as 3 doubles, pad - one 64-byte line, so that the search kernel needs ONE round trip for it
-  int* pack_first = nullptr;  // [B][N]  work list of the packed search: first selected position of pack p
-  int* pack_count = nullptr;  // [B][N]  ... and number of features in it
-  int* n_packs = nullptr;     // [B]
 
   // ---- EKF update workspaces (device) ----
   double* At = nullptr;    // [B][mld][ld]   (P H^T)^T, k-major; column ld-1 carries nu

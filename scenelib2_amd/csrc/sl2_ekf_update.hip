@@ -282,6 +282,7 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
+#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
 __global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ St, double* __restrict__ LinvT,
                                                   const int* __restrict__ m_count, int mld, int nblk_max, int J) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -330,9 +331,11 @@ __global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ St, doubl
     }
   }
 }
+#endif  // SL2_TESTING
 
 // k_chol_panel: L[I][J] = S[I][J] * L_JJ^-T for every block row I > J; one wave
 // per 32x32 tile.  In k-major storage: new[k][i] = sum_p Linv[k][p] * St[J+p][I+i].
+#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
 __global__ void __launch_bounds__(64) k_chol_panel(double* __restrict__ St, const double* __restrict__ LinvT,
                                                    const int* __restrict__ m_count, int mld, int nblk_max, int J) {
   const int b = blockIdx.y, lane = threadIdx.x;
@@ -365,8 +368,10 @@ __global__ void __launch_bounds__(64) k_chol_panel(double* __restrict__ St, cons
       for (int r = 0; r < 4; ++r)
         Sb[(size_t)(J * 32 + 16 * kt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[kt][it][r];
 }
+#endif  // SL2_TESTING
 
 // k_chol_trail: S[I][K] -= L[I][J] L[K][J]^T for J < K <= I; one wave per tile.
+#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
 __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, const int* __restrict__ m_count, int mld, int J) {
   const int b = blockIdx.y, lane = threadIdx.x;
   const int cnt = m_count[b];
@@ -405,6 +410,7 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
       for (int r = 0; r < 4; ++r)
         Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r];
 }
+#endif  // SL2_TESTING
 
 constexpr int kFusedMaxBlocks = 16;   // the one-launch Cholesky is used up to this many 32-blocks
 
@@ -499,6 +505,7 @@ __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int
   tile_store(Sb, mld, K * 32, I * 32, lo, hi, acc);
 }
 
+#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
 __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St, double* __restrict__ LinvT,
                                                         const int* __restrict__ m_count, int mld, int nblk_max, long long* trace) {
   const int b = blockIdx.x;
@@ -619,6 +626,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
     }
   }
 }
+#endif  // SL2_TESTING
 
 #undef TR
 
@@ -819,6 +827,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 // an explicit two-stage register pipeline, 1.04 ms at 256 VGPRs — each loses the
 // occupancy that hides the chain's latency.  This version: see profiles/.)
 // ---------------------------------------------------------------------------
+#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
 template <bool HALF>
 __device__ __forceinline__ void fwd_kloop(v4d acc[2][2], const double* __restrict__ lrow, const double* vrow, int mld, int ld,
                                           int kend) {
@@ -893,6 +902,7 @@ __global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, d
     }
   }
 }
+#endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
 // k_fwdsub_lds<NB>: forward substitution with BOTH operands on chip.  A workgroup of four
@@ -1129,25 +1139,32 @@ __global__ void __launch_bounds__(256) k_fwdsub_ksplit(const double* __restrict_
   }
 }
 
-static bool launch_fwdsub_lds(sl2_engine* e, int B) {
+static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done) {
+  *done = true;
   // small batches: the chain-shortening kernel (one 16-column strip per workgroup, products dealt to its four waves)
   if (e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !e->root->no_ksplit) {
+    LaunchScope ls(e, "k_fwdsub_ksplit", true);
     hipLaunchKernelGGL(k_fwdsub_ksplit, dim3(xcd_grid(e->ld / 16, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                        e->m_count, e->ld, e->mld, e->nblk_max, B);
-    return true;
+    SL2_HIP(hipGetLastError());
+    return SL2_OK;
   }
+  if (e->nblk_max > 13) { *done = false; return SL2_OK; }     // beyond the register-resident strip: the grouped form
   const dim3 grid(xcd_grid(e->ld / 64, B)), block(256);
+  LaunchScope ls(e, "k_fwdsub_lds", true);
 #define SL2_FWD_CASE(NBV)                                                                                           \
   case NBV:                                                                                                         \
     hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
                        e->ld, e->mld, e->nblk_max, B, 0, 0, e->ld / 64, NBV);                                       \
-    return true;
+    break;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
     SL2_FWD_CASE(8) SL2_FWD_CASE(9) SL2_FWD_CASE(10) SL2_FWD_CASE(11) SL2_FWD_CASE(12) SL2_FWD_CASE(13)
-    default: return false;
+    default: break;
   }
 #undef SL2_FWD_CASE
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
 }
 
 constexpr int kSyrkKC = 16;       // K rows per chunk (k_syrk, k_fwd_gemm)
@@ -1290,30 +1307,49 @@ __global__ void __launch_bounds__(256) k_chol_syrk(double* __restrict__ St, cons
 
 constexpr int kCholPanelBlocks = 4;
 
-static void launch_chol_panels(sl2_engine* e, int B) {
+static int launch_chol_panels(sl2_engine* e, int B) {
   for (int p0 = 0; p0 < e->nblk_max; p0 += kCholPanelBlocks) {
     const int nb = e->nblk_max - p0 < kCholPanelBlocks ? e->nblk_max - p0 : kCholPanelBlocks;
-    hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb,
-                       (long long*)nullptr);
+    {
+      LaunchScope ls(e, "k_chol_left", true);
+      hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb,
+                         (long long*)nullptr);
+      SL2_HIP(hipGetLastError());
+    }
     const int c0 = (p0 + nb) * 32;
     if (c0 >= e->mld) break;
     const int ntile = (e->mld - c0) / 64;      // mld is a multiple of 64 for these sizes (sl2_create)
-    hipLaunchKernelGGL((k_fwdsub_lds<kCholPanelBlocks>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
-                       e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
-    hipLaunchKernelGGL(k_chol_syrk, dim3(xcd_grid(ntile * (ntile + 1) / 2, B)), dim3(256), 0, e->stream, e->St, e->m_count, e->mld,
-                       B, p0 * 32, nb * 32, c0);
+    {
+      LaunchScope ls(e, "k_fwdsub_lds@chol", true);
+      hipLaunchKernelGGL((k_fwdsub_lds<kCholPanelBlocks>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
+                         e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
+      SL2_HIP(hipGetLastError());
+    }
+    {
+      LaunchScope ls(e, "k_chol_syrk", true);
+      hipLaunchKernelGGL(k_chol_syrk, dim3(xcd_grid(ntile * (ntile + 1) / 2, B)), dim3(256), 0, e->stream, e->St, e->m_count, e->mld,
+                         B, p0 * 32, nb * 32, c0);
+      SL2_HIP(hipGetLastError());
+    }
   }
+  return SL2_OK;
 }
 
 // substitution in groups of eight block rows, for systems of more than 13 blocks
-static void launch_fwdsub_grouped(sl2_engine* e, int B) {
+static int launch_fwdsub_grouped(sl2_engine* e, int B) {
   for (int J0 = 0; J0 < e->nblk_max; J0 += 8) {
-    if (J0 > 0)
+    if (J0 > 0) {
+      LaunchScope ls(e, "k_fwd_gemm", true);
       hipLaunchKernelGGL(k_fwd_gemm, dim3(xcd_grid(4 * (e->ld / 64), B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->m_count,
                          e->ld, e->mld, B, J0);
+      SL2_HIP(hipGetLastError());
+    }
+    LaunchScope ls(e, "k_fwdsub_lds", true);
     hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                        e->m_count, e->ld, e->mld, e->nblk_max, B, J0, 0, e->ld / 64, 8);
+    SL2_HIP(hipGetLastError());
   }
+  return SL2_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -1536,17 +1572,25 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
 }
 #endif  // SL2_TESTING
 
+// Profiling scopes carry the SYMBOL of the kernel they bracket (so that the bench's per-kernel times and rocprofv3's
+// kernel_stats.csv join on the name); "@phase" tells two uses of one kernel apart (k_fwdsub_lds is also the panel solve of
+// the large-map Cholesky).
 static int launch_update_range(sl2_engine* e) {
   const int B = e->B;     // (succ_idx / m_count, the successful measurements in selection order, come from k_search_score)
-  if (e->ld <= 2048 && e->mld <= 1024 && e->root->build_variant == 1) {
-    LaunchScope ls(e, "k_build_A", true);
+#ifdef SL2_TESTING
+  const int build_variant = e->root->build_variant, chol_variant = e->root->chol_variant, fwd_variant = e->root->fwd_variant;
+#else
+  const int build_variant = 1, chol_variant = 1, fwd_variant = 1;
+#endif
+  if (e->ld <= 2048 && e->mld <= 1024 && build_variant == 1) {
+    LaunchScope ls(e, "k_build_AS", true);
     // workgroups per sequence: enough to put ~512 on the chip
     // One workgroup per sequence from batch 1024 on (one exact round of four per CU at 1024; it needs the launch in front
     // of it - k_search_score - to consist of single-wave workgroups, see launch_search: 0.33-0.35 ms on every box tried;
     // three workgroups per sequence are indifferent to what ran before but take 0.346-0.377 depending on the box).  Smaller
     // batches: ~3000 workgroups in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
     int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
-    if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (SL2_BUILD_SPLIT)
+    if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;
@@ -1560,7 +1604,7 @@ static int launch_update_range(sl2_engine* e) {
                          e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
     }
     SL2_HIP(hipGetLastError());
-  } else {
+  } else {      // maps beyond 2048 state columns / 512 measured features: A, then S from A
     {
       LaunchScope ls(e, "k_build_A", true);
       const int threads = e->ld <= 512 ? e->ld : 512;
@@ -1576,55 +1620,75 @@ static int launch_update_range(sl2_engine* e) {
       SL2_HIP(hipGetLastError());
     }
   }
-  if (e->nblk_max > kFusedMaxBlocks && e->root->chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
-    LaunchScope ls(e, "k_chol_fused");
-    launch_chol_panels(e, B);
-    SL2_HIP(hipGetLastError());
-  } else if (e->nblk_max <= kFusedMaxBlocks && e->root->chol_variant >= 1) {
-    LaunchScope ls(e, "k_chol_fused");
-    if (e->root->chol_variant == 1)
-      hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, 0,
-                         e->nblk_max, (long long*)e->root->chol_trace);
-    else
-      hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
-                         (long long*)e->root->chol_trace);
+  // sl2_create sizes the innovation system so that one of the first two branches always applies (mld a multiple of 128
+  // beyond kFusedMaxBlocks blocks)
+  if (e->nblk_max > kFusedMaxBlocks && chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
+    int rc = launch_chol_panels(e, B);
+    if (rc != SL2_OK) return rc;
+  } else if (e->nblk_max <= kFusedMaxBlocks && chol_variant == 1) {
+    LaunchScope ls(e, "k_chol_left", true);
+    hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, 0,
+                       e->nblk_max, (long long*)e->root->chol_trace);
     SL2_HIP(hipGetLastError());
   } else {
-  for (int J = 0; J < e->nblk_max; ++J) {
-      {
-        LaunchScope ls(e, "k_chol_diag");
-        hipLaunchKernelGGL(k_chol_diag, dim3(B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, J);
-        SL2_HIP(hipGetLastError());
-      }
-      const int rem = e->nblk_max - 1 - J;
-      if (rem > 0) {
+#ifdef SL2_TESTING
+    if (e->nblk_max <= kFusedMaxBlocks && chol_variant == 2) {
+      LaunchScope ls(e, "k_chol_fused4", true);
+      hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
+                         (long long*)e->root->chol_trace);
+      SL2_HIP(hipGetLastError());
+    } else {
+      for (int J = 0; J < e->nblk_max; ++J) {
         {
-          LaunchScope ls(e, "k_chol_panel");
-          hipLaunchKernelGGL(k_chol_panel, dim3(rem, B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld,
-                             e->nblk_max, J);
+          LaunchScope ls(e, "k_chol_diag");
+          hipLaunchKernelGGL(k_chol_diag, dim3(B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, J);
           SL2_HIP(hipGetLastError());
         }
-        {
-          LaunchScope ls(e, "k_chol_trail");
-          hipLaunchKernelGGL(k_chol_trail, dim3(rem * (rem + 1) / 2, B), dim3(64), 0, e->stream, e->St, e->m_count, e->mld, J);
-          SL2_HIP(hipGetLastError());
+        const int rem = e->nblk_max - 1 - J;
+        if (rem > 0) {
+          {
+            LaunchScope ls(e, "k_chol_panel");
+            hipLaunchKernelGGL(k_chol_panel, dim3(rem, B), dim3(64), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld,
+                               e->nblk_max, J);
+            SL2_HIP(hipGetLastError());
+          }
+          {
+            LaunchScope ls(e, "k_chol_trail");
+            hipLaunchKernelGGL(k_chol_trail, dim3(rem * (rem + 1) / 2, B), dim3(64), 0, e->stream, e->St, e->m_count, e->mld, J);
+            SL2_HIP(hipGetLastError());
+          }
         }
       }
     }
+#else
+    set_error("launch_update: no factorisation for this system size (sl2_create should have padded it)");
+    return SL2_ERR_INVALID;
+#endif
   }
   {
-    LaunchScope ls(e, "k_fwdsub", true);
     bool done = false;
-    if (e->root->fwd_variant == 1) {
-      done = launch_fwdsub_lds(e, B);
+    if (fwd_variant == 1) {
+      int rc = launch_fwdsub_lds(e, B, &done);
+      if (rc != SL2_OK) return rc;
       // the grouped form works on 64-row tiles: it needs mld to be a multiple of 64 (sl2_create pads systems of more
-      // than 16 blocks to 128)
-      if (!done && e->mld % 64 == 0) { launch_fwdsub_grouped(e, B); done = true; }
+      // than 13 blocks to 64, of more than 16 to 128)
+      if (!done && e->mld % 64 == 0) {
+        rc = launch_fwdsub_grouped(e, B);
+        if (rc != SL2_OK) return rc;
+        done = true;
+      }
     }
-    if (!done)
+    if (!done) {
+#ifdef SL2_TESTING
+      LaunchScope ls(e, "k_fwdsub", true);
       hipLaunchKernelGGL(k_fwdsub, dim3(xcd_grid(e->ld / 64, B)), dim3(128), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                          e->m_count, e->ld, e->mld, e->nblk_max, B);
-    SL2_HIP(hipGetLastError());
+      SL2_HIP(hipGetLastError());
+#else
+      set_error("launch_update: no substitution kernel for this system size (sl2_create should have padded it)");
+      return SL2_ERR_INVALID;
+#endif
+    }
   }
   {
     LaunchScope ls(e, "k_syrk", true);

@@ -158,8 +158,7 @@ static int build_groups(sl2_engine* e, int G) {
     g->sel_idx = e->sel_idx + f * N; g->n_sel = e->n_sel + f; g->n_vis = e->n_vis + f; g->meas_ok = e->meas_ok + f * N;
     g->meas_score = e->meas_score + f * N; g->succ_idx = e->succ_idx + f * N; g->m_count = e->m_count + f;
     g->srch_i = e->srch_i + f * N * 8; g->srch_d = e->srch_d + f * N * 4; g->srch_res = e->srch_res + f * N * 8; g->srch_sel = e->srch_sel + f * N * 16;
-    g->pack_first = e->pack_first + f * N; g->pack_count = e->pack_count + f * N; g->n_packs = e->n_packs + f;
-    g->work = e->work + f * 4; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
+    g->work = e->work + f * kWorkDoubles; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
     g->part_i = e->part_i + f * kPartInts; g->part_d = e->part_d + f * kPartDoubles;
     g->particles = e->particles + f * kMaxParticles * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
@@ -290,6 +289,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (nsel > max_features) nsel = max_features;
   e->nsel_max = nsel;
   e->mld = round_up(2 * nsel, 32);
+  if (e->mld / 32 > 13) e->mld = round_up(2 * nsel, 64);    // beyond the one-launch substitution: 64-row tiles (k_fwd_gemm)
   if (e->mld / 32 > 16) e->mld = round_up(2 * nsel, 128);   // large systems are factored in 128-column panels
   e->nblk_max = e->mld / 32;
   const size_t B = batch, N = max_features, ld = e->ld, mld = e->mld;
@@ -327,14 +327,11 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->meas_score, B * N));
   A(dmalloc(&e->succ_idx, B * N));
   A(dmalloc(&e->m_count, B));
-  A(dmalloc(&e->work, B * 4));
+  A(dmalloc(&e->work, B * kWorkDoubles));
   A(dmalloc(&e->srch_i, B * N * 8));
   A(dmalloc(&e->srch_d, B * N * 4));
   A(dmalloc(&e->srch_res, B * N * 8));
   A(dmalloc(&e->srch_sel, B * N * 16));
-  A(dmalloc(&e->pack_first, B * N));
-  A(dmalloc(&e->pack_count, B * N));
-  A(dmalloc(&e->n_packs, B));
   A(dmalloc(&e->At, B * mld * ld));
   A(dmalloc(&e->Vt, B * mld * ld));
   A(dmalloc(&e->St, B * mld * mld));
@@ -352,6 +349,11 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   }
   SL2_HIP(hipDeviceSynchronize());
   e->root = e;
+  int G = 1;
+#ifdef SL2_TESTING
+  // Development switches of the TEST build of the library (libscenelib2_amd_test.so, scripts/variants.sh): the product
+  // library never reads the environment - there the kernel variants are chosen through sl2_set_search_variant /
+  // sl2_set_update_variant / sl2_set_groups only.
   if (const char* v = getenv("SL2_FWD_VARIANT")) e->fwd_variant = atoi(v);
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
   if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
@@ -359,10 +361,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (const char* v = getenv("SL2_BUILD_SPLIT")) e->build_split = atoi(v);
   if (const char* v = getenv("SL2_SCORE_THREADS")) e->score_threads = atoi(v);
   if (getenv("SL2_NO_KSPLIT")) e->no_ksplit = 1;
+  if (const char* env = getenv("SL2_GROUPS")) if (atoi(env) > 0) G = atoi(env);
+#endif
   {
-    int G = 1;
-    const char* env = getenv("SL2_GROUPS");
-    if (env && atoi(env) > 0) G = atoi(env);
     int rc2 = build_groups(e, G);
     if (rc2 != SL2_OK) return rc2;
   }
@@ -395,7 +396,7 @@ void sl2_destroy(sl2_engine* e) {
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
-                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel, e->pack_first, e->pack_count, e->n_packs,
+                  e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
                   e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
@@ -516,7 +517,7 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
 }
 
 int sl2_set_search_variant(sl2_engine* e, int variant) {
-  if (!e || variant < 0 || variant > 4) return SL2_ERR_INVALID;
+  if (!e || variant < 0 || variant > 1) return SL2_ERR_INVALID;
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   e->step_graphs.clear();
   e->search_variant = variant;
@@ -540,6 +541,13 @@ int sl2_debug_chol_trace(sl2_engine* e, long long* out, size_t n) {
 
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
   if (!e || chol_variant < 0 || chol_variant > 2 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
+#ifndef SL2_TESTING
+  if (chol_variant != 1 || fwd_variant != 1) {
+    set_error("sl2_set_update_variant: the superseded kernel variants are compiled into the TEST build of the library only "
+              "(libscenelib2_amd_test.so); this library runs chol_variant = 1, fwd_variant = 1");
+    return SL2_ERR_INVALID;
+  }
+#endif
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   e->step_graphs.clear();
   e->chol_variant = chol_variant;
@@ -1092,24 +1100,25 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
   return SL2_OK;
 }
 
-int sl2_get_step_work(sl2_engine* e, double out[11]) {
+int sl2_get_step_work(sl2_engine* e, double out[12]) {
   if (!e || !out) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  std::vector<double> w((size_t)e->B * 4);
+  std::vector<double> w((size_t)e->B * kWorkDoubles);
   std::vector<int> mc(e->B), flags((size_t)e->B * e->N), slots(e->B);
   SL2_HIP(hipMemcpy(w.data(), e->work, sizeof(double) * w.size(), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(mc.data(), e->m_count, sizeof(int) * e->B, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(flags.data(), e->f_flags, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots, sizeof(int) * e->B, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 11; ++k) out[k] = 0.0;
+  for (int k = 0; k < 12; ++k) out[k] = 0.0;
   const double frame_bytes = (double)e->cam.width * e->cam.height;
   for (int b = 0; b < e->B; ++b) {
-    const double win = w[(size_t)b * 4 + 0];
+    const double win = w[(size_t)b * kWorkDoubles + 0];
     out[0] += win < frame_bytes ? win : frame_bytes;
-    out[1] += w[(size_t)b * 4 + 1];
-    out[2] += w[(size_t)b * 4 + 2];
-    out[10] += w[(size_t)b * 4 + 3];
+    out[1] += w[(size_t)b * kWorkDoubles + 1];
+    out[2] += w[(size_t)b * kWorkDoubles + 2];
+    out[10] += w[(size_t)b * kWorkDoubles + 3];
+    out[11] += w[(size_t)b * kWorkDoubles + 4];
     double n = 13;
     for (int f = 0; f < slots[b]; ++f) if (flags[(size_t)b * e->N + f] & FF_ACTIVE) n += 3;
     const double m = 2.0 * mc[b];

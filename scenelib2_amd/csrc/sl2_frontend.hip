@@ -158,14 +158,12 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
                                                 const int* __restrict__ n_slots, const double* __restrict__ xp_org,
                                                 int* __restrict__ sel_idx, int* __restrict__ n_sel, int* __restrict__ n_vis,
                                                 double* __restrict__ last_r, const int* __restrict__ srch_i,
-                                                const double* __restrict__ srch_d, int* __restrict__ srch_sel,
-                                                int* __restrict__ pack_first, int* __restrict__ pack_count,
-                                                int* __restrict__ n_packs, int N, int n_want, int make_packs) {
+                                                const double* __restrict__ srch_d, int* __restrict__ srch_sel, int N,
+                                                int n_want) {
   extern __shared__ double s_dyn[];
   double* s_score = s_dyn;                 // [N]
   int* s_vis = (int*)(s_dyn + N);          // [N]
-  int* s_nu = s_vis + N;                   // [N] search-window width of the k-th selected feature
-  int* s_nv = s_nu + N;                    // [N] ... and height
+  int* s_nu = s_vis + N;                   // [N] rank accumulator
   __shared__ int s_nvis, s_zero_rank, s_last;
   const int b = blockIdx.x, tid = threadIdx.x;
   FTR(1, 0);
@@ -195,7 +193,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
   for (int i = tid; i < ns; i += blockDim.x) {
     if (!s_vis[i]) s_score[i] = -1.0;
     else if (s_score[i] != s_score[i]) s_score[i] = -0.5;
-    s_nu[i] = 0;                            // rank accumulator (s_nu takes the window widths further down)
+    s_nu[i] = 0;                            // rank accumulator
   }
   __syncthreads();
   // rank = number of features that come before i.  With fewer features than threads the j range is split over
@@ -248,8 +246,6 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
       sel_idx[(size_t)b * N + rank] = i;
       f_flags[(size_t)b * N + i] |= FF_SELECTED;
       const int* si = srch_i + ((size_t)b * N + i) * 8;
-      s_nu[rank] = si[3];
-      s_nv[rank] = si[5];
       // the selected position's search record in ONE 64-byte line: slot, window, PuInv (what the search kernel reads)
       int* rec = srch_sel + ((size_t)b * N + rank) * 16;
       rec[0] = i;
@@ -260,45 +256,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
       recd[0] = sd[0]; recd[1] = sd[1]; recd[2] = sd[2];
     }
   }
-  __syncthreads();
   FTR(1, 3);
-  // Work list of the packed search kernel: consecutive selected features share one wavefront as
-  // long as their candidate columns fit 64 lanes (<= 8 features, <= 160 window rows of LDS).
-  // A window too large for the LDS tile gets a wavefront of its own (exact baseline path).
-  // The greedy segmentation is a chain, but the length of the pack that STARTS at k depends on k alone: every
-  // thread computes it for its k (<= 8 look-ahead reads), then one thread follows the chain (~25 hops).  (Walked
-  // feature by feature by one thread - in LDS or on the scalar unit - this phase was half of the kernel.)
-  // (only the packed column-walk variant of the search reads the pack lists)
-  for (int k = tid; make_packs && k < limit; k += blockDim.x) {
-    int cnt = 0;
-    if (s_nu[k] > kPackMaxNu || s_nv[k] > kPackMaxNv) {
-      cnt = 1;
-    } else {
-      int lanes = 0, rows = 0;
-      while (k + cnt < limit && cnt < 8) {
-        const int nu_c = s_nu[k + cnt], nv_c = s_nv[k + cnt];
-        const int w = nu_c > 0 ? nu_c : 1, hh = (nv_c > 0 ? nv_c : 0) + 10;
-        if (nu_c > kPackMaxNu || nv_c > kPackMaxNv) break;
-        if (lanes + w > 64 || rows + hh > kPackMaxRows) break;
-        lanes += w; rows += hh; ++cnt;
-      }
-      if (cnt == 0) cnt = 1;
-    }
-    s_vis[k] = cnt;          // s_vis (the ranks) is free again
-  }
-  __syncthreads();
-  if (tid == 0 && make_packs) {
-    int np = 0, k = 0;
-    while (k < limit) {
-      const int cnt = s_vis[k];
-      pack_first[(size_t)b * N + np] = k;
-      pack_count[(size_t)b * N + np] = cnt;
-      ++np;
-      k += cnt;
-    }
-    n_packs[b] = np;
-  }
-  FTR(1, 4);
   if (tid == 0) {
     n_sel[b] = limit;
     n_vis[b] = s_nvis;
@@ -532,8 +490,7 @@ int launch_select(sl2_engine* e, int n) {
   if (n > e->nsel_max) n = e->nsel_max;
   const size_t shm = (size_t)e->N * (sizeof(double) + 3 * sizeof(int));
   hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
-                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->pack_first, e->pack_count, e->n_packs, e->N, n,
-                     e->root->search_variant == 2 ? 1 : 0);
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->N, n);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

@@ -1,17 +1,18 @@
-// Elliptical normalised-SSD patch search — MonoSLAM::elliptical_search
+// Elliptical normalised-SSD patch search - MonoSLAM::elliptical_search
 // (monoslam.cpp:401-477) + correlate2_warning (improc/improc.cpp:55-134).
 //
-// One 64-lane wavefront per (sequence, selected feature).  Integer sums are exact
-// int32; the deciding score is the reference's FP64 expression (ncc_score in
-// sl2_math.hpp, -ffp-contract=off) so the arg-min, the "<=" last-candidate-wins
-// tie rule (Q2), the sigma >= 10 tests (Q3) and the 0.40 threshold are decided on
-// bit-identical numbers.
+// One 64-lane wavefront per search.  Integer sums are exact int32; the deciding score is the reference's FP64
+// expression (ncc_score in sl2_math.hpp, -ffp-contract=off) so the arg-min, the "<=" last-candidate-wins tie rule (Q2),
+// the sigma >= 10 tests (Q3) and the 0.40 threshold are decided on bit-identical numbers.
 //
-// Variant 0 ("baseline"): lane = candidate, 121-pixel loop straight from
-// global/L2, full FP64 epilogue per candidate.  Kept as the simple, obviously
-// faithful kernel; it is also the exact fallback of variant 1.
-//
-// Variant 1 ("column walk", production): see search_core_v1 below.
+// Two search cores:
+//   search_core_v0    ("exact"): lane = candidate, 121-pixel loop straight from global / L2, full FP64 epilogue per
+//                     candidate.  The simple, obviously faithful kernel; also the fallback of the matrix-core walk.
+//   search_core_mfma  ("matrix-core walk", production): the three 11x11 window sums of 256 candidates at a time come out
+//                     of the int8 matrix cores; candidates are ranked in FP32 from the exact integers and the unique
+//                     near-best one is scored in FP64; whatever that cannot decide exactly goes to search_core_v0.
+// (The column-walk kernels of rounds 1-2 - one feature per wavefront, and several features packed into one - and the
+// first matrix-core kernel were removed in round 3; profiles/r03_search_v3_v4_* holds the last side-by-side run.)
 #include "sl2_common.hpp"
 
 namespace sl2 {
@@ -94,274 +95,30 @@ __device__ __forceinline__ SearchResult search_core_v0(const uint8_t* __restrict
   return r;
 }
 
-// ---------------------------------------------------------------------------
-// Variant 1 ("column walk"): the search window is staged once in LDS with coalesced
-// row loads; the 11x11 template lives in 33 SGPRs; a lane owns one candidate column u
-// (several lanes share a column, each a segment of v) and walks down the rows keeping
-// the last 11 image rows of its 11-byte strip in registers, so each new candidate
-// costs ONE new row fetch, sliding row sums for sum(g1), sum(g1^2) and 33
-// v_dot4_u32_u8 for the cross term.  All sums are exact int32.
-//
-// Candidates are ranked on rho_f = cov/sqrt(var0 var1) in FP32 from the exact
-// integers (error < 1e-6).  Only a candidate within 4e-6 of the best can be the
-// reference's winner; if there is exactly one such candidate its integer sums are
-// handed to the scoring pass (k_search_score, or scored in place when DEFER is
-// off), which evaluates the reference's FP64 score and thresholds.  Anything the
-// fast path cannot decide exactly (several near-best candidates, the sigma == 10
-// boundary, windows larger than the LDS tile) returns code -1 and the caller runs
-// search_core_v0 — same results, just slower.
-// ---------------------------------------------------------------------------
-constexpr int kWinPitchDw = 20;   // LDS row pitch in dwords (80 B)
-constexpr int kWinRows = 64;
-constexpr int kMaxNu = 51, kMaxNv = 54;
-
 __device__ __forceinline__ unsigned udot4(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_udot4(a, b, c, false); }
 // full-rate 24-bit multiply: the patch sums are < 2^24 (S1 <= 121*255, S2, X <= 121*255^2), products < 2^31
 __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 
-// tpl: packed template (33 dwords + sum g0 + sum g0^2 + sigma flag) or nullptr -> built from patch bytes
-template <bool DEFER>
-__device__ __forceinline__ SearchResult search_core_v1(const uint8_t* __restrict__ image, int width,
-                                                       const unsigned* __restrict__ tpl, const uint8_t* __restrict__ patch,
-                                                       const SearchBounds sb, double a, double b, double c,
-                                                       unsigned* s_win) {
-  const int lane = threadIdx.x & 63;
-  const int nu_all = sb.urelfinish - sb.urelstart + 1;
-  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
-  SearchResult res;
-  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
-  res.S1 = res.S2 = res.X = 0;
-  if (nu_all <= 0 || nv_all <= 0) return res;
-
-  // ---- template -> 33 wave-uniform dwords (row r: bytes 0..10, byte 11 = 0) ----
-  unsigned tv = 0;
-  if (tpl) {
-    if (lane < 36) tv = tpl[lane];
-  } else if (lane < 33) {
-    const int r = lane / 3, d = lane - 3 * r;
-    for (int k = 0; k < 4; ++k) {
-      const int col = 4 * d + k;
-      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
-      tv |= byte << (8 * k);
-    }
-  }
-  unsigned T[33];
-#pragma unroll
-  for (int i = 0; i < 33; ++i) T[i] = __builtin_amdgcn_readlane(tv, i);
-  int Sg0, Sg0sq;
-  bool patch_ok;
-  if (tpl) {
-    Sg0 = (int)__builtin_amdgcn_readlane(tv, 33);
-    Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
-    patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
-  } else {
-    unsigned uSg0 = 0, uSg0sq = 0;
-#pragma unroll
-    for (int i = 0; i < 33; ++i) { uSg0 = udot4(T[i], 0x01010101u, uSg0); uSg0sq = udot4(T[i], T[i], uSg0sq); }
-    Sg0 = (int)uSg0; Sg0sq = (int)uSg0sq;
-    // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
-    const double g0bar = (double)Sg0 / 121.0;
-    const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
-    const double sigmag0 = sqrt(varg0);
-    patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
-  }
-  const int D0 = 121 * Sg0sq - Sg0 * Sg0;          // n^2 var0 > 0 when patch_ok
-  const float d0f = (float)D0;
-
-  // running per-lane state over every block of the window
-  float best_q = -3.0e38f, second_q = -3.0e38f;
-  int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
-  int need_exact = 0;
-  int ncand_lane = 0;
-
-  // A window larger than the LDS tile (kMaxNu x kMaxNv candidates) is walked block by block: each block is staged and
-  // walked like a window of its own, the lanes keep their two best candidates across blocks, and the decision is taken
-  // once at the end.  (Windows of this size are the rule at 1280x720; the exact baseline kernel they used to fall
-  // back to costs ten times as much per candidate.)
-  for (int ub = 0; ub < nu_all; ub += kMaxNu) {
-    const int nu = min(kMaxNu, nu_all - ub);
-    for (int vb = 0; vb < nv_all; vb += kMaxNv) {
-      const int nv = min(kMaxNv, nv_all - vb);
-      if (ub + vb > 0) __syncthreads();            // the previous block's walk is done with the tile
-
-      // ---- stage the block: coalesced dword-aligned row loads, 8 row passes in flight at a time ----
-      const int x0 = sb.ucentre + sb.urelstart + ub - 5, y0 = sb.vcentre + sb.vrelstart + vb - 5;
-      const int Hw = nv + 10;
-      const size_t base_addr = (size_t)image + (size_t)y0 * width + x0;
-      {
-        const int k = lane & 15, rsub = lane >> 4;   // 16 dwords per row, 4 rows per pass
-        for (int r0 = 0; r0 < Hw; r0 += 32) {
-          unsigned val[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 4 * u + rsub;
-            unsigned v = 0;
-            if (r < Hw) {
-              const size_t addr = base_addr + (size_t)r * width;
-              const size_t al = addr & ~(size_t)3;
-              const int o = (int)(addr & 3);
-              const int need = (o + nu + 10 + 3) >> 2;     // <= 16
-              if (k < need) v = *(const unsigned*)(al + 4 * (size_t)k);
-            }
-            val[u] = v;
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int r = r0 + 4 * u + rsub;
-            if (r < Hw) {
-              s_win[r * kWinPitchDw + k] = val[u];
-              if (k == 0) s_win[r * kWinPitchDw + 16] = 0u;
-            }
-          }
-        }
-      }
-
-      // ---- ellipse membership (exact FP64 test): lane u builds the bit mask over v of its column ----
-      unsigned long long colmask = 0ull;
-      if (lane < nu) {
-        const int urel = sb.urelstart + ub + lane;
-        for (int vi = 0; vi < nv; ++vi)
-          if (in_ellipse(a, b, c, urel, sb.vrelstart + vb + vi)) colmask |= 1ull << vi;
-      }
-      ncand_lane += __popcll(colmask);
-      __syncthreads();                                 // block is in LDS
-      if (!patch_ok) continue;                         // every candidate is skipped (sdpatch < 10): only counted
-
-      // ---- column walk ----
-      const int nseg = 64 / nu;                       // >= 1
-      const int vs = (nv + nseg - 1) / nseg;          // rows of candidates per segment
-      const int seg = lane / nu, ui = lane - seg * nu;
-      const int vstart = seg * vs;
-      const bool active = (seg < nseg) && (vstart < nv);
-      const int vlen = active ? min(vs, nv - vstart) : 0;
-      unsigned long long mymask;
-      {
-        const unsigned lo = (unsigned)__shfl((int)(unsigned)(colmask & 0xffffffffull), ui, 64);
-        const unsigned hi = (unsigned)__shfl((int)(unsigned)(colmask >> 32), ui, 64);
-        mymask = active ? (((unsigned long long)hi << 32) | lo) : 0ull;
-      }
-      const int wmod = width & 3;
-      const int o_first = (int)(base_addr & 3);
-      const int tmax = vs + 10;
-
-      unsigned ring[11][3];
-      int rs1[11], rs2[11];
-#pragma unroll
-      for (int i = 0; i < 11; ++i) { rs1[i] = 0; rs2[i] = 0; ring[i][0] = ring[i][1] = ring[i][2] = 0; }
-      int S1 = 0, S2 = 0;
-
-      for (int tb = 0; tb < tmax; tb += 11) {
-#pragma unroll
-        for (int s = 0; s < 11; ++s) {
-          const int t = tb + s;
-          if (t < tmax) {
-            const bool row_ok = active && (t < vlen + 10);
-            // fetch window row (vstart + t), bytes ui .. ui+11
-            unsigned r0 = 0, r1 = 0, r2 = 0;
-            if (row_ok) {
-              const int wr = vstart + t;
-              const int bo = ((o_first + wr * wmod) & 3) + ui;
-              const int k0 = bo >> 2, sh = bo & 3;
-              const unsigned* rowp = s_win + wr * kWinPitchDw + k0;
-              const unsigned d0 = rowp[0], d1 = rowp[1], d2 = rowp[2], d3 = rowp[3];
-              r0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-              r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-              r2 = __builtin_amdgcn_alignbyte(d3, d2, sh) & 0x00ffffffu;
-            }
-            const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
-            const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
-            S1 += n1 - rs1[s];
-            S2 += n2 - rs2[s];
-            rs1[s] = n1; rs2[s] = n2;
-            ring[s][0] = r0; ring[s][1] = r1; ring[s][2] = r2;
-            if (t >= 10) {
-              const int vi = vstart + t - 10;
-              const bool cand = row_ok && ((mymask >> vi) & 1ull);
-              if (cand) {
-                unsigned X0 = 0, X1 = 0, X2 = 0;      // three independent accumulation chains
-#pragma unroll
-                for (int j = 0; j < 11; ++j) {
-                  const int slot = (s + 1 + j) % 11;
-                  X0 = udot4(ring[slot][0], T[3 * j + 0], X0);
-                  X1 = udot4(ring[slot][1], T[3 * j + 1], X1);
-                  X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
-                }
-                const unsigned X = X0 + X1 + X2;
-                const int D1 = mul24(121, S2) - mul24(S1, S1);   // n^2 var1, exact (all factors < 2^24)
-                if (D1 == 1464100) need_exact = 1;            // sigma1 == 10 boundary: decided in FP64 only
-                if (D1 > 1464100) {                           // sigma1 >= 10 for certain
-                  const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);   // n^2 cov, exact
-                  const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);   // ~ rho
-                  const int idx = (ub + ui) * nv_all + (vb + vi);
-                  if (q > best_q) {
-                    second_q = best_q;
-                    best_q = q; best_idx = idx; best_S1 = S1; best_S2 = S2; best_X = (int)X;
-                  } else if (q > second_q) {
-                    second_q = q;
-                  }
-                }
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  int ncand = ncand_lane;
-  for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
-  res.ncand = ncand;
-  if (!patch_ok) return res;
-  // ---- decide ----
-  float gmax = best_q;
-  for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
-  const float thr = gmax - 4.0e-6f;
-  const bool lane_amb = (second_q >= thr) && (best_idx >= 0);
-  const bool lane_near = (best_idx >= 0) && (best_q >= thr);
-  const unsigned long long near_mask = __ballot(lane_near);
-  if (__any(need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
-  if (near_mask == 0ull) return res;               // nothing passed the sigma test: not found
-  const int wl = __ffsll((long long)near_mask) - 1;  // the one lane holding the only possible winner
-  const int w_idx = __shfl(best_idx, wl, 64);
-  res.S1 = __shfl(best_S1, wl, 64); res.S2 = __shfl(best_S2, wl, 64); res.X = __shfl(best_X, wl, 64);
-  res.found = 1;
-  res.u = sb.ucentre + sb.urelstart + w_idx / nv_all;
-  res.v = sb.vcentre + sb.vrelstart + w_idx % nv_all;
-  if (DEFER) { res.code = 1; return res; }
-  double sd0, sd1;
-  const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
-  if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {   // cannot happen (D1 > bound), kept exact
-    res.found = 0; res.u = res.v = 0;
-    return res;
-  }
-  res.score = corr;
-  res.ok = !(corr > kCorrThresh2) ? 1 : 0;
-  return res;
-}
-
 // ---------------------------------------------------------------------------
-// Variant 3 ("matrix-core walk", production): the three 11x11 window sums of every candidate come out of the
-// int8 matrix cores instead of a per-lane column walk.
+// The matrix-core walk.
 //
 // For a 16 (rows v) x 16 (columns u) tile of candidates the cross term is a sum of eleven Toeplitz products,
 //     X[v][u] = sum_i  I[v+i][0..31] . Tt_i[0..31][u],     Tt_i[k][u] = T[i][k-u]  (0 <= k-u < 11, else 0),
 // i.e. a 16 x (11*32) by (11*32) x 16 integer GEMM: six v_mfma_i32_16x16x64_i8 (two template rows per instruction).
 // The same A operand against a Toeplitz matrix of ones gives sum(g1); sum(g1^2) uses two more byte planes, the high
 // and the low byte of the squared pixel (g^2 = 256 H + L), against the ones matrix.  Pixels and template are offset by
-// 128 to fit the signed int8 operands and the offsets are taken out again in exact integer arithmetic:
-//     sum g1 = S1' + 128*121,   sum g0 g1 = X' + 128 S1' + 128 sum g0,   sum g1^2 = 256 (H' + 15488) + L' + 15488.
-// 24 MFMAs per 256 candidates replace 33 + 6 v_dot4 per candidate and per row; a lane ends up holding the three
-// exact int32 sums of four candidates (C/D layout: column = lane & 15, row = 4 (lane >> 4) + register), ranks them
-// in FP32 exactly like variant 1 and hands the unique near-best candidate to the FP64 scoring pass.  No ring of image
-// rows, no per-lane template: ~70 VGPRs instead of 156, so twice the wavefronts hide the staging latency.
-//
-// One wavefront per (sequence, selected feature).  The window is staged band by band (16 candidate rows x 32 candidate
-// columns: 27 x 48 bytes per plane) with coalesced, dword-aligned row loads; any window size is walked tile by tile,
-// so nothing falls back for being large.  What the fast path cannot decide exactly (several near-best candidates, the
-// sigma == 10 boundary) returns code -1 and the caller runs search_core_v0, as for variant 1.
+// 128 to fit the signed int8 operands: 24 MFMAs per 256 candidates, and a lane ends up holding the three exact int32
+// sums of four candidates (C/D layout: column = lane & 15, row = 4 (lane >> 4) + register).
 //
 // Which byte of an operand register pairs with which k of the instruction does not matter here: lane group g = lane >> 4
 // and byte e of A always meet lane group g, byte e of B, and both operands are built from (g, e) -> (template row
 // 2p + (g >> 1), window byte 16 (g & 1) + e).
+//
+// Candidates are ranked on rho_f = cov / sqrt(var0 var1) in FP32 from the exact integers (error < 1e-6).  Only a
+// candidate within 4e-6 of the best can be the reference's winner; if there is exactly one such candidate its integer
+// sums are handed to the scoring pass (k_search_score, or scored in place by the stateless kernel), which evaluates the
+// reference's FP64 score and thresholds.  Several near-best candidates, or a candidate on the sigma == 10 boundary,
+// return code -1 and the caller runs search_core_v0 - same results, just slower.
 // ---------------------------------------------------------------------------
 #ifdef SL2_SEARCH_TRACE
 __device__ long long* g_search_trace = nullptr;     // development only: 8 cycle stamps per workgroup
@@ -401,68 +158,6 @@ __device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int of
   return r;
 }
 
-// ---- band staging: rows_needed (<= 26) rows x ndw (<= 11) dwords of the frame -> three byte planes (g - 128, high and
-// low byte of g^2, each - 128).  Split into "issue the loads" and "consume them", so that the engine kernel can have the
-// next feature's window in flight while it works on the current one.  The band's dwords are dealt out to the lanes
-// densely (lane -> (row, dword) by a division by the band's own width), so a typical 24 x 7-dword window takes three
-// passes, not seven; loads are plain dword loads at byte addresses (unaligned-access mode), and the last dword of a row
-// is fetched from four bytes before the row's end and shifted, so that nothing beyond the window is ever touched.
-constexpr int kMfPasses = 5;                   // ceil(26 * 11 / 64)
-struct MfBand { int base, rows_needed, bytes_needed, ndw; float rcp; };
-__device__ __forceinline__ MfBand mf_band(const SearchBounds& sb, int nu_all, int nv_all, int up, int vt, int width) {
-  MfBand bd;
-  bd.base = (sb.vcentre + sb.vrelstart + 16 * vt - 5) * width + (sb.ucentre + sb.urelstart + 16 * up - 5);   // < 2^31
-  bd.rows_needed = min(nv_all - 16 * vt, 16) + 10;          // <= 26
-  bd.bytes_needed = min(nu_all - 16 * up, 32) + 10;          // 11 .. 42
-  bd.ndw = (bd.bytes_needed + 3) >> 2;                       // 3 .. 11
-  bd.rcp = __builtin_amdgcn_rcpf((float)bd.ndw);
-  return bd;
-}
-// lane's (row, dword) of pass ps; false when the lane has nothing to do in that pass
-__device__ __forceinline__ bool mf_band_slot(const MfBand& bd, int ps, int lane, int* r, int* k) {
-  const int idx = ps * 64 + lane;
-  const int rr = (int)(((float)idx + 0.5f) * bd.rcp);        // idx / ndw: (idx + 1/2) / ndw is >= 0.04 away from an integer
-  *r = rr;
-  *k = idx - mul24(rr, bd.ndw);
-  return rr < bd.rows_needed;
-}
-__device__ __forceinline__ void mf_band_loads(const uint8_t* __restrict__ image, int width, const MfBand bd, int lane,
-                                              unsigned (&val)[kMfPasses]) {
-#pragma unroll
-  for (int ps = 0; ps < kMfPasses; ++ps) {
-    if (ps * 64 < bd.rows_needed * bd.ndw) {                // wave-uniform
-      int r, k;
-      unsigned v = 0;
-      if (mf_band_slot(bd, ps, lane, &r, &k)) {
-        const int pos = min(4 * k, bd.bytes_needed - 4);
-        __builtin_memcpy(&v, image + (unsigned)(bd.base + mul24(r, width) + pos), 4);
-      }
-      val[ps] = v;
-    }
-  }
-}
-__device__ __forceinline__ void mf_band_store(const unsigned (&val)[kMfPasses], const MfBand bd, unsigned* s_I, unsigned* s_H,
-                                              unsigned* s_L, int lane) {
-#pragma unroll
-  for (int ps = 0; ps < kMfPasses; ++ps) {
-    if (ps * 64 < bd.rows_needed * bd.ndw) {
-      int r, k;
-      if (mf_band_slot(bd, ps, lane, &r, &k)) {
-        const int pos = min(4 * k, bd.bytes_needed - 4);
-        const unsigned d = val[ps] >> (8 * (4 * k - pos));
-        const unsigned lo = d & 0x00ff00ffu, hi = (d >> 8) & 0x00ff00ffu;
-        const unsigned sqlo = mf_sq_pairs(lo), sqhi = mf_sq_pairs(hi);
-        const unsigned Hd = ((sqlo >> 8) & 0x00ff00ffu) | (sqhi & 0xff00ff00u);
-        const unsigned Ld = (sqlo & 0x00ff00ffu) | ((sqhi << 8) & 0xff00ff00u);
-        const int idx = mul24(r, kMfPitchDw) + k;
-        s_I[idx] = d ^ 0x80808080u;
-        s_H[idx] = Hd ^ 0x80808080u;
-        s_L[idx] = Ld ^ 0x80808080u;
-      }
-    }
-  }
-}
-
 // padded template rows in LDS: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones.
 // mf_tpl_init writes everything that does not depend on the template (once per wavefront), mf_tpl_store the 33 data
 // dwords: tv = the packed template dword of lanes 0..32 (row lane / 3, bytes 4 (lane % 3) .., byte 11 = 0).  The two
@@ -483,355 +178,18 @@ __device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned* s_T, int lan
   }
 }
 
-// wave-wide reductions on the VALU cross-lane path (six DPP operations and a readlane, no LDS round trips): four xor /
-// mirror steps inside each row of 16 lanes, then row_bcast15 / row_bcast31 carry the partial results up to lane 63
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int mf_dpp_i(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-  v += mf_dpp_i<0xB1, 0xf>(v);        // quad_perm [1,0,3,2]
-  v += mf_dpp_i<0x4E, 0xf>(v);        // quad_perm [2,3,0,1]
-  v += mf_dpp_i<0x141, 0xf>(v);       // row_half_mirror
-  v += mf_dpp_i<0x140, 0xf>(v);       // row_mirror: every lane of a row holds the row's sum
-  v += mf_dpp_i<0x142, 0xa>(v);       // row_bcast15 into rows 1 and 3
-  v += mf_dpp_i<0x143, 0xc>(v);       // row_bcast31 into rows 2 and 3
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ float wave_max_f32(float x) {
-  auto step = [](float v, int o) { return fmaxf(v, __int_as_float(o)); };
-  // identity of max for the lanes a bcast does not reach: the lane's own value (old = v is not expressible with a
-  // template on the value, so the masked rows are re-maxed with themselves)
-  int v = __float_as_int(x);
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false)));
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false)));
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false)));
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false)));
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false)));
-  v = __float_as_int(step(__int_as_float(v), __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false)));
-  return __int_as_float(__builtin_amdgcn_readlane(v, 63));
-}
-
-// running state of one search: per lane the best and second-best FP32 rank, the integer sums of the best, counters
-struct MfState {
-  float best_q, second_q;
-  int best_idx, best_S1, best_S2, best_X, need_exact, ncand;
-  __device__ __forceinline__ void reset() {
-    best_q = -3.0e38f; second_q = -3.0e38f; best_idx = -1; best_S1 = best_S2 = best_X = 0; need_exact = 0; ncand = 0;
-  }
-};
-
-// the (up to two) 16 x 16 candidate tiles of the band in LDS: 24 MFMAs each, then the lane's four candidates per tile
-__device__ __forceinline__ void mf_band_tiles(const unsigned* s_I, const unsigned* s_H, const unsigned* s_L, const unsigned* s_T,
-                                              int up, int vt, int TU, int nu_all, int nv_all, int urelstart, int vrelstart,
-                                              double a, double b2, double c, int Sg0, float d0f, bool patch_ok, int j, int g,
-                                              MfState& st) {
-  const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
-  const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
-  const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
-  for (int ut = up; ut < min(up + 2, TU); ++ut) {
-    mf_v4i accX = {0, 0, 0, 0}, acc1 = accX, accH = accX, accL = accX;
-    if (patch_ok) {                      // (a flat template: every candidate is skipped, they are only counted)
-      const int abase = j * (kMfPitchDw * 4) + 16 * ((ut - up) + (g & 1)) + (g >> 1) * (kMfPitchDw * 4);
-#pragma unroll 2
-      for (int p = 0; p < 6; ++p) {
-        const int aoff = abase + 2 * p * (kMfPitchDw * 4);            // multiple of 16
-        const mf_v4i aI = *(const mf_v4i*)((const char*)s_I + aoff);
-        const mf_v4i aH = *(const mf_v4i*)((const char*)s_H + aoff);
-        const mf_v4i aL = *(const mf_v4i*)((const char*)s_L + aoff);
-        const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
-        const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
-        accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, accX, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, acc1, 0, 0, 0);
-        accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, accH, 0, 0, 0);
-        accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, accL, 0, 0, 0);
-      }
-    }
-    // ---- the lane's four candidates: column ui, rows 16 vt + 4 g + reg.  Ellipse membership is the reference's
-    // expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9 with the u-only factors hoisted (same values, same order).
-    // Straight-line code with selects: the per-candidate branches cost more (scalar traffic, issue bubbles) than the
-    // arithmetic they skip.
-    const int ui = 16 * ut + j;
-    const double du = (double)(urelstart + ui);
-    const double e_uu = a * du * du, e_u = b2 * du;
-    const int idx0 = mul24(ui, nv_all) + 16 * vt + 4 * g;
-    const bool col_ok = ui < nu_all;
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      const int vi = 16 * vt + 4 * g + reg;
-      const double dv = (double)(vrelstart + vi);
-      const bool cand = col_ok && vi < nv_all && (e_uu + e_u * dv + c * dv * dv < kNoSigma * kNoSigma);
-      const int s1p = acc1[reg];
-      const int S1 = s1p + 15488;
-      const int S2 = ((accH[reg] + 15488) << 8) + accL[reg] + 15488;
-      const int X = accX[reg] + 128 * s1p + 128 * Sg0;
-      const int D1 = mul24(121, S2) - mul24(S1, S1);
-      const int Nc = mul24(121, X) - mul24(Sg0, S1);
-      const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
-      st.ncand += cand ? 1 : 0;
-      st.need_exact |= (cand && D1 == 1464100) ? 1 : 0;          // sigma1 == 10 boundary: decided in FP64 only
-      const float qq = (cand && D1 > 1464100 && patch_ok) ? q : -3.0e38f;
-      const bool better = qq > st.best_q;
-      st.second_q = __builtin_amdgcn_fmed3f(st.best_q, st.second_q, qq);    // second of {best, second, new}
-      st.best_q = better ? qq : st.best_q;
-      st.best_idx = better ? idx0 + reg : st.best_idx;
-      st.best_S1 = better ? S1 : st.best_S1;
-      st.best_S2 = better ? S2 : st.best_S2;
-      st.best_X = better ? X : st.best_X;
-    }
-  }
-}
-
-// wave-wide decision (as variant 1): code 1 = unique near-best candidate, its sums handed on; -1 = exact path needed
-template <bool DEFER>
-__device__ __forceinline__ SearchResult mf_decide(const MfState& st, const SearchBounds& sb, int nv_all, int Sg0, int Sg0sq,
-                                                  bool patch_ok) {
-  SearchResult res;
-  res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.score = 1000000.0;
-  res.S1 = res.S2 = res.X = 0;
-  res.ncand = wave_sum_i32(st.ncand);
-  if (!patch_ok) return res;
-  const float gmax = wave_max_f32(st.best_q);
-  const float thr = gmax - 4.0e-6f;
-  const bool lane_amb = (st.second_q >= thr) && (st.best_idx >= 0);
-  const bool lane_near = (st.best_idx >= 0) && (st.best_q >= thr);
-  const unsigned long long near_mask = __ballot(lane_near);
-  if (__any(st.need_exact) || __any(lane_amb) || __popcll(near_mask) > 1) { res.code = -1; return res; }
-  if (near_mask == 0ull) return res;
-  const int wl = __ffsll((long long)near_mask) - 1;
-  const int w_idx = __shfl(st.best_idx, wl, 64);
-  res.S1 = __shfl(st.best_S1, wl, 64); res.S2 = __shfl(st.best_S2, wl, 64); res.X = __shfl(st.best_X, wl, 64);
-  res.found = 1;
-  res.u = sb.ucentre + sb.urelstart + w_idx / nv_all;
-  res.v = sb.vcentre + sb.vrelstart + w_idx % nv_all;
-  if (DEFER) { res.code = 1; return res; }
-  double sd0, sd1;
-  const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
-  if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {
-    res.found = 0; res.u = res.v = 0;
-    return res;
-  }
-  res.score = corr;
-  res.ok = !(corr > kCorrThresh2) ? 1 : 0;
-  return res;
-}
-
-// One search, one wavefront, nothing in flight across calls: the stateless batch API (templates as raw 121 bytes).
-__device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width,
-                                                         const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
-                                                         double b, double c, unsigned* s_pl, unsigned* s_T) {
-  const int lane = threadIdx.x & 63;
-  const int nu_all = sb.urelfinish - sb.urelstart + 1;
-  const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
-  if (nu_all <= 0 || nv_all <= 0) {
-    SearchResult res;
-    res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
-    res.S1 = res.S2 = res.X = 0;
-    return res;
-  }
-  unsigned tv = 0;
-  if (lane < 33) {
-    const int r = lane / 3, d = lane - 3 * r;
-    for (int kk = 0; kk < 4; ++kk) {
-      const int col = 4 * d + kk;
-      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
-      tv |= byte << (8 * kk);
-    }
-  }
-  unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
-  for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
-  const int Sg0 = (int)s1, Sg0sq = (int)s2;
-  // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
-  const double g0bar = (double)Sg0 / 121.0;
-  const double varg0 = (double)Sg0sq / 121.0 - (g0bar * g0bar);
-  const double sigmag0 = sqrt(varg0);
-  const bool patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
-  const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
-  mf_tpl_init(s_T, lane);
-  mf_tpl_store(tv, s_T, lane);
-
-  const int j = lane & 15, g = lane >> 4;
-  unsigned* s_I = s_pl;
-  unsigned* s_H = s_pl + kMfPlaneDw;
-  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
-  MfState st;
-  st.reset();
-  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
-  for (int vt = 0; vt < TV; ++vt)
-    for (int up = 0; up < TU; up += 2) {
-      if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
-      const MfBand bd = mf_band(sb, nu_all, nv_all, up, vt, width);
-      unsigned val[kMfPasses];
-      mf_band_loads(image, width, bd, lane, val);
-      mf_band_store(val, bd, s_I, s_H, s_L, lane);
-      __syncthreads();
-      mf_band_tiles(s_I, s_H, s_L, s_T, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, Sg0, d0f, patch_ok,
-                    j, g, st);
-    }
-  return mf_decide<false>(st, sb, nv_all, Sg0, Sg0sq, patch_ok);
-}
-
 // ---------------------------------------------------------------------------
-// Engine kernels.  k_search: one wave per (sequence, selected position), XCD-mapped so
-// that all windows of one frame go through one XCD's L2.  It writes a compact result
-// record; k_search_score (one THREAD per selected position, all lanes busy) evaluates
-// the deferred FP64 scores and does the reference's bookkeeping
-// (successful_/failed_measurement_of_feature, monoslam.cpp:479-496).
-// ---------------------------------------------------------------------------
-template <int VARIANT>
-__global__ void __launch_bounds__(64) k_search(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
-                                               const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
-                                               const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
-                                               const int* __restrict__ n_sel, int* __restrict__ srch_res,
-                                               double* __restrict__ meas_score, int N, int nsel_max, int B) {
-  int b, k;
-  if (!xcd_map(nsel_max, B, &b, &k)) return;
-  if (k >= n_sel[b]) return;
-  __shared__ unsigned s_win[kWinRows * kWinPitchDw];
-  const int f = sel_idx[(size_t)b * N + k];
-  const size_t fi = (size_t)b * N + f;
-  const SearchBounds sb = bounds_from_desc(srch_i + fi * 8);
-  const double a = srch_d[fi * 4], bq = srch_d[fi * 4 + 1], c = srch_d[fi * 4 + 2];
-  const uint8_t* img = frames + (size_t)b * seq_stride;
-  const uint8_t* pbytes = patch + fi * kPatchStride;
-  SearchResult r;
-  r.code = -1;
-  if (VARIANT == 1) r = search_core_v1<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a, bq, c, s_win);
-  const bool fell_back = r.code < 0;
-  if (fell_back) r = search_core_v0(img, width, pbytes, sb, a, bq, c);
-  if ((threadIdx.x & 63) == 0) {
-    int* o = srch_res + ((size_t)b * N + k) * 8;
-    o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
-    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | ((VARIANT != 0 && fell_back) ? 4 : 0);
-    meas_score[(size_t)b * N + k] = r.score;
-  }
-}
-
-// Variant 3 engine kernel.  One wavefront works through kMfChunk consecutive selected positions of one sequence
-// (XCD-mapped like k_search: a sequence's frame stays in one XCD's L2).  A feature's search is a chain of dependent
-// memory round trips - record, template + window, LDS - that takes ~18 000 cycles for ~3 000 cycles of issue, so the
-// loop is software-pipelined: the four 64-byte records of the chunk come with one coalesced load (lane = dword), and
-// while feature i is in the matrix cores and being scored, the template and the first window band of feature i + 1 are
-// already in flight (eight VGPRs).  Held to the register budget of SL2_MF_WAVES wavefronts per SIMD.
-constexpr int kMfChunk = 4;
-#ifndef SL2_MF_WAVES
-#define SL2_MF_WAVES 4
-#endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
-k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, const uint8_t* __restrict__ patch,
-              const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
-              double* __restrict__ meas_score, int N, int nchunks, int B, int chunk) {
-  int b, ch;
-  if (!xcd_map(nchunks, B, &b, &ch)) return;
-  STR(0);
-  __shared__ __attribute__((aligned(16))) unsigned s_pl[3 * kMfPlaneDw];
-  __shared__ unsigned s_T[kMfTplDw];
-  const int lane = threadIdx.x;
-  const int k0 = ch * chunk;
-  const int nsel = n_sel[b];
-  if (k0 >= nsel) return;
-  const int nf = min(chunk, nsel - k0);
-  const uint8_t* img = frames + (size_t)b * seq_stride;
-  const int j = lane & 15, g = lane >> 4;
-  unsigned* s_I = s_pl;
-  unsigned* s_H = s_pl + kMfPlaneDw;
-  unsigned* s_L = s_pl + 2 * kMfPlaneDw;
-
-  // the record k_select wrote for selected position k (one 64-byte line; uniform address: scalar loads)
-  struct Rec { int f, nu_all, nv_all; SearchBounds sb; double a, b, c; };
-  auto record = [&](int i) {
-    const int* rec = srch_sel + ((size_t)b * N + k0 + i) * 16;
-    Rec r;
-    r.f = rec[0];
-    r.sb.ucentre = rec[1]; r.sb.vcentre = rec[2]; r.sb.urelstart = rec[3]; r.nu_all = rec[4];
-    r.sb.vrelstart = rec[5]; r.nv_all = rec[6]; r.sb.halfwidth = rec[7]; r.sb.halfheight = 0;
-    r.sb.urelfinish = r.sb.urelstart + r.nu_all - 1; r.sb.vrelfinish = r.sb.vrelstart + r.nv_all - 1;
-    const double* recd = (const double*)(rec + 8);
-    r.a = recd[0]; r.b = recd[1]; r.c = recd[2];
-    return r;
-  };
-
-  mf_tpl_init(s_T, lane);
-  const int tslot = (lane < 33) ? (lane / 3) * kMfPitchDw + 4 + lane % 3 : 0;      // where this lane's template dword goes
-  const unsigned tmask = (lane % 3 == 2) ? 0x00ffffffu : 0xffffffffu;
-  unsigned pf_val[kMfPasses];
-  unsigned pf_tv = 0;
-  Rec rc = record(0);
-  {
-    if (rc.nu_all > 0 && rc.nv_all > 0) mf_band_loads(img, width, mf_band(rc.sb, rc.nu_all, rc.nv_all, 0, 0, width), lane, pf_val);
-    const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rc.f) * kPatchStride + kPatchPackedOffset);
-    pf_tv = tpl[min(lane, 35)];
-  }
-  STR(1);
-  for (int i = 0; i < nf; ++i) {
-    // the next position's record: scalar loads issued here, consumed after the barrier below (clamped index: the last
-    // iteration re-reads its own record instead of branching)
-    const Rec rn = record(min(i + 1, nf - 1));
-    const int nu_all = rc.nu_all, nv_all = rc.nv_all;
-    const bool geom_ok = nu_all > 0 && nv_all > 0;
-    const unsigned tv = pf_tv;
-    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 33), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
-    const bool patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
-    const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
-    if (i > 0) __syncthreads();                       // feature i - 1 is done with the LDS
-    if (geom_ok) {
-      if (lane < 33) s_T[tslot] = (tv ^ 0x80808080u) & tmask;
-      mf_band_store(pf_val, mf_band(rc.sb, nu_all, nv_all, 0, 0, width), s_I, s_H, s_L, lane);
-    }
-    __syncthreads();
-    if (i + 1 < nf) {                                 // next feature's template and first band: in flight from here on
-      if (rn.nu_all > 0 && rn.nv_all > 0)
-        mf_band_loads(img, width, mf_band(rn.sb, rn.nu_all, rn.nv_all, 0, 0, width), lane, pf_val);
-      const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rn.f) * kPatchStride + kPatchPackedOffset);
-      pf_tv = tpl[min(lane, 35)];
-    }
-    MfState st;
-    st.reset();
-    SearchResult r;
-    r.code = 0; r.ok = 0; r.found = 0; r.u = 0; r.v = 0; r.ncand = 0; r.score = 1000000.0; r.S1 = r.S2 = r.X = 0;
-    if (geom_ok) {
-      const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
-      mf_band_tiles(s_I, s_H, s_L, s_T, 0, 0, TU, nu_all, nv_all, rc.sb.urelstart, rc.sb.vrelstart, rc.a, 2 * rc.b, rc.c, Sg0, d0f,
-                    patch_ok, j, g, st);
-      for (int vt = 0; vt < TV; ++vt)                 // the other bands of a large window: staged synchronously
-        for (int up = (vt == 0 ? 2 : 0); up < TU; up += 2) {
-          __syncthreads();
-          const MfBand bd = mf_band(rc.sb, nu_all, nv_all, up, vt, width);
-          unsigned val[kMfPasses];
-          mf_band_loads(img, width, bd, lane, val);
-          mf_band_store(val, bd, s_I, s_H, s_L, lane);
-          __syncthreads();
-          mf_band_tiles(s_I, s_H, s_L, s_T, up, vt, TU, nu_all, nv_all, rc.sb.urelstart, rc.sb.vrelstart, rc.a, 2 * rc.b, rc.c,
-                        Sg0, d0f, patch_ok, j, g, st);
-        }
-      r = mf_decide<true>(st, rc.sb, nv_all, Sg0, Sg0sq, patch_ok);
-    }
-    const bool fell_back = r.code < 0;
-    if (fell_back) r = search_core_v0(img, width, patch + ((size_t)b * N + rc.f) * kPatchStride, rc.sb, rc.a, rc.b, rc.c);
-    if (lane == 0) {
-      int* o = srch_res + ((size_t)b * N + k0 + i) * 8;
-      o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
-      o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | (fell_back ? 4 : 0);
-      meas_score[(size_t)b * N + k0 + i] = r.score;
-    }
-    rc = rn;
-  }
-  STR(6);
-}
-
-// ---------------------------------------------------------------------------
-// Variant 4 ("lean matrix-core walk", production from round 3): the arithmetic of variant 3 - the same int8 Toeplitz
-// products, the same operand layout, the same FP32 rank + exact FP64 decision - re-costed for vector-instruction issue,
-// which is what bounds this kernel (round 2: 551 vector instructions per searched feature, matrix pipes 23 % busy):
+// Round 3 re-costed this kernel for vector-instruction issue, which is what bounds it (round 2: 551 vector instructions
+// per searched feature with the matrix pipes 23 % busy; now ~380, PMC SQ_INSTS_VALU in profiles/r03_search_*):
 //   * the window band is staged in 16-byte pieces (one global_load_dwordx4 and three ds_write_b128 per lane: a 26 x 26
 //     byte band is ONE pass of 52 lanes instead of three passes of dwords), the byte planes come out of v_perm_b32;
-//   * the Toeplitz operand of the ones matrix is loaded once per wavefront, the six template operands once per feature
-//     (not per tile);
+//   * the Toeplitz operand of the ones matrix is loaded once per wavefront;
 //   * the offsets of the signed operands are never taken out per candidate: variance and covariance are shift
-//     invariant, so D1 = 121 w + s1 (-30976 - s1) + K and Nc = 121 x + (15488 - sum g0) s1 straight from the
+//     invariant, so D1 = 121 w - (S1^2 - K) and Nc = 121 x + (15488 - sum g0) s1 come straight from the
 //     accumulators (s1 = sum(g - 128), w = 256 H' + L', x = the raw cross term); only the winner's sums are converted;
-//   * candidate counts and the sigma == 10 flag live in scalar registers (popcount / or of compare masks), the
-//     per-row terms of the ellipse expression are formed once per band, and the winning lane stores its own record.
+//   * candidate counts and the sigma == 10 flag live in scalar registers (popcount / or of compare masks: m4_mask below),
+//     a tile none of whose 256 slots lies inside the ellipse is skipped, the wave-wide maximum is six DPP instructions,
+//     and the winning lane stores its own record.
 // ---------------------------------------------------------------------------
 constexpr int kM4Pitch = 48;                     // bytes per LDS row: three 16-byte pieces (32 candidate columns + 10)
 constexpr int kM4Rows = 28;                      // 16 candidate rows + 10 + the partner row of template row 10
@@ -985,7 +343,8 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
       m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & m4_gt_f64(kNoSigma * kNoSigma, e_uu + e_u * dv + c * dv * dv);
       un.ncand += __popcll(m_cand[reg]);
     }
-    if (!patch_ok) continue;             // (a flat template: every candidate is skipped, they are only counted)
+    // (a flat template: every candidate is skipped, they are only counted; a corner tile of a tilted ellipse may be empty)
+    if (!patch_ok || (m_cand[0] | m_cand[1] | m_cand[2] | m_cand[3]) == 0ull) continue;
     mf_v4i accX, acc1, accH, accL;
     const mf_v4i zero = {0, 0, 0, 0};
     const char* ap = s_pl + j * kM4Pitch + 16 * ((ut - up) + (g & 1)) + (g >> 1) * kM4Pitch;
@@ -1024,7 +383,7 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
 }
 
 // One search, one wavefront, nothing in flight across calls: the stateless batch API (templates as raw 121 bytes).
-__device__ __forceinline__ SearchResult search_core_m4(const uint8_t* __restrict__ image, int width, int frame_bytes,
+__device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width, int frame_bytes,
                                                        const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
                                                        double b, double c, char* s_pl, unsigned* s_T) {
   const int lane = threadIdx.x & 63;
@@ -1099,11 +458,45 @@ __device__ __forceinline__ SearchResult search_core_m4(const uint8_t* __restrict
   return res;
 }
 
-// Variant 4 engine kernel: the work split and the software pipeline of k_search_mfma (one wavefront walks `chunk`
-// consecutive selected positions of one sequence, XCD-mapped; the next position's template and first band are in flight
-// while the current one is in the matrix cores).
+// ---------------------------------------------------------------------------
+// Engine kernels.  k_search_exact: one wave per (sequence, selected position) on search_core_v0, XCD-mapped so that all
+// windows of one frame go through one XCD's L2 (search variant 0: the cross-check of the matrix-core walk).  Both search
+// kernels write a compact result record; k_search_score (one THREAD per selected position, all lanes busy) evaluates the
+// deferred FP64 scores and does the reference's bookkeeping (successful_/failed_measurement_of_feature,
+// monoslam.cpp:479-496).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_search_exact(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
+                                                     const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
+                                                     const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
+                                                     const int* __restrict__ n_sel, int* __restrict__ srch_res,
+                                                     double* __restrict__ meas_score, int N, int nsel_max, int B) {
+  int b, k;
+  if (!xcd_map(nsel_max, B, &b, &k)) return;
+  if (k >= n_sel[b]) return;
+  const int f = sel_idx[(size_t)b * N + k];
+  const size_t fi = (size_t)b * N + f;
+  const SearchBounds sb = bounds_from_desc(srch_i + fi * 8);
+  const double a = srch_d[fi * 4], bq = srch_d[fi * 4 + 1], c = srch_d[fi * 4 + 2];
+  const SearchResult r = search_core_v0(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, sb, a, bq, c);
+  if ((threadIdx.x & 63) == 0) {
+    int* o = srch_res + ((size_t)b * N + k) * 8;
+    o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+    o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0);
+    meas_score[(size_t)b * N + k] = r.score;
+  }
+}
+
+constexpr int kMfChunk = 4;
+#ifndef SL2_MF_WAVES
+#define SL2_MF_WAVES 4
+#endif
+// Engine kernel.  One wavefront works through `chunk` consecutive selected positions of one sequence (XCD-mapped: a
+// sequence's frame stays in one XCD's L2).  A feature's search is a chain of dependent memory round trips - record,
+// template + window, LDS - so the loop is software-pipelined: while position i is in the matrix cores and being scored,
+// the template and the first window band of position i + 1 are already in flight.  Held to the register budget of
+// SL2_MF_WAVES wavefronts per SIMD.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
-k_search_m4(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int frame_bytes, const uint8_t* __restrict__ patch,
+k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int frame_bytes, const uint8_t* __restrict__ patch,
             const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
             double* __restrict__ meas_score, int N, int nchunks, int B, int chunk) {
   int b, ch;
@@ -1199,7 +592,7 @@ k_search_m4(const uint8_t* __restrict__ frames, size_t seq_stride, int width, in
           m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kS, d0f, patch_ok,
                         j, g, st, un);
         }
-      // ---- decision (as variants 1 and 3): a unique near-best candidate goes on to k_search_score with its exact sums
+      // ---- decision: a unique near-best candidate goes on to k_search_score with its exact sums
       if (patch_ok) {
         const float gmax = m4_wave_max(st.best_q);
         if (gmax > -1.0e38f) {
@@ -1241,317 +634,6 @@ k_search_m4(const uint8_t* __restrict__ frames, size_t seq_stride, int width, in
   STR(6);
 }
 
-// ---------------------------------------------------------------------------
-// Variant 2 ("packed column walk", production): same arithmetic as variant 1, but one
-// wavefront serves SEVERAL features at once.  With 3-sigma ellipses of ~15 columns a single
-// feature keeps a quarter of the lanes busy and pays the 10-row warm-up of the sliding
-// window for 4-5 candidate rows; here every lane owns one candidate column of one feature
-// and walks ALL of its rows, so the warm-up is amortised over ~15 candidate rows and the
-// lanes are full (k_select builds the packs: consecutive selected features whose columns
-// fit 64 lanes).  The template is then per lane (33 VGPRs) instead of wave-uniform, and the
-// near-best decision is a segmented reduction over each feature's lanes.  Features the fast
-// path cannot decide exactly, or whose window exceeds the LDS tile, go through
-// search_core_v0 inside the same wavefront.
-// ---------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ T seg_reduce_max(T val, int gid, int lane) {
-  for (int off = 1; off < 64; off <<= 1) {
-    const T v = __shfl_down(val, off, 64);
-    const int g2 = __shfl_down(gid, off, 64);
-    if (lane + off < 64 && g2 == gid && v > val) val = v;
-  }
-  return val;   // valid in the first lane of each segment
-}
-__device__ __forceinline__ int seg_reduce_sum(int val, int gid, int lane) {
-  for (int off = 1; off < 64; off <<= 1) {
-    const int v = __shfl_down(val, off, 64);
-    const int g2 = __shfl_down(gid, off, 64);
-    if (lane + off < 64 && g2 == gid) val += v;
-  }
-  return val;
-}
-
-__global__ void __launch_bounds__(64) k_search_packed(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
-                                                      const uint8_t* __restrict__ patch, const int* __restrict__ srch_i,
-                                                      const double* __restrict__ srch_d, const int* __restrict__ sel_idx,
-                                                      const int* __restrict__ pack_first, const int* __restrict__ pack_count,
-                                                      const int* __restrict__ n_packs, int* __restrict__ srch_res,
-                                                      double* __restrict__ meas_score, int N, int nsel_max, int B) {
-  int b, p;
-  if (!xcd_map(nsel_max, B, &b, &p)) return;
-  if (p >= n_packs[b]) return;
-  __shared__ unsigned s_win[kPackMaxRows * kWinPitchDw];
-  const int lane = threadIdx.x;
-  STR(0);
-  const int first = pack_first[(size_t)b * N + p], cnt = pack_count[(size_t)b * N + p];
-  const uint8_t* img = frames + (size_t)b * seq_stride;
-  // ---- descriptors: lane g < cnt holds feature g of the pack ----
-  int d_f = 0, d_uc = 0, d_vc = 0, d_us = 0, d_nu = 0, d_vs = 0, d_nv = 0, d_hw = 0, d_hh = 0;
-  double d_a = 0, d_b = 0, d_c = 0;
-  if (lane < cnt) {
-    d_f = sel_idx[(size_t)b * N + first + lane];
-    const int* si = srch_i + ((size_t)b * N + d_f) * 8;
-    d_uc = si[0]; d_vc = si[1]; d_us = si[2]; d_nu = si[3]; d_vs = si[4]; d_nv = si[5]; d_hw = si[6]; d_hh = si[7];
-    const double* sd = srch_d + ((size_t)b * N + d_f) * 4;
-    d_a = sd[0]; d_b = sd[1]; d_c = sd[2];
-  }
-  // a window too large for the pack tile comes alone: the blocked column walk (search_core_v1), and only if that cannot
-  // decide exactly, the baseline path
-  {
-    const int nu0 = __shfl(d_nu, 0, 64), nv0 = __shfl(d_nv, 0, 64);
-    if (cnt == 1 && (nu0 > kPackMaxNu || nv0 > kPackMaxNv)) {
-      SearchBounds sb;
-      sb.ucentre = __shfl(d_uc, 0, 64); sb.vcentre = __shfl(d_vc, 0, 64);
-      sb.urelstart = __shfl(d_us, 0, 64); sb.urelfinish = sb.urelstart + nu0 - 1;
-      sb.vrelstart = __shfl(d_vs, 0, 64); sb.vrelfinish = sb.vrelstart + nv0 - 1;
-      sb.halfwidth = __shfl(d_hw, 0, 64); sb.halfheight = __shfl(d_hh, 0, 64);
-      const int f0 = __shfl(d_f, 0, 64);
-      const uint8_t* pbytes = patch + ((size_t)b * N + f0) * kPatchStride;
-      const double a0 = __shfl(d_a, 0, 64), b0 = __shfl(d_b, 0, 64), c0 = __shfl(d_c, 0, 64);
-      SearchResult r = search_core_v1<true>(img, width, (const unsigned*)(pbytes + kPatchPackedOffset), pbytes, sb, a0, b0, c0, s_win);
-      int* o = srch_res + ((size_t)b * N + first) * 8;
-      if (r.code >= 0) {
-        if (lane == 0) {
-          o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand; o[7] = r.found ? 1 : 0;
-          meas_score[(size_t)b * N + first] = 1000000.0;
-        }
-        return;
-      }
-      r = search_core_v0(img, width, pbytes, sb, a0, b0, c0);
-      if (lane == 0) {
-        o[0] = 0; o[1] = r.u; o[2] = r.v; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = r.ncand;
-        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
-        meas_score[(size_t)b * N + first] = r.score;
-      }
-      return;
-    }
-  }
-  // ---- lane -> (feature g, column ui); LDS row offset of each feature's window ----
-  int my_g = -1, lane_off = 0, row_off = 0;
-  {
-    int lacc = 0, racc = 0;
-    for (int g = 0; g < cnt; ++g) {
-      const int nu_g = __shfl(d_nu, g, 64), nv_g = __shfl(d_nv, g, 64);
-      const int w = nu_g > 0 ? nu_g : 1, hh = (nv_g > 0 ? nv_g : 0) + 10;
-      if (lane >= lacc && lane < lacc + w) { my_g = g; lane_off = lacc; row_off = racc; }
-      lacc += w; racc += hh;
-    }
-  }
-  const int gs = my_g < 0 ? 0 : my_g;
-  const int f_my = __shfl(d_f, gs, 64);
-  const int uc = __shfl(d_uc, gs, 64), vc = __shfl(d_vc, gs, 64), us = __shfl(d_us, gs, 64), vs0 = __shfl(d_vs, gs, 64);
-  const int nu = __shfl(d_nu, gs, 64), nv = __shfl(d_nv, gs, 64);
-  const double a = __shfl(d_a, gs, 64), bq = __shfl(d_b, gs, 64), c = __shfl(d_c, gs, 64);
-  const int ui = lane - lane_off;
-  const bool geom_ok = (my_g >= 0) && nu > 0 && nv > 0;
-  int nvmax = geom_ok ? nv : 0;
-  for (int off = 32; off > 0; off >>= 1) nvmax = max(nvmax, __shfl_xor(nvmax, off, 64));
-
-  STR(1);
-  // ---- stage every feature's window (coalesced row loads, dword aligned).  The loads of 8 row
-  // passes are issued before their LDS stores, so HBM latency is paid once per 32 rows and not
-  // once per 4 (a naive load->store loop serialised ~1 us per pass and dominated the wavefront).
-  {
-    __shared__ int s_meta[8][4];   // per feature: image offset of its window, nu, rows, first LDS row
-    int racc = 0;   // exclusive prefix of the window rows (all lanes take part in every shuffle)
-    for (int g = 0; g < 8; ++g) {
-      const int nv_g = __shfl(d_nv, g, 64);
-      if (g < lane && g < cnt) racc += (nv_g > 0 ? nv_g : 0) + 10;
-    }
-    if (lane < 8) {
-      const bool okg = lane < cnt && d_nu > 0 && d_nv > 0;
-      s_meta[lane][0] = okg ? (d_vc + d_vs - 5) * width + (d_uc + d_us - 5) : 0;
-      s_meta[lane][1] = okg ? d_nu : 0;
-      s_meta[lane][2] = (lane < cnt) ? (d_nv > 0 ? d_nv : 0) + 10 : 0x3fffffff;
-      s_meta[lane][3] = racc;
-    }
-    __syncthreads();
-    int total_rows = 0;
-    for (int g = 0; g < cnt; ++g) { const int nv_g = __shfl(d_nv, g, 64); total_rows += (nv_g > 0 ? nv_g : 0) + 10; }
-    // per LDS row: dword-aligned byte offset of its first staged dword in the frame, and how many dwords to fetch
-    __shared__ int2 s_row[kPackMaxRows];
-    const int img_lo = (int)((size_t)img & 3);
-    for (int R = lane; R < total_rows; R += 64) {
-      int g = 0;
-#pragma unroll
-      for (int q = 1; q < 8; ++q)
-        if (q < cnt && R >= s_meta[q][3]) g = q;
-      const int m_nu = s_meta[g][1];
-      const int byteoff = s_meta[g][0] + (R - s_meta[g][3]) * width;
-      const int o = (img_lo + byteoff) & 3;
-      s_row[R] = make_int2(byteoff - o, m_nu > 0 ? (o + m_nu + 10 + 3) >> 2 : 0);   // need <= 16
-    }
-    __syncthreads();
-    const int k = lane & 15, rsub = lane >> 4;
-    const uint8_t* img_k = img + 4 * k;
-    for (int R0 = 0; R0 < total_rows; R0 += 32) {
-      unsigned val[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int R = R0 + rsub + 4 * u;
-        unsigned v = 0;
-        if (R < total_rows) {
-          const int2 mr = s_row[R];
-          if (k < mr.y) v = *(const unsigned*)(img_k + mr.x);
-        }
-        val[u] = v;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int R = R0 + rsub + 4 * u;
-        if (R < total_rows) {
-          s_win[R * kWinPitchDw + k] = val[u];
-          if (k == 0) s_win[R * kWinPitchDw + 16] = 0u;
-        }
-      }
-    }
-  }
-  STR(2);
-  // ---- per-lane template (lanes of one feature read the same addresses) ----
-  const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + f_my) * kPatchStride + kPatchPackedOffset);
-  unsigned T[33];
-#pragma unroll
-  for (int i = 0; i < 33; ++i) T[i] = tpl[i];
-  const int Sg0 = (int)tpl[33], Sg0sq = (int)tpl[34];
-  const bool patch_ok = tpl[35] != 0;
-  // ---- ellipse membership of my column ----
-  unsigned long long mymask = 0ull;
-  for (int vi = 0; vi < nvmax; ++vi)
-    if (geom_ok && vi < nv && in_ellipse(a, bq, c, us + ui, vs0 + vi)) mymask |= 1ull << vi;
-  const int D0 = 121 * Sg0sq - Sg0 * Sg0;
-  const size_t base_my = (size_t)img + (size_t)(vc + vs0 - 5) * width + (uc + us - 5);
-  const int o_first = (int)(base_my & 3), wmod = width & 3;
-  const bool walk = geom_ok && patch_ok;
-  const int tmax = nvmax + 10;
-  __syncthreads();
-  STR(3);
-
-  unsigned ring[11][3];
-  int rs1[11], rs2[11];
-#pragma unroll
-  for (int i = 0; i < 11; ++i) { rs1[i] = 0; rs2[i] = 0; ring[i][0] = ring[i][1] = ring[i][2] = 0; }
-  int S1 = 0, S2 = 0;
-  float best_q = -3.0e38f, second_q = -3.0e38f;
-  int best_idx = -1, best_S1 = 0, best_S2 = 0, best_X = 0;
-  int need_exact = 0;
-  const float d0f = (float)D0;
-  int o_cur = o_first;
-  const unsigned* rowb = s_win + row_off * kWinPitchDw;
-  for (int tb = 0; tb < tmax; tb += 11) {
-#pragma unroll
-    for (int s = 0; s < 11; ++s) {
-      const int t = tb + s;
-      if (t < tmax) {
-        const bool row_ok = walk && (t < nv + 10);
-        unsigned r0 = 0, r1 = 0, r2 = 0;
-        if (row_ok) {
-          const int bo = o_cur + ui;
-          const int k0 = bo >> 2, sh = bo & 3;
-          const unsigned* rowp = rowb + k0;
-          const unsigned q0 = rowp[0], q1 = rowp[1], q2 = rowp[2], q3 = rowp[3];
-          r0 = __builtin_amdgcn_alignbyte(q1, q0, sh);
-          r1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
-          r2 = __builtin_amdgcn_alignbyte(q3, q2, sh) & 0x00ffffffu;
-        }
-        o_cur = (o_cur + wmod) & 3;       // byte phase of the next window row (strength-reduced t * width)
-        rowb += kWinPitchDw;
-        const int n1 = (int)(udot4(r0, 0x01010101u, 0u) + udot4(r1, 0x01010101u, 0u) + udot4(r2, 0x01010101u, 0u));
-        const int n2 = (int)(udot4(r0, r0, 0u) + udot4(r1, r1, 0u) + udot4(r2, r2, 0u));
-        S1 += n1 - rs1[s];
-        S2 += n2 - rs2[s];
-        rs1[s] = n1; rs2[s] = n2;
-        ring[s][0] = r0; ring[s][1] = r1; ring[s][2] = r2;
-        if (t >= 10) {
-          const int vi = t - 10;
-          const bool cand = row_ok && ((mymask >> vi) & 1ull);
-          if (cand) {
-            unsigned X0 = 0, X1 = 0, X2 = 0;
-#pragma unroll
-            for (int j = 0; j < 11; ++j) {
-              const int slot = (s + 1 + j) % 11;
-              X0 = udot4(ring[slot][0], T[3 * j + 0], X0);
-              X1 = udot4(ring[slot][1], T[3 * j + 1], X1);
-              X2 = udot4(ring[slot][2], T[3 * j + 2], X2);
-            }
-            const unsigned X = X0 + X1 + X2;
-            const int D1 = mul24(121, S2) - mul24(S1, S1);
-            if (D1 == 1464100) need_exact = 1;
-            if (D1 > 1464100) {
-              const int Nc = mul24(121, (int)X) - mul24(Sg0, S1);
-              const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
-              if (q > best_q) {
-                second_q = best_q;
-                best_q = q; best_idx = ui * nv + vi; best_S1 = S1; best_S2 = S2; best_X = (int)X;
-              } else if (q > second_q) {
-                second_q = q;
-              }
-            }
-          }
-        }
-      }
-    }
-  }
-  STR(4);
-  // ---- per-feature decision (segmented over the feature's lanes) ----
-  const int gid = my_g;
-  float gmax = seg_reduce_max(best_q, gid, lane);
-  gmax = __shfl(gmax, lane_off, 64);
-  const float thr = gmax - 4.0e-6f;
-  const bool lane_near = (my_g >= 0) && (best_idx >= 0) && (best_q >= thr);
-  const bool lane_amb = (my_g >= 0) && (best_idx >= 0) && (second_q >= thr);
-  const unsigned long long near_b = __ballot(lane_near), bad_b = __ballot(lane_amb || (need_exact != 0));
-  const int w = nu > 0 ? nu : 1;
-  const unsigned long long gm = ((w >= 64) ? ~0ull : ((1ull << w) - 1ull)) << lane_off;
-  const int n_near = __popcll(near_b & gm);
-  const bool fb = ((bad_b & gm) != 0ull) || n_near > 1;
-  int ncand = seg_reduce_sum(__popcll(mymask), gid, lane);
-  int code = 0, ru = 0, rv = 0, rS1 = 0, rS2 = 0, rX = 0, found = 0;
-  {
-    const int wl = (n_near == 1) ? (__ffsll((long long)(near_b & gm)) - 1) : lane;
-    const int w_idx = __shfl(best_idx, wl, 64);
-    const int w_S1 = __shfl(best_S1, wl, 64), w_S2 = __shfl(best_S2, wl, 64), w_X = __shfl(best_X, wl, 64);
-    if (fb) code = -1;
-    else if (n_near == 1) {
-      code = 1; found = 1;
-      ru = uc + us + w_idx / nv; rv = vc + vs0 + w_idx % nv;
-      rS1 = w_S1; rS2 = w_S2; rX = w_X;
-    }
-  }
-  const bool leader = (my_g >= 0) && (ui == 0);
-  if (leader && code >= 0) {
-    int* o = srch_res + ((size_t)b * N + first + my_g) * 8;
-    o[0] = code; o[1] = ru; o[2] = rv; o[3] = rS1; o[4] = rS2; o[5] = rX; o[6] = ncand; o[7] = found;
-    meas_score[(size_t)b * N + first + my_g] = 1000000.0;
-  }
-  STR(5);
-  // ---- exact fallback for the features that need it (rare) ----
-  const unsigned long long fb_leaders = __ballot(leader && code < 0);
-  if (fb_leaders != 0ull) {
-    for (int g = 0; g < cnt; ++g) {
-      // leader lane of feature g
-      int lacc = 0;
-      for (int q = 0; q < g; ++q) { const int nq = __shfl(d_nu, q, 64); lacc += nq > 0 ? nq : 1; }
-      if (!((fb_leaders >> lacc) & 1ull)) continue;
-      SearchBounds sb;
-      const int nu_g = __shfl(d_nu, g, 64), nv_g = __shfl(d_nv, g, 64);
-      sb.ucentre = __shfl(d_uc, g, 64); sb.vcentre = __shfl(d_vc, g, 64);
-      sb.urelstart = __shfl(d_us, g, 64); sb.urelfinish = sb.urelstart + nu_g - 1;
-      sb.vrelstart = __shfl(d_vs, g, 64); sb.vrelfinish = sb.vrelstart + nv_g - 1;
-      sb.halfwidth = __shfl(d_hw, g, 64); sb.halfheight = __shfl(d_hh, g, 64);
-      const int fg = __shfl(d_f, g, 64);
-      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + fg) * kPatchStride, sb, __shfl(d_a, g, 64),
-                                            __shfl(d_b, g, 64), __shfl(d_c, g, 64));
-      if (lane == 0) {
-        int* o = srch_res + ((size_t)b * N + first + g) * 8;
-        o[0] = 0; o[1] = r.u; o[2] = r.v; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = r.ncand;
-        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
-        meas_score[(size_t)b * N + first + g] = r.score;
-      }
-    }
-  }
-  STR(6);
-}
-
 // One workgroup per sequence, one thread per selected position.  Besides the deferred FP64 scores and the reference's
 // bookkeeping it compacts the successful measurements in selected_feature_list_ order (construct_total_measurement_stuff,
 // monoslam.cpp:548-572: succ_idx / m_count, what the EKF update reads) and leaves the step's work counters - a launch
@@ -1566,9 +648,9 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        int* __restrict__ succ_idx, int* __restrict__ m_count, int N) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   __shared__ int s_wcnt[16];
-  __shared__ double s_red[16][4];
+  __shared__ double s_red[16][kWorkDoubles];
   const int ns = n_sel[b];
-  double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0;
+  double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0, w_tiles = 0.0;
   int base = 0;
   for (int k0 = 0; k0 < ns; k0 += (int)blockDim.x) {
     const int k = k0 + tid;
@@ -1603,6 +685,7 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
       const int* si = srch_i + fi * 8;
       w_win += (double)(2 * si[6] + 11) * (double)(2 * si[7] + 11);
       w_n += 1.0; w_cand += (double)o[6]; w_fb += (o[7] & 4) ? 1.0 : 0.0;
+      w_tiles += (double)(((si[3] > 0 ? si[3] : 0) + 15) >> 4) * (double)(((si[5] > 0 ? si[5] : 0) + 15) >> 4);
     }
     // order-preserving compaction of the successes of this round of positions
     const unsigned long long mask = __ballot(ok != 0);
@@ -1621,35 +704,33 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
   if (tid == 0) m_count[b] = base;
   for (int off = 32; off > 0; off >>= 1) {
     w_win += __shfl_xor(w_win, off, 64); w_n += __shfl_xor(w_n, off, 64);
-    w_cand += __shfl_xor(w_cand, off, 64); w_fb += __shfl_xor(w_fb, off, 64);
+    w_cand += __shfl_xor(w_cand, off, 64); w_fb += __shfl_xor(w_fb, off, 64); w_tiles += __shfl_xor(w_tiles, off, 64);
   }
-  if (lane == 0) { s_red[wave][0] = w_win; s_red[wave][1] = w_n; s_red[wave][2] = w_cand; s_red[wave][3] = w_fb; }
+  if (lane == 0) { s_red[wave][0] = w_win; s_red[wave][1] = w_n; s_red[wave][2] = w_cand; s_red[wave][3] = w_fb; s_red[wave][4] = w_tiles; }
   __syncthreads();
-  if (tid < 4) {
+  if (tid < kWorkDoubles) {
     double acc = 0.0;
     for (int w = 0; w < nwave; ++w) acc += s_red[w][tid];
-    work[b * 4 + tid] = acc;
+    work[b * kWorkDoubles + tid] = acc;
   }
 }
 
-// Stateless batch kernel (C-ABI seam S1): grid (count), one wave per search.
+// Stateless batch kernel (C-ABI seam S1): grid (count), one wave per search.  VARIANT 0 = exact, 1 = matrix-core walk.
 template <int VARIANT>
 __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__ images, int width, int height,
                                                      const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
                                                      const double* __restrict__ centre, const double* __restrict__ puinv,
                                                      int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
   const int i = blockIdx.x;
-  __shared__ __attribute__((aligned(16))) unsigned s_win[VARIANT == 3 ? 3 * kM4Plane / 4 : (VARIANT == 2 ? 3 * kMfPlaneDw : kWinRows * kWinPitchDw)];
-  __shared__ unsigned s_tpl[VARIANT >= 2 ? kMfTplDw : 1];
+  __shared__ __attribute__((aligned(16))) char s_pl[VARIANT == 1 ? 3 * kM4Plane : 16];
+  __shared__ unsigned s_tpl[VARIANT == 1 ? kMfTplDw : 1];
   const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
   const double a = puinv[i * 3], b = puinv[i * 3 + 1], c = puinv[i * 3 + 2];
   const SearchBounds sb = search_bounds(ce, a, b, c, width, height);
   const uint8_t* img = images + (size_t)image_index[i] * width * height;
   SearchResult r;
   r.code = -1;
-  if (VARIANT == 1) r = search_core_v1<false>(img, width, nullptr, patches + (size_t)i * 121, sb, a, b, c, s_win);
-  if (VARIANT == 2) r = search_core_mfma(img, width, patches + (size_t)i * 121, sb, a, b, c, s_win, s_tpl);
-  if (VARIANT == 3) r = search_core_m4(img, width, width * height, patches + (size_t)i * 121, sb, a, b, c, (char*)s_win, s_tpl);
+  if (VARIANT == 1) r = search_core_mfma(img, width, width * height, patches + (size_t)i * 121, sb, a, b, c, s_pl, s_tpl);
   if (r.code < 0) r = search_core_v0(img, width, patches + (size_t)i * 121, sb, a, b, c);
   if ((threadIdx.x & 63) == 0) {
     ok[i] = r.ok;
@@ -1668,35 +749,22 @@ namespace sl2 {
 
 int launch_search(sl2_engine* e) {
   {
-    LaunchScope ls(e, "k_search", true);
-    dim3 grid(xcd_grid(e->nsel_max, e->B));
-    if (e->root->search_variant == 2)
-      hipLaunchKernelGGL(k_search_packed, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
-                         e->srch_i, e->srch_d, e->sel_idx, e->pack_first, e->pack_count, e->n_packs, e->srch_res,
-                         e->meas_score, e->N, e->nsel_max, e->B);
-    else if (e->root->search_variant == 3) {
+    if (e->root->search_variant == 0) {
+      LaunchScope ls(e, "k_search_exact", true);
+      hipLaunchKernelGGL(k_search_exact, dim3(xcd_grid(e->nsel_max, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+                         e->cam.width, e->patch, e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N,
+                         e->nsel_max, e->B);
+    } else {
+      LaunchScope ls(e, "k_search_mfma", true);
       // positions per wavefront: kMfChunk when the batch fills the chip's wave slots (4096 at four per SIMD), fewer at
       // small batches - the positions of a wavefront run one after the other (18 us for four at batch 1)
       int chunk = (int)(((long long)e->B * e->nsel_max + 4095) / 4096);
       chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
-                         e->cam.width, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score, e->N, nchunks, e->B, chunk);
-    }
-    else if (e->root->search_variant == 4) {
-      int chunk = (int)(((long long)e->B * e->nsel_max + 4095) / 4096);
-      chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
-      const int nchunks = (e->nsel_max + chunk - 1) / chunk;
-      hipLaunchKernelGGL(k_search_m4, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,
                          e->N, nchunks, e->B, chunk);
     }
-    else if (e->root->search_variant == 0)
-      hipLaunchKernelGGL(k_search<0>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
-                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
-    else
-      hipLaunchKernelGGL(k_search<1>, grid, dim3(64), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width, e->patch,
-                         e->srch_i, e->srch_d, e->sel_idx, e->n_sel, e->srch_res, e->meas_score, e->N, e->nsel_max, e->B);
     SL2_HIP(hipGetLastError());
   }
   {
@@ -1729,7 +797,7 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
     set_error("sl2_elliptical_search_batch: null pointer or bad count");
     return SL2_ERR_INVALID;
   }
-  if (variant < 0 || variant > 3) return SL2_ERR_INVALID;
+  if (variant < 0 || variant > 1) { set_error("sl2_elliptical_search_batch: variant must be 0 (exact kernel) or 1 (matrix-core walk)"); return SL2_ERR_INVALID; }
   if (width < kBoxSize || height < kBoxSize) { set_error("sl2_elliptical_search_batch: image smaller than the 11x11 patch"); return SL2_ERR_INVALID; }
   for (int i = 0; i < count; ++i)
     if (image_index[i] < 0 || image_index[i] >= nimages) {
@@ -1770,10 +838,6 @@ extern "C" int sl2_elliptical_search_batch(int device, const uint8_t* images, in
   SL2_HIP(hipMemcpy(d_pu, puinv, sizeof(double) * 3 * count, hipMemcpyHostToDevice));
   if (variant == 0)
     hipLaunchKernelGGL(k_search_batch<0>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
-  else if (variant == 3)
-    hipLaunchKernelGGL(k_search_batch<3>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
-  else if (variant == 2)
-    hipLaunchKernelGGL(k_search_batch<2>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   else
     hipLaunchKernelGGL(k_search_batch<1>, dim3(count), dim3(64), 0, 0, d_img, width, height, d_idx, d_pat, d_ce, d_pu, d_ok, d_uv, d_sc);
   SL2_HIP(hipGetLastError());

@@ -23,8 +23,8 @@ from .config import load_config, read_pgm, resolve_identifier
 class Engine:
     """B independent MonoSLAM instances on one GPU (one HIP stream)."""
 
-    def __init__(self, cam, params, batch, max_features, device=0, stream=None):
-        self.L = _lib.load()
+    def __init__(self, cam, params, batch, max_features, device=0, stream=None, lib=None):
+        self.L = lib or _lib.load()          # lib = _lib.load_testing(): the TEST build (kernel variants, hooks)
         self.cam = dict(cam)
         self.params = dict(params)
         self.batch = int(batch)
@@ -34,9 +34,12 @@ class Engine:
         self._cam = _lib.make_camera(cam)
         self._prm = _lib.make_params(params)
         h = _lib.vp()
-        _lib.check(self.L.sl2_create(C.byref(self._cam), C.byref(self._prm), self.batch, self.max_features,
+        self._ck(self.L.sl2_create(C.byref(self._cam), C.byref(self._prm), self.batch, self.max_features,
                                      self.device, _lib.vp(stream) if stream else None, C.byref(h)))
         self.h = h
+
+    def _ck(self, rc):
+        _lib.check(rc, self.L)
 
     def close(self):
         if getattr(self, "h", None):
@@ -54,13 +57,13 @@ class Engine:
         xv = np.ascontiguousarray(xv, dtype=np.float64).reshape(-1, 13)
         Pxx = np.ascontiguousarray(Pxx, dtype=np.float64).reshape(-1, 13, 13)
         assert xv.shape[0] == Pxx.shape[0]
-        _lib.check(self.L.sl2_set_vehicle_state(self.h, seq0, xv.shape[0], _lib.dp(xv), _lib.dp(Pxx)))
+        self._ck(self.L.sl2_set_vehicle_state(self.h, seq0, xv.shape[0], _lib.dp(xv), _lib.dp(Pxx)))
 
     def get_vehicle_state(self, seq0=0, nseq=None):
         nseq = self.batch - seq0 if nseq is None else nseq
         xv = np.zeros((nseq, 13))
         Pxx = np.zeros((nseq, 13, 13))
-        _lib.check(self.L.sl2_get_vehicle_state(self.h, seq0, nseq, _lib.dp(xv), _lib.dp(Pxx)))
+        self._ck(self.L.sl2_get_vehicle_state(self.h, seq0, nseq, _lib.dp(xv), _lib.dp(Pxx)))
         return xv, Pxx
 
     def add_known_features(self, y, xp_org, patches, seq0=0):
@@ -69,13 +72,13 @@ class Engine:
         nseq, nfeat = y.shape[0], y.shape[1]
         xp = np.ascontiguousarray(xp_org, dtype=np.float64).reshape(nseq, nfeat, 7)
         p = np.ascontiguousarray(patches, dtype=np.uint8).reshape(nseq, nfeat, 121)
-        _lib.check(self.L.sl2_add_known_features(self.h, seq0, nseq, nfeat, _lib.dp(y), _lib.dp(xp), _lib.u8p(p)))
+        self._ck(self.L.sl2_add_known_features(self.h, seq0, nseq, nfeat, _lib.dp(y), _lib.dp(xp), _lib.u8p(p)))
 
     def set_feature_covariances(self, Pyy, seq0=0):
         """Pyy [nseq][nfeat][3][3]: prior covariance of the first nfeat features of each sequence."""
         P = np.ascontiguousarray(Pyy, dtype=np.float64)
         nseq, nfeat = P.shape[0], P.shape[1]
-        _lib.check(self.L.sl2_set_feature_covariances(self.h, seq0, nseq, nfeat, _lib.dp(P.reshape(nseq, nfeat, 9))))
+        self._ck(self.L.sl2_set_feature_covariances(self.h, seq0, nseq, nfeat, _lib.dp(P.reshape(nseq, nfeat, 9))))
 
     # ---- stepping ----------------------------------------------------------
     def _frames_arg(self, frames, seq_stride, on_device):
@@ -86,66 +89,66 @@ class Engine:
 
     def go_one_step(self, frames, save_trajectory=False, enable_mapping=False, on_device=False, seq_stride=0):
         ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
-        _lib.check(self.L.sl2_go_one_step(self.h, ptr, stride, dev, int(save_trajectory), int(enable_mapping)))
+        self._ck(self.L.sl2_go_one_step(self.h, ptr, stride, dev, int(save_trajectory), int(enable_mapping)))
         if keep is not None:
             self.synchronize()  # host buffer must outlive the async H2D copy
 
     def set_groups(self, groups):
-        _lib.check(self.L.sl2_set_groups(self.h, int(groups)))
+        self._ck(self.L.sl2_set_groups(self.h, int(groups)))
 
     def set_graph_mode(self, enabled=True):
-        _lib.check(self.L.sl2_set_graph_mode(self.h, int(bool(enabled))))
+        self._ck(self.L.sl2_set_graph_mode(self.h, int(bool(enabled))))
 
     def set_search_variant(self, variant):
-        _lib.check(self.L.sl2_set_search_variant(self.h, int(variant)))
+        self._ck(self.L.sl2_set_search_variant(self.h, int(variant)))
 
     def set_update_variant(self, chol_variant=1, fwd_variant=1):
-        _lib.check(self.L.sl2_set_update_variant(self.h, int(chol_variant), int(fwd_variant)))
+        self._ck(self.L.sl2_set_update_variant(self.h, int(chol_variant), int(fwd_variant)))
 
     def kalman_filter_predict(self):
-        _lib.check(self.L.sl2_kalman_filter_predict(self.h))
+        self._ck(self.L.sl2_kalman_filter_predict(self.h))
 
     def auto_select_n_features(self, n):
-        _lib.check(self.L.sl2_auto_select_n_features(self.h, int(n)))
+        self._ck(self.L.sl2_auto_select_n_features(self.h, int(n)))
 
     def make_measurements(self, frames, on_device=False, seq_stride=0):
         ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
-        _lib.check(self.L.sl2_make_measurements(self.h, ptr, stride, dev))
+        self._ck(self.L.sl2_make_measurements(self.h, ptr, stride, dev))
         if keep is not None:
             self.synchronize()
 
     def kalman_filter_update(self):
-        _lib.check(self.L.sl2_kalman_filter_update(self.h))
+        self._ck(self.L.sl2_kalman_filter_update(self.h))
 
     def finish_step(self, save_trajectory=False):
-        _lib.check(self.L.sl2_finish_step(self.h, int(save_trajectory)))
+        self._ck(self.L.sl2_finish_step(self.h, int(save_trajectory)))
 
     def synchronize(self):
-        _lib.check(self.L.sl2_synchronize(self.h))
+        self._ck(self.L.sl2_synchronize(self.h))
 
     # ---- state access ------------------------------------------------------
     def total_state_sizes(self, seq0=0, nseq=None):
         nseq = self.batch - seq0 if nseq is None else nseq
         out = np.zeros(nseq, dtype=np.int32)
-        _lib.check(self.L.sl2_get_total_state_sizes(self.h, seq0, nseq, _lib.ip(out)))
+        self._ck(self.L.sl2_get_total_state_sizes(self.h, seq0, nseq, _lib.ip(out)))
         return out
 
     def total_state(self, seq):
         n = int(self.total_state_sizes(seq, 1)[0])
         x = np.zeros(n)
-        _lib.check(self.L.sl2_get_total_state(self.h, seq, _lib.dp(x), n))
+        self._ck(self.L.sl2_get_total_state(self.h, seq, _lib.dp(x), n))
         return x
 
     def total_covariance(self, seq):
         n = int(self.total_state_sizes(seq, 1)[0])
         P = np.zeros((n, n))
-        _lib.check(self.L.sl2_get_total_covariance(self.h, seq, _lib.dp(P), n))
+        self._ck(self.L.sl2_get_total_covariance(self.h, seq, _lib.dp(P), n))
         return P
 
     def features(self, seq, include_deleted=False):
         arr = (_lib.sl2_feature_info * self.max_features)()
         cnt = C.c_int(0)
-        _lib.check(self.L.sl2_get_features(self.h, seq, arr, self.max_features, int(include_deleted), C.byref(cnt)))
+        self._ck(self.L.sl2_get_features(self.h, seq, arr, self.max_features, int(include_deleted), C.byref(cnt)))
         out = []
         for i in range(cnt.value):
             f = arr[i]
@@ -168,7 +171,7 @@ class Engine:
         ints = np.zeros(16, dtype=np.int32)
         dbl = np.zeros(9)
         parts = np.zeros((capacity, 12))
-        _lib.check(self.L.sl2_get_partial_feature(self.h, seq, _lib.ip(ints), _lib.dp(dbl), _lib.dp(parts), capacity))
+        self._ck(self.L.sl2_get_partial_feature(self.h, seq, _lib.ip(ints), _lib.dp(dbl), _lib.dp(parts), capacity))
         info = dict(n_partial=int(ints[0]), initialised=int(ints[12]), converted=int(ints[13]), deleted=int(ints[14]),
                     uu=int(ints[5]), vv=int(ints[6]), region_defined=int(ints[7]), ustart=int(ints[8]), vstart=int(ints[9]),
                     ufinish=int(ints[10]), vfinish=int(ints[11]), created=int(ints[15]), evbest=float(dbl[8]))
@@ -182,14 +185,14 @@ class Engine:
     def selection(self, seq):
         labels = np.zeros(self.max_features, dtype=np.int32)
         counters = np.zeros(3, dtype=np.int32)
-        _lib.check(self.L.sl2_get_selection(self.h, seq, _lib.ip(labels), self.max_features, _lib.ip(counters)))
+        self._ck(self.L.sl2_get_selection(self.h, seq, _lib.ip(labels), self.max_features, _lib.ip(counters)))
         return labels[:counters[1]].copy(), dict(visible=int(counters[0]), selected=int(counters[1]),
                                                  measurement_size=int(counters[2]))
 
     def trajectory(self, seq, capacity=1000):
         out = np.zeros((capacity, 3))
         cnt = C.c_int(0)
-        _lib.check(self.L.sl2_get_trajectory(self.h, seq, _lib.dp(out), capacity, C.byref(cnt)))
+        self._ck(self.L.sl2_get_trajectory(self.h, seq, _lib.dp(out), capacity, C.byref(cnt)))
         return out[:cnt.value].copy()
 
     def position_log(self, seq0=0, nseq=None, capacity=1000):
@@ -197,18 +200,19 @@ class Engine:
         nseq = self.batch - seq0 if nseq is None else nseq
         out = np.zeros((nseq, capacity, 3))
         cnt = C.c_int(0)
-        _lib.check(self.L.sl2_get_position_log(self.h, seq0, nseq, _lib.dp(out), capacity, C.byref(cnt)))
+        self._ck(self.L.sl2_get_position_log(self.h, seq0, nseq, _lib.dp(out), capacity, C.byref(cnt)))
         return out.reshape(-1)[: nseq * cnt.value * 3].reshape(nseq, cnt.value, 3).copy()
 
     def set_feature_counters(self, seq, label, attempted, successful):
         # test hook: lives in the TEST build of the library only (include/scenelib2_amd_testing.h)
-        _lib.check(_lib.load_testing().sl2_set_feature_counters(self.h, seq, label, attempted, successful))
+        T = _lib.load_testing()
+        _lib.check(T.sl2_set_feature_counters(self.h, seq, label, attempted, successful), T)
 
     def delete_features(self, labels, seq0=0):
         """mark_feature_by_lab + delete_feature, one label per sequence (-1: none); returns the per-sequence bool."""
         lab = np.ascontiguousarray(labels, dtype=np.int32)
         done = np.zeros(lab.size, dtype=np.int32)
-        _lib.check(self.L.sl2_delete_features(self.h, int(seq0), lab.size, _lib.ip(lab), _lib.ip(done)))
+        self._ck(self.L.sl2_delete_features(self.h, int(seq0), lab.size, _lib.ip(lab), _lib.ip(done)))
         return done.astype(bool)
 
     def initialise_feature(self, frames, uv, on_device=False, seq_stride=0):
@@ -216,41 +220,41 @@ class Engine:
         ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
         sel = np.ascontiguousarray(uv, dtype=np.int32).reshape(self.batch, 2)
         created = np.zeros(self.batch, dtype=np.int32)
-        _lib.check(self.L.sl2_initialise_feature(self.h, ptr, stride, dev, _lib.ip(sel), _lib.ip(created)))
+        self._ck(self.L.sl2_initialise_feature(self.h, ptr, stride, dev, _lib.ip(sel), _lib.ip(created)))
         return created.astype(bool)
 
     def initialise_auto_feature(self, frames, on_device=False, seq_stride=0):
         """MonoSLAM::InitialiseAutoFeature for every sequence; returns created [batch]."""
         ptr, stride, dev, keep = self._frames_arg(frames, seq_stride, on_device)
         created = np.zeros(self.batch, dtype=np.int32)
-        _lib.check(self.L.sl2_initialise_auto_feature(self.h, ptr, stride, dev, _lib.ip(created)))
+        self._ck(self.L.sl2_initialise_auto_feature(self.h, ptr, stride, dev, _lib.ip(created)))
         return created.astype(bool)
 
     def save_patch(self, seq, label, path):
         """MonoSLAM::SavePatch: Feature::patch_ of the feature with this label as PNG (or PGM by extension)."""
-        _lib.check(self.L.sl2_save_patch(self.h, int(seq), int(label), os.fsencode(path)))
+        self._ck(self.L.sl2_save_patch(self.h, int(seq), int(label), os.fsencode(path)))
 
     def feature_patch(self, seq, label):
         """Feature::patch_ of the feature with this label (11x11 uint8)."""
         out = np.zeros((11, 11), dtype=np.uint8)
-        _lib.check(self.L.sl2_get_feature_patch(self.h, int(seq), int(label), _lib.u8p(out)))
+        self._ck(self.L.sl2_get_feature_patch(self.h, int(seq), int(label), _lib.u8p(out)))
         return out
 
     def status_flags(self):
         out = np.zeros(self.batch, dtype=np.int32)
-        _lib.check(self.L.sl2_get_status_flags(self.h, 0, self.batch, _lib.ip(out)))
+        self._ck(self.L.sl2_get_status_flags(self.h, 0, self.batch, _lib.ip(out)))
         return out
 
     # ---- profiling -----------------------------------------------------------
     def set_profile_focus(self, names=""):
-        _lib.check(self.L.sl2_set_profile_focus(self.h, names.encode() if names else None))
+        self._ck(self.L.sl2_set_profile_focus(self.h, names.encode() if names else None))
 
     def set_profiling(self, level):
         """0 off, 1 roofline kernels only, 2 every launch."""
-        _lib.check(self.L.sl2_set_profiling(self.h, int(level)))
+        self._ck(self.L.sl2_set_profiling(self.h, int(level)))
 
     def reset_kernel_times(self):
-        _lib.check(self.L.sl2_reset_kernel_times(self.h))
+        self._ck(self.L.sl2_reset_kernel_times(self.h))
 
     def kernel_times(self):
         n = self.L.sl2_kernel_count(self.h)
@@ -259,15 +263,15 @@ class Engine:
             name = C.c_char_p()
             ms = C.c_double(0)
             cnt = C.c_int64(0)
-            _lib.check(self.L.sl2_get_kernel_time(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            self._ck(self.L.sl2_get_kernel_time(self.h, i, C.byref(name), C.byref(ms), C.byref(cnt)))
             out[name.value.decode()] = dict(total_ms=ms.value, launches=cnt.value)
         return out
 
     def step_work(self):
-        w = np.zeros(11)
-        _lib.check(self.L.sl2_get_step_work(self.h, _lib.dp(w)))
+        w = np.zeros(12)
+        self._ck(self.L.sl2_get_step_work(self.h, _lib.dp(w)))
         keys = ["window_bytes", "searched", "candidates", "sum_m", "sum_m2", "sum_m3", "sum_n", "sum_nm", "sum_nnm",
-                "sum_nmm", "search_fallbacks"]
+                "sum_nmm", "search_fallbacks", "search_tiles"]
         return dict(zip(keys, w.tolist()))
 
 

@@ -1,4 +1,4 @@
-"""Development aid: phase cycle stamps inside k_search_mfma (SL2_SEARCH_VARIANT=3, default) or k_search_packed (=2) (SL2_SEARCH_TRACE build:
+"""Development aid: phase cycle stamps inside k_search_mfma (SL2_SEARCH_TRACE build:
    make -C scenelib2_amd/csrc trace ; SL2_LIB_PATH=scenelib2_amd/libscenelib2_amd_trace.so python scripts/search_trace.py)."""
 import ctypes as C
 import os
@@ -32,14 +32,9 @@ def main():
     t = tr[act].astype(np.float64)
     print("active waves:", int(act.sum()))
     tot = (t[:, 6] - t[:, 0]).mean()
-    if os.environ.get("SL2_SEARCH_VARIANT", "3") == "3":     # k_search_mfma stamps: 0 = entry, 1 = first loads issued, 6 = exit
-        print("entry -> first template / band loads issued  mean %8.0f cycles" % (t[:, 1] - t[:, 0]).mean())
-        print("pipelined loop over the wavefront's positions mean %8.0f cycles" % (t[:, 6] - t[:, 1]).mean())
-    else:
-        d = np.diff(t[:, :7], axis=1)
-        names = ["descriptors+lane map", "staging", "template+ellipse mask", "column walk", "decision", "fallback"]
-        for i, nme in enumerate(names):
-            print("%-24s mean %8.0f cycles  (%4.1f %%)" % (nme, d[:, i].mean(), 100 * d[:, i].mean() / tot))
+    # k_search_mfma stamps: 0 = entry, 1 = first loads issued, 6 = exit
+    print("entry -> first template / band loads issued  mean %8.0f cycles" % (t[:, 1] - t[:, 0]).mean())
+    print("pipelined loop over the wavefront's positions mean %8.0f cycles" % (t[:, 6] - t[:, 1]).mean())
     print("total per wave mean %.0f cycles, p95 %.0f" % (tot, np.percentile(t[:, 6] - t[:, 0], 95)))
     print("launch span %.0f cycles" % (t[:, 6].max() - t[:, 0].min()))
 

@@ -18,7 +18,7 @@ class Pair:
     """B synthetic sequences: frames, oracle instances and one engine."""
 
     def __init__(self, n_features, n_frames, batch=1, cam=None, n_select=None, seq0=0, max_features=None,
-                 feature_counts=None, make_engine=True, feature_sigma=0.0, **spec_kw):
+                 feature_counts=None, make_engine=True, feature_sigma=0.0, lib=None, **spec_kw):
         self.cam = cam or synth.default_camera()
         self.N = n_features
         self.B = batch
@@ -50,7 +50,8 @@ class Pair:
             self.oracles.append(s)
         self.engine = None
         if make_engine:
-            self.engine = Engine(self.cam, self.params, batch, max_features or max(n_features, 1))
+            # lib = _lib.load_testing(): the TEST build of the library (superseded kernel variants, SL2_* switches)
+            self.engine = Engine(self.cam, self.params, batch, max_features or max(n_features, 1), lib=lib)
             self.engine.set_vehicle_state(np.stack([s.xv0 for s in self.specs]), np.stack([s.Pxx0 for s in self.specs]))
             for b in range(batch):
                 nf = self.specs[b].feat_y.shape[0]

@@ -35,6 +35,11 @@ def test_bench_line_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert d["parity"]["traj_rmse_vs_oracle"] <= 1e-4          # BASELINE.json's tolerance
+    # profiling scopes are kernel symbols (they join with rocprofv3's kernel_stats.csv); the search roofline carries its
+    # matrix-core floor next to the HBM fraction
+    assert {"k_syrk", "k_build_AS", "k_chol_left", "k_search_mfma", "k_search_score"} <= set(d["kernels"])
+    rs = d["roofline_search"]
+    assert rs["kernel"] == "k_search_mfma" and rs["mfma_floor_us"] > 0 and "valu_insts_per_search" in rs
 
 
 def test_bench_self_spawns_ranks():
@@ -51,6 +56,8 @@ def test_bench_self_spawns_ranks():
     assert d["n_gpus"] == 2 and d["gathered_states"] == 32 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]
     assert d["cpu_baseline"] is None                      # rank 0 at N = 1 only
+    # ... but every rank checks a sample of its own sequences against the reference build: values, not shapes
+    assert d["parity"]["ranks_checked"] == 2 and d["parity"]["traj_rmse_vs_oracle"] <= 1e-9
 
 
 def test_bench_rccl_path_single_rank():
@@ -85,4 +92,5 @@ def test_bench_under_torch_distributed_run():
     assert len(lines) == 1, out.stdout[-1500:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["gathered_states"] == 32 and d["steps"] == 3 and d["warmup"] == 2
+    assert d["parity"]["ranks_checked"] == 2 and d["parity"]["traj_rmse_vs_oracle"] <= 1e-9
     assert abs(d["value"] - 2 * 16 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]

@@ -113,6 +113,7 @@ def per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W,
     """A rank's leg of the parity check in a multi-GPU run: the first `nseq` sequences of this rank's shard, the first
     `nframes` frames, against oracle/_ref/libref.so (the oracle restatement when that library is absent), on the same
     bytes the GPU consumed.  All ranks call this (it ends in two collectives); returns the job-wide summary."""
+    from scenelib2_amd import sharding
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as oa
     use_ref = oa.ref_available()

@@ -31,6 +31,7 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
 // registers and loops over the features (3 coalesced row reads of P + 2 coalesced row
 // writes of At per feature, each a full contiguous row for the workgroup).
 // ---------------------------------------------------------------------------
+#ifdef SL2_TESTING   // maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
 __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                  const int* __restrict__ succ_idx, const int* __restrict__ m_count,
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, c
     }
   }
 }
+#endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
 // k_build_AS: k_build_A and k_build_S in one pass (state sizes up to 1024 columns): the rows of
@@ -194,12 +196,325 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   }
 }
 
+#ifdef SL2_TESTING
+// ---------------------------------------------------------------------------
+// k_build_AS_tiles (round 3; TEST build, SL2_BUILD_VARIANT=2): A^T = (P H^T)^T and S = H A + R from the UPPER block
+// triangle of P only.  Correct (the parity tests pass on it) and it moves 1.2 GB instead of 1.64, but it is SLOWER than
+// k_build_AS: 0.44 ms per launch against 0.29-0.30 on the same box (profiles/r03_build_tiles_*).  What it costs is not bytes
+// but the life of a workgroup: ~34 k cycles of which 60 % are waits (two dependent memory round trips, nine barriers, serial
+// per-thread chains), at two workgroups per CU because the tile, the staged results and the records take 80 KB of LDS.
+// k_build_AS keeps 20 waves per CU streaming full rows.  Kept as the measured alternative; DESIGN.md section 9.
+//
+// k_build_AS above streams the three rows of P of every measured feature in full - all of P, both triangles: 0.8 GB of
+// the launch's 1.64 GB at batch 1024 x 100 features - with one workgroup per sequence walking 25 dependent batches.  Here
+// one workgroup owns one 64 x 64 tile (I, J), J >= I, of a sequence's P (the tiles k_syrk works on), loads it once into
+// LDS and produces every entry of A^T that needs it:
+//   row role     A^T[a_f][j], j in J, for the measured features f whose first state index lies in tile row I
+//                (sum_c Hy[c] P[pos_f + c][j]: rows of the tile), and
+//   column role  A^T[a_f][i], i in I, for the features of tile column J (sum_c Hy[c] P[i][pos_f + c]: columns of the
+//                tile, i.e. the lower-triangle entries P[pos_f + c][i] read through their mirrors), I < J only;
+// the pose part sum_c Hx[c] P[c][.] comes from the seven pose rows over the same columns.  Every entry of A^T is written
+// exactly once, in 512-byte row segments.  A feature whose three rows straddle a tile boundary is handled with two halo
+// rows / columns around the tile (for a diagonal tile the halo rows are the mirrors of the halo columns).
+// The measurements are stacked in SLOT order (k_search_score), so the features of a tile are consecutive rows of A^T and
+// S[t][k] = Hx_t A^T[k][0..6] + Hy_t A^T[k][pos_t ..] for (k in I, t in J) is a contiguous block of the k-major S,
+// formed here from the row-role results still in LDS (A^T[k][0..6] is recomputed from the pose rows: 70 multiply-adds).
+// Summation order of every entry = that of k_build_A / k_build_AS.
+// Traffic at batch 1024 x 100 features: 0.5 GB of P (15 tiles) + 0.57 GB of A^T + 0.16 GB of S instead of 1.64 GB, and
+// 15 independent workgroups per sequence instead of one chain.
+// ---------------------------------------------------------------------------
+constexpr int kBtF = 22;          // measured features whose first state index lies in one 64-wide tile: at most ceil(64 / 3)
+constexpr int kBtW = 66;          // tile edge + two halo rows / columns
+constexpr int kBtP = 67;          // LDS pitch of the tile (odd: column reads are conflict-free)
+constexpr int kBtFD = 24;         // doubles per feature record: Hx[2][7], Hy[2][3], R, nu[2], local position
+constexpr int kBtThreads = 512;
+
+// One output row of A^T over eight columns, with the row's ten coefficients in registers: the summation order of k_build_A
+// (pose part c = 0..6, then the feature's three rows / columns).  ROWS: the feature's states are rows of the tile (row
+// role), else columns (column role).
+template <bool ROWS>
+__device__ __forceinline__ void bt_row_chunk(const double* __restrict__ sT, const double* __restrict__ pose, const double* __restrict__ F,
+                                             int r, int j0, int nj, int jstep, double* __restrict__ out) {
+  double hx[7], hy[3];
+#pragma unroll
+  for (int c = 0; c < 7; ++c) hx[c] = F[r * 7 + c];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) hy[c] = F[14 + r * 3 + c];
+  const int lp = (int)F[23];
+#pragma unroll 4
+  for (int jj = 0; jj < nj; ++jj) {
+    const int j = j0 + jj * jstep;     // (lanes of one row take neighbouring columns: LDS banks)
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < 7; ++c) acc += pose[c * kBtW + j] * hx[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc += (ROWS ? sT[(lp + c) * kBtP + j] : sT[j * kBtP + lp + c]) * hy[c];
+    out[j] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __restrict__ P, const double* __restrict__ f_Hx,
+                                                               const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
+                                                               const double* __restrict__ f_R, const int* __restrict__ succ_idx,
+                                                               const int* __restrict__ m_count, double* __restrict__ At,
+                                                               double* __restrict__ St, int N, int ld, int mld, int B) {
+  int b, t;
+  const int nt = ld / 64;
+  if (!xcd_map(nt * (nt + 1) / 2, B, &b, &t)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  int tj = 0;
+  while (t > tj) { t -= tj + 1; ++tj; }
+  const int ti = t;                       // ti <= tj
+  const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
+  const int tid = threadIdx.x;
+  const int r0 = ti * 64, c0 = tj * 64;
+  const bool diag = ti == tj;
+  const int* sidx = succ_idx + (size_t)b * N;
+  const double* Pb = P + (size_t)b * ld * ld;
+  double* Ab = At + (size_t)b * mld * ld;
+  double* Sb = St + (size_t)b * mld * mld;
+
+  __shared__ double sT[kBtW * kBtP];           // the tile with its halo: sT[i][j] = P[r0 + i][c0 + j]
+  __shared__ double sPose[2][7][kBtW];         // [0]: pose rows over the columns of J, [1]: over the columns of I
+  __shared__ double sXX[7][7];                 // P[c][c'], c, c' < 7
+  __shared__ double sF[2][kBtF][kBtFD];        // [0]: the measured features of tile row I, [1]: of tile column J
+  __shared__ double sA[2 * kBtF][kBtW];        // results of a role (the row role with its two halo columns: what S is formed from)
+  __shared__ double sU[2][2 * kBtF][7];        // A^T[k][0..6] of the features of I ([0]) and of J ([1])
+  __shared__ int sIdx[256];                    // the first entries of succ_idx
+
+  // ---- every global load the workgroup needs is requested before the first wait: the tile (four 16-byte pieces per
+  // lane), its halo, the pose rows and the measurement list.  (Loaded phase by phase - list, records, tile, halo, pose
+  // rows, each loop iteration waiting for its own data - a workgroup lived through ~15 memory round trips: 0.69 ms per
+  // launch against 0.30 for k_build_AS.) ----
+  double2 tv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
+    tv[u] = *(const double2*)(Pb + (size_t)(r0 + row) * ld + c0 + c2);
+  }
+  // halo columns (P[r0 + i][c0 + 64 + h]), halo rows (P[r0 + 64 + h][c0 + j]; in a diagonal tile the mirrors of the halo
+  // columns: the tile below the diagonal one is a lower tile) and the corner
+  double hv = 0.0;
+  if (tid < 128) {
+    if (c0 + 64 < ld) hv = Pb[(size_t)(r0 + (tid >> 1)) * ld + c0 + 64 + (tid & 1)];
+  } else if (tid < 256) {
+    if (!diag && r0 + 64 < ld) hv = Pb[(size_t)(r0 + 64 + (tid & 1)) * ld + c0 + ((tid - 128) >> 1)];
+  } else if (tid < 260) {
+    if (r0 + 64 < ld && c0 + 64 < ld) hv = Pb[(size_t)(r0 + 64 + ((tid - 256) >> 1)) * ld + c0 + 64 + (tid & 1)];
+  } else if (tid < 320) {
+    if (tid - 260 < 49) hv = Pb[(size_t)((tid - 260) / 7) * ld + ((tid - 260) % 7)];
+  }
+  // pose rows: what k_build_A reads as pc[c] of column i: P[i][c] for i < 13 (the vehicle block is general), else P[c][i]
+  double pv[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + kBtThreads * u;
+    double v = 0.0;
+    if (idx < 2 * 7 * kBtW) {
+      const int side = idx / (7 * kBtW), rem = idx - side * (7 * kBtW);
+      const int c = rem / kBtW, jj = rem - c * kBtW;
+      const int col = (side ? r0 : c0) + jj;
+      if (col < ld) v = (col < 13) ? Pb[(size_t)col * ld + c] : Pb[(size_t)c * ld + col];
+    }
+    pv[u] = v;
+  }
+
+  // ---- ranks of the first measured feature of tile rows ti, ti + 1, tj, tj + 1 (succ_idx is ascending) ----
+  int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+  for (int i0 = 0; i0 < cnt; i0 += kBtThreads) {
+    const int fv = (i0 + tid < cnt) ? sidx[i0 + tid] : -1;
+    if (i0 == 0 && tid < 256) sIdx[tid] = fv;
+    const int tl = fv >= 0 ? ((13 + 3 * fv) >> 6) : 0x3fffffff;
+    n0 += __syncthreads_count(tl < ti);
+    n1 += __syncthreads_count(tl <= ti);
+    n2 += __syncthreads_count(tl < tj);
+    n3 += __syncthreads_count(tl <= tj);
+  }
+  const int nfI = n1 - n0, nfJ = diag ? 0 : n3 - n2;     // <= kBtF each (the features of a diagonal tile are all "I")
+  const int aI = 2 * n0, aJ = 2 * n2;                    // first row of A^T / S of either group
+  const bool work = nfI > 0 || nfJ > 0;
+
+  if (work) {
+    // ---- feature records ----
+    const int nrec = (nfI + nfJ) * kBtFD;
+    double rv[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int idx = tid + kBtThreads * u;
+      double v = 0.0;
+      if (idx < nrec) {
+        const int e = idx / kBtFD, q = idx - e * kBtFD;
+        const int side = e < nfI ? 0 : 1, el = side ? e - nfI : e;
+        const int li = (side ? n2 : n0) + el;
+        const int f = li < 256 ? sIdx[li] : sidx[li];
+        const size_t fi = (size_t)b * N + f;
+        if (q < 14) v = f_Hx[fi * 14 + q];
+        else if (q < 20) v = f_Hy[fi * 6 + (q - 14)];
+        else if (q == 20) v = f_R[fi];
+        else if (q < 23) v = f_nu[fi * 2 + (q - 21)];
+        else v = (double)(13 + 3 * f - (side ? c0 : r0));
+      }
+      rv[u] = v;
+    }
+    // ---- everything into LDS ----
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
+      sT[row * kBtP + c2] = tv[u].x;
+      sT[row * kBtP + c2 + 1] = tv[u].y;
+    }
+    if (tid < 128) {
+      const int i = tid >> 1, h = tid & 1;
+      sT[i * kBtP + 64 + h] = hv;
+      if (diag) sT[(64 + h) * kBtP + i] = hv;
+    } else if (tid < 256) {
+      if (!diag) sT[(64 + (tid & 1)) * kBtP + ((tid - 128) >> 1)] = hv;
+    } else if (tid < 260) {
+      sT[(64 + ((tid - 256) >> 1)) * kBtP + 64 + (tid & 1)] = hv;
+    } else if (tid < 309) {
+      sXX[(tid - 260) / 7][(tid - 260) % 7] = hv;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + kBtThreads * u;
+      if (idx < 2 * 7 * kBtW) (&sPose[0][0][0])[idx] = pv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int idx = tid + kBtThreads * u;
+      if (idx < nrec) (&sF[0][0][0])[idx < nfI * kBtFD ? idx : (kBtF * kBtFD + idx - nfI * kBtFD)] = rv[u];
+    }
+  }
+  __syncthreads();
+
+  if (work) {
+    // ---- row role: A^T[aI + 2 e + r][c0 + j] -> sA; a thread owns one output row over eight columns (chunk 8 = the two
+    // halo columns, kept for S only: they belong to the next tile column of A^T) ----
+    if (tid < 2 * nfI * 9) {
+      const int a = tid / 9, ch = tid - a * 9;
+      bt_row_chunk<true>(sT, &sPose[0][0][0], sF[0][a >> 1], a & 1, ch < 8 ? ch : 64, ch < 8 ? 8 : 2, ch < 8 ? 8 : 1, sA[a]);
+      if (c0 + 64 == ld && ch == 7) sA[a][63] = sF[0][a >> 1][21 + (a & 1)];       // column ld - 1 carries the innovation
+    }
+    // ---- A^T[k][0..6] of both groups (columns < 13: the pose part reads P[c][c'], the feature part the pose rows at the
+    // feature's own columns, i.e. the mirrors of P[pos + c'][c]) ----
+    for (int idx = tid; idx < (nfI + nfJ) * 14; idx += kBtThreads) {
+      const int e = idx / 14, rc = idx - e * 14, r = rc / 7, c = rc - r * 7;
+      const int side = e < nfI ? 0 : 1, el = side ? e - nfI : e;
+      const double* F = sF[side][el];
+      const int lp = (int)F[23];
+      double acc = 0.0;
+#pragma unroll
+      for (int c2 = 0; c2 < 7; ++c2) acc += sXX[c][c2] * F[r * 7 + c2];
+#pragma unroll
+      for (int c2 = 0; c2 < 3; ++c2) acc += sPose[side ? 0 : 1][c][lp + c2] * F[14 + r * 3 + c2];
+      sU[side][2 * el + r][c] = acc;
+    }
+  }
+  __syncthreads();
+
+  if (work && nfI > 0) {
+    // ---- the row-role results leave in 512-byte row segments ----
+    for (int idx = tid; idx < 2 * nfI * 32; idx += kBtThreads) {
+      const int a = idx >> 5, c2 = (idx & 31) * 2;
+      double2 v;
+      v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
+      *(double2*)(Ab + (size_t)(aI + a) * ld + c0 + c2) = v;
+    }
+    // ---- S: St[k][t] = H_t . A_k for k in the rows of I, t in the rows of J (stored where (t | 31) >= k: the blocks on and
+    // below the block diagonal and the full diagonal blocks).  A thread owns one t (its coefficients in registers) and walks
+    // the k's of its wavefront. ----
+    const int sj = diag ? 0 : 1;
+    const int nk = 2 * nfI, ntt = 2 * (diag ? nfI : nfJ);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (lane < ntt) {
+      const int tt = lane, at = aJ + tt;
+      const double* Ft = sF[sj][tt >> 1];
+      const int r = tt & 1, lp = (int)Ft[23];
+      double hx[7], hy[3];
+#pragma unroll
+      for (int c = 0; c < 7; ++c) hx[c] = Ft[r * 7 + c];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) hy[c] = Ft[14 + r * 3 + c];
+      const double Rt = Ft[20];
+      for (int kk = wv; kk < nk; kk += kBtThreads / 64) {
+        const int ak = aI + kk;
+        if ((at | 31) >= ak) {
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) acc += hx[c] * sU[0][kk][c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) acc += hy[c] * sA[kk][lp + c];
+          if (at == ak) acc += Rt;
+          Sb[(size_t)ak * mld + at] = acc;
+        }
+        // the transposed position St[t][k] = H_k . A_t is stored too where row t and column k share a diagonal 32-block
+        // (features of two tiles inside one block of S): A_t at the columns of feature k is a column-role value
+        if (!diag && (ak | 31) >= at) {
+          const double* Fk = sF[0][kk >> 1];
+          const int rk = kk & 1, lpk = (int)Fk[23];
+          double acc = 0.0;
+#pragma unroll
+          for (int c = 0; c < 7; ++c) acc += Fk[rk * 7 + c] * sU[1][tt][c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double a_tc = 0.0;                     // A^T[at][r0 + lpk + c], as the column role forms it
+#pragma unroll
+            for (int c2 = 0; c2 < 7; ++c2) a_tc += sPose[1][c2][lpk + c] * hx[c2];
+#pragma unroll
+            for (int c2 = 0; c2 < 3; ++c2) a_tc += sT[(lpk + c) * kBtP + lp + c2] * hy[c2];
+            acc += Fk[14 + rk * 3 + c] * a_tc;
+          }
+          Sb[(size_t)at * mld + ak] = acc;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- column role: A^T[aJ + 2 e + r][r0 + i] through the mirrors P[i][pos + c] (sA is free again) ----
+  if (nfJ > 0) {
+    if (tid < 2 * nfJ * 8) {
+      const int a = tid >> 3, ch = tid & 7;
+      bt_row_chunk<false>(sT, &sPose[1][0][0], sF[1][a >> 1], a & 1, ch, 8, 8, sA[a]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2 * nfJ * 32; idx += kBtThreads) {
+      const int a = idx >> 5, c2 = (idx & 31) * 2;
+      double2 v;
+      v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
+      *(double2*)(Ab + (size_t)(aJ + a) * ld + r0 + c2) = v;
+    }
+  }
+
+  // ---- padding: rows of A^T up to the 32-multiple are zero (each diagonal-tile workgroup clears its 64 columns); S is the
+  // identity there (first workgroup of the sequence) ----
+  if (diag) {
+    for (int idx = tid; idx < (mp - m) * 64; idx += kBtThreads) Ab[(size_t)(m + (idx >> 6)) * ld + c0 + (idx & 63)] = 0.0;
+    if (tj == 0) {
+      const int npad = mp - m;
+      for (int idx = tid; idx < mp * npad; idx += kBtThreads) {       // columns m .. mp of every row
+        const int k = idx / npad, tcol = m + (idx - k * npad);
+        Sb[(size_t)k * mld + tcol] = (k == tcol) ? 1.0 : 0.0;
+      }
+      const int nlow = m - (mp - 32);                                 // rows m .. mp: the measured columns of the last block
+      for (int idx = tid; idx < npad * nlow; idx += kBtThreads) {
+        const int k = m + idx / nlow, tcol = (mp - 32) + (idx - (idx / nlow) * nlow);
+        Sb[(size_t)k * mld + tcol] = 0.0;
+      }
+    }
+  }
+}
+
+#endif  // SL2_TESTING
+
 // ---------------------------------------------------------------------------
 // k_build_S: S = H A + R, stored St[c][r] = S[r][c] (32x32 blocks on and below the block
 // diagonal; the factorisation reads r >= c plus the full diagonal blocks).  Padding: identity.  A thread owns one row
 // a of H (its 10 non-zeros in registers) and loops over 32 columns bb: per column
 // 7 wave-uniform loads (pose part of At row bb) + 3 gathered loads within that row.
 // ---------------------------------------------------------------------------
+#ifdef SL2_TESTING   // maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
 __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, const double* __restrict__ f_Hx,
                                                  const double* __restrict__ f_Hy, const double* __restrict__ f_R,
                                                  const int* __restrict__ succ_idx, const int* __restrict__ m_count,
@@ -247,6 +562,7 @@ __global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, 
     Sb[(size_t)bb * mld + a] = v;
   }
 }
+#endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
 // Blocked Cholesky of S (right-looking over 32x32 blocks, three launches per
@@ -1576,19 +1892,43 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
 // kernel_stats.csv join on the name); "@phase" tells two uses of one kernel apart (k_fwdsub_lds is also the panel solve of
 // the large-map Cholesky).
 static int launch_update_range(sl2_engine* e) {
-  const int B = e->B;     // (succ_idx / m_count, the successful measurements in selection order, come from k_search_score)
+  const int B = e->B;     // (succ_idx / m_count, the successful measurements in slot order, come from k_search_score)
 #ifdef SL2_TESTING
   const int build_variant = e->root->build_variant, chol_variant = e->root->chol_variant, fwd_variant = e->root->fwd_variant;
 #else
-  const int build_variant = 1, chol_variant = 1, fwd_variant = 1;
+  const int chol_variant = 1, fwd_variant = 1;
 #endif
-  if (e->ld <= 2048 && e->mld <= 1024 && build_variant == 1) {
+#ifdef SL2_TESTING
+  if (build_variant == 2) {
+    // A^T and S from the upper block triangle of P: one workgroup per 64 x 64 tile (measured slower: see the kernel)
+    LaunchScope ls(e, "k_build_AS_tiles", true);
+    const int nt = e->ld / 64;
+    hipLaunchKernelGGL(k_build_AS_tiles, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
+                       e->f_nu, e->f_R, e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld, B);
+    SL2_HIP(hipGetLastError());
+  } else if (build_variant == 0) {
+    {
+      LaunchScope ls(e, "k_build_A", true);
+      const int threads = e->ld <= 512 ? e->ld : 512;
+      hipLaunchKernelGGL(k_build_A, dim3(B), dim3(threads), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx,
+                         e->m_count, e->At, e->N, e->ld, e->mld);
+      SL2_HIP(hipGetLastError());
+    }
+    {
+      LaunchScope ls(e, "k_build_S");
+      dim3 grid(e->mld / 32, (e->mld + 255) / 256, B);
+      hipLaunchKernelGGL(k_build_S, grid, dim3(256), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
+                         e->St, e->N, e->ld, e->mld);
+      SL2_HIP(hipGetLastError());
+    }
+  } else
+#endif
+  {
+    // sl2_create admits maps of up to 2048 state columns / 512 measured features
     LaunchScope ls(e, "k_build_AS", true);
-    // workgroups per sequence: enough to put ~512 on the chip
     // One workgroup per sequence from batch 1024 on (one exact round of four per CU at 1024; it needs the launch in front
-    // of it - k_search_score - to consist of single-wave workgroups, see launch_search: 0.33-0.35 ms on every box tried;
-    // three workgroups per sequence are indifferent to what ran before but take 0.346-0.377 depending on the box).  Smaller
-    // batches: ~3000 workgroups in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
+    // of it - k_search_score - to consist of single-wave workgroups, see launch_search).  Smaller batches: ~3000 workgroups
+    // in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
     int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
     if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
     if (nsplit < 1) nsplit = 1;
@@ -1604,21 +1944,6 @@ static int launch_update_range(sl2_engine* e) {
                          e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
     }
     SL2_HIP(hipGetLastError());
-  } else {      // maps beyond 2048 state columns / 512 measured features: A, then S from A
-    {
-      LaunchScope ls(e, "k_build_A", true);
-      const int threads = e->ld <= 512 ? e->ld : 512;
-      hipLaunchKernelGGL(k_build_A, dim3(B), dim3(threads), 0, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx,
-                         e->m_count, e->At, e->N, e->ld, e->mld);
-      SL2_HIP(hipGetLastError());
-    }
-    {
-      LaunchScope ls(e, "k_build_S");
-      dim3 grid(e->mld / 32, (e->mld + 255) / 256, B);
-      hipLaunchKernelGGL(k_build_S, grid, dim3(256), 0, e->stream, e->At, e->f_Hx, e->f_Hy, e->f_R, e->succ_idx, e->m_count,
-                         e->St, e->N, e->ld, e->mld);
-      SL2_HIP(hipGetLastError());
-    }
   }
   // sl2_create sizes the innovation system so that one of the first two branches always applies (mld a multiple of 128
   // beyond kFusedMaxBlocks blocks)

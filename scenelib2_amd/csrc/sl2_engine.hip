@@ -292,6 +292,12 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (e->mld / 32 > 13) e->mld = round_up(2 * nsel, 64);    // beyond the one-launch substitution: 64-row tiles (k_fwd_gemm)
   if (e->mld / 32 > 16) e->mld = round_up(2 * nsel, 128);   // large systems are factored in 128-column panels
   e->nblk_max = e->mld / 32;
+#ifndef SL2_TESTING
+  if (e->ld > 2048 || e->mld > 1024) {   // k_build_AS: two state columns per thread of a 1024-thread workgroup, one H row per thread
+    set_error("sl2_create: at most 676 feature slots (2048 state columns) and 512 features measured per frame");
+    return SL2_ERR_CAPACITY;
+  }
+#endif
   const size_t B = batch, N = max_features, ld = e->ld, mld = e->mld;
   int r = SL2_OK;
 #define A(call) do { r = (call); if (r != SL2_OK) { return r; } } while (0)

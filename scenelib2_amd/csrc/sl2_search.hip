@@ -635,8 +635,8 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
 }
 
 // One workgroup per sequence, one thread per selected position.  Besides the deferred FP64 scores and the reference's
-// bookkeeping it compacts the successful measurements in selected_feature_list_ order (construct_total_measurement_stuff,
-// monoslam.cpp:548-572: succ_idx / m_count, what the EKF update reads) and leaves the step's work counters - a launch
+// bookkeeping it compacts the successful measurements (succ_idx / m_count, what the EKF update reads: see the comment at
+// the compaction) and leaves the step's work counters - a launch
 // of its own for the compaction and a memset + atomics for the counters were 10 us of a single-sequence step.
 __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ srch_res, const int* __restrict__ srch_i,
                                                        const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
@@ -647,20 +647,21 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        double* __restrict__ meas_score, double* __restrict__ work,
                                                        int* __restrict__ succ_idx, int* __restrict__ m_count, int N) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
+  extern __shared__ int s_flag[];        // [N] successful measurement of slot i in this frame
   __shared__ int s_wcnt[16];
   __shared__ double s_red[16][kWorkDoubles];
   const int ns = n_sel[b];
   double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0, w_tiles = 0.0;
-  int base = 0;
+  for (int i = tid; i < N; i += (int)blockDim.x) s_flag[i] = 0;
+  __syncthreads();
   for (int k0 = 0; k0 < ns; k0 += (int)blockDim.x) {
     const int k = k0 + tid;
-    int ok = 0, f = 0;
     if (k < ns) {
-      f = sel_idx[(size_t)b * N + k];
+      const int f = sel_idx[(size_t)b * N + k];
       const size_t fi = (size_t)b * N + f;
       const int* o = srch_res + ((size_t)b * N + k) * 8;
       const int code = o[0];
-      ok = (o[7] & 2) ? 1 : 0;
+      int ok = (o[7] & 2) ? 1 : 0;
       double score = meas_score[(size_t)b * N + k];
       if (code == 1) {   // deferred: the only candidate that can win; reference FP64 score + thresholds
         const unsigned* packed = (const unsigned*)(patch + fi * kPatchStride + kPatchPackedOffset);
@@ -678,6 +679,7 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
         f_z[fi * 2] = (double)o[1]; f_z[fi * 2 + 1] = (double)o[2];
         f_nu[fi * 2] = (double)o[1] - h0; f_nu[fi * 2 + 1] = (double)o[2] - h1;   // func_nui
         fl |= FF_SUCCESS;
+        s_flag[f] = 1;
       } else {
         fl &= ~FF_SUCCESS;
       }
@@ -687,8 +689,17 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
       w_n += 1.0; w_cand += (double)o[6]; w_fb += (o[7] & 4) ? 1.0 : 0.0;
       w_tiles += (double)(((si[3] > 0 ? si[3] : 0) + 15) >> 4) * (double)(((si[5] > 0 ? si[5] : 0) + 15) >> 4);
     }
-    // order-preserving compaction of the successes of this round of positions
-    const unsigned long long mask = __ballot(ok != 0);
+  }
+  __syncthreads();
+  // The successful measurements, compacted in SLOT order (= feature_list_ order).  The reference stacks them in
+  // selected_feature_list_ order (construct_total_measurement_stuff, monoslam.cpp:548-572); any order of the rows of H gives
+  // the same update, and with this one the features of a 64-column tile of P are consecutive rows of A^T and consecutive
+  // rows / columns of S, which is what lets k_build_AS_tiles write whole blocks (sl2_ekf_update.hip).
+  int base = 0;
+  for (int i0 = 0; i0 < N; i0 += (int)blockDim.x) {
+    const int i = i0 + tid;
+    const bool ok = i < N && s_flag[i] != 0;
+    const unsigned long long mask = __ballot(ok);
     if (lane == 0) s_wcnt[wave] = __popcll(mask);
     __syncthreads();
     int off = base, total = 0;
@@ -697,7 +708,7 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
       if (w < wave) off += c;
       total += c;
     }
-    if (ok) succ_idx[(size_t)b * N + off + __popcll(mask & ((1ull << lane) - 1ull))] = f;
+    if (ok) succ_idx[(size_t)b * N + off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
     base += total;
     __syncthreads();
   }
@@ -778,7 +789,7 @@ int launch_search(sl2_engine* e) {
     if (threads > 1024) threads = 1024;
     if (e->B >= 256) threads = 64;
     if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
-    hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), 0, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
+    hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * e->N, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
                        e->succ_idx, e->m_count, e->N);
     SL2_HIP(hipGetLastError());

@@ -388,6 +388,25 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("build_variant,n_features", [(2, 100), (2, 37), (2, 7), (0, 60)])
+def test_build_variants_of_the_test_library(build_variant, n_features, monkeypatch):
+    """The measured alternatives to k_build_AS kept in the TEST build: k_build_AS_tiles (SL2_BUILD_VARIANT=2: A^T and S from
+    the upper block triangle of P, tile by tile, with features that straddle a tile boundary) and the two-pass k_build_A +
+    k_build_S (0).  Same filter as the oracle, deletions included."""
+    from scenelib2_amd import _lib
+    monkeypatch.setenv("SL2_BUILD_VARIANT", str(build_variant))
+    pr = Pair(n_features, 6, batch=3, feature_sigma=0.004, lib=_lib.load_testing())
+    monkeypatch.delenv("SL2_BUILD_VARIANT", raising=False)
+    for k in range(6):
+        if k == 3 and n_features > 10:
+            for b in range(3):                              # a retired slot in the middle of the map
+                pr.oracles[b].delete_feature(4 + b)
+            pr.engine.delete_features(np.array([4, 5, 6], dtype=np.int32))
+        pr.step_both(k)
+        pr.compare_state(1e-9, 1e-8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n_features", [5, 24, 60, 100])
 def test_both_substitution_kernels_on_small_batches(n_features, monkeypatch):
     """Up to eight sequences the forward substitution runs in k_fwdsub_ksplit (a block row's products dealt to four waves), larger

@@ -134,7 +134,8 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
  * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
  * enable_mapping != 0 runs the feature-initialisation tail (monoslam.cpp:152-170: AutoInitialiseFeature behind the
  * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) for the shipped max_features_to_init_at_once = 1 and up to
- * 128 particles; other settings are rejected with SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not take a
+ * 1024 depth particles (params.number_of_particles; the shipped value is 100); other settings are rejected with
+ * SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not take a
  * new feature because all max_features slots hold live features. */
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
                     int save_trajectory, int enable_mapping);

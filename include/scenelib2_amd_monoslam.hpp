@@ -397,8 +397,8 @@ class MonoSLAM {
     // feature_init_info_vector_ (at most one entry: max_features_to_init_at_once = 1 is what the device path runs)
     int32_t pi[16];
     double pd[9];
-    std::vector<double> parts((size_t)128 * 12);
-    check(sl2_get_partial_feature(eng_, 0, pi, pd, parts.data(), 128), "sl2_get_partial_feature");
+    std::vector<double> parts((size_t)1024 * 12);            // params.number_of_particles <= 1024
+    check(sl2_get_partial_feature(eng_, 0, pi, pd, parts.data(), 1024), "sl2_get_partial_feature");
     feature_init_info_vector_.clear();
     uu_ = pi[5]; vv_ = pi[6];
     init_feature_search_region_defined_flag_ = pi[7] != 0;

@@ -42,7 +42,7 @@ enum : int {
 
 constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
 // feature initialisation (one partially initialised feature per sequence)
-constexpr int kMaxParticles = 128;       // upper bound of params.number_of_particles
+constexpr int kMaxParticles = 1024;      // upper bound of params.number_of_particles (k_map_particles: one thread per particle)
 constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2], z[2], SInv(00,01,11), detS, success
 constexpr int kPartInts = 16, kPartDoubles = 4;   // per-sequence record of the partial feature (part_i / part_d)
 enum : int { kPartActive = 0, kPartLabel, kPartAttempts, kPartNp, kPartMaking, kPartUU, kPartVV, kPartRegionValid,
@@ -125,10 +125,11 @@ struct sl2_engine {
   int ppos = 0;                          // first column of the partial feature's six states (13 + 3N)
   int* part_i = nullptr;                 // [B][kPartInts]
   double* part_d = nullptr;              // [B][kPartDoubles]  mean, covariance of lambda, evbest of the last detection
-  double* particles = nullptr;           // [B][kMaxParticles][kParticleDoubles]
+  int pcap = 128;                        // particle slots per sequence: roundup(params.number_of_particles, 64)
+  double* particles = nullptr;           // [B][pcap][kParticleDoubles]
   unsigned long long* rand48 = nullptr;  // [B]  drand48 state (srand48(0) at Init, monoslam.cpp:1968)
   double* prev_r = nullptr;              // [B][3] camera position before the prediction (speed estimate, :121-124)
-  int* me_desc = nullptr;                // [B][kMaxParticles][8] search ellipses of the particles
+  int* me_desc = nullptr;                // [B][pcap][8] search ellipses of the particles
   double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
   int* owner_map = nullptr;              // [B][H][W] which particle ellipse scores a position (kOwnerFree between searches)
   bool mapping_used = false;

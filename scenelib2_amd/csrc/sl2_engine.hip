@@ -143,7 +143,7 @@ static int build_groups(sl2_engine* e, int G) {
     sl2_engine* g = new sl2_engine();
     g->device = e->device; g->cam = e->cam; g->prm = e->prm;
     g->B = count; g->N = e->N; g->ld = e->ld; g->nsel_max = e->nsel_max; g->mld = e->mld; g->nblk_max = e->nblk_max;
-    g->ppos = e->ppos;
+    g->ppos = e->ppos; g->pcap = e->pcap;
     g->root = e; g->group_first = first;
     if (G == 1) g->stream = e->stream; else SL2_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     const size_t f = first;
@@ -161,8 +161,8 @@ static int build_groups(sl2_engine* e, int G) {
     g->work = e->work + f * kWorkDoubles; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
     g->part_i = e->part_i + f * kPartInts; g->part_d = e->part_d + f * kPartDoubles;
-    g->particles = e->particles + f * kMaxParticles * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
-    g->me_desc = e->me_desc + f * kMaxParticles * 8;
+    g->particles = e->particles + f * e->pcap * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
+    g->me_desc = e->me_desc + f * e->pcap * 8;
     e->groups.push_back(g);
   }
   return SL2_OK;
@@ -292,6 +292,11 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (e->mld / 32 > 13) e->mld = round_up(2 * nsel, 64);    // beyond the one-launch substitution: 64-row tiles (k_fwd_gemm)
   if (e->mld / 32 > 16) e->mld = round_up(2 * nsel, 128);   // large systems are factored in 128-column panels
   e->nblk_max = e->mld / 32;
+  {   // depth particles of the partially initialised feature: any count up to 1024 (the reference loops over any number)
+    int np = params->number_of_particles;
+    np = np < 1 ? 1 : (np > kMaxParticles ? kMaxParticles : np);
+    e->pcap = round_up(np, 64);
+  }
 #ifndef SL2_TESTING
   if (e->ld > 2048 || e->mld > 1024) {   // k_build_AS: two state columns per thread of a 1024-thread workgroup, one H row per thread
     set_error("sl2_create: at most 676 feature slots (2048 state columns) and 512 features measured per frame");
@@ -344,10 +349,10 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->LinvT, B * (size_t)e->nblk_max * 1024));
   A(dmalloc(&e->part_i, B * kPartInts));
   A(dmalloc(&e->part_d, B * kPartDoubles));
-  A(dmalloc(&e->particles, B * kMaxParticles * kParticleDoubles));
+  A(dmalloc(&e->particles, B * (size_t)e->pcap * kParticleDoubles));
   A(dmalloc(&e->rand48, B));
   A(dmalloc(&e->prev_r, B * 3));
-  A(dmalloc(&e->me_desc, B * kMaxParticles * 8));
+  A(dmalloc(&e->me_desc, B * (size_t)e->pcap * 8));
 #undef A
   {  // srand48(0) in MonoSLAM::Init (monoslam.cpp:1968), one generator per sequence
     std::vector<unsigned long long> seeds(B, kRand48Seed0);
@@ -610,7 +615,7 @@ static int enable_feature_initialisation(sl2_engine* e) {
   if (e->mapping_used) return SL2_OK;
   // what this engine supports is the shipped configuration (data/SceneLib2.cfg:62 max_features_to_init_at_once = 1)
   if (e->prm.max_features_to_init_at_once != 1 || e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
-    set_error("feature initialisation: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 128");
+    set_error("feature initialisation: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 1024");
     return SL2_ERR_INVALID;
   }
   if (e->groups.size() > 1) { set_error("feature initialisation: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
@@ -910,7 +915,7 @@ int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, 
   if (particles && pi[kPartActive]) {
     const int n = pi[kPartNp] < capacity ? pi[kPartNp] : capacity;
     if (n > 0)
-      SL2_HIP(hipMemcpy(particles, e->particles + (size_t)seq * kMaxParticles * kParticleDoubles, sizeof(double) * n * kParticleDoubles,
+      SL2_HIP(hipMemcpy(particles, e->particles + (size_t)seq * e->pcap * kParticleDoubles, sizeof(double) * n * kParticleDoubles,
                         hipMemcpyDeviceToHost));
   }
   return SL2_OK;

@@ -25,6 +25,7 @@ struct MapParams {
   int force;      // InitialiseAutoFeature (monoslam.cpp:1535-1541): no speed gate, no visible-feature count
   int keep_visible, n_particles, min_particles, erase_after;
   double min_lambda, max_lambda, sd_ratio, prune_threshold, dt;
+  int pcap;       // particle slots per sequence in `particles` / `me_desc` (sl2_engine::pcap)
 };
 
 // ---------------------------------------------------------------------------
@@ -242,7 +243,7 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     const double lambda_step = (1.0 / double(mp.n_particles)) * (mp.max_lambda - mp.min_lambda);
     const double uniform_probability = 1.0 / double(mp.n_particles);
     double lambda = mp.min_lambda;
-    double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
+    double* pp = particles + (size_t)b * mp.pcap * kParticleDoubles;
     for (int i = 0; i < mp.n_particles; ++i) {
       double* o = pp + (size_t)i * kParticleDoubles;
       for (int k = 0; k < kParticleDoubles; ++k) o[k] = 0.0;
@@ -260,10 +261,10 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
 // ---------------------------------------------------------------------------
 // k_map_particles: one workgroup per sequence, one thread per particle.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
+__global__ void __launch_bounds__(1024) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
                                                                  int* __restrict__ part_i, double* __restrict__ particles,
                                                                  int* __restrict__ me_desc, double* __restrict__ last_r,
-                                                                 CameraParams cam, int ld, int ppos) {
+                                                                 CameraParams cam, int ld, int ppos, int pcap) {
   const int b = blockIdx.x, tid = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive]) return;
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* _
   double xp[7], ypi[6];
   for (int i = 0; i < 7; ++i) xp[i] = xb[i];
   for (int i = 0; i < 6; ++i) ypi[i] = xb[ppos + i];
-  double* o = particles + ((size_t)b * kMaxParticles + tid) * kParticleDoubles;
+  double* o = particles + ((size_t)b * pcap + tid) * kParticleDoubles;
   double h[2], Hx[14], Hy[12], Rn;
   part_measurement_model(cam, xp, ypi, o[0], h, Hx, Hy, &Rn);
   double Pxx7[49], Pxy7[42], Pyy[36], S[4];
@@ -301,42 +302,42 @@ __global__ void __launch_bounds__(kMaxParticles) k_map_particles(const double* _
   o[3] = h[0]; o[4] = h[1];
   o[7] = a; o[8] = bq; o[9] = c;
   o[10] = det2_partial_pivot_lu(S);
-  me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * kMaxParticles + tid) * 8);
+  me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * pcap + tid) * 8);
 }
 
 __global__ void __launch_bounds__(256) k_map_me_mark(int width, int height, const int* __restrict__ part_i,
                                                      const int* __restrict__ me_desc, const double* __restrict__ particles,
-                                                     int* __restrict__ owner) {
+                                                     int* __restrict__ owner, int pcap) {
   const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6);      // one particle ellipse per wavefront
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
-  me_mark_ellipse_wave(me_desc + ((size_t)b * kMaxParticles + p) * 8,
-                       particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
+  me_mark_ellipse_wave(me_desc + ((size_t)b * pcap + p) * 8,
+                       particles + ((size_t)b * pcap + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
 }
 
 __global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
                                                        const uint8_t* __restrict__ patch, const int* __restrict__ part_i,
                                                        const int* __restrict__ me_desc, int* __restrict__ owner,
-                                                       double* __restrict__ score_map, int N, int height) {
+                                                       double* __restrict__ score_map, int N, int height, int pcap) {
   const int b = blockIdx.y;
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking]) return;
   const size_t fi = (size_t)b * N + pi[kPartLabel];
-  me_score_union_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + (size_t)b * kMaxParticles * 8,
+  me_score_union_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + (size_t)b * pcap * 8,
                     pi[kPartNp], owner + (size_t)b * width * height, score_map + (size_t)b * width * height, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
                                                        const int* __restrict__ me_desc, double* __restrict__ particles,
-                                                       const double* __restrict__ score_map) {
+                                                       const double* __restrict__ score_map, int pcap) {
   const int wave = threadIdx.x >> 6;
   const int b = blockIdx.y, p = blockIdx.x * 4 + wave;                     // one particle ellipse per wavefront
   const int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
-  double* o = particles + ((size_t)b * kMaxParticles + p) * kParticleDoubles;
+  double* o = particles + ((size_t)b * pcap + p) * kParticleDoubles;
   __shared__ int s_res4[4][4];
   int* s_res = s_res4[wave];
-  me_argmin_wave(width, me_desc + ((size_t)b * kMaxParticles + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
+  me_argmin_wave(width, me_desc + ((size_t)b * pcap + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
   if ((threadIdx.x & 63) == 0) {
     if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
       o[5] = (double)s_res[1];
@@ -366,12 +367,12 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   __shared__ int s_action;         // 0 none, 1 convert, 2 delete
   __shared__ int s_np;
   __shared__ double s_lambda, s_plambda, s_total;
-  __shared__ double s_p[kMaxParticles * kParticleDoubles];
+  extern __shared__ double s_p[];        // [number_of_particles][kParticleDoubles]
   // The particle list lives in LDS for the duration of the update: the per-particle arithmetic (likelihood, division
   // by the total, pruning test, compaction) runs on all lanes; every SUM is formed by lane 0 in list order, which is
   // the reference's order (the sums decide the bits of the weights, and through them pruning and conversion).
   const bool active = pi[kPartActive] != 0, making = active && pi[kPartMaking] != 0;
-  double* pp = particles + (size_t)b * kMaxParticles * kParticleDoubles;
+  double* pp = particles + (size_t)b * mp.pcap * kParticleDoubles;
   int np = active ? pi[kPartNp] : 0;
   if (lane == 0) { s_action = 0; s_np = np; }
   if (making) {
@@ -712,6 +713,7 @@ static MapParams map_params(const sl2_engine* e, int enable_mapping, int save_tr
   mp.min_lambda = e->prm.min_lambda; mp.max_lambda = e->prm.max_lambda;
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
+  mp.pcap = e->root->pcap;
   return mp;
 }
 
@@ -759,6 +761,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.min_lambda = e->prm.min_lambda; mp.max_lambda = e->prm.max_lambda;
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
+  mp.pcap = e->root->pcap;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
   if (enable_mapping) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
@@ -782,32 +785,32 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_particles");
-    hipLaunchKernelGGL(k_map_particles, dim3(B), dim3(kMaxParticles), 0, e->stream, e->x, e->P, e->part_i, e->particles, e->me_desc,
-                       e->last_r, e->cam, e->ld, e->ppos);
+    hipLaunchKernelGGL(k_map_particles, dim3(B), dim3(e->root->pcap), 0, e->stream, e->x, e->P, e->part_i, e->particles, e->me_desc,
+                       e->last_r, e->cam, e->ld, e->ppos, e->root->pcap);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_me_mark");
     hipLaunchKernelGGL(k_map_me_mark, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->owner_map);
+                       e->owner_map, e->root->pcap);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_me_scores");
     const int nslices = B >= 512 ? 2 : (B >= 64 ? 4 : 16);     // row slices of the union's bounding box per sequence
     hipLaunchKernelGGL(k_map_me_scores, dim3(nslices, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
-                       e->part_i, e->me_desc, e->owner_map, e->score_map, e->N, H);
+                       e->part_i, e->me_desc, e->owner_map, e->score_map, e->N, H, e->root->pcap);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_me_argmin");
     hipLaunchKernelGGL(k_map_me_argmin, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->score_map);
+                       e->score_map, e->root->pcap);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_update");
-    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i, e->part_d,
+    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), sizeof(double) * kParticleDoubles * (size_t)mp.n_particles, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i, e->part_d,
                        e->particles, e->traj, e->traj_count, e->last_r, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }

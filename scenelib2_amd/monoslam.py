@@ -165,7 +165,7 @@ class Engine:
                             y_direction=np.array(f.y_direction[:])))
         return out
 
-    def partial_feature(self, seq, capacity=128):
+    def partial_feature(self, seq, capacity=1024):
         """The partially initialised feature of a sequence (FeatureInitInfo + particles), or None; plus the mapping
         counters of the sequence under key 'info' either way."""
         ints = np.zeros(16, dtype=np.int32)

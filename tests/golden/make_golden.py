@@ -17,6 +17,7 @@ products).  /root/reference does not exist on the GPU box, hence the committed v
 * ref_seq100.npz    — 12 frames of a 100-feature sequence (n = 313, the BASELINE headline shape, 5 mm feature prior):
                       per frame xv, the measured pixels and match flags; final total state; of the final 313 x 313
                       covariance the vehicle block, the diagonal, the Frobenius norm and 256 sampled entries.
+* ref_seq200.npz    — the same for 6 frames of a 640x480 / 200-feature sequence (n = 613, BASELINE configs[3]'s shape).
 """
 import hashlib
 import os
@@ -56,16 +57,21 @@ def shipped_cfg_with_absolute_identifiers(dst_dir):
     return path
 
 
-SEQ100 = dict(n_features=100, n_frames=12, seq_index=3, feature_sigma=0.005)
+SEQ100 = dict(n_features=100, n_frames=12, seq_index=3, feature_sigma=0.005, width=320, height=240)
+SEQ200 = dict(n_features=200, n_frames=6, seq_index=11, feature_sigma=0.005, width=640, height=480)     # BASELINE configs[3] shape
+
+
+def seq_inputs(S):
+    from scenelib2_amd import synth
+    cam = synth.default_camera(S["width"], S["height"])
+    params = synth.default_params(S["n_features"])
+    spec, tpl, frames, _ = synth.make_sequence(cam, S["n_features"], S["n_frames"], seq_index=S["seq_index"],
+                                               tex=synth.make_texture())
+    return cam, params, spec, tpl, frames
 
 
 def seq100_inputs():
-    from scenelib2_amd import synth
-    cam = synth.default_camera()
-    params = synth.default_params(SEQ100["n_features"])
-    spec, tpl, frames, _ = synth.make_sequence(cam, SEQ100["n_features"], SEQ100["n_frames"], seq_index=SEQ100["seq_index"],
-                                               tex=synth.make_texture())
-    return cam, params, spec, tpl, frames
+    return seq_inputs(SEQ100)
 
 
 def seq100_sample_index(n=313, count=256):
@@ -120,27 +126,28 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_mapping.npz"), events=np.array(events, np.int32), pos=np.array(pos),
                         x=r.total_state(), P=r.total_covariance(), frames_sha256=hashlib.sha256(frames_m.tobytes()).hexdigest())
 
-    # ---- the headline shape
-    cam, params, spec, tpl, frames = seq100_inputs()
-    N = SEQ100["n_features"]
-    r = oa.RefSLAM(cam, params["delta_t"], N)
-    r.set_state(spec.xv0, spec.Pxx0)
-    for i in range(N):
-        r.add_known_feature(spec.feat_y[i], spec.poses[0], tpl[i])
-    for i in range(N):
-        r.set_feature_Pyy(i, np.eye(3) * SEQ100["feature_sigma"] ** 2)
-    xv, z, ok = [], [], []
-    for k in range(SEQ100["n_frames"]):
-        r.go_one_step(frames[k], False)
-        xv.append(r.get_state()[0])
-        f = [r.feature(i) for i in range(N)]
-        ok.append(np.array([q["selected"] and q["success"] for q in f]))
-        z.append(np.array([q["z"] for q in f]))
-    P = r.total_covariance()
-    ii, jj = seq100_sample_index(P.shape[0])
-    np.savez_compressed(os.path.join(HERE, "ref_seq100.npz"), xv=np.array(xv), z=np.array(z), ok=np.array(ok),
-                        x=r.total_state(), Pxx=P[:13, :13], Pdiag=np.diag(P).copy(), Pfro=np.linalg.norm(P),
-                        Psample=P[ii, jj], frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
+    # ---- the headline shape (n = 313) and the configs[3] shape (n = 613)
+    for S, name in ((SEQ100, "ref_seq100.npz"), (SEQ200, "ref_seq200.npz")):
+        cam, params, spec, tpl, frames = seq_inputs(S)
+        N = S["n_features"]
+        r = oa.RefSLAM(cam, params["delta_t"], N)
+        r.set_state(spec.xv0, spec.Pxx0)
+        for i in range(N):
+            r.add_known_feature(spec.feat_y[i], spec.poses[0], tpl[i])
+        for i in range(N):
+            r.set_feature_Pyy(i, np.eye(3) * S["feature_sigma"] ** 2)
+        xv, z, ok = [], [], []
+        for k in range(S["n_frames"]):
+            r.go_one_step(frames[k], False)
+            xv.append(r.get_state()[0])
+            f = [r.feature(i) for i in range(N)]
+            ok.append(np.array([q["selected"] and q["success"] for q in f]))
+            z.append(np.array([q["z"] for q in f]))
+        P = r.total_covariance()
+        ii, jj = seq100_sample_index(P.shape[0])
+        np.savez_compressed(os.path.join(HERE, name), xv=np.array(xv), z=np.array(z), ok=np.array(ok),
+                            x=r.total_state(), Pxx=P[:13, :13], Pdiag=np.diag(P).copy(), Pfro=np.linalg.norm(P),
+                            Psample=P[ii, jj], frames_sha256=hashlib.sha256(frames.tobytes()).hexdigest())
     print("golden fixtures written")
 
 

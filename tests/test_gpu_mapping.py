@@ -67,6 +67,38 @@ def test_mapping_step_by_step_matches_oracle():
     assert t0.shape == t1.shape and np.abs(t0 - t1).max() < 1e-9       # trajectory_store_ incl. its stale-scratch entries (Q12)
 
 
+def test_mapping_with_300_depth_particles():
+    """params.number_of_particles beyond the shipped 100 (the reference loops over any number, monoslam.cpp:1347-1400; the
+    engine takes up to 1024: one thread per particle in k_map_particles, the particle list of k_map_update in dynamic
+    LDS): events, particle sets and state against the oracle."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=30)
+    params = dict(params); params["number_of_particles"] = 300; params["min_number_of_particles"] = 40
+    s = oracle_for(cam, params, spec, templates, oa)
+    eng = _engine(cam, params, spec, templates)
+    seen = 0
+    for k in range(1, 31):
+        s.go_one_step(frames[k], False, True)
+        eng.go_one_step(frames[k][None], enable_mapping=True)
+        info, got = s.mapping_info(), eng.partial_feature(0, capacity=512)
+        assert [got["info"][key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
+               [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], k
+        pf = s.partial_feature(0, max_particles=512)
+        if pf is not None:
+            g = got["pf"]
+            assert g["n_particles"] == pf["n_particles"], k
+            seen = max(seen, pf["n_particles"])
+            a, b = g["particles"], pf["particles"]
+            assert np.array_equal(a[:, 0], b[:, 0]) and np.allclose(a[:, 1], b[:, 1], rtol=1e-9, atol=1e-300), k
+            if pf["making"]:
+                assert np.array_equal(a[:, 11], b[:, 11]), k
+        x0, x1 = s.total_state(), eng.total_state(0)
+        assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, k
+    assert seen == 300 and s.mapping_info()["initialised"] >= 2
+    p3 = dict(params); p3["number_of_particles"] = 2000
+    with pytest.raises(_lib.Sl2Error):
+        _engine(cam, p3, spec, templates).go_one_step(frames[1][None], enable_mapping=True)
+
+
 def test_mapping_rejects_unsupported_settings_and_needs_flag():
     from scenelib2_amd import _lib
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=3)

@@ -213,18 +213,53 @@ def test_delete_bad_features_matches_reference_walk():
     assert 3 not in [f["label"] for f in pr.engine.features(0)]
 
 
-@pytest.mark.parametrize("width,height,n_features,n_frames,batch", [(640, 480, 200, 3, 2), (640, 480, 224, 2, 1), (1280, 720, 500, 2, 1)])
+@pytest.mark.parametrize("width,height,n_features,n_frames,batch", [(640, 480, 200, 10, 8), (640, 480, 224, 2, 1), (1280, 720, 500, 10, 8)])
 def test_larger_baseline_shapes(width, height, n_features, n_frames, batch):
-    """BASELINE configs 4 and 5 shapes (640x480 / 200 features, n = 613; 1280x720 / 500 features,
-    n = 1513, m up to 1000: 32 Cholesky blocks) at a batch the oracle can follow."""
+    """BASELINE configs[3] and configs[4] shapes (640x480 / 200 features, n = 613; 1280x720 / 500 features, n = 1513, m up
+    to 1000: 32 Cholesky blocks, panel-wise factorisation, grouped substitution) over ten frames of eight different
+    sequences, every frame against the oracle (its eight objects step on a thread pool)."""
+    import os
     cam = synth.default_camera(width, height)
-    pr = Pair(n_features, n_frames, batch=batch, cam=cam)
+    pr = Pair(n_features, n_frames, batch=batch, cam=cam, feature_sigma=0.005 if batch > 1 else 0.0)
     for k in range(n_frames):
-        pr.step_both(k)
+        pr.step_both(k, threads=min(batch, os.cpu_count() or 1))
         worst = pr.compare_state(TOL_X, 2e-8)
     _, cnt = pr.engine.selection(0)
     assert cnt["measurement_size"] > 1.5 * n_features     # most features matched
     assert not pr.engine.status_flags().any()
+
+
+def test_engine_matches_reference_golden_at_configs3_shape():
+    """The HIP path against REFERENCE outputs at n = 613 (640x480, 200 features, 5 mm prior, 6 frames):
+    tests/golden/ref_seq200.npz, produced by the reference's own translation units like ref_seq100.npz."""
+    import hashlib
+    import sys
+    sys.path.insert(0, golden_path(""))
+    import make_golden as mg
+    g = np.load(golden_path("ref_seq200.npz"))
+    cam, params, spec, tpl, frames = mg.seq_inputs(mg.SEQ200)
+    assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
+    N, B = mg.SEQ200["n_features"], 2
+    eng = Engine(cam, params, B, N)
+    eng.set_vehicle_state(np.tile(spec.xv0, (B, 1)), np.tile(spec.Pxx0, (B, 1, 1)))
+    eng.add_known_features(np.tile(spec.feat_y, (B, 1, 1)), np.tile(spec.poses[0], (B, N, 1)), np.tile(tpl, (B, 1, 1, 1)))
+    eng.set_feature_covariances(np.tile(np.eye(3) * mg.SEQ200["feature_sigma"] ** 2, (B, N, 1, 1)))
+    for k in range(mg.SEQ200["n_frames"]):
+        eng.go_one_step(np.tile(frames[k], (B, 1, 1)))
+        xe, _ = eng.get_vehicle_state(1, 1)
+        assert np.abs(xe[0] - g["xv"][k]).max() <= TOL_X, k
+        f = eng.features(1)
+        ok = np.array([q["selected"] and q["success"] for q in f])
+        assert np.array_equal(ok, g["ok"][k]), k
+        assert np.array_equal(np.array([q["z"] for q in f])[ok], g["z"][k][ok]), k
+    P = eng.total_covariance(1)
+    ii, jj = mg.seq100_sample_index(P.shape[0])
+    scale = np.abs(g["Pdiag"]).max()
+    assert np.abs(eng.total_state(1) - g["x"]).max() <= TOL_X
+    assert np.abs(P[:13, :13] - g["Pxx"]).max() <= 2e-8 * np.abs(g["Pxx"]).max()
+    assert np.abs(np.diag(P) - g["Pdiag"]).max() <= 2e-8 * scale
+    assert abs(np.linalg.norm(P) - float(g["Pfro"])) <= 2e-8 * float(g["Pfro"])
+    assert np.abs(P[ii, jj] - g["Psample"]).max() <= 2e-8 * scale
 
 
 def test_large_ragged_batch_runs_the_panel_kernels():

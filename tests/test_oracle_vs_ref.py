@@ -448,6 +448,50 @@ def test_reference_init_on_the_shipped_cfg(tmp_path):
         assert np.array_equal(zr[sel], gold["z"][k][sel])
 
 
+def test_two_features_initialised_at_once_what_the_reference_does():
+    """params.max_features_to_init_at_once = 2 and 200 depth particles: the settings the HIP engine does NOT run (it keeps one
+    partially initialised feature per sequence and refuses other values of the key with SL2_ERR_INVALID: INTEGRATION.md).
+    This pins what the reference does there, oracle against the reference's own code: two partially initialised features
+    in flight (twelve extra states), each matched with its own particle set, and - when the FIRST of them converts while
+    the second is still partial - convert_from_partially_to_fully_initialised moves the later feature's
+    position_in_total_state_vector_ by 6 instead of 3 (feature.cpp:254, quirk Q28): from then on that feature's
+    recorded position no longer is where construct_total_state puts it.  The oracle reproduces it bug for bug."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60, v_amp=0.5)
+    params = dict(params)
+    params["max_features_to_init_at_once"] = 2
+    params["number_of_particles"] = 200
+    params["number_of_features_to_keep_visible"] = 14
+    o = oracle_for(cam, params, spec, templates, oa)
+    r = oa.RefSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
+    r.set_mapping_params(params)
+    r.set_state(spec.xv0, spec.Pxx0)
+    xo = spec.xp_org()
+    for i in range(spec.n_features):
+        r.add_known_feature(spec.feat_y[i], xo[i], templates[i])
+    max_partial, q28 = 0, 0
+    for k in range(1, 61):
+        o.go_one_step(frames[k], False, True)
+        r.go_one_step(frames[k], False, True)
+        io, ir = o.mapping_info(), r.mapping_info()
+        assert io["n_partial"] == ir["n_partial"], (k, io, ir)
+        max_partial = max(max_partial, ir["n_partial"])
+        kinds = r.feature_kinds()
+        assert np.array_equal(o.feature_kinds(), kinds), k
+        for j in range(ir["n_partial"]):
+            po, pr = o.partial_feature(j, max_particles=256), r.partial_feature(j, max_particles=256)
+            assert (po["label"], po["n_particles"], po["attempts"], po["making"]) == \
+                   (pr["label"], pr["n_particles"], pr["attempts"], pr["making"]), (k, j)
+            assert np.array_equal(po["particles"][:, 0], pr["particles"][:, 0]), (k, j)
+        compare(o, r, tol=1e-10, what="two-at-once frame %d" % k)
+        # Q28: a feature whose recorded position differs from the running sum of the state sizes in front of it
+        pos = 13
+        for i in range(r.num_features):
+            q28 += int(r.feature(i)["pos"] != pos)
+            pos += int(kinds[i][0])
+    assert max_partial == 2, "the scene never had two partially initialised features in flight"
+    assert q28 > 0, "Q28 (position moved by 6 instead of 3) never showed: no conversion happened next to a second partial feature"
+
+
 def test_manual_and_auto_initialisation_buttons():
     """The three buttons of examples/MonoSlamSceneLib1.cpp:191-205 outside GoOneStep: InitialiseFeature at a clicked pixel
     (monoslam.cpp:1211-1235), InitialiseAutoFeature (:1535-1541) and SavePatch (:1551-1572), then ordinary frames with

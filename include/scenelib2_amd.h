@@ -152,8 +152,9 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
  * partially initialised feature is created at pixel (uu_, vv_) = (uv[2 s], uv[2 s + 1]) of that sequence's frame - the
  * 11 x 11 patch copied from the frame, the semi-infinite line from the current pose, number_of_particles depth hypotheses
  * - exactly as the feature-initialisation tail of sl2_go_one_step creates one.  Later steps match and convert it
- * (MatchPartiallyInitialisedFeatures runs in every step from now on, like monoslam.cpp:167).  uv: host [batch][2].
- * created: host [batch], may be NULL (the call then stays asynchronous); 1 = a feature was created.  It is NOT created -
+ * (MatchPartiallyInitialisedFeatures runs in every step from now on, like monoslam.cpp:167).  uv: host [batch][2], consumed
+ * before the call returns (pageable, pinned or registered memory alike).
+ * created: host [batch], may be NULL (the kernels then stay asynchronous); 1 = a feature was created.  It is NOT created -
  * and the reference would have created it - when the sequence already has a partially initialised feature (this engine
  * carries one at a time, the shipped max_features_to_init_at_once = 1), when the patch would leave the frame (the
  * reference reads out of bounds), or when the label slots are exhausted (SL2_STATUS_LABELS_EXHAUSTED). */
@@ -303,14 +304,16 @@ int sl2_get_position_log(sl2_engine* e, int seq0, int nseq, double* out, int cap
  * fully initialised feature with that label existed and was removed (partially initialised ones are removed by the engine's
  * own sell-by / conversion logic only).  The label is never reused (its slot may be).  Synchronises. */
 int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels, int32_t* deleted);
-/* Per-sequence status bits (sticky).  SL2_STATUS_NONFINITE: NaN / Inf seen in the state (e.g. the omega == 0 hazard, Q10).
- * SL2_STATUS_LABELS_EXHAUSTED: feature initialisation wanted a new feature but every one of the sequence's max_features slots
- * holds a LIVE feature (the reference's feature_list_ is unbounded).  Deleted features do not count: their slots are squeezed
- * out, in feature_list_ order, when a sequence runs out of slots, and labels (Feature::label_ = next_free_label_++) are kept
- * apart from slots and never reused - a sequence may hand out any number of labels over its lifetime (maps of more than 2048
- * state columns - max_features > 676 - keep retired slots: there the bit also rises when the slots run out).  When the bit is set the
- * sequence keeps tracking its map but initialises no further features.  Callers that run with enable_mapping must poll
- * this (the MonoSLAM adapters do, and raise). */
+/* Per-sequence status bits.  SL2_STATUS_NONFINITE (sticky): NaN / Inf seen in the state (e.g. the omega == 0 hazard, Q10).
+ * SL2_STATUS_LABELS_EXHAUSTED: the LAST feature initialisation that was called for (speed gate and visible-feature count of
+ * GoOneStep, or one of the two initialise-feature entry points) could not take place because every one of the sequence's
+ * max_features slots holds a LIVE feature (the reference's feature_list_ is unbounded).  Deleted features do not count:
+ * their slots are squeezed out, in feature_list_ order, when a sequence runs out of slots, and labels (Feature::label_ =
+ * next_free_label_++) are kept apart from slots and never reused - a sequence may hand out any number of labels over its
+ * lifetime.  The bit is cleared again by the next initialisation attempt that finds room (after a feature has been deleted),
+ * so a temporarily full map is not a permanent condition.  While it is set the sequence keeps tracking its map but
+ * initialises no further features.  Callers that run with enable_mapping must poll this (the MonoSLAM adapters do, and
+ * raise when the bit RISES). */
 #define SL2_STATUS_NONFINITE 1
 #define SL2_STATUS_LABELS_EXHAUSTED 2
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);

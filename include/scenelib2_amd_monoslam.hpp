@@ -173,9 +173,11 @@ class MonoSLAM {
     if (enable_mapping) {   // feature_list_ is unbounded in the reference; here at most max_features LIVE features: never silently
       int32_t flags = 0;
       check(sl2_get_status_flags(eng_, 0, 1, &flags), "sl2_get_status_flags");
-      if (flags & SL2_STATUS_LABELS_EXHAUSTED)
+      const bool full = (flags & SL2_STATUS_LABELS_EXHAUSTED) != 0, rose = full && !map_full_;
+      map_full_ = full;
+      if (rose)             // once per episode: the bit clears again when a deletion has made room
         throw std::runtime_error("MonoSLAM::GoOneStep: all max_features feature slots hold live features: mapping can "
-                                 "initialise no further features; construct MonoSLAM with a larger max_features");
+                                 "initialise no features until one is deleted; construct MonoSLAM with a larger max_features");
     }
     return true;
   }
@@ -427,6 +429,7 @@ class MonoSLAM {
   }
 
   int max_features_, device_;
+  bool map_full_ = false;
   sl2_engine* eng_ = nullptr;
 };
 

@@ -483,13 +483,10 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
   bool lacking = false;
   for (int s = 0; s < nseq; ++s) lacking = lacking || slots[s] + nfeat > e->N;
   if (lacking) {        // slots of deleted features are given back first (the reference's feature_list_ simply shrinks)
-    sl2_engine* g = e->groups.empty() ? e : e->groups[0];
-    if (e->groups.size() <= 1) {
-      int rc = launch_compact_slots(g, nfeat);
-      if (rc != SL2_OK) return rc;
-      { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-      SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
-    }
+    int rc = for_each_group(e, [nfeat](sl2_engine* g) { return launch_compact_slots(g, nfeat); });     // every sequence group
+    if (rc != SL2_OK) return rc;
+    { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+    SL2_HIP(hipMemcpy(slots.data(), e->n_slots + seq0, sizeof(int) * nseq, hipMemcpyDeviceToHost));
   }
   for (int s = 0; s < nseq; ++s)
     if (slots[s] + nfeat > e->N) { set_error("sl2_add_known_features: feature capacity exceeded"); return SL2_ERR_CAPACITY; }
@@ -641,8 +638,10 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
   g->score_map = e->score_map; g->owner_map = e->owner_map;
   if (uv) {
     if (!e->init_uv) SL2_HIP(hipMalloc((void**)&e->init_uv, sizeof(int) * 2 * e->B));
+    // the caller's buffer may be pinned or registered memory, for which an asynchronous copy really is asynchronous: the copy
+    // is waited for, so that uv need not outlive the call (a few hundred bytes; the call synchronises for `created` anyway)
     SL2_HIP(hipMemcpyAsync(e->init_uv, uv, sizeof(int) * 2 * e->B, hipMemcpyHostToDevice, e->stream));
-    // (pageable source: the copy has been staged by the time the call returns)
+    SL2_HIP(hipStreamSynchronize(e->stream));
     rc = launch_manual_init(g, e->init_uv);
   } else {
     rc = launch_auto_init(g);

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
       if (ns >= N) {
         status[b] |= 2;            // the map is full: cannot reserve a label (capacity chosen at sl2_create)
       } else {
+        status[b] &= ~2;           // (the bit tells about the LAST attempt: room again after deletions / the slot squeeze)
         // FindNonOverlappingRegion (:867-943): where will the image centre be in ten steps?
         double xv[13], f[13], A44[16], B43[12];
         for (int i = 0; i < 13; ++i) xv[i] = xb[i];
@@ -698,6 +699,7 @@ __global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, c
   if (u < 5 || v < 5 || u > width - 6 || v > height - 6) return;       // the 11 x 11 patch must lie inside the frame
   if (pi[kPartActive]) return;                                         // one partially initialised feature at a time
   if (n_slots[b] >= N) { status[b] |= 2; return; }
+  status[b] &= ~2;
   pi[kPartUU] = u; pi[kPartVV] = v;
   pi[kPartRegionValid] = 1;
   part_d[(size_t)b * kPartDoubles + 2] = 1.0e300;                      // no score threshold on a manual selection

@@ -352,9 +352,13 @@ class MonoSLAM:
         self._engine.go_one_step(f.reshape(1, -1), save_trajectory, enable_mapping)
         # the reference's feature_list_ is unbounded; the engine holds at most max_features LIVE features per sequence
         # (deleted ones give their slots back): a full map must not pass silently (SL2_STATUS_LABELS_EXHAUSTED)
-        if enable_mapping and int(self._engine.status_flags()[0]) & 2:
-            raise RuntimeError("MonoSLAM: all %d feature slots hold live features (max_features); mapping has stopped "
-                               "initialising features - create the engine with a larger max_features" % self._max_features)
+        if enable_mapping:
+            full = bool(int(self._engine.status_flags()[0]) & 2)
+            rose, self._map_full = full and not getattr(self, "_map_full", False), full
+            if rose:          # (once per episode: the step itself has been applied; the bit clears when a slot frees up)
+                raise RuntimeError("MonoSLAM: all %d feature slots hold live features (max_features); mapping cannot "
+                                   "initialise features until one is deleted - create the engine with a larger max_features"
+                                   % self._max_features)
         return True  # the reference always returns true (monoslam.cpp:179)
 
     def _frame(self, frame):
@@ -371,8 +375,9 @@ class MonoSLAM:
     def InitialiseAutoFeature(self, frame):
         created = bool(self._engine.initialise_auto_feature(self._frame(frame))[0])
         info = self._engine.partial_feature(0)["info"]
-        self.uu_, self.vv_ = info["uu"], info["vv"]
-        self.location_selected_flag_ = bool(info.get("location_selected", created))
+        if created or info["region_defined"]:   # (a refused call - a partially initialised feature is still in flight: no region
+            self.uu_, self.vv_ = info["uu"], info["vv"]          # was searched - leaves the selection alone)
+            self.location_selected_flag_ = True
         return created
 
     # MonoSLAM::mark_feature_by_lab — monoslam.cpp:743-768

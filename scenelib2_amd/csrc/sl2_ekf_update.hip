@@ -1552,13 +1552,14 @@ __global__ void __launch_bounds__(256) k_fwd_gemm(double* __restrict__ At, const
 }
 
 // ---------------------------------------------------------------------------
-// Cholesky of systems with more than 16 blocks (launch_chol_panels): right-looking over PANELS of four block columns
-// (128 columns), so that the trailing matrix is read and written once per 128 columns instead of once per 32 (the
-// launch-per-block kernels are bound by exactly that traffic: 22 GB per factorisation at m = 1000, batch 256):
-//   k_chol_left (J0, 4 blocks)      factor the 128x128 diagonal sub-matrix in one launch
-//   k_fwdsub_lds<4> on S itself     panel solve X = S[below][panel] L_dd^-T  (S is k-major: the panel's columns are rows
+// Cholesky of systems with more than 16 blocks (launch_chol_panels): right-looking over PANELS of eight block columns
+// (256 columns; four in rounds 1-2), so that the trailing matrix is read and written once per panel instead of once per 32
+// columns (the launch-per-block kernels are bound by exactly that traffic: 22 GB per factorisation at m = 1000, batch 256):
+//   k_chol_left (J0, 8 blocks)      factor the 256x256 diagonal sub-matrix in one launch
+//   k_fwdsub_lds<8> on S itself     panel solve X = S[below][panel] L_dd^-T  (S is k-major: the panel's columns are rows
 //                                   of St, i.e. exactly the right-hand-side layout of the EKF substitution)
-//   k_chol_syrk                     S[below][below] -= X X^T, 64x64 tiles of the lower block triangle, K = 128
+//   k_chol_syrk                     S[below][below] -= X X^T, 64x64 tiles of the lower block triangle, K = 256
+// (with K = 128 a tile of the trailing update had eight K-chunks to amortise its read-modify-write over: 38 TFLOP/s)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_chol_syrk(double* __restrict__ St, const int* __restrict__ m_count, int mld, int B,
                                                    int k0, int kp, int c0) {
@@ -1624,8 +1625,10 @@ __global__ void __launch_bounds__(256) k_chol_syrk(double* __restrict__ St, cons
 constexpr int kCholPanelBlocks = 4;
 
 static int launch_chol_panels(sl2_engine* e, int B) {
-  for (int p0 = 0; p0 < e->nblk_max; p0 += kCholPanelBlocks) {
-    const int nb = e->nblk_max - p0 < kCholPanelBlocks ? e->nblk_max - p0 : kCholPanelBlocks;
+  // panel width in 32-blocks: 4 (128 columns) or 8 (256 columns: half as many trailing updates, each with twice the K)
+  const int pb = e->root->chol_panel == 8 ? 8 : kCholPanelBlocks;
+  for (int p0 = 0; p0 < e->nblk_max; p0 += pb) {
+    const int nb = e->nblk_max - p0 < pb ? e->nblk_max - p0 : pb;
     {
       LaunchScope ls(e, "k_chol_left", true);
       hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, p0, nb,
@@ -1637,8 +1640,12 @@ static int launch_chol_panels(sl2_engine* e, int B) {
     const int ntile = (e->mld - c0) / 64;      // mld is a multiple of 64 for these sizes (sl2_create)
     {
       LaunchScope ls(e, "k_fwdsub_lds@chol", true);
-      hipLaunchKernelGGL((k_fwdsub_lds<kCholPanelBlocks>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
-                         e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
+      if (pb == 8)
+        hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
+                           e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
+      else
+        hipLaunchKernelGGL((k_fwdsub_lds<kCholPanelBlocks>), dim3(xcd_grid(ntile, B)), dim3(256), 0, e->stream, e->St, e->St, e->St,
+                           e->LinvT, e->m_count, e->mld, e->mld, e->nblk_max, B, p0, c0, ntile, nb);
       SL2_HIP(hipGetLastError());
     }
     {

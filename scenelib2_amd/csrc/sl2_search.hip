@@ -771,6 +771,7 @@ int launch_search(sl2_engine* e) {
       // small batches - the positions of a wavefront run one after the other (18 us for four at batch 1)
       int chunk = (int)(((long long)e->B * e->nsel_max + 4095) / 4096);
       chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
+      if (e->root->search_chunk > 0) chunk = e->root->search_chunk;        // experiments (TEST build: SL2_SEARCH_CHUNK)
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,

@@ -14,6 +14,6 @@ for sw in "$@"; do
   python - <<PY
 import json
 d=json.load(open("$OUT/ab_$i.json"))
-print("[%s]" % "$sw", round(d['value']), round(d['ms_per_step'],4), {k:round(v['ms_per_step'],4) for k,v in list(d['kernels'].items())[:6]})
+print("[%s]" % "$sw", round(d['value']), round(d['ms_per_step'],4), {k:round(v['ms_per_step'],4) for k,v in list(d["kernels"].items())[:int(__import__("os").environ.get("NK","6"))]})
 PY
 done; done | tee -a $OUT/ab_summary.txt

@@ -30,13 +30,14 @@ prof)
   ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/$OUT/prof -o bench -- python $OLDPWD/bench.py --cpu-sample 0 --no-profile > $OLDPWD/$OUT/prof_bench.json 2> $OLDPWD/$OUT/prof.err ); echo "prof exit $?"
   find $OUT/prof -name "*stats*" | head; for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f; done ;;
 pmc)
-  # separate passes (PMC only with --kernel-trace; never with sys/runtime traces)
+  # separate passes (PMC only with --kernel-trace; never with sys/runtime traces); 30 warm-up steps so that the last three
+  # dispatches of every kernel are steady-state steps (PMC_LAST=3)
   i=0
   for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     i=$((i+1))
-    ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
+    ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 30 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
   done
-  python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
+  PMC_LAST=3 PMC_GIT=${PMC_GIT:-unknown} python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
 c4|c5)
   # BASELINE configs[3] / configs[4] per GPU: bench line, rocprofv3 kernel stats, FETCH / WRITE passes
   if [ $st = c4 ]; then SHAPE="--width 640 --height 480 --features 200 --batch 1024 --steps 20 --warmup 10"; else SHAPE="--width 1280 --height 720 --features 500 --batch 512 --steps 10 --warmup 6"; fi

@@ -160,7 +160,8 @@ struct sl2_engine {
   int* n_vis = nullptr;       // [B]
   int* meas_ok = nullptr;     // [B][N]   per selected position k
   double* meas_score = nullptr;  // [B][N]
-  int* succ_idx = nullptr;    // [B][N]   successful feature slots in selection order
+  int* succ_idx = nullptr;    // [B][N]   successful feature slots, ascending (slot order)
+  int* f_arow = nullptr;      // [B][N]   per slot: first row of A^T / S of its measurement (2 x rank among the successes), -1 = none this frame
   int* m_count = nullptr;     // [B]      number of successful features (m = 2 * m_count)
   double* work = nullptr;     // [B][kWorkDoubles]   window bytes, searched, candidates, exact-fallback searches, candidate tiles
   int* srch_i = nullptr;      // [B][N][8]  per-feature search window: ucentre, vcentre, urelstart, nu, vrelstart, nv, hw, hh

@@ -253,60 +253,45 @@ __device__ __forceinline__ void bt_row_chunk(const double* __restrict__ sT, cons
   }
 }
 
-__global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __restrict__ P, const double* __restrict__ f_Hx,
-                                                               const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
-                                                               const double* __restrict__ f_R, const int* __restrict__ succ_idx,
-                                                               const int* __restrict__ m_count, double* __restrict__ At,
-                                                               double* __restrict__ St, int N, int ld, int mld, int B) {
-  int b, t;
-  const int nt = ld / 64;
-  if (!xcd_map(nt * (nt + 1) / 2, B, &b, &t)) return;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  int tj = 0;
-  while (t > tj) { t -= tj + 1; ++tj; }
-  const int ti = t;                       // ti <= tj
-  const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
-  const int tid = threadIdx.x;
+// what a lane holds of a tile between its loads and their way into LDS
+struct BtRegs { double2 tv[4]; double hv; int arow; double pv[2]; double rv[3]; };
+
+// Every global load one tile needs: the feature slots whose first state index lies in tile row I / tile column J are known
+// from the tile indices alone, so the tile (four 16-byte pieces per lane), its halo, the pose rows, the slots' Jacobians and
+// their rows in A^T (f_arow, written by k_search_score) are requested together.  (The first versions found their features
+// by counting the measurement list and then fetched the records: a second, dependent round trip and nine barriers; and
+// loading phase by phase, each loop iteration waiting for its own data, cost ~15 round trips.)
+__device__ __forceinline__ void bt_load(BtRegs& R, const double* __restrict__ Pb, const double* __restrict__ f_Hx,
+                                        const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
+                                        const double* __restrict__ f_R, const int* __restrict__ f_arow, size_t bN, int N, int ld,
+                                        int ti, int tj, int tid) {
   const int r0 = ti * 64, c0 = tj * 64;
   const bool diag = ti == tj;
-  const int* sidx = succ_idx + (size_t)b * N;
-  const double* Pb = P + (size_t)b * ld * ld;
-  double* Ab = At + (size_t)b * mld * ld;
-  double* Sb = St + (size_t)b * mld * mld;
-
-  __shared__ double sT[kBtW * kBtP];           // the tile with its halo: sT[i][j] = P[r0 + i][c0 + j]
-  __shared__ double sPose[2][7][kBtW];         // [0]: pose rows over the columns of J, [1]: over the columns of I
-  __shared__ double sXX[7][7];                 // P[c][c'], c, c' < 7
-  __shared__ double sF[2][kBtF][kBtFD];        // [0]: the measured features of tile row I, [1]: of tile column J
-  __shared__ double sA[2 * kBtF][kBtW];        // results of a role (the row role with its two halo columns: what S is formed from)
-  __shared__ double sU[2][2 * kBtF][7];        // A^T[k][0..6] of the features of I ([0]) and of J ([1])
-  __shared__ int sIdx[256];                    // the first entries of succ_idx
-
-  // ---- every global load the workgroup needs is requested before the first wait: the tile (four 16-byte pieces per
-  // lane), its halo, the pose rows and the measurement list.  (Loaded phase by phase - list, records, tile, halo, pose
-  // rows, each loop iteration waiting for its own data - a workgroup lived through ~15 memory round trips: 0.69 ms per
-  // launch against 0.30 for k_build_AS.) ----
-  double2 tv[4];
+  const int fI0 = r0 >= 13 ? (r0 - 13 + 2) / 3 : 0, fJ0 = c0 >= 13 ? (c0 - 13 + 2) / 3 : 0;
+  const int fI1 = min(N, (r0 + 64 - 13 + 2) / 3), fJ1 = min(N, (c0 + 64 - 13 + 2) / 3);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
-    tv[u] = *(const double2*)(Pb + (size_t)(r0 + row) * ld + c0 + c2);
+    R.tv[u] = *(const double2*)(Pb + (size_t)(r0 + row) * ld + c0 + c2);
   }
   // halo columns (P[r0 + i][c0 + 64 + h]), halo rows (P[r0 + 64 + h][c0 + j]; in a diagonal tile the mirrors of the halo
-  // columns: the tile below the diagonal one is a lower tile) and the corner
-  double hv = 0.0;
+  // columns: the tile below the diagonal one is a lower tile), the corner, P[0..6][0..6] and the slots' rows of A^T
+  R.hv = 0.0;
+  R.arow = -1;
   if (tid < 128) {
-    if (c0 + 64 < ld) hv = Pb[(size_t)(r0 + (tid >> 1)) * ld + c0 + 64 + (tid & 1)];
+    if (c0 + 64 < ld) R.hv = Pb[(size_t)(r0 + (tid >> 1)) * ld + c0 + 64 + (tid & 1)];
   } else if (tid < 256) {
-    if (!diag && r0 + 64 < ld) hv = Pb[(size_t)(r0 + 64 + (tid & 1)) * ld + c0 + ((tid - 128) >> 1)];
+    if (!diag && r0 + 64 < ld) R.hv = Pb[(size_t)(r0 + 64 + (tid & 1)) * ld + c0 + ((tid - 128) >> 1)];
   } else if (tid < 260) {
-    if (r0 + 64 < ld && c0 + 64 < ld) hv = Pb[(size_t)(r0 + 64 + ((tid - 256) >> 1)) * ld + c0 + 64 + (tid & 1)];
+    if (r0 + 64 < ld && c0 + 64 < ld) R.hv = Pb[(size_t)(r0 + 64 + ((tid - 256) >> 1)) * ld + c0 + 64 + (tid & 1)];
   } else if (tid < 320) {
-    if (tid - 260 < 49) hv = Pb[(size_t)((tid - 260) / 7) * ld + ((tid - 260) % 7)];
+    if (tid - 260 < 49) R.hv = Pb[(size_t)((tid - 260) / 7) * ld + ((tid - 260) % 7)];
+  } else if (tid < 320 + 2 * kBtF) {
+    const int side = (tid - 320) / kBtF, e = (tid - 320) - side * kBtF;
+    const int f = (side ? fJ0 : fI0) + e;
+    if (f < (side ? fJ1 : fI1) && !(side && diag)) R.arow = f_arow[bN + f];
   }
   // pose rows: what k_build_A reads as pc[c] of column i: P[i][c] for i < 13 (the vehicle block is general), else P[c][i]
-  double pv[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int idx = tid + kBtThreads * u;
@@ -317,118 +302,154 @@ __global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __r
       const int col = (side ? r0 : c0) + jj;
       if (col < ld) v = (col < 13) ? Pb[(size_t)col * ld + c] : Pb[(size_t)c * ld + col];
     }
-    pv[u] = v;
+    R.pv[u] = v;
   }
-
-  // ---- ranks of the first measured feature of tile rows ti, ti + 1, tj, tj + 1 (succ_idx is ascending) ----
-  int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-  for (int i0 = 0; i0 < cnt; i0 += kBtThreads) {
-    const int fv = (i0 + tid < cnt) ? sidx[i0 + tid] : -1;
-    if (i0 == 0 && tid < 256) sIdx[tid] = fv;
-    const int tl = fv >= 0 ? ((13 + 3 * fv) >> 6) : 0x3fffffff;
-    n0 += __syncthreads_count(tl < ti);
-    n1 += __syncthreads_count(tl <= ti);
-    n2 += __syncthreads_count(tl < tj);
-    n3 += __syncthreads_count(tl <= tj);
-  }
-  const int nfI = n1 - n0, nfJ = diag ? 0 : n3 - n2;     // <= kBtF each (the features of a diagonal tile are all "I")
-  const int aI = 2 * n0, aJ = 2 * n2;                    // first row of A^T / S of either group
-  const bool work = nfI > 0 || nfJ > 0;
-
-  if (work) {
-    // ---- feature records ----
-    const int nrec = (nfI + nfJ) * kBtFD;
-    double rv[3];
+  // slot records (Jacobians of unmeasured slots are fetched too: they are never used)
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int idx = tid + kBtThreads * u;
-      double v = 0.0;
-      if (idx < nrec) {
-        const int e = idx / kBtFD, q = idx - e * kBtFD;
-        const int side = e < nfI ? 0 : 1, el = side ? e - nfI : e;
-        const int li = (side ? n2 : n0) + el;
-        const int f = li < 256 ? sIdx[li] : sidx[li];
-        const size_t fi = (size_t)b * N + f;
+  for (int u = 0; u < 3; ++u) {
+    const int idx = tid + kBtThreads * u;
+    double v = 0.0;
+    if (idx < 2 * kBtF * kBtFD) {
+      const int se = idx / kBtFD, q = idx - se * kBtFD;
+      const int side = se / kBtF, e = se - side * kBtF;
+      const int f = (side ? fJ0 : fI0) + e;
+      if (f < (side ? fJ1 : fI1) && !(side && diag)) {
+        const size_t fi = bN + f;
         if (q < 14) v = f_Hx[fi * 14 + q];
         else if (q < 20) v = f_Hy[fi * 6 + (q - 14)];
         else if (q == 20) v = f_R[fi];
         else if (q < 23) v = f_nu[fi * 2 + (q - 21)];
         else v = (double)(13 + 3 * f - (side ? c0 : r0));
       }
-      rv[u] = v;
     }
-    // ---- everything into LDS ----
+    R.rv[u] = v;
+  }
+}
+
+// k_build_AS_tiles<false>: one upper tile per workgroup (80 KB of LDS, two workgroups per CU).  Every phase of a workgroup's
+// life is exposed at that occupancy: loads and staging 0.16-0.20 ms of the launch's 0.40, results 0.055, row role 0.036,
+// S 0.065, column role 0.022 (profiles/r03_build_tiles_ab.txt).
+// k_build_AS_tiles<true>: a workgroup walks `tiles_per_wg` consecutive upper tiles of one sequence with the loads of the next
+// tile in flight while the current one is worked on.  The 29 registers of prefetch push the kernel to 212 VGPRs = one
+// workgroup per CU, and the chain of phases of ONE tile is what bounds it: 0.69 ms at 15 tiles per workgroup, 0.79 at one.
+template <bool PERSIST>
+__global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __restrict__ P, const double* __restrict__ f_Hx,
+                                                               const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
+                                                               const double* __restrict__ f_R, const int* __restrict__ f_arow,
+                                                               const int* __restrict__ m_count, double* __restrict__ At,
+                                                               double* __restrict__ St, int N, int ld, int mld, int B, int skip,
+                                                               int tiles_per_wg) {
+  // skip: timing probes only (bit 0 row role, 1 S, 2 column role, 3 the stores of A^T)
+  int b, grp;
+  const int nt = ld / 64, ntile = nt * (nt + 1) / 2;
+  const int ngrp = (ntile + tiles_per_wg - 1) / tiles_per_wg;
+  if (!xcd_map(ngrp, B, &b, &grp)) return;
+  const int cnt = m_count[b];
+  if (cnt == 0) return;
+  const int t_first = grp * tiles_per_wg, t_last = PERSIST ? min(ntile, t_first + tiles_per_wg) : t_first + 1;
+  int tj = 0, ti = t_first;
+  while (ti > tj) { ti -= tj + 1; ++tj; }           // ti <= tj
+  const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
+  const int tid = threadIdx.x;
+  const double* Pb = P + (size_t)b * ld * ld;
+  double* Ab = At + (size_t)b * mld * ld;
+  double* Sb = St + (size_t)b * mld * mld;
+
+  __shared__ double sT[kBtW * kBtP];           // the tile with its halo: sT[i][j] = P[r0 + i][c0 + j]
+  __shared__ double sPose[2][7][kBtW];         // [0]: pose rows over the columns of J, [1]: over the columns of I
+  __shared__ double sXX[7][7];                 // P[c][c'], c, c' < 7
+  __shared__ double sF[2][kBtF][kBtFD];        // [0]: the feature slots of tile row I, [1]: of tile column J (slot-local index)
+  __shared__ double sA[2 * kBtF][kBtW];        // results of a role (the row role with its two halo columns: what S is formed from)
+  __shared__ double sU[2][2 * kBtF][7];        // A^T[k][0..6] of the slots of I ([0]) and of J ([1])
+  __shared__ int sArow[2][kBtF];               // first row of A^T / S of a slot's feature (f_arow), -1 = not measured this frame
+
+  BtRegs R;
+  bt_load(R, Pb, f_Hx, f_Hy, f_nu, f_R, f_arow, (size_t)b * N, N, ld, ti, tj, tid);
+  for (int tcur = t_first; tcur < t_last; ++tcur) {
+  const int r0 = ti * 64, c0 = tj * 64;
+  const bool diag = ti == tj;
+  if (PERSIST && tcur > t_first) __syncthreads();         // the previous tile is done with the LDS
+  // ---- everything into LDS ----
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
-      sT[row * kBtP + c2] = tv[u].x;
-      sT[row * kBtP + c2 + 1] = tv[u].y;
-    }
-    if (tid < 128) {
-      const int i = tid >> 1, h = tid & 1;
-      sT[i * kBtP + 64 + h] = hv;
-      if (diag) sT[(64 + h) * kBtP + i] = hv;
-    } else if (tid < 256) {
-      if (!diag) sT[(64 + (tid & 1)) * kBtP + ((tid - 128) >> 1)] = hv;
-    } else if (tid < 260) {
-      sT[(64 + ((tid - 256) >> 1)) * kBtP + 64 + (tid & 1)] = hv;
-    } else if (tid < 309) {
-      sXX[(tid - 260) / 7][(tid - 260) % 7] = hv;
-    }
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
+    sT[row * kBtP + c2] = R.tv[u].x;
+    sT[row * kBtP + c2 + 1] = R.tv[u].y;
+  }
+  if (tid < 128) {
+    const int i = tid >> 1, h = tid & 1;
+    sT[i * kBtP + 64 + h] = R.hv;
+    if (diag) sT[(64 + h) * kBtP + i] = R.hv;
+  } else if (tid < 256) {
+    if (!diag) sT[(64 + (tid & 1)) * kBtP + ((tid - 128) >> 1)] = R.hv;
+  } else if (tid < 260) {
+    sT[(64 + ((tid - 256) >> 1)) * kBtP + 64 + (tid & 1)] = R.hv;
+  } else if (tid < 309) {
+    sXX[(tid - 260) / 7][(tid - 260) % 7] = R.hv;
+  } else if (tid >= 320 && tid < 320 + 2 * kBtF) {
+    (&sArow[0][0])[tid - 320] = R.arow;
+  }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int idx = tid + kBtThreads * u;
-      if (idx < 2 * 7 * kBtW) (&sPose[0][0][0])[idx] = pv[u];
-    }
+  for (int u = 0; u < 2; ++u) {
+    const int idx = tid + kBtThreads * u;
+    if (idx < 2 * 7 * kBtW) (&sPose[0][0][0])[idx] = R.pv[u];
+  }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      const int idx = tid + kBtThreads * u;
-      if (idx < nrec) (&sF[0][0][0])[idx < nfI * kBtFD ? idx : (kBtF * kBtFD + idx - nfI * kBtFD)] = rv[u];
-    }
+  for (int u = 0; u < 3; ++u) {
+    const int idx = tid + kBtThreads * u;
+    if (idx < 2 * kBtF * kBtFD) (&sF[0][0][0])[idx] = R.rv[u];
   }
   __syncthreads();
+  {   // the next tile's loads fly under this tile's arithmetic
+    int ni = ti + 1, nj = tj;
+    if (ni > nj) { ni = 0; ++nj; }
+    if (PERSIST && tcur + 1 < t_last) bt_load(R, Pb, f_Hx, f_Hy, f_nu, f_R, f_arow, (size_t)b * N, N, ld, ni, nj, tid);
+  }
 
-  if (work) {
-    // ---- row role: A^T[aI + 2 e + r][c0 + j] -> sA; a thread owns one output row over eight columns (chunk 8 = the two
-    // halo columns, kept for S only: they belong to the next tile column of A^T) ----
-    if (tid < 2 * nfI * 9) {
-      const int a = tid / 9, ch = tid - a * 9;
+  // ---- row role: A^T[arow_e + r][c0 + j] -> sA[2 e + r]; a thread owns one output row over eight columns (chunk 8 = the
+  // two halo columns, kept for S only: they belong to the next tile column of A^T) ----
+  if (!(skip & 1) && tid < 2 * kBtF * 9) {
+    const int a = tid / 9, ch = tid - a * 9;
+    if (sArow[0][a >> 1] >= 0) {
       bt_row_chunk<true>(sT, &sPose[0][0][0], sF[0][a >> 1], a & 1, ch < 8 ? ch : 64, ch < 8 ? 8 : 2, ch < 8 ? 8 : 1, sA[a]);
       if (c0 + 64 == ld && ch == 7) sA[a][63] = sF[0][a >> 1][21 + (a & 1)];       // column ld - 1 carries the innovation
     }
-    // ---- A^T[k][0..6] of both groups (columns < 13: the pose part reads P[c][c'], the feature part the pose rows at the
-    // feature's own columns, i.e. the mirrors of P[pos + c'][c]) ----
-    for (int idx = tid; idx < (nfI + nfJ) * 14; idx += kBtThreads) {
-      const int e = idx / 14, rc = idx - e * 14, r = rc / 7, c = rc - r * 7;
-      const int side = e < nfI ? 0 : 1, el = side ? e - nfI : e;
-      const double* F = sF[side][el];
-      const int lp = (int)F[23];
-      double acc = 0.0;
+  }
+  // ---- A^T[k][0..6] of both groups (columns < 13: the pose part reads P[c][c'], the feature part the pose rows at the
+  // feature's own columns, i.e. the mirrors of P[pos + c'][c]) ----
+  for (int idx = tid; idx < 2 * kBtF * 14; idx += kBtThreads) {
+    const int se = idx / 14, rc = idx - se * 14, r = rc / 7, c = rc - r * 7;
+    const int side = se / kBtF, e = se - side * kBtF;
+    if (sArow[side][e] < 0) continue;
+    const double* F = sF[side][e];
+    const int lp = (int)F[23];
+    double acc = 0.0;
 #pragma unroll
-      for (int c2 = 0; c2 < 7; ++c2) acc += sXX[c][c2] * F[r * 7 + c2];
+    for (int c2 = 0; c2 < 7; ++c2) acc += sXX[c][c2] * F[r * 7 + c2];
 #pragma unroll
-      for (int c2 = 0; c2 < 3; ++c2) acc += sPose[side ? 0 : 1][c][lp + c2] * F[14 + r * 3 + c2];
-      sU[side][2 * el + r][c] = acc;
-    }
+    for (int c2 = 0; c2 < 3; ++c2) acc += sPose[side ? 0 : 1][c][lp + c2] * F[14 + r * 3 + c2];
+    sU[side][2 * e + r][c] = acc;
   }
   __syncthreads();
 
-  if (work && nfI > 0) {
+  {
     // ---- the row-role results leave in 512-byte row segments ----
-    for (int idx = tid; idx < 2 * nfI * 32; idx += kBtThreads) {
+    for (int idx = tid; !(skip & 8) && idx < 2 * kBtF * 32; idx += kBtThreads) {
       const int a = idx >> 5, c2 = (idx & 31) * 2;
+      const int ar = sArow[0][a >> 1];
+      if (ar < 0) continue;
       double2 v;
       v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
-      *(double2*)(Ab + (size_t)(aI + a) * ld + c0 + c2) = v;
+      *(double2*)(Ab + (size_t)(ar + (a & 1)) * ld + c0 + c2) = v;
     }
     // ---- S: St[k][t] = H_t . A_k for k in the rows of I, t in the rows of J (stored where (t | 31) >= k: the blocks on and
     // below the block diagonal and the full diagonal blocks).  A thread owns one t (its coefficients in registers) and walks
     // the k's of its wavefront. ----
     const int sj = diag ? 0 : 1;
-    const int nk = 2 * nfI, ntt = 2 * (diag ? nfI : nfJ);
     const int lane = tid & 63, wv = tid >> 6;
-    if (lane < ntt) {
-      const int tt = lane, at = aJ + tt;
+    const int art = (lane < 2 * kBtF && !(skip & 2)) ? sArow[sj][lane >> 1] : -1;
+    if (art >= 0) {
+      const int tt = lane, at = art + (tt & 1);
       const double* Ft = sF[sj][tt >> 1];
       const int r = tt & 1, lp = (int)Ft[23];
       double hx[7], hy[3];
@@ -437,8 +458,10 @@ __global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __r
 #pragma unroll
       for (int c = 0; c < 3; ++c) hy[c] = Ft[14 + r * 3 + c];
       const double Rt = Ft[20];
-      for (int kk = wv; kk < nk; kk += kBtThreads / 64) {
-        const int ak = aI + kk;
+      for (int kk = wv; kk < 2 * kBtF; kk += kBtThreads / 64) {
+        const int ark = sArow[0][kk >> 1];
+        if (ark < 0) continue;
+        const int ak = ark + (kk & 1);
         if ((at | 31) >= ak) {
           double acc = 0.0;
 #pragma unroll
@@ -470,20 +493,22 @@ __global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __r
       }
     }
   }
-  __syncthreads();
 
-  // ---- column role: A^T[aJ + 2 e + r][r0 + i] through the mirrors P[i][pos + c] (sA is free again) ----
-  if (nfJ > 0) {
-    if (tid < 2 * nfJ * 8) {
+  // ---- column role: A^T[arow_e + r][r0 + i] through the mirrors P[i][pos + c] (sA is free again) ----
+  if (!diag) {
+    __syncthreads();
+    if (!(skip & 4) && tid < 2 * kBtF * 8) {
       const int a = tid >> 3, ch = tid & 7;
-      bt_row_chunk<false>(sT, &sPose[1][0][0], sF[1][a >> 1], a & 1, ch, 8, 8, sA[a]);
+      if (sArow[1][a >> 1] >= 0) bt_row_chunk<false>(sT, &sPose[1][0][0], sF[1][a >> 1], a & 1, ch, 8, 8, sA[a]);
     }
     __syncthreads();
-    for (int idx = tid; idx < 2 * nfJ * 32; idx += kBtThreads) {
+    for (int idx = tid; !(skip & 8) && idx < 2 * kBtF * 32; idx += kBtThreads) {
       const int a = idx >> 5, c2 = (idx & 31) * 2;
+      const int ar = sArow[1][a >> 1];
+      if (ar < 0) continue;
       double2 v;
       v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
-      *(double2*)(Ab + (size_t)(aJ + a) * ld + r0 + c2) = v;
+      *(double2*)(Ab + (size_t)(ar + (a & 1)) * ld + r0 + c2) = v;
     }
   }
 
@@ -504,8 +529,9 @@ __global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __r
       }
     }
   }
+  if (++ti > tj) { ti = 0; ++tj; }
+  }   // tiles of this workgroup
 }
-
 #endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
@@ -1895,6 +1921,16 @@ __global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, i
 }
 #endif  // SL2_TESTING
 
+#ifdef SL2_TESTING
+// tiles a workgroup of k_build_AS_tiles walks (SL2_BUILD_SPLIT >> 8 overrides; its low byte is the probes' skip mask), and the
+// resulting workgroups per sequence
+static int bt_tiles_per_wg(const sl2_engine* e) { return (e->root->build_split >> 8) > 0 ? (e->root->build_split >> 8) : 1; }
+static int bt_groups(const sl2_engine* e) {
+  const int nt = e->ld / 64, ntile = nt * (nt + 1) / 2, k = bt_tiles_per_wg(e);
+  return (ntile + k - 1) / k;
+}
+#endif
+
 // Profiling scopes carry the SYMBOL of the kernel they bracket (so that the bench's per-kernel times and rocprofv3's
 // kernel_stats.csv join on the name); "@phase" tells two uses of one kernel apart (k_fwdsub_lds is also the panel solve of
 // the large-map Cholesky).
@@ -1906,12 +1942,25 @@ static int launch_update_range(sl2_engine* e) {
   const int chol_variant = 1, fwd_variant = 1;
 #endif
 #ifdef SL2_TESTING
+  if (build_variant == 3) {
+    // timing probe: the tile kernel as a SHADOW launch (its A^T goes to Vt, which the substitution overwrites anyway, its S to
+    // a scratch buffer), so that phases of it can be switched off (SL2_BUILD_SPLIT = skip mask) without touching the filter
+    static double* s_scratch = nullptr;
+    static size_t s_scratch_n = 0;
+    const size_t need = (size_t)e->root->B * e->mld * e->mld;
+    if (s_scratch_n < need) { if (s_scratch) (void)hipFree(s_scratch); SL2_HIP(hipMalloc((void**)&s_scratch, sizeof(double) * need)); s_scratch_n = need; }
+    LaunchScope ls(e, "k_build_AS_tiles", true);
+    const int nt = e->ld / 64;
+    hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
+                       e->f_nu, e->f_R, e->f_arow, e->m_count, e->Vt, s_scratch, e->N, e->ld, e->mld, B, e->root->build_split & 255, bt_tiles_per_wg(e));
+    SL2_HIP(hipGetLastError());
+  }
   if (build_variant == 2) {
     // A^T and S from the upper block triangle of P: one workgroup per 64 x 64 tile (measured slower: see the kernel)
     LaunchScope ls(e, "k_build_AS_tiles", true);
     const int nt = e->ld / 64;
-    hipLaunchKernelGGL(k_build_AS_tiles, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
-                       e->f_nu, e->f_R, e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld, B);
+    hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
+                       e->f_nu, e->f_R, e->f_arow, e->m_count, e->At, e->St, e->N, e->ld, e->mld, B, 0, bt_tiles_per_wg(e));
     SL2_HIP(hipGetLastError());
   } else if (build_variant == 0) {
     {
@@ -1937,7 +1986,7 @@ static int launch_update_range(sl2_engine* e) {
     // of it - k_search_score - to consist of single-wave workgroups, see launch_search).  Smaller batches: ~3000 workgroups
     // in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
     int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
-    if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
+    if (e->root->build_split > 0 && e->root->build_variant != 3) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;

@@ -156,7 +156,7 @@ static int build_groups(sl2_engine* e, int G) {
     g->f_h = e->f_h + f * N * 2; g->f_Hx = e->f_Hx + f * N * 14; g->f_Hy = e->f_Hy + f * N * 6; g->f_R = e->f_R + f * N;
     g->f_S = e->f_S + f * N * 4; g->f_score = e->f_score + f * N; g->f_z = e->f_z + f * N * 2; g->f_nu = e->f_nu + f * N * 2;
     g->sel_idx = e->sel_idx + f * N; g->n_sel = e->n_sel + f; g->n_vis = e->n_vis + f; g->meas_ok = e->meas_ok + f * N;
-    g->meas_score = e->meas_score + f * N; g->succ_idx = e->succ_idx + f * N; g->m_count = e->m_count + f;
+    g->meas_score = e->meas_score + f * N; g->succ_idx = e->succ_idx + f * N; g->f_arow = e->f_arow + f * N; g->m_count = e->m_count + f;
     g->srch_i = e->srch_i + f * N * 8; g->srch_d = e->srch_d + f * N * 4; g->srch_res = e->srch_res + f * N * 8; g->srch_sel = e->srch_sel + f * N * 16;
     g->work = e->work + f * kWorkDoubles; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
@@ -337,6 +337,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->meas_ok, B * N));
   A(dmalloc(&e->meas_score, B * N));
   A(dmalloc(&e->succ_idx, B * N));
+  A(dmalloc(&e->f_arow, B * N));
   A(dmalloc(&e->m_count, B));
   A(dmalloc(&e->work, B * kWorkDoubles));
   A(dmalloc(&e->srch_i, B * N * 8));
@@ -408,7 +409,7 @@ void sl2_destroy(sl2_engine* e) {
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   void* ptrs[] = {e->x, e->P, e->patch, e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful,
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
-                  e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->m_count,
+                  e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->f_arow, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
                   e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);

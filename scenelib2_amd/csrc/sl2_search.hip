@@ -645,7 +645,8 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        double* __restrict__ f_nu, int* __restrict__ attempted,
                                                        int* __restrict__ successful, int* __restrict__ meas_ok,
                                                        double* __restrict__ meas_score, double* __restrict__ work,
-                                                       int* __restrict__ succ_idx, int* __restrict__ m_count, int N) {
+                                                       int* __restrict__ succ_idx, int* __restrict__ f_arow,
+                                                       int* __restrict__ m_count, int N) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   extern __shared__ int s_flag[];        // [N] successful measurement of slot i in this frame
   __shared__ int s_wcnt[16];
@@ -708,7 +709,9 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
       if (w < wave) off += c;
       total += c;
     }
-    if (ok) succ_idx[(size_t)b * N + off + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    const int rank = off + __popcll(mask & ((1ull << lane) - 1ull));
+    if (ok) succ_idx[(size_t)b * N + rank] = i;
+    if (i < N) f_arow[(size_t)b * N + i] = ok ? 2 * rank : -1;       // (what k_build_AS_tiles indexes by slot)
     base += total;
     __syncthreads();
   }
@@ -792,7 +795,7 @@ int launch_search(sl2_engine* e) {
     if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
     hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * e->N, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
-                       e->succ_idx, e->m_count, e->N);
+                       e->succ_idx, e->f_arow, e->m_count, e->N);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

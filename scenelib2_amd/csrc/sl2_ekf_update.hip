@@ -985,6 +985,109 @@ __global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St,
 // (The first version updated the whole diagonal tile in a phase of its own at the top of the column, M0 alone with
 // three waves waiting: 0.8 + 2.6 J kcycles of a 20-40 kcycle column, scripts/chol_trace.py.)
 // ---------------------------------------------------------------------------
+// ---- the D wave's routine: [A; I] -> [L; L^-T] by column Cholesky, a row per lane (lanes 0..31: the diagonal tile, lanes
+// 32..63: the identity), 32 columns unrolled ------------------------------------------------------------------------------
+// A wave on its own issues one instruction every ~2.5 ns whatever its kind (s_waitcnt and s_nop included), dependent or not
+// (scripts/dwave_bench.hip: the routine's time follows its instruction count, 2300 -> 5.9 us): the routine is bound by the
+// number of instructions, not by the "dependent chain" the first rounds blamed.  Column c needs the scalars l[cc], cc > c,
+// in every lane.  Through v_readlane that is three instructions a product (two v_readlane_b32, one v_fma_f64 with an SGPR
+// pair): 1488 of the 2300.  Here only the product the next pivot waits for goes that way; the others are stored to LDS as a
+// column and come back as wave-uniform ds_read_b128 (two scalars an instruction) one column later: 1.5 instructions a
+// product.  The compiler places a ds_read right in front of its use and waits on the spot (that form measured no gain at
+// all), so the reads, their s_waitcnt and the order of the pieces are pinned with asm statements: the scalars of a column
+// are fetched in two halves, each as soon as the registers of the same half of the previous column are free, and are in
+// flight over the other half's products and the next column's pivot arithmetic.  No masking of the upper triangle (those
+// lanes' values are never read by another lane and never stored), 1 / sqrt by v_rsq_f64 and one cubic step.
+// 1436 instructions, 3.65 us a block alone (5.9 before), 4.3 with a wave on every SIMD (6.5).
+typedef double DPair __attribute__((ext_vector_type(2)));
+template <int K> struct DCol {                         // column K: products cc = K+1 .. K+F through v_readlane, the rest through LDS
+  static constexpr int F = (11 - K) > 1 ? (11 - K) : 1;  // at most 20 scalars of a column in registers at a time (24: spills at the 128-register budget)
+  static constexpr int B0 = K + F + 1;
+  static constexpr int NB = (32 - B0) > 0 ? (32 - B0) : 0;
+  static constexpr bool ODD = (B0 & 1) != 0;
+  static constexpr int P0 = B0 + (ODD ? 1 : 0);        // first index of the aligned pairs
+  static constexpr int NP = (32 - P0) > 0 ? (32 - P0) / 2 : 0;
+  static constexpr int H = (NP + 1) / 2;               // pairs guarded by the first wait
+};
+struct DScal { double s; DPair p[12]; };
+template <int K, int I, int END> __device__ __forceinline__ void d_read_pairs(DScal& t, unsigned colbase) {
+  if constexpr (I < END) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t.p[I]) : "v"(colbase), "i"(((K & 1) * 64 + DCol<K>::P0 + 2 * I) * 8) : "memory");
+    d_read_pairs<K, I + 1, END>(t, colbase);
+  }
+}
+// The scalars of column K are fetched in two halves, each as soon as the registers of the same half of column K - 1 are
+// free, so that a half is in flight over the other half's products AND the next column's chain (the chain alone, ~16
+// instructions, does not cover a burst of eight ds_read_b128).
+template <int K> struct DHalfA { static constexpr int N = DCol<K>::NB > 0 ? (DCol<K>::ODD ? 1 : 0) + DCol<K>::H : 0; };
+template <int K> __device__ __forceinline__ void d_read_a(DScal& t, unsigned colbase, double& token) {
+  if constexpr (DCol<K>::NB > 0) {
+    asm volatile("" : "+v"(token) :: "memory");
+    if constexpr (DCol<K>::ODD)
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(t.s) : "v"(colbase), "i"(((K & 1) * 64 + DCol<K>::B0) * 8) : "memory");
+    d_read_pairs<K, 0, DCol<K>::H>(t, colbase);
+  }
+}
+template <int K> __device__ __forceinline__ void d_read_b(DScal& t, unsigned colbase, double& token) {
+  if constexpr (DCol<K>::NP > DCol<K>::H) {
+    asm volatile("" : "+v"(token) :: "memory");
+    d_read_pairs<K, DCol<K>::H, DCol<K>::NP>(t, colbase);
+  }
+}
+template <int K, int I, int END> __device__ __forceinline__ void d_guard(DScal& t) {   // the products with p[I..END) stay behind the wait
+  if constexpr (I < END) {
+    asm volatile("" : "+v"(t.p[I]));
+    d_guard<K, I + 1, END>(t);
+  }
+}
+template <int K, int I, int END> __device__ __forceinline__ void d_fma_pairs(DScal& t, double (&a)[32]) {
+  if constexpr (I < END) {
+    constexpr int cc = DCol<K>::P0 + 2 * I;
+    a[cc] = __builtin_fma(-a[K], t.p[I].x, a[cc]);
+    a[cc + 1] = __builtin_fma(-a[K], t.p[I].y, a[cc + 1]);
+    d_fma_pairs<K, I + 1, END>(t, a);
+  }
+}
+template <int K> __device__ __forceinline__ void d_apply_a(DScal& t, double (&a)[32], double after) {
+  using D = DCol<K>;
+  if constexpr (D::NB > 0) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(t.s) : "v"(after), "i"(D::NP - D::H));     // behind it: the second half
+    d_guard<K, 0, D::H>(t);
+    if constexpr (D::ODD) a[D::B0] = __builtin_fma(-a[K], t.s, a[D::B0]);
+    d_fma_pairs<K, 0, D::H>(t, a);
+  }
+}
+template <int K> __device__ __forceinline__ void d_apply_b(DScal& t, double (&a)[32]) {
+  using D = DCol<K>;
+  if constexpr (D::NP > D::H) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(t.p[D::H]) : "i"(DHalfA<K + 1>::N));      // behind it: the next column's first half
+    d_guard<K, D::H + 1, D::NP>(t);
+    d_fma_pairs<K, D::H, D::NP>(t, a);
+  }
+}
+// 1 / sqrt(p): v_rsq_f64 (5e-8) and one cubically convergent step, five dependent instructions (two Newton steps: seven)
+__device__ __forceinline__ double rsqrt_halley(double p) {
+  const double y = __builtin_amdgcn_rsq(p);
+  const double r = __builtin_fma(-(p * y), y, 1.0);
+  return __builtin_fma(y * r, __builtin_fma(r, 0.375, 0.5), y);
+}
+template <int C> __device__ __forceinline__ void d_column(double (&a)[32], DScal& t, unsigned colbase, double* col_store,
+                                                          double* row_store) {
+  const double piv = readlane_f64(a[C], C);
+  const double l = a[C] * rsqrt_halley(piv);
+  a[C] = l;
+  if constexpr (DCol<C>::NB > 0) col_store[(C & 1) * 64] = l;
+#pragma unroll
+  for (int f = 1; f <= DCol<C>::F; ++f)
+    if (C + f < 32) a[C + f] = __builtin_fma(-l, readlane_f64(l, C + f), a[C + f]);
+  if constexpr (C > 0) d_apply_a<C - 1>(t, a, C + 1 < 32 ? a[C + 1] : l);
+  d_read_a<C>(t, colbase, a[DCol<C>::P0 + 2 * DCol<C>::H - 1 < 32 ? DCol<C>::P0 + 2 * DCol<C>::H - 1 : 31]);
+  if constexpr (C > 0) d_apply_b<C - 1>(t, a);
+  d_read_b<C>(t, colbase, a[31]);
+  if constexpr (C > 0) row_store[C - 1] = a[C - 1];    // column C - 1 is done with
+  if constexpr (C + 1 < 32) d_column<C + 1>(a, t, colbase, col_store, row_store);
+}
+
 // acc(I, J) -= sum_{K < kend} L[J][K-block] L[I][K-block]^T (kend = J: the complete left-looking update)
 __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int kend, int lo, int hi) {
   Tile32 acc = tile_load(Sb, mld, J * 32, I * 32, lo, hi);
@@ -1042,6 +1145,8 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
   __shared__ double sTile[32][33];
   __shared__ double sLinv[32 * kLinvPitch];
   __shared__ double sNext[1024];      // the next diagonal tile (partial), MFMA fragment order
+  __shared__ __attribute__((aligned(16))) double sCol[2][64];   // the D wave's last two columns of L (scalar operands of its products)
+  __shared__ double sIdent[32][33];   // the identity the D wave starts its inverse from
   double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
   LinvT += (size_t)J0 * 1024;
 #ifdef SL2_CHOL_TRACE
@@ -1063,6 +1168,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
         for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = t.f[jt][it][r4];
   };
   if (mw == 0) diag_to_lds(tile_load(Sb, mld, 0, 0, lane & 15, lane >> 4), lane & 15, lane >> 4);
+  for (int i = threadIdx.x; i < 32 * 33; i += 256) (&sIdent[0][0])[i] = (i / 33 == i % 33) ? 1.0 : 0.0;
   __syncthreads();
   for (int J = 0; J < nblk; ++J) {
     const int o = J * 32;
@@ -1080,24 +1186,15 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       const int r = lane_j & 31;
       const bool low = lane_j < 32;
       double a[32];
+      const double* src = low ? &sTile[r][0] : &sIdent[r][0];
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const double v = sTile[r][c];
-        a[c] = low ? v : ((r == c) ? 1.0 : 0.0);
-      }
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const double piv = readlane_f64(a[c], c);
-        const double dinv = fast_rsqrt(piv);
-        const double l = (!low || r >= c) ? a[c] * dinv : 0.0;
-        a[c] = l;
-#pragma unroll
-        for (int cc = c + 1; cc < 32; ++cc) a[cc] -= l * readlane_f64(l, cc);
-      }
-      if (!low) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sLinv[r * kLinvPitch + c] = a[c];
-      }
+      for (int c = 0; c < 32; ++c) a[c] = src[c];
+      // rows of L^-T (lanes 32..63) go to sLinv as their columns finish; the rows of L, which nobody reads, back into sTile
+      double* rows = low ? &sTile[r][0] : &sLinv[r * kLinvPitch];
+      DScal t;
+      t.s = 0.0;
+      d_column<0>(a, t, (unsigned)(size_t)(__attribute__((address_space(3))) double*)&sCol[0][0], &sCol[0][lane_j], rows);
+      rows[31] = a[31];
       __builtin_amdgcn_s_setprio(0);
     } else {
       // The column's update tasks - tile (J+1, J), the next diagonal tile (J+1, J+1) as far as finished columns go, then the
@@ -2074,9 +2171,10 @@ static int launch_update_range(sl2_engine* e) {
   {
     LaunchScope ls(e, "k_syrk", true);
     const int nt = e->ld / 64;
-#ifdef SL2_CHOL_TRACE
+#ifdef SL2_CHOL_TRACE   // the stamp buffer is the Cholesky's unless SL2_TRACE_SYRK is set (scripts/syrk_clock.py sets it)
+    static const bool trace_syrk = getenv("SL2_TRACE_SYRK") != nullptr;
     hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count,
-                       e->ld, e->mld, B, (long long*)e->root->chol_trace);
+                       e->ld, e->mld, B, trace_syrk ? (long long*)e->root->chol_trace : nullptr);
 #else
     hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, B)), dim3(256), 0, e->stream, e->Vt, e->P, e->x, e->m_count,
                        e->ld, e->mld, B);

@@ -77,7 +77,9 @@ def main():
             p1 = np.where(ok, t[:, :, 1] - t[:, :, 0], np.nan).mean(0)
             p2 = np.where(ok, t[:, :, 2] - t[:, :, 1], np.nan).mean(0)
             p3 = np.where(ok, t[:, :, 3] - t[:, :, 2], np.nan).mean(0)
-            print(nm, "P1 (incl. wait X0):", p1[:7], " X1->before X2:", p2[:7], " X2->before X3:", p3[:7])
+            print(nm, "P2 (loop top -> before X2):", (p1 + p2)[:7], " wait X2 + P3 (-> before X3):", p3[:7])
+        col = np.where(tr[:, 0, 1:, 0] != 0, tr[:, 0, 1:, 0] - tr[:, 0, :-1, 0], 0).astype(np.float64)
+        print("D wave, loop top to loop top per column:", col.mean(0)[:7])
         tot = (tr[:, 0, :, 3].max(1) - tr[:, 0, 0, 0]).astype(np.float64)
         print("mean total cycles per sequence:", tot.mean(), "max", tot.max())
         return

@@ -3,6 +3,7 @@ SL2_LIB_PATH=scenelib2_amd/libscenelib2_amd_trace.so).  With R workgroups reside
 launch duration in CYCLES; against the launch's duration in seconds (HIP events) that is the clock the CUs ran at."""
 import ctypes as C
 import os
+os.environ.setdefault("SL2_TRACE_SYRK", "1")   # the trace build stamps k_chol_left by default
 import sys
 
 import numpy as np

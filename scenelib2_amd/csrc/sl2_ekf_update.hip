@@ -1588,7 +1588,7 @@ static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done) {
     SL2_HIP(hipGetLastError());
     return SL2_OK;
   }
-  if (e->nblk_max > 13) { *done = false; return SL2_OK; }     // beyond the register-resident strip: the grouped form
+  if (e->nblk_max > e->root->group_from) { *done = false; return SL2_OK; }     // beyond the register-resident strip (13 blocks): the grouped form
   const dim3 grid(xcd_grid(e->ld / 64, B)), block(256);
   LaunchScope ls(e, "k_fwdsub_lds", true);
 #define SL2_FWD_CASE(NBV)                                                                                           \
@@ -1606,8 +1606,67 @@ static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done) {
   return SL2_OK;
 }
 
-constexpr int kSyrkKC = 16;       // K rows per chunk (k_syrk, k_fwd_gemm)
-constexpr int kSyrkPitch = 80;    // doubles per LDS row (64 + 16)
+constexpr int kSyrkKC = 16;       // K rows per chunk (k_syrk, k_fwd_gemm, k_chol_syrk)
+
+// ---------------------------------------------------------------------------
+// The K loop of k_syrk as a building block for the large-map GEMMs (k_fwd_gemm, k_chol_syrk): a 64x64 tile, four waves of
+// 32x32, acc[it][jt][r] += sum_k A[k][wi + 16 it + 4 r + hi] * B[k][wj + 16 jt + lo] over `nchunk` chunks of 16 k-rows,
+// both operands k-major in memory (row segments), staged through the 32 KB swapped-half-row LDS layout with the register
+// prefetch two chunks ahead.  (Rounds 1-2 ran these two kernels on the first SYRK pipeline - 40 KB at pitch 80, one
+// chunk ahead: 49.5 and 39 TFLOP/s at configs[4] against k_syrk's 59.)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void kpanel_product(const double* __restrict__ A, size_t lda, const double* __restrict__ Bm, size_t ldb,
+                                               int nchunk, bool idle, int wi, int wj, double (&sAB)[2][2][kSyrkKC * 64],
+                                               v4d (&acc)[2][2]) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lo = lane & 15, hi = lane >> 4;
+  const int kr = tid >> 4, c2 = (tid & 15) * 2;
+  const double* gA = A + (size_t)kr * lda + c2;
+  const double* gB = Bm + (size_t)kr * ldb + c2;
+  struct Stage { double2 a0, a1, b0, b1; };
+  auto stage_load = [&](int chunk) {
+    Stage r;
+    r.a0 = *(const double2*)(gA + (size_t)chunk * kSyrkKC * lda); r.a1 = *(const double2*)(gA + (size_t)chunk * kSyrkKC * lda + 32);
+    r.b0 = *(const double2*)(gB + (size_t)chunk * kSyrkKC * ldb); r.b1 = *(const double2*)(gB + (size_t)chunk * kSyrkKC * ldb + 32);
+    return r;
+  };
+  auto stage_store = [&](int buf, const Stage& r) {
+    const int cs = c2 ^ ((kr & 1) << 4);
+    *(double2*)&sAB[buf][0][kr * 64 + cs] = r.a0;
+    *(double2*)&sAB[buf][0][kr * 64 + 32 + cs] = r.a1;
+    *(double2*)&sAB[buf][1][kr * 64 + cs] = r.b0;
+    *(double2*)&sAB[buf][1][kr * 64 + 32 + cs] = r.b1;
+  };
+  auto chunk_mfma = [&](int buf) {
+    const int sw = (hi & 1) << 4;
+    const double* pa = &sAB[buf][0][hi * 64 + wi + lo];
+    const double* pb = &sAB[buf][1][hi * 64 + wj + lo];
+#pragma unroll
+    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
+      const double a0 = pa[ks * 256 + sw], a1 = pa[ks * 256 + (sw ^ 16)];
+      const double b0 = pb[ks * 256 + sw], b1 = pb[ks * 256 + (sw ^ 16)];
+      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
+      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
+      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
+      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+    }
+  };
+  if (nchunk <= 0) return;
+  Stage r0 = stage_load(0);
+  Stage r1 = r0;
+  if (nchunk > 1) r1 = stage_load(1);
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    stage_store(0, r0);
+    __syncthreads();
+    if (ch + 2 < nchunk) r0 = stage_load(ch + 2);
+    if (!idle) chunk_mfma(0);
+    if (ch + 1 >= nchunk) break;
+    stage_store(1, r1);
+    __syncthreads();
+    if (ch + 3 < nchunk) r1 = stage_load(ch + 3);
+    if (!idle) chunk_mfma(1);
+  }
+}
 
 // ---------------------------------------------------------------------------
 // k_fwd_gemm: At[R0 .. R0+256) -= L[R0 .. R0+256)[0 .. R0) * Vt[0 .. R0), the contribution of the already
@@ -1615,7 +1674,7 @@ constexpr int kSyrkPitch = 80;    // doubles per LDS row (64 + 16)
 // both operands streamed through double-buffered LDS in chunks of 16 k-rows like k_syrk (L is stored
 // k-major in St, so both staging reads are row segments).
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_fwd_gemm(double* __restrict__ At, const double* __restrict__ Vt,
+__global__ void __launch_bounds__(256, 4) k_fwd_gemm(double* __restrict__ At, const double* __restrict__ Vt,
                                                   const double* __restrict__ St, const int* __restrict__ m_count, int ld, int mld,
                                                   int B, int J0) {
   int b, t;
@@ -1633,36 +1692,11 @@ __global__ void __launch_bounds__(256) k_fwd_gemm(double* __restrict__ At, const
   double* Ab = At + (size_t)b * mld * ld;
   const double* Vb = Vt + (size_t)b * mld * ld;
   const double* Sb = St + (size_t)b * mld * mld;
-  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
-  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
-  const int kr = tid >> 4, c4 = (tid & 15) * 4;
-  const double* gA = Sb + (size_t)kr * mld + r0 + c4;     // L[r0 + c][k] = St[k][r0 + c]
-  const double* gB = Vb + (size_t)kr * ld + c0 + c4;
-  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  __shared__ double sAB[2][2][kSyrkKC * 64];
   v4d acc[2][2];
   for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
-  const int nchunk = R0 / kSyrkKC;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
-    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
-    __syncthreads();
-    if (ch + 1 < nchunk) {
-      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * mld);
-      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * ld);
-    }
-    const double* pa = &sA[buf][hi * kSyrkPitch + wi + lo];
-    const double* pb = &sB[buf][hi * kSyrkPitch + wj + lo];
-#pragma unroll
-    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
-      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
-      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
-      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-    }
-  }
+  // L[r0 + c][k] = St[k][r0 + c]: both operands are row segments
+  kpanel_product(Sb + r0, (size_t)mld, Vb + c0, (size_t)ld, R0 / kSyrkKC, false, wi, wj, sAB, acc);
 #pragma unroll
   for (int it = 0; it < 2; ++it)
 #pragma unroll
@@ -1696,44 +1730,22 @@ __global__ void __launch_bounds__(256) k_chol_syrk(double* __restrict__ St, cons
   while (t > ti) { t -= ti + 1; ++ti; }
   const int tj = t;                       // tj <= ti : column block j <= row block i (lower triangle, stored St[j][i])
   const int j0 = c0 + tj * 64, i0 = c0 + ti * 64;
-  if (i0 >= mp && j0 >= mp) return;
-  if (j0 >= mp) return;
+  if (j0 >= mp || i0 >= mp) return;       // (j0 <= i0; tiles of the padding are never read)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lo = lane & 15, hi = lane >> 4;
   const int wj = (wave >> 1) * 32, wi = (wave & 1) * 32;
   double* Sb = St + (size_t)b * mld * mld;
-  __shared__ double sA[2][kSyrkKC * kSyrkPitch];
-  __shared__ double sB[2][kSyrkKC * kSyrkPitch];
-  const int kr = tid >> 4, c4 = (tid & 15) * 4;
-  const double* gA = Sb + (size_t)(k0 + kr) * mld + j0 + c4;     // X[j0 + c][k] = St[k][j0 + c]
-  const double* gB = Sb + (size_t)(k0 + kr) * mld + i0 + c4;
-  double4 ra = *(const double4*)gA, rb = *(const double4*)gB;
+  __shared__ double sAB[2][2][kSyrkKC * 64];
   v4d acc[2][2];
   for (int a = 0; a < 2; ++a) for (int c = 0; c < 2; ++c) acc[a][c] = (v4d){0, 0, 0, 0};
   // rows of the panel beyond this sequence's own (padded) system are never initialised: stop at mp
   const int kvalid = (mp - k0 < kp) ? mp - k0 : kp;
-  const int nchunk = kvalid / kSyrkKC;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const int buf = ch & 1;
-    *(double4*)&sA[buf][kr * kSyrkPitch + c4] = ra;
-    *(double4*)&sB[buf][kr * kSyrkPitch + c4] = rb;
-    __syncthreads();
-    if (ch + 1 < nchunk) {
-      ra = *(const double4*)(gA + (size_t)(ch + 1) * kSyrkKC * mld);
-      rb = *(const double4*)(gB + (size_t)(ch + 1) * kSyrkKC * mld);
-    }
-    const double* pa = &sA[buf][hi * kSyrkPitch + wj + lo];
-    const double* pb = &sB[buf][hi * kSyrkPitch + wi + lo];
-#pragma unroll
-    for (int ks = 0; ks < kSyrkKC / 4; ++ks) {
-      const double a0 = pa[ks * 4 * kSyrkPitch], a1 = pa[ks * 4 * kSyrkPitch + 16];
-      const double b0 = pb[ks * 4 * kSyrkPitch], b1 = pb[ks * 4 * kSyrkPitch + 16];
-      acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-      acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-    }
-  }
+  // in a diagonal tile the block (rows j0 + 32 .., columns i0 ..) lies above the diagonal: nobody reads it
+  const bool idle = (ti == tj) && (wj > wi);
+  // X[j0 + c][k] = St[k][j0 + c]
+  kpanel_product(Sb + (size_t)k0 * mld + j0, (size_t)mld, Sb + (size_t)k0 * mld + i0, (size_t)mld, kvalid / kSyrkKC, idle, wj, wi, sAB,
+                 acc);
+  if (idle) return;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -2100,10 +2112,10 @@ static int launch_update_range(sl2_engine* e) {
   }
   // sl2_create sizes the innovation system so that one of the first two branches always applies (mld a multiple of 128
   // beyond kFusedMaxBlocks blocks)
-  if (e->nblk_max > kFusedMaxBlocks && chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
+  if (e->nblk_max > e->root->panel_from && chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
     int rc = launch_chol_panels(e, B);
     if (rc != SL2_OK) return rc;
-  } else if (e->nblk_max <= kFusedMaxBlocks && chol_variant == 1) {
+  } else if (e->nblk_max <= e->root->panel_from && chol_variant == 1) {
     LaunchScope ls(e, "k_chol_left", true);
     hipLaunchKernelGGL(k_chol_left, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max, 0,
                        e->nblk_max, (long long*)e->root->chol_trace);

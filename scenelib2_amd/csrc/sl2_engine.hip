@@ -288,9 +288,12 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (nsel < 1) nsel = 1;
   if (nsel > max_features) nsel = max_features;
   e->nsel_max = nsel;
+#ifdef SL2_TESTING   // TEST build: SL2_PANEL_FROM moves the block count from which the panel-wise / grouped forms take over
+  if (const char* v = getenv("SL2_PANEL_FROM")) e->panel_from = e->group_from = atoi(v);
+#endif
   e->mld = round_up(2 * nsel, 32);
-  if (e->mld / 32 > 13) e->mld = round_up(2 * nsel, 64);    // beyond the one-launch substitution: 64-row tiles (k_fwd_gemm)
-  if (e->mld / 32 > 16) e->mld = round_up(2 * nsel, 128);   // large systems are factored in 128-column panels
+  if (e->mld / 32 > e->group_from) e->mld = round_up(2 * nsel, 64);    // beyond the one-launch substitution: 64-row tiles (k_fwd_gemm)
+  if (e->mld / 32 > e->panel_from) e->mld = round_up(2 * nsel, 128);   // large systems are factored in panels of 128 / 256 columns
   e->nblk_max = e->mld / 32;
   {   // depth particles of the partially initialised feature: any count up to 1024 (the reference loops over any number)
     int np = params->number_of_particles;

@@ -822,6 +822,25 @@ __device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* 
   }
   return t;
 }
+// the same with the tile in registers: the fragment (k = 4 s8 + hi, i = 16 it + lo) of an accumulator IS the B operand of k-step s8
+__device__ __forceinline__ Tile32 tile_panel_regs(const double* sLinv, const Tile32& in, int lo, int hi) {
+  Tile32 t;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int it = 0; it < 2; ++it) t.f[kt][it] = (v4d){0, 0, 0, 0};
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    const int p = 4 * s8 + hi;
+    const double a0 = sLinv[p * kLinvPitch + lo], a1 = sLinv[p * kLinvPitch + 16 + lo];
+    const double b0 = in.f[s8 >> 2][0][s8 & 3], b1 = in.f[s8 >> 2][1][s8 & 3];
+    t.f[0][0] = mfma_f64(a0, b0, t.f[0][0]);
+    t.f[0][1] = mfma_f64(a0, b1, t.f[0][1]);
+    t.f[1][0] = mfma_f64(a1, b0, t.f[1][0]);
+    t.f[1][1] = mfma_f64(a1, b1, t.f[1][1]);
+  }
+  return t;
+}
 // trailing tile (K, I): acc[kk][ii] -= sum_p L[K*32+kk][o+p] L[I*32+ii][o+p], operands from memory
 __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int o, int K, int I, int lo, int hi) {
   Tile32 acc = tile_load(Sb, mld, K * 32, I * 32, lo, hi);
@@ -1178,6 +1197,15 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
     const bool more = J + 1 < nblk;
     TRL(0);
     TRL(1);
+    // P3 for the tiles that went through memory (tasks 3, 5, 6, 7, ...): the D wave (idle in that phase), M1 and M2 in turn
+    auto solve_stored = [&](int turn) {
+      for (int sidx = turn; ; sidx += 3) {
+        const int t = sidx == 0 ? 3 : sidx + 4;
+        if (J + t >= nblk) break;
+        const Tile32 u = tile_panel(sLinv, Sb, mld, o, (J + t) * 32, lo, hi);
+        tile_store(Sb, mld, o, (J + t) * 32, lo, hi, u);
+      }
+    };
     // ---- P2 ----
     if (isD) {
       // the diagonal factorisation is the critical path of the whole kernel (its wave shares a SIMD with MFMA waves of
@@ -1196,54 +1224,58 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       d_column<0>(a, t, (unsigned)(size_t)(__attribute__((address_space(3))) double*)&sCol[0][0], &sCol[0][lane_j], rows);
       rows[31] = a[31];
       __builtin_amdgcn_s_setprio(0);
+      TRL(2);
+      __syncthreads();                     // X2: L_JJ^-1 is in LDS, every tile of column J is updated
+      solve_stored(0);
     } else {
-      // The column's update tasks - tile (J+1, J), the next diagonal tile (J+1, J+1) as far as finished columns go, then the
-      // tiles (J+2, J) ... - are dealt M0, M1, M2, M0, ...: every task costs J tile products, so this is what balances the
+      // The column's update tasks - 0: tile (J+1, J); 1: the next diagonal tile (J+1, J+1) as far as finished columns go;
+      // t >= 2: tile (J+t, J) - are dealt M0, M1, M2, M0, ...: every task costs J tile products, so this is what balances the
       // three waves.  (M0 used to take (J+1, J) AND the next diagonal tile on top of its share of the others: 3 / 1 / 1 tasks
       // at J = 2, 2 / 0 / 0 at J = 5, and its 40-60 k cycles were the column's critical path next to 20-30 k for M1 / M2.)
       // The next diagonal tile is parked in LDS in fragment order (held in registers across the barrier and the panel solve
       // it spilled); M0 picks it up in P3.
+      // Round 3: a wave's FIRST tile (tasks 0 / 4 / 2 of M0 / M1 / M2) is updated last and stays in its registers across X2 -
+      // the accumulator fragment of the update is the B fragment of the panel solve - instead of going out to memory and
+      // coming back: 14 of a 7-block system's 21 tiles, 0.24 MB of a sequence's 1.1 MB of traffic in a bandwidth-bound
+      // kernel, and one store -> barrier -> load round trip less on M0's chain.
+      Tile32 kept;                         // the wave's first tile of the column, from its update to its solve
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kept.f[q >> 1][q & 1] = (v4d){0, 0, 0, 0};   // (left undefined it becomes a value carried around the J loop: 86 spilled registers)
+      int keptI = nblk;
       if (more) {                                   // (the last column has no tile below it)
-        if (mw == 0) {                              // task 0
-          const Tile32 t = tile_left_update(Sb, mld, J, J + 1, J, lo, hi);
-          tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, t);
-        }
         if (mw == 1) {                              // task 1
           const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
 #pragma unroll
           for (int k = 0; k < 16; ++k) sNext[k * 64 + lane_j] = dn.f[k >> 3][(k >> 2) & 1][k & 3];
         }
-        for (int I = J + 2 + (mw + 1) % 3; I < nblk; I += 3) {    // tasks 2, 3, 4, ...: M2, M0, M1, ...
-          const Tile32 t = tile_left_update(Sb, mld, J, I, J, lo, hi);
-          tile_store(Sb, mld, o, I * 32, lo, hi, t);
+        const int t_keep = mw == 0 ? 0 : (mw == 1 ? 4 : 2);
+        for (int t = t_keep + 3; J + t < nblk; t += 3) {          // the wave's later tiles: updated, stored
+          const Tile32 u = tile_left_update(Sb, mld, J, J + t, J, lo, hi);
+          tile_store(Sb, mld, o, (J + t) * 32, lo, hi, u);
         }
+        keptI = mw == 0 ? J + 1 : J + t_keep;
+        if (keptI < nblk) kept = tile_left_update(Sb, mld, J, keptI, J, lo, hi);
       }
-    }
-    TRL(2);
-    __syncthreads();                       // X2: L_JJ^-1 is in LDS, every tile of column J is updated
-    // ---- P3 ----
-    {
-      if (mw == 0 && more) {
-        const Tile32 l = tile_panel(sLinv, Sb, mld, o, (J + 1) * 32, lo, hi);
-        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, l);
-        Tile32 dn;
+      TRL(2);
+      __syncthreads();                     // X2 (the D wave meets it in its own branch)
+      // ---- P3 ----
+      if (keptI < nblk) {
+        const Tile32 l = tile_panel_regs(sLinv, kept, lo, hi);
+        tile_store(Sb, mld, o, keptI * 32, lo, hi, l);
+        if (mw == 0) {                     // the chain: the next diagonal tile minus the square of the tile just solved
+          Tile32 dn;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dn.f[q >> 3][(q >> 2) & 1][q & 3] = sNext[q * 64 + lane_j];
-        tile_diag_sub_regs(dn, l);
-        diag_to_lds(dn, lo, hi);
+          for (int q = 0; q < 16; ++q) dn.f[q >> 3][(q >> 2) & 1][q & 3] = sNext[q * 64 + lane_j];
+          tile_diag_sub_regs(dn, l);
+          diag_to_lds(dn, lo, hi);
+        }
       }
       if (mw == 2) {   // LinvT block to memory for the forward substitution, coalesced
         double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
 #pragma unroll
         for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
       }
-      // the other panel tiles: M1, M2 and the D wave (idle in this phase) in turn; M0 keeps to the chain above
-      const int turn = isD ? 2 : mw - 1;            // M0: -1
-      if (turn >= 0)
-        for (int I = J + 2 + turn; I < nblk; I += 3) {
-          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
-          tile_store(Sb, mld, o, I * 32, lo, hi, t);
-        }
+      if (mw >= 1) solve_stored(mw);       // M0 keeps to the chain above
     }
     TRL(3);
     if (more) __syncthreads();             // X3: column J of L is complete, the next diagonal tile is in LDS

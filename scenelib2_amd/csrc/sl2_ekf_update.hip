@@ -89,7 +89,9 @@ constexpr int kASBatch = 4;   // features per LDS batch (state sizes up to 1024 
 
 // NQ: columns per thread (thread t owns columns t, t + 1024, ...: NQ = 1 for ld <= 1024, 2 up to 2048 - the 1280x720 /
 // 500-feature configuration, ld = 1536); BATCH: features per LDS batch (2 * BATCH * ld doubles of LDS).
-template <int NQ, int BATCH>
+// UP (probe, TEST build: SL2_BUILD_VARIANT=4): entries of P in strictly lower 64x64 tiles are read through their mirrors -
+// a thread walks ITS OWN row of P to the right (the condition is wave-uniform: a wave's 64 columns lie in one tile column).
+template <int NQ, int BATCH, bool UP = false>
 __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                   const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
@@ -145,7 +147,8 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
           if (i < ld) {
             double py[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
+            for (int c = 0; c < 3; ++c)
+              py[c] = (UP && ((pos + c) >> 6) > (i >> 6)) ? Pb[(size_t)i * ld + pos + c] : Pb[(size_t)(pos + c) * ld + i];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
               double acc = 0.0;
@@ -2131,6 +2134,13 @@ static int launch_update_range(sl2_engine* e) {
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;
+#ifdef SL2_TESTING
+    if (build_variant == 4 && e->ld <= 1024) {
+      const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
+      hipLaunchKernelGGL((k_build_AS<1, kASBatch, true>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
+                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+    } else
+#endif
     if (e->ld <= 1024) {
       const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,

@@ -423,11 +423,12 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("build_variant,n_features", [(2, 100), (2, 37), (2, 7), (0, 60)])
+@pytest.mark.parametrize("build_variant,n_features", [(2, 100), (2, 37), (2, 7), (0, 60), (4, 100)])
 def test_build_variants_of_the_test_library(build_variant, n_features, monkeypatch):
     """The measured alternatives to k_build_AS kept in the TEST build: k_build_AS_tiles (SL2_BUILD_VARIANT=2: A^T and S from
-    the upper block triangle of P, tile by tile, with features that straddle a tile boundary) and the two-pass k_build_A +
-    k_build_S (0).  Same filter as the oracle, deletions included."""
+    the upper block triangle of P, tile by tile, with features that straddle a tile boundary), the two-pass k_build_A +
+    k_build_S (0) and the own-row probe (4: strictly lower tiles read through their mirrors).  Same filter as the oracle,
+    deletions included."""
     from scenelib2_amd import _lib
     monkeypatch.setenv("SL2_BUILD_VARIANT", str(build_variant))
     pr = Pair(n_features, 6, batch=3, feature_sigma=0.004, lib=_lib.load_testing())

@@ -143,6 +143,7 @@ struct sl2_engine {
   int no_ksplit = 0;
   int panel_from = 16;        // systems of more 32-blocks than this are factored panel-wise (launch_chol_panels) ...
   int group_from = 13;        // ... and substituted in groups of eight block rows (launch_fwdsub_grouped)
+  int fwd_group = 8;          // block rows per group of the grouped substitution (TEST build: SL2_FWD_GROUP = 4 | 8)
   int chol_panel = 8;         // 32-blocks per panel of the large-map Cholesky: 8 (256 columns; 4.3 ms against 5.05 with 4 at
                               // 512 x n = 1513, profiles/r03_c5_chol_panel_ab.txt); TEST build: SL2_CHOL_PANEL = 4 | 8
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice

@@ -1711,10 +1711,11 @@ __device__ __forceinline__ void kpanel_product(const double* __restrict__ A, siz
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 4) k_fwd_gemm(double* __restrict__ At, const double* __restrict__ Vt,
                                                   const double* __restrict__ St, const int* __restrict__ m_count, int ld, int mld,
-                                                  int B, int J0) {
+                                                  int B, int J0, int nrt) {
+  // nrt: 64-row tiles of the group (4 = eight block rows, 2 = four)
   int b, t;
   const int ntc = ld / 64;
-  if (!xcd_map(4 * ntc, B, &b, &t)) return;
+  if (!xcd_map(nrt * ntc, B, &b, &t)) return;
   const int cnt = m_count[b];
   if (cnt == 0) return;
   const int mp = (2 * cnt + 31) / 32 * 32;
@@ -1828,18 +1829,23 @@ static int launch_chol_panels(sl2_engine* e, int B) {
   return SL2_OK;
 }
 
-// substitution in groups of eight block rows, for systems of more than 13 blocks
+// substitution in groups of eight (or four: fwd_group) block rows, for systems of more than 13 blocks
 static int launch_fwdsub_grouped(sl2_engine* e, int B) {
-  for (int J0 = 0; J0 < e->nblk_max; J0 += 8) {
+  const int g = e->root->fwd_group == 4 ? 4 : 8;
+  for (int J0 = 0; J0 < e->nblk_max; J0 += g) {
     if (J0 > 0) {
       LaunchScope ls(e, "k_fwd_gemm", true);
-      hipLaunchKernelGGL(k_fwd_gemm, dim3(xcd_grid(4 * (e->ld / 64), B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->m_count,
-                         e->ld, e->mld, B, J0);
+      hipLaunchKernelGGL(k_fwd_gemm, dim3(xcd_grid((g / 2) * (e->ld / 64), B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St,
+                         e->m_count, e->ld, e->mld, B, J0, g / 2);
       SL2_HIP(hipGetLastError());
     }
     LaunchScope ls(e, "k_fwdsub_lds", true);
-    hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
-                       e->m_count, e->ld, e->mld, e->nblk_max, B, J0, 0, e->ld / 64, 8);
+    if (g == 4)
+      hipLaunchKernelGGL((k_fwdsub_lds<4>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                         e->m_count, e->ld, e->mld, e->nblk_max, B, J0, 0, e->ld / 64, 4);
+    else
+      hipLaunchKernelGGL((k_fwdsub_lds<8>), dim3(xcd_grid(e->ld / 64, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
+                         e->m_count, e->ld, e->mld, e->nblk_max, B, J0, 0, e->ld / 64, 8);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

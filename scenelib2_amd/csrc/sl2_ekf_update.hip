@@ -1863,7 +1863,7 @@ static int launch_fwdsub_grouped(sl2_engine* e, int B) {
 // k-rows read by one 32-lane group of a ds_read_b64 land on disjoint banks.
 // ---------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
+__global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
                                               const int* __restrict__ m_count, int ld, int mld, int B
 #ifdef SL2_CHOL_TRACE
                                               , long long* trace
@@ -1969,7 +1969,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
 #pragma unroll
         for (int r = 0; r < 4; ++r) pold[it][jt][r] = prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt];
   };
-  const bool want_tile = !idle && interior;
+  const bool want_tile = !idle;
   for (int ch = 0; ch < nchunk; ch += 2) {
     // even chunk: registers r0 -> buffer 0
     stage_store(0, r0);
@@ -1988,14 +1988,18 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
   if (want_tile) fetch_tile();
   if (idle) return;
   const bool mirror = (ti != tj) || (wi != wj);
-  // Row / column ld-1 (the innovation column riding along) only exists in the last tile row / column:
-  // every other 32x32 block takes the branch-free path.
-  if (interior) {
+  // Row / column ld-1 (the innovation column riding along) only exists in the last tile row / column, and there only in the
+  // last 16 x 16 quarter of a wave's block: every other quarter takes the branch-free path.  (Rounds 1-2 sent the whole
+  // 32x32 block of such a wave - 40 of a sequence's 210 quarters, 20 of which hold the column - down the element-wise path
+  // with its uncoalesced mirror stores.)
+  auto plain = [&](int it, int jt) { return interior || ((i0 + 16 * it + 16 < ld) && (j0 + 16 * jt + 16 < ld)); };
+  {
     double* prow = Pb + (size_t)(i0 + hi) * ld + j0 + lo;       // element (i0 + hi, j0 + lo)
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
+      for (int jt = 0; jt < 2; ++jt) {
+        if (!plain(it, jt)) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           if (diagw && it == 1 && jt == 0) continue;            // written below as the transpose of quarter (0, 1)
@@ -2003,6 +2007,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
           prow[(size_t)(16 * it + 4 * r) * ld + 16 * jt] = pn;
           acc[it][jt][r] = pn;
         }
+      }
     if (mirror || diagw) {
       // The mirror block goes through LDS so that its stores are row segments of 128 bytes like the direct ones (written
       // straight from the accumulator layout every store instruction touched 16 rows with 32 bytes each: the mirror cost
@@ -2016,6 +2021,7 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
           if (diagw && !(it == 0 && jt == 1)) continue;
+          if (!plain(it, jt)) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) sM[lo * 17 + 4 * r + hi] = acc[it][jt][r];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2024,13 +2030,14 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    return;
+    if (interior) return;
   }
   double* xb = x + (size_t)b * ld;
 #pragma unroll
   for (int it = 0; it < 2; ++it)
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < 2; ++jt) {
+      if (plain(it, jt)) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = i0 + 16 * it + hi + 4 * r, col = j0 + 16 * jt + lo;
@@ -2038,11 +2045,12 @@ __global__ void __launch_bounds__(256) k_syrk(const double* __restrict__ Vt, dou
         if (col == ld - 1) {
           if (row != ld - 1) xb[row] += v;  // x += V (L^-1 nu)
         } else if (row != ld - 1) {
-          const double pn = Pb[(size_t)row * ld + col] - v;
+          const double pn = pold[it][jt][r] - v;
           Pb[(size_t)row * ld + col] = pn;
           if (mirror) Pb[(size_t)col * ld + row] = pn;
         }
       }
+    }
 }
 
 #ifdef SL2_TESTING

@@ -461,6 +461,37 @@ def main():
             rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
             parity = dict(traj_rmse_vs_oracle=rmse, checker="reference build (oracle/_ref/libref.so)" if use_ref else "oracle",
                           sequences=sample, frames=cpu_frames, position_maxabs=float(np.abs(log - traj).max()))
+            # ... and over EVERY frame the engine stepped (warm-up, timed region and the bracketed extra steps) on a few
+            # sequences: positions after every frame plus the whole state vector / covariance after the last one.  Bounded to
+            # about a minute of host time (a sequence-frame of the reference costs ~7 ms x (n / 313)^3).
+            full_seq = max(1, min(8, B, ncores))
+            cost = 7e-3 * (n_state / 313.0) ** 3
+            full_frames = int(max(2, min(n_render, 60.0 / cost)))
+            allf2 = np.stack([d_frames.download((full_seq, H, W), np.uint8, offset=k * B * fb) for k in range(full_frames + 1)])
+            slams2 = [build(b) for b in range(full_seq)]
+            _, traj2 = oa.run_sequences(slams2, [np.ascontiguousarray(allf2[1:, b]) for b in range(full_seq)],
+                                        nthreads=min(ncores, full_seq), L=slams2[0].L)
+            log2 = eng.position_log(0, full_seq, capacity=n_render)[:, :full_frames]
+            parity["frames"] = full_frames
+            parity["frames_stepped"] = n_render
+            parity["covers_every_timed_frame"] = bool(full_frames >= Wm + K)
+            parity["full_length"] = dict(sequences=full_seq, frames=full_frames,
+                                         traj_rmse=float(np.sqrt(((log2 - traj2) ** 2).sum(axis=2).mean())),
+                                         position_maxabs=float(np.abs(log2 - traj2).max()))
+            parity["wide_sample"] = dict(sequences=sample, frames=cpu_frames, traj_rmse=rmse)
+            if full_frames == n_render:
+                # the engine stands at frame n_render: whole state and covariance against the reference's
+                dx, dP = 0.0, 0.0
+                for b in range(full_seq):
+                    xo, Po = slams2[b].total_state(), slams2[b].total_covariance()
+                    xg, Pg = eng.total_state(b), eng.total_covariance(b)
+                    if xo.shape == xg.shape:
+                        dx = max(dx, float(np.abs(xo - xg).max()))
+                        dP = max(dP, float(np.linalg.norm(Po - Pg) / max(np.linalg.norm(Po), 1e-300)))
+                    else:
+                        dx = dP = float("inf")
+                parity["full_length"]["final_state_maxabs"] = dx
+                parity["full_length"]["final_covariance_rel_fro"] = dP
 
         out = {
             "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)",

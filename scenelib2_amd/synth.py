@@ -91,7 +91,7 @@ class SequenceSpec:
     """Ground truth + filter initialisation of one synthetic sequence."""
 
     def __init__(self, cam, n_features, n_frames, seed, delta_t=1.0 / 30.0, depth=0.6, tex_extent=2.0,
-                 v_amp=0.06, w_amp=0.08):
+                 v_amp=0.06, w_amp=0.08, w_bias=(0.0, 0.0, 0.01), v_bias=(0.0, 0.0, 0.0)):
         self.cam = dict(cam)
         self.n_features = n_features
         self.n_frames = n_frames
@@ -107,7 +107,11 @@ class SequenceSpec:
         self.w_amp = w_amp * (0.5 + 0.5 * u[20:26].reshape(2, 3))
         self.w_freq = 0.2 + 0.4 * u[26:32].reshape(2, 3)
         self.w_phase = 2 * np.pi * u[32:38].reshape(2, 3)
-        self.w_bias = np.array([0.0, 0.0, 0.01])  # omega(0) != 0 (Q10), like data/SceneLib2.cfg:83
+        # omega(0) != 0 (Q10), like data/SceneLib2.cfg:83.  A larger z component rolls the camera about its optical axis:
+        # the features stay visible while their (unwarped) 11x11 templates stop matching - the natural way a feature
+        # earns delete_bad_features (monoslam.cpp:644-660); v_bias drifts the camera (features leave the view)
+        self.w_bias = np.asarray(w_bias, dtype=np.float64)
+        self.v_bias = np.asarray(v_bias, dtype=np.float64)
         self.r0 = np.array([0.0, 0.0, -depth])
         self.poses = self._integrate_path()
         self.xv0 = np.concatenate([self.poses[0], self.velocity(0.0), self.omega(0.0)])
@@ -116,7 +120,7 @@ class SequenceSpec:
         self.feat_px, self.feat_y = self._place_features(u[40:42])
 
     def velocity(self, t):
-        return (self.v_amp * np.sin(2 * np.pi * self.v_freq * t + self.v_phase)).sum(axis=0)
+        return (self.v_amp * np.sin(2 * np.pi * self.v_freq * t + self.v_phase)).sum(axis=0) + self.v_bias
 
     def omega(self, t):
         return (self.w_amp * np.sin(2 * np.pi * self.w_freq * t + self.w_phase)).sum(axis=0) + self.w_bias
@@ -124,7 +128,7 @@ class SequenceSpec:
     def _position(self, t):
         w = 2 * np.pi * self.v_freq
         integ = self.v_amp / w * (np.cos(self.v_phase) - np.cos(w * t + self.v_phase))
-        return self.r0 + integ.sum(axis=0)
+        return self.r0 + integ.sum(axis=0) + self.v_bias * t
 
     def _integrate_path(self, substeps=8):
         """poses[k] = (r, q) at t = k * delta_t, k = 0..n_frames (frame k of a run is pose k+1)."""

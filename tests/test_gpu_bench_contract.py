@@ -35,6 +35,11 @@ def test_bench_line_contract():
         assert key in c, key
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert d["parity"]["traj_rmse_vs_oracle"] <= 1e-4          # BASELINE.json's tolerance
+    # the parity leg follows EVERY frame the engine stepped (warm-up + timed + the bracketed extra steps) on a few sequences
+    p = d["parity"]
+    assert p["frames"] >= d["steps"] + d["warmup"] and p["covers_every_timed_frame"] is True
+    assert p["full_length"]["traj_rmse"] <= 1e-9 and p["full_length"]["final_state_maxabs"] <= 1e-9
+    assert p["full_length"]["final_covariance_rel_fro"] <= 1e-8
     # profiling scopes are kernel symbols (they join with rocprofv3's kernel_stats.csv); the search roofline carries its
     # matrix-core floor next to the HBM fraction
     assert {"k_syrk", "k_build_AS", "k_chol_left", "k_search_mfma", "k_search_score"} <= set(d["kernels"])

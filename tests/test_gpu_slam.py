@@ -88,6 +88,52 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
     assert not pr.engine.status_flags().any()
 
 
+def test_three_hundred_frames_with_natural_deletions_against_the_reference():
+    """300-frame sequences (30 x the deletion window of Q17) at the headline shape - 100 features, 5 mm
+    prior, dense covariance - four different sequences in one batch, EVERY frame against the reference's own translation
+    units (oracle/_ref/libref.so): measurements bit-exact, counters, selection order, total state 1e-9, total covariance
+    1e-8.  The camera rolls about its optical axis at 0.03 rad/s (0.3 rad over the run) on top of the usual path: the features stay visible
+    (visibility_test does not look at roll, full_feature_model.cpp:103-170) while their unwarped 11x11 templates stop
+    matching, so features earn delete_bad_features NATURALLY (monoslam.cpp:644-660: >= 10 attempts, < 50 % matched) - no
+    forced counters - and the filter still tracks the camera to the end."""
+    import os
+    B, N, F = 4, 100, 300
+    pr = Pair(N, F, batch=B, feature_sigma=0.005, checker="reference", w_bias=(0.0, 0.0, 0.03))
+    threads = min(B, os.cpu_count() or 1)
+    deleted_at = []
+    n_prev = [N] * B
+    worst = dict(x=0.0, P=0.0)
+    traj_o = np.zeros((B, F, 3))
+    traj_e = np.zeros((B, F, 3))
+    for k in range(F):
+        pr.step_both(k, threads=threads)
+        w = pr.compare_state(TOL_X, TOL_P)
+        worst = {q: max(worst[q], w[q]) for q in worst}
+        xe, _ = pr.engine.get_vehicle_state()
+        for b in range(B):
+            traj_o[b, k] = pr.oracles[b].get_state()[0][:3]
+            traj_e[b, k] = xe[b, :3]
+            n_now = pr.oracles[b].num_features
+            if n_now < n_prev[b]:
+                deleted_at.append((k, b, n_prev[b] - n_now))
+            n_prev[b] = n_now
+    n_deleted = sum(d[2] for d in deleted_at)
+    assert n_deleted > 0, "no feature was deleted: the path is too gentle"
+    assert sum(1 for b in range(B) if n_prev[b] < N) >= 2          # in more than one sequence
+    assert min(d[0] for d in deleted_at) >= 10                      # the rule needs ten attempts first
+    # the engine lost exactly the same features (compare_state checked labels frame by frame; here the end state)
+    for b in range(B):
+        assert len(pr.engine.features(b)) == n_prev[b]
+        assert len(pr.engine.features(b, include_deleted=True)) == N
+    rmse = np.sqrt(((traj_o - traj_e) ** 2).sum(axis=2).mean())
+    assert rmse <= 1e-9
+    truth = np.stack([s.poses[1:, :3] for s in pr.specs])
+    assert np.abs(traj_e - truth).max() < 0.1                       # still tracking after 10 s of roll
+    assert not pr.engine.status_flags().any()
+    print("300 frames x %d sequences: %d features deleted naturally (first at frame %d), worst |dx| %.2e, worst rel |dP| %.2e, "
+          "trajectory RMSE %.2e" % (B, n_deleted, min(d[0] for d in deleted_at), worst["x"], worst["P"], rmse))
+
+
 def _sigma_ten_block():
     """An 11x11 block whose population sigma is EXACTLY 10 (121 * sum g^2 - (sum g)^2 == 1464100): the boundary of the
     reference's `sdimage < 10` test (monoslam.cpp:458-461), which the fast search cores hand to the exact FP64 path."""

@@ -27,6 +27,15 @@
 extern "C" {
 #endif
 
+/* Version of this interface.  Bumped whenever an entry point changes meaning or a buffer it fills changes size; the
+ * library reports the version it was built from through sl2_api_version(), so a caller compiled against an older header can
+ * tell.  History: 1 = round 1; 2 = sl2_get_step_work fills 11 doubles, search variants 0-3; 3 = sl2_get_step_work fills 12
+ * doubles (out[11] = candidate tiles), search variants renumbered (1 = int8 matrix-core walk, 0 = exact kernel; 2 and 3 are
+ * gone and return SL2_ERR_INVALID), sl2_set_update_variant accepts only (1, 1) outside the TEST build; 4 = sl2_get_step_work
+ * takes the capacity of the caller's array, sl2_snapshot / sl2_snapshot_capacity, several partially initialised features per
+ * sequence (max_features_to_init_at_once > 1), sl2_get_partial_feature takes the index of the partial feature. */
+#define SL2_API_VERSION 4
+
 #define SL2_OK 0
 #define SL2_ERR_INVALID 1   /* bad argument */
 #define SL2_ERR_HIP 2       /* HIP runtime error (sl2_last_error() has the text) */
@@ -91,6 +100,8 @@ typedef struct sl2_feature_info {
 
 /* ------------------------------------------------------------------ lifecycle */
 
+/* SL2_API_VERSION of the library that is loaded (compare with the header's). */
+int sl2_api_version(void);
 /* Number of HIP devices visible (0 => every other call fails with SL2_ERR_NO_DEVICE). */
 int sl2_device_count(void);
 
@@ -189,7 +200,8 @@ int sl2_set_search_variant(sl2_engine* e, int variant);
  * Only the defaults (1, 1) are compiled into this library; the superseded variants live in the TEST build
  * (libscenelib2_amd_test.so, include/scenelib2_amd_testing.h), where this call selects them - here anything else
  * returns SL2_ERR_INVALID.  Systems of more than 16 blocks are factored panel-wise (k_chol_left + k_fwdsub_lds +
- * k_chol_syrk per 128 columns) and substituted in groups of eight block rows (k_fwd_gemm + k_fwdsub_lds) either way. */
+ * k_chol_syrk per 256 columns) and systems of more than 13 blocks substituted in groups of eight block rows (k_fwd_gemm +
+ * k_fwdsub_lds) either way. */
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);
@@ -288,6 +300,68 @@ int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, 
  * sl2_add_known_features, or the one copy_into_patch cut from the frame when the feature was initialised
  * (monoslam.cpp:1236-1250).  Labels of deleted features keep their last template. */
 int sl2_get_feature_patch(sl2_engine* e, int seq, int label, uint8_t* patch121);
+/* ---- one-call read-back of everything the reference exposes as public members (monoslam.h:158-218, feature.h:78-142) ----
+ *
+ * The reference's caller reads xv_, Pxx_, feature_list_[i]->{y_, Pxy_, Pyy_, h_, z_, S_, ...}, selected_feature_list_,
+ * trajectory_store_ and feature_init_info_vector_ straight out of the object after every GoOneStep
+ * (examples/MonoSlamSceneLib1.cpp:132-151, graphic/graphictool.cpp:130-167, 290-347).  sl2_snapshot is that read for one
+ * sequence: ONE kernel packs the blob below on the device and streams it into an engine-owned pinned host buffer, ONE
+ * stream synchronisation follows, and *blob points into that buffer (valid until the next sl2_snapshot / sl2_destroy on
+ * this engine; no allocation per call).
+ *
+ *   traj_cursor       number of trajectory_store_ pushes the caller has already seen (0 the first time): the blob carries
+ *                     the entries [max(traj_cursor, total - 1000), total) - the caller appends them and drops from the
+ *                     front beyond 1000 entries like monoslam.cpp:172-177;
+ *   patch_from_label  the 11 x 11 templates (Feature::patch_) of the live features whose label_ is >= this value are
+ *                     included (labels are handed out once and a feature's template never changes, so a caller that caches
+ *                     templates by label passes its next_free_label_ of the previous call; 0 = all, INT32_MAX = none).
+ *
+ * Blob layout (every section starts on an 8-byte boundary; offsets in bytes from the start of the blob):
+ *   sl2_snapshot_header
+ *   off_xv         double[13]                      xv_
+ *   off_Pxx        double[13][13]                  Pxx_
+ *   off_features   sl2_feature_info[n_features]    feature_list_ order, deleted features removed
+ *   off_cov        per feature, in the same order: Pxy_ (13 x d, row-major) then Pyy_ (d x d), d = state_size (3 or 6)
+ *   off_selection  int32[n_selected]               selected_feature_list_ as labels, selection order
+ *   off_traj       double[traj_count][3]           trajectory_store_ entries traj_first .. traj_first + traj_count - 1
+ *   off_partial    n_partial records, feature_init_info_vector_ order: sl2_partial_info, then double[n_particles][12]
+ *                  (lambda_, probability_, cumulative_probability_, m_h_(2), m_z_(2), m_SInv_(00, 01, 11), m_detS_,
+ *                  m_successful_measurement_flag_)
+ *   off_patches    n_patches records of 128 bytes: int32 label, uint8[121] patch (row-major), 3 bytes of padding */
+typedef struct sl2_snapshot_header {
+  int32_t magic;                               /* 0x53324c53 ("SL2S") */
+  int32_t api_version;                         /* SL2_API_VERSION of the library */
+  int32_t bytes;                               /* size of the whole blob */
+  int32_t seq;
+  int32_t n_features;                          /* feature_list_.size() */
+  int32_t total_state_size;                    /* total_state_size_ */
+  int32_t number_of_visible_features;          /* number_of_visible_features_ */
+  int32_t n_selected;                          /* selected_feature_list_.size() */
+  int32_t successful_measurement_vector_size;  /* successful_measurement_vector_size_ */
+  int32_t next_free_label;                     /* next_free_label_ */
+  int32_t status_flags;                        /* SL2_STATUS_* */
+  int32_t traj_total, traj_first, traj_count;
+  int32_t n_partial;                           /* feature_init_info_vector_.size() */
+  int32_t n_patches;
+  int32_t uu, vv;                              /* uu_, vv_ */
+  int32_t location_selected_flag;              /* location_selected_flag_ */
+  int32_t init_feature_search_region_defined_flag;
+  int32_t init_feature_search_region[4];       /* ustart, vstart, ufinish, vfinish */
+  int32_t off_xv, off_Pxx, off_features, off_cov, off_selection, off_traj, off_partial, off_patches;
+  int32_t steps_done;                          /* GoOneStep calls so far (low 31 bits) */
+  int32_t reserved[31];
+} sl2_snapshot_header;                         /* 256 bytes */
+typedef struct sl2_partial_info {              /* FeatureInitInfo, feature_init_info.h:77-118 */
+  int32_t label;                               /* fp_->label_ */
+  int32_t number_of_match_attempts;
+  int32_t n_particles;                         /* particle_vector_.size() */
+  int32_t making_measurement_on_this_step_flag;
+  double mean, covariance;                     /* mean_, covariance_ of lambda */
+} sl2_partial_info;                            /* 32 bytes, followed by the particles */
+/* Upper bound of a blob of this engine in bytes. */
+size_t sl2_snapshot_capacity(const sl2_engine* e);
+int sl2_snapshot(sl2_engine* e, int seq, int traj_cursor, int patch_from_label, const void** blob, size_t* bytes);
+
 /* selected_feature_list_ (labels, selection order) and per-step counters:
  * counters[0] = number_of_visible_features_, [1] = #selected,
  * [2] = successful_measurement_vector_size_. */
@@ -320,9 +394,9 @@ int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
 
 /* ------------------------------------------------------------------- profiling */
 
-/* enabled = 1: the roofline kernels (k_search, k_build_A, k_fwdsub, k_syrk) are bracketed by HIP
- * events on the engine's stream (8 events per step); enabled = 2: every kernel launch is; sl2_get_kernel_times returns accumulated milliseconds and
- * launch counts per kernel name since the last reset. */
+/* enabled = 1: the roofline kernels (k_search_mfma, k_build_AS, k_chol_left, k_fwdsub_lds, k_syrk and their large-map
+ * forms; narrowed by sl2_set_profile_focus) are bracketed by HIP events on the engine's stream; enabled = 2: every kernel
+ * launch is; sl2_get_kernel_time returns accumulated milliseconds and launch counts per kernel symbol since the last reset. */
 int sl2_set_profiling(sl2_engine* e, int enabled);
 /* Level 1 brackets only the kernels named here (comma separated scope names, e.g. "k_syrk,k_search_mfma"; NULL or "" = the
  * four large ones): every bracket is two event markers on the stream, and four of them cost 1-3 % of a step. */
@@ -338,7 +412,10 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
  * out[10] = searches that took the exact fallback kernel path,
  * out[11] = 16 x 16 candidate tiles of the search windows, sum_f ceil(nu / 16) ceil(nv / 16): the matrix-core work of
  * k_search_mfma (24 v_mfma_i32_16x16x64_i8 per tile) */
-int sl2_get_step_work(sl2_engine* e, double out[12]);
+#define SL2_STEP_WORK_COUNT 12
+/* capacity = length of the caller's array: min(capacity, SL2_STEP_WORK_COUNT) values are written (a caller built against a
+ * header with fewer entries is never overrun; one built against more sees the extra entries untouched). */
+int sl2_get_step_work(sl2_engine* e, double* out, int capacity);
 
 /* ------------------------------------------------------------- synthetic input */
 

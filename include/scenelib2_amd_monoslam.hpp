@@ -16,13 +16,15 @@
 //     integrator's site; frames must be 8-bit, single channel, continuous;
 //   * Init() parses the cfg itself ("name = value;", '#' comments: the pangolin::Var file format), absent keys read 0.
 // The per-frame arithmetic happens on the GPU behind sl2_go_one_step; after every call the public members are refreshed
-// from the engine (refresh_public_members), so reads between frames see what the reference's members would hold.
+// from the engine by ONE sl2_snapshot call (refresh_public_members: one kernel, one synchronisation), so reads between
+// frames see what the reference's members would hold.
 #ifndef SCENELIB2_AMD_MONOSLAM_HPP
 #define SCENELIB2_AMD_MONOSLAM_HPP
 
 #include <scenelib2_amd.h>
 
 #include <array>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -134,6 +136,7 @@ class MonoSLAM {
     prm.successful_match_fraction = successful_match_fraction_;
     if (sl2_device_count() < 1) throw std::runtime_error("MonoSLAM::Init: no HIP device (the engine has no CPU path)");
     if (eng_) { sl2_destroy(eng_); eng_ = nullptr; }
+    traj_seen_ = 0; patch_seen_ = 0; patch_cache_.clear(); feature_list_.clear(); trajectory_store_.clear();
     check(sl2_create(&cam, &prm, 1, max_features_, device_, nullptr, &eng_), "sl2_create");
 
     static const char* xv_keys[13] = {"state.rw_x", "state.rw_y", "state.rw_z", "state.qwr_w", "state.qwr_x", "state.qwr_y", "state.qwr_z",
@@ -166,13 +169,18 @@ class MonoSLAM {
   bool GoOneStep(const Frame& frame, bool save_trajectory, bool enable_mapping) {
     if (!eng_ || !frame.data || frame.cols != camera_->width_ || frame.rows != camera_->height_)
       throw std::runtime_error("MonoSLAM::GoOneStep: frame does not match the camera");
+    const auto t0 = std::chrono::steady_clock::now();
     check(sl2_go_one_step(eng_, frame.data, (size_t)frame.cols * frame.rows, frame.on_device ? 1 : 0, save_trajectory ? 1 : 0,
                           enable_mapping ? 1 : 0),
           "sl2_go_one_step");
+    if (measure_timing_) check(sl2_synchronize(eng_), "sl2_synchronize");   // only to SPLIT the time; costs a second wait
+    const auto t1 = std::chrono::steady_clock::now();
     refresh_public_members();
+    const auto t2 = std::chrono::steady_clock::now();
+    last_step_us_ = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    last_refresh_us_ = std::chrono::duration<double, std::micro>(t2 - t1).count();
     if (enable_mapping) {   // feature_list_ is unbounded in the reference; here at most max_features LIVE features: never silently
-      int32_t flags = 0;
-      check(sl2_get_status_flags(eng_, 0, 1, &flags), "sl2_get_status_flags");
+      const int32_t flags = status_flags_;     // (came with the snapshot)
       const bool full = (flags & SL2_STATUS_LABELS_EXHAUSTED) != 0, rose = full && !map_full_;
       map_full_ = full;
       if (rose)             // once per episode: the bit clears again when a deletion has made room
@@ -279,6 +287,12 @@ class MonoSLAM {
   }
 
   sl2_engine* engine() { return eng_; }
+  // Wall time of the last GoOneStep: the sl2_go_one_step call and the read-back of the public members (one sl2_snapshot).
+  // The step is asynchronous, so without measure_timing_ the first figure is its enqueue time and the second one holds the
+  // wait for the GPU; with measure_timing_ = true a synchronisation is inserted between the two and they are the step and
+  // the read-back proper (examples/monoslam_adapter --latency).
+  bool measure_timing_ = false;
+  double last_step_us_ = 0.0, last_refresh_us_ = 0.0;
 
   // ---- public data members, names as in monoslam.h:158-218 ----
   std::unique_ptr<Camera> camera_;
@@ -338,23 +352,52 @@ class MonoSLAM {
     return it == kv.end() ? 0.0 : std::atof(it->second.c_str());
   }
 
-  // What the reference's members hold after a step, read back through the C ABI.
+  // What the reference's members hold after a step: ONE sl2_snapshot call (one kernel, one stream synchronisation, no
+  // allocation inside the library) instead of a dozen blocking accessors.  Feature objects are kept across frames and
+  // matched by label_ (a label is handed out once), templates are requested only for labels not seen before, and only the
+  // trajectory_store_ entries pushed since the last call cross the bus.
   void refresh_public_members() {
-    check(sl2_get_vehicle_state(eng_, 0, 1, xv_.data(), Pxx_.data()), "sl2_get_vehicle_state");
-    int32_t size = 13;
-    check(sl2_get_total_state_sizes(eng_, 0, 1, &size), "sl2_get_total_state_sizes");
-    total_state_size_ = size;
-    std::vector<double> P((size_t)size * size);
-    check(sl2_get_total_covariance(eng_, 0, P.data(), size), "sl2_get_total_covariance");
-    std::vector<sl2_feature_info> fi(max_features_);
-    int n = 0;
-    check(sl2_get_features(eng_, 0, fi.data(), max_features_, 0, &n), "sl2_get_features");
-    feature_list_.clear();
-    next_free_label_ = 0;
-    for (int i = 0; i < n; ++i) {
-      std::unique_ptr<Feature> f(new Feature());
+    const void* blob = nullptr;
+    size_t nbytes = 0;
+    check(sl2_snapshot(eng_, 0, traj_seen_, patch_seen_, &blob, &nbytes), "sl2_snapshot");
+    const unsigned char* base = static_cast<const unsigned char*>(blob);
+    const sl2_snapshot_header& hd = *reinterpret_cast<const sl2_snapshot_header*>(base);
+    if (hd.api_version != SL2_API_VERSION) throw std::runtime_error("scenelib2_amd: library / header version mismatch");
+    std::memcpy(xv_.data(), base + hd.off_xv, sizeof(double) * 13);
+    std::memcpy(Pxx_.data(), base + hd.off_Pxx, sizeof(double) * 169);
+    total_state_size_ = hd.total_state_size;
+    number_of_visible_features_ = hd.number_of_visible_features;
+    successful_measurement_vector_size_ = hd.successful_measurement_vector_size;
+    next_free_label_ = hd.next_free_label;
+    status_flags_ = hd.status_flags;
+    // templates of the labels this object has not seen yet
+    for (int k = 0; k < hd.n_patches; ++k) {
+      const unsigned char* rec = base + hd.off_patches + (size_t)k * 128;
+      int32_t lab;
+      std::memcpy(&lab, rec, 4);
+      std::memcpy(patch_cache_[lab].data(), rec + 4, SL2_PATCH_BYTES);
+    }
+    patch_seen_ = hd.next_free_label;
+    // feature_list_: reuse the objects of the features that are still there (list order never changes: features are only
+    // appended and erased)
+    std::vector<std::unique_ptr<Feature>> old;
+    old.swap(feature_list_);
+    size_t oi = 0;
+    const sl2_feature_info* fi = reinterpret_cast<const sl2_feature_info*>(base + hd.off_features);
+    const double* cov = reinterpret_cast<const double*>(base + hd.off_cov);
+    feature_list_.reserve(hd.n_features);
+    for (int i = 0; i < hd.n_features; ++i) {
       const sl2_feature_info& s = fi[i];
-      f->label_ = s.label;
+      std::unique_ptr<Feature> f;
+      while (oi < old.size() && old[oi]->label_ != s.label) ++oi;      // erased features drop out here
+      if (oi < old.size()) f = std::move(old[oi++]);
+      else {
+        f.reset(new Feature());
+        f->label_ = s.label;
+        auto it = patch_cache_.find(s.label);
+        if (it != patch_cache_.end()) f->patch_ = it->second;
+        else check(sl2_get_feature_patch(eng_, 0, s.label, f->patch_.data()), "sl2_get_feature_patch");   // (not reached)
+      }
       f->fully_initialised_flag_ = s.fully_initialised_flag != 0;
       f->selected_flag_ = s.selected_flag != 0;
       f->successful_measurement_flag_ = s.successful_measurement_flag != 0;
@@ -371,52 +414,43 @@ class MonoSLAM {
       for (int r = 0; r < 2; ++r)
         for (int c = 0; c < 7; ++c) f->dh_by_dxv_[r * 13 + c] = s.dh_by_dxp[r * 7 + c];
       for (int k = 0; k < 6; ++k) f->dh_by_dy_[k] = s.dh_by_dy[k];
-      const int pos = s.position_in_total_state_vector, d = s.state_size;
-      f->Pxy_.resize((size_t)13 * d);
-      f->Pyy_.resize((size_t)d * d);
-      for (int r = 0; r < 13; ++r)
-        for (int c = 0; c < d; ++c) f->Pxy_[(size_t)r * d + c] = P[(size_t)r * size + pos + c];
-      for (int r = 0; r < d; ++r)
-        for (int c = 0; c < d; ++c) f->Pyy_[(size_t)r * d + c] = P[(size_t)(pos + r) * size + pos + c];
-      check(sl2_get_feature_patch(eng_, 0, s.label, f->patch_.data()), "sl2_get_feature_patch");
-      if (s.label >= next_free_label_) next_free_label_ = s.label + 1;
+      const int d = s.state_size;
+      f->Pxy_.assign(cov, cov + 13 * d);
+      f->Pyy_.assign(cov + 13 * d, cov + 13 * d + d * d);
+      cov += 13 * d + d * d;
       feature_list_.push_back(std::move(f));
     }
-    std::vector<int32_t> labels(max_features_);
-    int32_t counters[3] = {0, 0, 0};
-    check(sl2_get_selection(eng_, 0, labels.data(), max_features_, counters), "sl2_get_selection");
-    number_of_visible_features_ = counters[0];
-    successful_measurement_vector_size_ = counters[2];
+    const int32_t* sel = reinterpret_cast<const int32_t*>(base + hd.off_selection);
     selected_feature_list_.clear();
-    for (int k = 0; k < counters[1]; ++k)
+    for (int k = 0; k < hd.n_selected; ++k)
       for (auto& f : feature_list_)
-        if (f->label_ == labels[k]) { selected_feature_list_.push_back(f.get()); break; }
-    std::vector<double> tr(3 * 1000);
-    int cnt = 0;
-    check(sl2_get_trajectory(eng_, 0, tr.data(), 1000, &cnt), "sl2_get_trajectory");
-    trajectory_store_.resize(cnt);
-    for (int k = 0; k < cnt; ++k) trajectory_store_[k] = {{tr[3 * k], tr[3 * k + 1], tr[3 * k + 2]}};
-    // feature_init_info_vector_ (at most one entry: max_features_to_init_at_once = 1 is what the device path runs)
-    int32_t pi[16];
-    double pd[9];
-    std::vector<double> parts((size_t)1024 * 12);            // params.number_of_particles <= 1024
-    check(sl2_get_partial_feature(eng_, 0, pi, pd, parts.data(), 1024), "sl2_get_partial_feature");
+        if (f->label_ == sel[k]) { selected_feature_list_.push_back(f.get()); break; }
+    // trajectory_store_: append what is new, keep at most 1000 entries (monoslam.cpp:172-177)
+    const double* tr = reinterpret_cast<const double*>(base + hd.off_traj);
+    if (hd.traj_first > traj_seen_) trajectory_store_.clear();     // (more than 1000 pushes between two calls)
+    for (int k = 0; k < hd.traj_count; ++k) trajectory_store_.push_back({{tr[3 * k], tr[3 * k + 1], tr[3 * k + 2]}});
+    if (trajectory_store_.size() > 1000) trajectory_store_.erase(trajectory_store_.begin(), trajectory_store_.end() - 1000);
+    traj_seen_ = hd.traj_total;
+    // feature_init_info_vector_
+    uu_ = hd.uu; vv_ = hd.vv;
+    init_feature_search_region_defined_flag_ = hd.init_feature_search_region_defined_flag != 0;
+    init_feature_search_ustart_ = hd.init_feature_search_region[0]; init_feature_search_vstart_ = hd.init_feature_search_region[1];
+    init_feature_search_ufinish_ = hd.init_feature_search_region[2]; init_feature_search_vfinish_ = hd.init_feature_search_region[3];
+    location_selected_flag_ = hd.location_selected_flag != 0;
     feature_init_info_vector_.clear();
-    uu_ = pi[5]; vv_ = pi[6];
-    init_feature_search_region_defined_flag_ = pi[7] != 0;
-    init_feature_search_ustart_ = pi[8]; init_feature_search_vstart_ = pi[9];
-    init_feature_search_ufinish_ = pi[10]; init_feature_search_vfinish_ = pi[11];
-    location_selected_flag_ = pi[15] != 0;
-    if (pi[0]) {
+    const unsigned char* pp = base + hd.off_partial;
+    for (int j = 0; j < hd.n_partial; ++j) {
+      const sl2_partial_info& pinfo = *reinterpret_cast<const sl2_partial_info*>(pp);
+      const double* parts = reinterpret_cast<const double*>(pp + sizeof(sl2_partial_info));
       FeatureInitInfo info;
       for (auto& f : feature_list_)
-        if (f->label_ == pi[1]) info.fp_ = f.get();
-      info.number_of_match_attempts_ = pi[2];
-      info.making_measurement_on_this_step_flag_ = pi[4] != 0;
-      info.mean_ = pd[0]; info.covariance_ = pd[1];
-      info.particle_vector_.resize(pi[3]);
-      for (int k = 0; k < pi[3]; ++k) {
-        const double* o = &parts[(size_t)k * 12];
+        if (f->label_ == pinfo.label) info.fp_ = f.get();
+      info.number_of_match_attempts_ = pinfo.number_of_match_attempts;
+      info.making_measurement_on_this_step_flag_ = pinfo.making_measurement_on_this_step_flag != 0;
+      info.mean_ = pinfo.mean; info.covariance_ = pinfo.covariance;
+      info.particle_vector_.resize(pinfo.n_particles);
+      for (int k = 0; k < pinfo.n_particles; ++k) {
+        const double* o = parts + (size_t)k * 12;
         Particle& p = info.particle_vector_[k];
         p.lambda_ = o[0]; p.probability_ = o[1]; p.cumulative_probability_ = o[2];
         p.m_h_ = {{o[3], o[4]}}; p.m_z_ = {{o[5], o[6]}};
@@ -425,9 +459,12 @@ class MonoSLAM {
         p.m_successful_measurement_flag_ = o[11] != 0.0;
       }
       feature_init_info_vector_.push_back(std::move(info));
+      pp += sizeof(sl2_partial_info) + (size_t)pinfo.n_particles * 12 * sizeof(double);
     }
   }
 
+  int traj_seen_ = 0, patch_seen_ = 0, status_flags_ = 0;
+  std::map<int, std::array<uint8_t, SL2_PATCH_BYTES>> patch_cache_;
   int max_features_, device_;
   bool map_full_ = false;
   sl2_engine* eng_ = nullptr;

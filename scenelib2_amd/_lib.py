@@ -60,16 +60,33 @@ class sl2_feature_info(C.Structure):
                 ("fully_initialised_flag", C.c_int32), ("state_size", C.c_int32), ("y_direction", C.c_double * 3)]
 
 
+class sl2_snapshot_header(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "magic", "api_version", "bytes", "seq", "n_features", "total_state_size", "number_of_visible_features", "n_selected",
+        "successful_measurement_vector_size", "next_free_label", "status_flags", "traj_total", "traj_first", "traj_count",
+        "n_partial", "n_patches", "uu", "vv", "location_selected_flag", "init_feature_search_region_defined_flag")] + \
+        [("init_feature_search_region", C.c_int32 * 4)] + \
+        [(n, C.c_int32) for n in ("off_xv", "off_Pxx", "off_features", "off_cov", "off_selection", "off_traj", "off_partial",
+                                  "off_patches", "steps_done")] + [("reserved", C.c_int32 * 31)]
+
+
+class sl2_partial_info(C.Structure):
+    _fields_ = [("label", C.c_int32), ("number_of_match_attempts", C.c_int32), ("n_particles", C.c_int32),
+                ("making_measurement_on_this_step_flag", C.c_int32), ("mean", C.c_double), ("covariance", C.c_double)]
+
+
+assert C.sizeof(sl2_snapshot_header) == 256 and C.sizeof(sl2_partial_info) == 32
+
 # every symbol include/scenelib2_amd.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = [
-    "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
+    "sl2_api_version", "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
     "sl2_go_one_step", "sl2_initialise_feature", "sl2_initialise_auto_feature", "sl2_save_patch", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
-    "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
+    "sl2_snapshot_capacity", "sl2_snapshot", "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
     "sl2_dev_download",
@@ -155,7 +172,11 @@ def _bind(L):
     L.sl2_reset_kernel_times.argtypes = [vp]
     L.sl2_kernel_count.argtypes = [vp]
     L.sl2_get_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_dp, C.POINTER(C.c_int64)]
-    L.sl2_get_step_work.argtypes = [vp, c_dp]
+    L.sl2_get_step_work.argtypes = [vp, c_dp, C.c_int]
+    L.sl2_api_version.restype = C.c_int
+    L.sl2_snapshot_capacity.argtypes = [vp]
+    L.sl2_snapshot_capacity.restype = C.c_size_t
+    L.sl2_snapshot.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.sl2_synth_render_host.argtypes = [C.POINTER(sl2_camera), c_u8p, C.c_int, C.c_double, c_dp, c_dp, C.c_int, c_u8p]
     L.sl2_synth_render_device.argtypes = [C.c_int, vp, C.POINTER(sl2_camera), vp, C.c_int, C.c_double, vp, vp,
                                           C.c_int, vp]

@@ -178,6 +178,15 @@ struct sl2_engine {
   double* St = nullptr;    // [B][mld][mld]  St[c][r] = S[r][c]; overwritten by L (same layout)
   double* LinvT = nullptr; // [B][nblk_max][32][32]  LinvT[p][k] = (L_JJ^-1)[k][p]
 
+  // ---- engine-owned staging of the state accessors (no allocation per call; released by sl2_destroy) ----
+  void* snap_stage = nullptr;     // device: the packed blob of sl2_snapshot
+  void* snap_host = nullptr;      // pinned + mapped host memory the blob is streamed into (what sl2_snapshot returns)
+  void* snap_host_dev = nullptr;  // its device-side address
+  void* acc_dev = nullptr;        // device scratch of the get / set accessors (grown on demand)
+  size_t acc_dev_bytes = 0;
+  void* acc_host = nullptr;       // pinned host scratch of the same calls
+  size_t acc_host_bytes = 0;
+
   uint8_t* frames_buf = nullptr;  // [B][W*H] staging for host frames
   const uint8_t* cur_frames = nullptr;
   size_t cur_stride = 0;

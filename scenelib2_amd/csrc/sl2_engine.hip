@@ -119,6 +119,25 @@ static int fetch_vec(std::vector<T>& v, const T* dev, size_t off, size_t n) {
   return SL2_OK;
 }
 
+// Engine-owned scratch of the accessors: a device buffer and a pinned host buffer that only ever grow.  (The accessors used
+// to hipMalloc / hipFree per call - a device-wide synchronisation each - and leaked both buffers on an error return.)
+static int acc_scratch(sl2_engine* e, size_t dev_bytes, size_t host_bytes) {
+  sl2_engine* r = e->root;
+  if (dev_bytes > r->acc_dev_bytes) {
+    if (r->acc_dev) { SL2_HIP(hipFree(r->acc_dev)); r->acc_dev = nullptr; r->acc_dev_bytes = 0; }
+    const size_t want = (dev_bytes + 4095) & ~(size_t)4095;
+    SL2_HIP(hipMalloc(&r->acc_dev, want));
+    r->acc_dev_bytes = want;
+  }
+  if (host_bytes > r->acc_host_bytes) {
+    if (r->acc_host) { SL2_HIP(hipHostFree(r->acc_host)); r->acc_host = nullptr; r->acc_host_bytes = 0; }
+    const size_t want = (host_bytes + 4095) & ~(size_t)4095;
+    SL2_HIP(hipHostMalloc(&r->acc_host, want, hipHostMallocDefault));
+    r->acc_host_bytes = want;
+  }
+  return SL2_OK;
+}
+
 }  // namespace sl2
 
 #ifdef SL2_TESTING
@@ -254,6 +273,8 @@ int sl2_engine::fold_events() {
 extern "C" {
 
 const char* sl2_last_error(void) { return g_err.c_str(); }
+
+int sl2_api_version(void) { return SL2_API_VERSION; }
 
 int sl2_device_count(void) {
   int n = 0;
@@ -417,6 +438,10 @@ void sl2_destroy(sl2_engine* e) {
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
                   e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (e->snap_stage) hipFree(e->snap_stage);
+  if (e->snap_host) hipHostFree(e->snap_host);
+  if (e->acc_dev) hipFree(e->acc_dev);
+  if (e->acc_host) hipHostFree(e->acc_host);
   for (auto& pe : e->pending) { hipEventDestroy(pe.start); hipEventDestroy(pe.stop); }
   for (auto ev : e->event_pool) hipEventDestroy(ev);
   if (e->own_stream) hipStreamDestroy(e->stream);
@@ -437,31 +462,33 @@ int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, c
   if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  double *dxv = nullptr, *dP = nullptr;
-  SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
-  SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
-  SL2_HIP(hipMemcpyAsync(dxv, xv, sizeof(double) * 13 * nseq, hipMemcpyHostToDevice, e->stream));
-  SL2_HIP(hipMemcpyAsync(dP, Pxx, sizeof(double) * 169 * nseq, hipMemcpyHostToDevice, e->stream));
+  const size_t nx = (size_t)13 * nseq, nP = (size_t)169 * nseq;
+  { int _rc = acc_scratch(e, sizeof(double) * (nx + nP), 0); if (_rc != SL2_OK) return _rc; }
+  double* dxv = (double*)e->acc_dev;
+  double* dP = dxv + nx;
+  SL2_HIP(hipMemcpyAsync(dxv, xv, sizeof(double) * nx, hipMemcpyHostToDevice, e->stream));
+  SL2_HIP(hipMemcpyAsync(dP, Pxx, sizeof(double) * nP, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_set_vehicle, dim3(nseq), dim3(64), 0, e->stream, e->x, e->P, dxv, dP, seq0, e->ld);
   SL2_HIP(hipGetLastError());
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  hipFree(dxv); hipFree(dP);
   return SL2_OK;
 }
 
 int sl2_get_vehicle_state(sl2_engine* e, int seq0, int nseq, double* xv, double* Pxx) {
   if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  double *dxv = nullptr, *dP = nullptr;
-  SL2_HIP(hipMalloc(&dxv, sizeof(double) * 13 * nseq));
-  SL2_HIP(hipMalloc(&dP, sizeof(double) * 169 * nseq));
+  const size_t nx = (size_t)13 * nseq, nP = (size_t)169 * nseq;
+  { int _rc = acc_scratch(e, sizeof(double) * (nx + nP), sizeof(double) * (nx + nP)); if (_rc != SL2_OK) return _rc; }
+  double* dxv = (double*)e->acc_dev;
+  double* dP = dxv + nx;
+  // one gather kernel, ONE copy into the engine's pinned scratch, one synchronisation (the root stream is ordered behind
+  // the sequence groups' streams by the join at the end of every stepping call)
   hipLaunchKernelGGL(k_get_vehicle, dim3(nseq), dim3(64), 0, e->stream, e->x, e->P, dxv, dP, seq0, e->ld);
   SL2_HIP(hipGetLastError());
-  SL2_HIP(hipMemcpyAsync(xv, dxv, sizeof(double) * 13 * nseq, hipMemcpyDeviceToHost, e->stream));
-  SL2_HIP(hipMemcpyAsync(Pxx, dP, sizeof(double) * 169 * nseq, hipMemcpyDeviceToHost, e->stream));
+  SL2_HIP(hipMemcpyAsync(e->acc_host, dxv, sizeof(double) * (nx + nP), hipMemcpyDeviceToHost, e->stream));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  hipFree(dxv); hipFree(dP);
+  memcpy(xv, e->acc_host, sizeof(double) * nx);
+  memcpy(Pxx, (const double*)e->acc_host + nx, sizeof(double) * nP);
   return SL2_OK;
 }
 
@@ -469,14 +496,13 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
   if (!range_ok(e, seq0, nseq) || nfeat <= 0 || nfeat > e->N || !Pyy) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  double* d = nullptr;
   const size_t cnt = (size_t)nseq * nfeat * 9;
-  SL2_HIP(hipMalloc(&d, sizeof(double) * cnt));
+  { int _rc = acc_scratch(e, sizeof(double) * cnt, 0); if (_rc != SL2_OK) return _rc; }
+  double* d = (double*)e->acc_dev;
   SL2_HIP(hipMemcpyAsync(d, Pyy, sizeof(double) * cnt, hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(k_set_feature_cov, dim3(nseq), dim3(256), 0, e->stream, e->P, d, seq0, nfeat, e->ld);
   SL2_HIP(hipGetLastError());
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  hipFree(d);
   return SL2_OK;
 }
 
@@ -497,12 +523,11 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
   }
   for (int s = 0; s < nseq; ++s)
     if (slots[s] + nfeat > e->N) { set_error("sl2_add_known_features: feature capacity exceeded"); return SL2_ERR_CAPACITY; }
-  double *dy = nullptr, *dxp = nullptr;
-  uint8_t* dp = nullptr;
   const size_t cnt = (size_t)nseq * nfeat;
-  SL2_HIP(hipMalloc(&dy, sizeof(double) * 3 * cnt));
-  SL2_HIP(hipMalloc(&dxp, sizeof(double) * 7 * cnt));
-  SL2_HIP(hipMalloc(&dp, 121 * cnt));
+  { int _rc = acc_scratch(e, sizeof(double) * 10 * cnt + 121 * cnt, 0); if (_rc != SL2_OK) return _rc; }
+  double* dy = (double*)e->acc_dev;
+  double* dxp = dy + 3 * cnt;
+  uint8_t* dp = (uint8_t*)(dxp + 7 * cnt);
   SL2_HIP(hipMemcpyAsync(dy, y, sizeof(double) * 3 * cnt, hipMemcpyHostToDevice, e->stream));
   SL2_HIP(hipMemcpyAsync(dxp, xp_org, sizeof(double) * 7 * cnt, hipMemcpyHostToDevice, e->stream));
   SL2_HIP(hipMemcpyAsync(dp, patches, 121 * cnt, hipMemcpyHostToDevice, e->stream));
@@ -510,7 +535,6 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
                      e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
   SL2_HIP(hipGetLastError());
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  hipFree(dy); hipFree(dxp); hipFree(dp);
   return SL2_OK;
 }
 
@@ -1117,8 +1141,9 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
   return SL2_OK;
 }
 
-int sl2_get_step_work(sl2_engine* e, double out[12]) {
-  if (!e || !out) return SL2_ERR_INVALID;
+int sl2_get_step_work(sl2_engine* e, double* out_caller, int capacity) {
+  if (!e || !out_caller || capacity < 1) return SL2_ERR_INVALID;
+  double out[SL2_STEP_WORK_COUNT];
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   std::vector<double> w((size_t)e->B * kWorkDoubles);
@@ -1127,7 +1152,7 @@ int sl2_get_step_work(sl2_engine* e, double out[12]) {
   SL2_HIP(hipMemcpy(mc.data(), e->m_count, sizeof(int) * e->B, hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(flags.data(), e->f_flags, sizeof(int) * flags.size(), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(slots.data(), e->n_slots, sizeof(int) * e->B, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 12; ++k) out[k] = 0.0;
+  for (int k = 0; k < SL2_STEP_WORK_COUNT; ++k) out[k] = 0.0;
   const double frame_bytes = (double)e->cam.width * e->cam.height;
   for (int b = 0; b < e->B; ++b) {
     const double win = w[(size_t)b * kWorkDoubles + 0];
@@ -1141,6 +1166,7 @@ int sl2_get_step_work(sl2_engine* e, double out[12]) {
     const double m = 2.0 * mc[b];
     out[3] += m; out[4] += m * m; out[5] += m * m * m; out[6] += n; out[7] += n * m; out[8] += n * n * m; out[9] += n * m * m;
   }
+  for (int k = 0; k < capacity && k < SL2_STEP_WORK_COUNT; ++k) out_caller[k] = out[k];   // never beyond the caller's array
   return SL2_OK;
 }
 

@@ -145,6 +145,39 @@ class Engine:
         self._ck(self.L.sl2_get_total_covariance(self.h, seq, _lib.dp(P), n))
         return P
 
+    def snapshot(self, seq, traj_cursor=0, patch_from_label=0):
+        """sl2_snapshot: everything the reference exposes as public members of one sequence, in ONE call (one kernel, one
+        synchronisation).  Returns a dict of numpy arrays / python values decoded from the blob."""
+        blob, nbytes = _lib.vp(), C.c_size_t(0)
+        self._ck(self.L.sl2_snapshot(self.h, int(seq), int(traj_cursor), int(patch_from_label), C.byref(blob), C.byref(nbytes)))
+        raw = C.string_at(blob.value, nbytes.value)      # the engine's pinned buffer is reused by the next call: copy out
+        h = _lib.sl2_snapshot_header.from_buffer_copy(raw[:256])
+        assert h.magic == 0x53324C53 and h.bytes == nbytes.value
+        f64 = lambda off, n: np.frombuffer(raw, dtype=np.float64, count=n, offset=off).copy()
+        out = dict(header=h, xv=f64(h.off_xv, 13), Pxx=f64(h.off_Pxx, 169).reshape(13, 13), features=[], partial=[], patches={})
+        fsz = C.sizeof(_lib.sl2_feature_info)
+        cov = h.off_cov
+        for i in range(h.n_features):
+            f = _lib.sl2_feature_info.from_buffer_copy(raw[h.off_features + i * fsz: h.off_features + (i + 1) * fsz])
+            d = f.state_size
+            Pxy = f64(cov, 13 * d).reshape(13, d)
+            Pyy = f64(cov + 13 * d * 8, d * d).reshape(d, d)
+            cov += (13 * d + d * d) * 8
+            out["features"].append(dict(info=f, label=f.label, Pxy=Pxy, Pyy=Pyy))
+        out["selection"] = np.frombuffer(raw, dtype=np.int32, count=h.n_selected, offset=h.off_selection).copy()
+        out["trajectory"] = f64(h.off_traj, 3 * h.traj_count).reshape(-1, 3)
+        off = h.off_partial
+        for _ in range(h.n_partial):
+            pi = _lib.sl2_partial_info.from_buffer_copy(raw[off: off + 32])
+            parts = f64(off + 32, 12 * pi.n_particles).reshape(-1, 12)
+            out["partial"].append(dict(info=pi, particles=parts))
+            off += 32 + 96 * pi.n_particles
+        for k in range(h.n_patches):
+            o = h.off_patches + 128 * k
+            lab = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=o)[0])
+            out["patches"][lab] = np.frombuffer(raw, dtype=np.uint8, count=121, offset=o + 4).reshape(11, 11).copy()
+        return out
+
     def features(self, seq, include_deleted=False):
         arr = (_lib.sl2_feature_info * self.max_features)()
         cnt = C.c_int(0)
@@ -269,7 +302,7 @@ class Engine:
 
     def step_work(self):
         w = np.zeros(12)
-        self._ck(self.L.sl2_get_step_work(self.h, _lib.dp(w)))
+        self._ck(self.L.sl2_get_step_work(self.h, _lib.dp(w), w.size))
         keys = ["window_bytes", "searched", "candidates", "sum_m", "sum_m2", "sum_m3", "sum_n", "sum_nm", "sum_nnm",
                 "sum_nmm", "search_fallbacks", "search_tiles"]
         return dict(zip(keys, w.tolist()))

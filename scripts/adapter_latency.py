@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Cost of USING the drop-in ("what's weak" 6): examples/monoslam_adapter - the reference example's loop
+(examples/MonoSlamSceneLib1.cpp:132-151: GetFrame, GoOneStep, then every public member GraphicTool reads refreshed) - timed
+end to end per frame on (a) a single 320x240 sequence with 100 known features (BASELINE configs[1]), (b) the reference's
+default workload: a dozen features, mapping on, and (c) the shipped cfg (four known features).  Writes one JSON object.
+
+    python scripts/adapter_latency.py [out.json]
+"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+from scenelib2_amd import ingest, synth  # noqa: E402
+from test_gpu_headless_example import _write_scene  # noqa: E402
+from mapping_helpers import make_mapping_sequence  # noqa: E402
+
+
+def run(exe, cfg, fd, mapping, out):
+    cmd = [exe, "--cfg", cfg, "--frames", fd, "--latency", out] + (["--mapping"] if mapping else [])
+    subprocess.run(cmd, check=True, timeout=600)
+    return json.load(open(out))
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "adapter_latency.json")
+    exe = os.path.join(ROOT, "examples", "monoslam_adapter")
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        # (a) configs[1]: 100 known features, all selected, mapping off, 120 frames
+        cam = synth.default_camera()
+        N, F = 100, 120
+        params = synth.default_params(N)
+        spec, tpl, frames, frame0 = synth.make_sequence(cam, N, F, seq_index=0)
+        allf = np.concatenate([frame0[None], frames])
+        da = os.path.join(d, "a"); os.makedirs(da)
+        cfg, fd = _write_scene(da, cam, params, spec, allf, tpl)
+        res["configs1_100_features"] = run(exe, cfg, fd, False, os.path.join(d, "a.json"))
+        # (b) the reference's default workload: few known features, mapping on (the map grows to about a dozen)
+        cam2, params2, spec2, frames2, tpl2 = make_mapping_sequence(n_frames=120)
+        db = os.path.join(d, "b"); os.makedirs(db)
+        cfg2, fd2 = _write_scene(db, cam2, params2, spec2, frames2, tpl2)
+        res["mapping_on_dozen_features"] = run(exe, cfg2, fd2, True, os.path.join(d, "b.json"))
+        # (c) the shipped cfg with its four known patches; the frame of the golden fixture repeated (the dataset's own
+        # sequence is not in this image)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "ref_shipped.npz"))
+        dc = os.path.join(d, "c", "frames"); os.makedirs(dc)
+        for k in range(60):
+            ingest.write_pgm(os.path.join(dc, "%05d.pgm" % k), g["frame"])
+        res["shipped_cfg_4_features"] = run(exe, os.path.join(ROOT, "tests", "golden", "scenelib2_shipped.cfg"), dc, False,
+                                            os.path.join(d, "c.json"))
+    res["note"] = ("wall time per frame of the reference example's loop written against include/scenelib2_amd_monoslam.hpp: "
+                   "frame_us = sl2_ingest_next + GoOneStep; go_one_step_us = sl2_go_one_step + one sl2_snapshot (one kernel, one "
+                   "stream synchronisation, no hipMemcpy) + unpacking into the MonoSLAM-shaped members; step_us / readback_us = "
+                   "the same with a synchronisation between the two")
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -127,10 +127,15 @@ __device__ long long* g_search_trace = nullptr;     // development only: 8 cycle
 #define STR(slot) do { } while (0)
 #endif
 
-constexpr int kMfPitchDw = 12;                 // 48-byte rows: 32 candidate columns + 10 + pad, 16-byte aligned
-constexpr int kMfRows = 28;                    // 16 candidate rows + 10 + the partner row of template row 10
-constexpr int kMfPlaneDw = kMfRows * kMfPitchDw;
-constexpr int kMfTplDw = 13 * kMfPitchDw + 4;  // 11 template rows + a zero row + the ones row, zero padded
+constexpr int kMfPitchDw = 12;                 // 48-byte template rows: 16 zeros + 11 bytes + zeros
+// Four copies of the padded template, copy c = the rows moved left by c bytes (round 4).  A lane group of a template read
+// (32 lanes: 16 candidate columns x 2 halves of the window bytes) touches dwords 1..8 of copy 0 and 0..7 of copies 1-3 of
+// one row, so the copies start at dwords 3, 172, 340, 508 = banks 3, 12, 20, 28 (mod 32): the group's 32 addresses fall on
+// 32 different banks.  (With equal strides one bank was used twice: SQ_LDS_BANK_CONFLICT +4.8e6 per launch.)
+constexpr int kMfCopyDw = 168;                 // 13 rows x 12 dwords + 12 of padding
+__host__ __device__ constexpr int mf_copy_base(int c) { return 3 + c * kMfCopyDw + (c ? 1 : 0); }
+constexpr int kMfTplDw = mf_copy_base(3) + kMfCopyDw;          // 676 dwords (a multiple of four: zeroed in 16-byte stores)
+static_assert(kMfTplDw % 4 == 0, "s_T is cleared with ds_write_b128");
 typedef int mf_v4i __attribute__((ext_vector_type(4)));
 typedef unsigned short mf_us2 __attribute__((ext_vector_type(2)));
 
@@ -143,12 +148,12 @@ __device__ __forceinline__ unsigned mf_sq_pairs(unsigned packed_u16x2) {   // (x
   return r;
 }
 
-// 16 bytes of padded template row `row` starting at byte `off` (1..32) of its 48-byte LDS row: five aligned dwords and
-// four v_alignbyte.  (gfx950 runs in unaligned-access mode and a single ds_read_b128 at a byte address works - the
-// compiler emits it for an align-1 copy - but it is slow: the kernel took 0.150 ms with it against 0.119 ms this way.)
+// 16 bytes of padded template row `row` (copy 0) starting at byte `off` (1..32) of its 48-byte LDS row: five aligned dwords
+// and four v_alignbyte.  Used for the operands of the ones matrix only (once per wavefront).  (gfx950 runs in
+// unaligned-access mode and a single ds_read_b128 at a byte address works but is slow: 0.150 ms against 0.119 ms.)
 __device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int off) {
   mf_v4i r;
-  const unsigned* p = s_T + row * kMfPitchDw + (off >> 2);
+  const unsigned* p = s_T + mf_copy_base(0) + row * kMfPitchDw + (off >> 2);
   const int sh = off & 3;
   const unsigned q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4];
   r.x = (int)__builtin_amdgcn_alignbyte(q1, q0, sh);
@@ -157,27 +162,62 @@ __device__ __forceinline__ mf_v4i mf_load_b(const unsigned* s_T, int row, int of
   r.w = (int)__builtin_amdgcn_alignbyte(q4, q3, sh);
   return r;
 }
-
-// padded template rows in LDS: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones.
-// mf_tpl_init writes everything that does not depend on the template (once per wavefront), mf_tpl_store the 33 data
-// dwords: tv = the packed template dword of lanes 0..32 (row lane / 3, bytes 4 (lane % 3) .., byte 11 = 0).  The two
-// touch disjoint dwords, so no barrier is needed between them.
-__device__ __forceinline__ void mf_tpl_init(unsigned* s_T, int lane) {
-  for (int i = lane; i < kMfTplDw; i += 64) {
-    const int r = i / kMfPitchDw, cc = i - r * kMfPitchDw;
-    const bool mid = cc >= 4 && cc <= 6;
-    if (!(mid && r < 11)) s_T[i] = (mid && r == 12) ? (cc == 6 ? 0x00010101u : 0x01010101u) : 0u;
-  }
+// The template operand of a lane is the 16 bytes at byte `off` = 16 + 16 (g & 1) - j of a padded row: a different
+// alignment for every candidate column j.  Rounds 2-3 read five dwords and shifted them with four v_alignbyte per operand
+// (24 vector instructions per candidate tile, in a kernel bound by vector issue).  Now the padded rows are kept four
+// times, copy c moved left by c bytes, so the operand is four ALIGNED dwords of copy off & 3 (two ds_read2_b32, no vector
+// instruction); the copies cost three v_alignbyte and three more ds_write_b32 per feature.
+__device__ __forceinline__ const unsigned* mf_b_base(const unsigned* s_T, int g, int off) {
+  const int c = off & 3;
+  return s_T + (3 + c * kMfCopyDw + (c ? 1 : 0)) + (g >> 1) * kMfPitchDw + (off >> 2);
 }
-__device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned* s_T, int lane) {
-  if (lane < 33) {
-    const int r = lane / 3, d = lane - 3 * r;
-    unsigned val = tv ^ 0x80808080u;
-    if (d == 2) val &= 0x00ffffffu;
-    s_T[r * kMfPitchDw + 4 + d] = val;
-  }
+__device__ __forceinline__ mf_v4i mf_load_b4(const unsigned* bp, int p) {     // template rows 2 p + (g >> 1)
+  mf_v4i r;
+  r.x = (int)bp[24 * p]; r.y = (int)bp[24 * p + 1]; r.z = (int)bp[24 * p + 2]; r.w = (int)bp[24 * p + 3];
+  return r;
 }
 
+// padded template rows in LDS, copy 0: row r = [16 x 0][T[r][0..10] - 128][21 x 0]; row 11 = zeros; row 12 = ones (copy 0
+// only).  mf_tpl_init clears the array, mf_tpl_ones writes the ones row (both once per wavefront), mf_tpl_store the
+// 4 x 44 data dwords of a template.  Lane layout of a template in registers (mf_tpl_index): lane 4 r + q holds dword q - 1 of row r
+// (q = 0: nothing, the 16 zero bytes in front of the row), lanes 48 / 49 / 50 hold sum g0, sum g0^2 and the patch-sigma
+// flag.  Row r of a copy is then one quad of lanes, and the dword that follows a lane's own is its right neighbour's
+// (v_mov_dpp row_shl:1; the last lane of a row's quad meets the zero of the next row's q = 0 lane, lane 15 of a DPP row
+// reads zero by bound_ctrl).
+__device__ __forceinline__ void mf_tpl_init(unsigned* s_T, int lane) {      // (a barrier must follow before mf_tpl_store)
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 z = {0u, 0u, 0u, 0u};
+  for (int i = lane; i < kMfTplDw / 4; i += 64) ((u4*)s_T)[i] = z;
+}
+__device__ __forceinline__ void mf_tpl_ones(unsigned* s_T, int lane) {      // after the barrier that follows mf_tpl_init
+  if (lane < 3) s_T[mf_copy_base(0) + 12 * kMfPitchDw + 4 + lane] = (lane == 2) ? 0x00010101u : 0x01010101u;
+}
+__device__ __forceinline__ int mf_tpl_index(int lane) {       // which dword of the packed record (sl2_common.hpp) a lane loads
+  const int r = lane >> 2, q = lane & 3;
+  return lane < 44 ? (q ? 3 * r + q - 1 : 0) : (lane >= 48 && lane <= 50 ? 33 + (lane - 48) : 0);
+}
+__device__ __forceinline__ unsigned mf_tpl_mask(int lane) {   // bytes of the lane's dword that are template pixels
+  const int q = lane & 3;
+  return lane < 44 ? (q == 0 ? 0u : (q == 3 ? 0x00ffffffu : 0xffffffffu)) : 0u;
+}
+__device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned tmask, unsigned* s_T, int lane) {
+  const unsigned x = (tv ^ 0x80808080u) & tmask;
+  const unsigned nx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+  if (lane < 44) {
+    unsigned* o = s_T + (lane >> 2) * kMfPitchDw + 3 + (lane & 3);
+    o[mf_copy_base(0)] = x;
+    o[mf_copy_base(1)] = __builtin_amdgcn_alignbyte(nx, x, 1);
+    o[mf_copy_base(2)] = __builtin_amdgcn_alignbyte(nx, x, 2);
+    o[mf_copy_base(3)] = __builtin_amdgcn_alignbyte(nx, x, 3);
+  }
+}
+
+// Round 4 (profiles/r04_search_*): the band's LDS layout and the four pre-shifted template copies are bank-conflict free
+// (SQ_LDS_BANK_CONFLICT 9.07e6 -> 3.0e5 per launch), the template operand costs no vector instruction, the byte-plane
+// offsets come back through the accumulators' start values, key and pixel sum share a register, the sigma == 10 boundary
+// is checked for the winner only, and the ellipse is classified in FP32 with an exact FP64 fallback: 193 -> 137 vector
+// instructions per candidate tile, 332 -> 318 per search (per-search fixed work - staging, byte planes, decision - is now
+// the larger part), 0.092 -> 0.0887 ms per launch on the same box.
 // ---------------------------------------------------------------------------
 // Round 3 re-costed this kernel for vector-instruction issue, which is what bounds it (round 2: 551 vector instructions
 // per searched feature with the matrix pipes 23 % busy; now ~380, PMC SQ_INSTS_VALU in profiles/r03_search_*):
@@ -191,12 +231,20 @@ __device__ __forceinline__ void mf_tpl_store(unsigned tv, unsigned* s_T, int lan
 //     a tile none of whose 256 slots lies inside the ellipse is skipped, the wave-wide maximum is six DPP instructions,
 //     and the winning lane stores its own record.
 // ---------------------------------------------------------------------------
-constexpr int kM4Pitch = 48;                     // bytes per LDS row: three 16-byte pieces (32 candidate columns + 10)
-constexpr int kM4Rows = 28;                      // 16 candidate rows + 10 + the partner row of template row 10
-constexpr int kM4Plane = kM4Rows * kM4Pitch;     // bytes per plane
+// LDS layout of a band (round 4): plane -> 16-byte column chunk (0..2: 32 candidate columns + 10) -> row (32 slots of 16
+// bytes, 27 used: 16 candidate rows + 10 + the partner row of template row 10).  An A operand is the 16-byte piece
+// (row j + (g >> 1) + 2 p, chunk tile + (g & 1)); ds_read_b128 is serviced in four 16-lane groups ({0-3, 12-15, 20-27},
+// ...) over 16 slots of 16 bytes, and with the chunk stride a multiple of 16 slots the lanes of a group - eight rows of
+// one chunk, the other eight rows of the next - fall on 16 different slots.  (Rounds 2-3 kept a row's three pieces side
+// by side, pitch 48: every group had five slots used twice - SQ_LDS_BANK_CONFLICT 9.1e6 per launch, 2.3 per LDS instruction,
+// profiles/r03_final_pmc_summary.txt.)  The band is staged chunk-major too (consecutive lanes = consecutive rows of one
+// chunk), so the eight lanes of a ds_write_b128 group write eight different slots.
+constexpr int kM4RowSlots = 32;                  // 16-byte slots per chunk column
+constexpr int kM4Chunk = kM4RowSlots * 16;       // bytes per chunk column
+constexpr int kM4Plane = 3 * kM4Chunk;           // bytes per plane
 typedef unsigned m4_u4 __attribute__((ext_vector_type(4)));
 
-struct M4Band { int base, rows_needed, nchunk, ntask; unsigned mul; };
+struct M4Band { int base, rows_needed, nchunk, ntask; };
 __device__ __forceinline__ M4Band m4_band(int ucentre, int vcentre, int urelstart, int vrelstart, int nu_all, int nv_all, int up,
                                           int vt, int width) {
   M4Band bd;
@@ -205,7 +253,6 @@ __device__ __forceinline__ M4Band m4_band(int ucentre, int vcentre, int urelstar
   const int bytes_needed = min(nu_all - 16 * up, 32) + 10;     // 11 .. 42
   bd.nchunk = (bytes_needed + 15) >> 4;                        // 1 .. 3
   bd.ntask = bd.rows_needed * bd.nchunk;                       // <= 78
-  bd.mul = bd.nchunk == 1 ? 128u : (bd.nchunk == 2 ? 64u : 43u);   // (idx * mul) >> 7 == idx / nchunk for idx < 128
   return bd;
 }
 // the band's 16-byte pieces in flight: two passes of 64 lanes; lds = byte offset of the piece inside a plane, -1 = this
@@ -219,8 +266,8 @@ __device__ __forceinline__ bool m4_band_loads(const uint8_t* __restrict__ img, i
     if (ps * 64 < bd.ntask) {                                  // wave-uniform
       if (ps) asm volatile("" ::: "memory");                   // (a real branch: the second pass is the exception, not to be speculated)
       const int idx = ps * 64 + lane;
-      const int row = (int)(((unsigned)idx * bd.mul) >> 7);
-      const int chunk = idx - mul24(row, bd.nchunk);
+      const int chunk = (idx >= bd.rows_needed ? 1 : 0) + (idx >= 2 * bd.rows_needed ? 1 : 0);     // chunk-major: idx = chunk * rows + row
+      const int row = idx - mul24(chunk, bd.rows_needed);
       const bool valid = idx < bd.ntask;
       const int off = bd.base + mul24(row, width) + 16 * chunk;
       // A piece may reach up to 37 bytes beyond its window row; inside the frame that is harmless (the bytes land in
@@ -229,7 +276,7 @@ __device__ __forceinline__ bool m4_band_loads(const uint8_t* __restrict__ img, i
       const bool ov = valid && off > frame_bytes - 16;
       over |= ov;
       __builtin_memcpy(&pf.v[ps], img + min(off, frame_bytes - 16), 16);
-      pf.lds[ps] = valid ? ((mul24(row, kM4Pitch) + 16 * chunk) | (ov ? 0x40000000 : 0)) : -1;
+      pf.lds[ps] = valid ? ((16 * row + kM4Chunk * chunk) | (ov ? 0x40000000 : 0)) : -1;
     }
   }
   return __any(over);
@@ -250,8 +297,8 @@ __device__ __forceinline__ void m4_band_fix(const uint8_t* __restrict__ img, int
   for (int ps = 0; ps < 2; ++ps) {
     if (ps * 64 < bd.ntask && pf.lds[ps] >= 0 && (pf.lds[ps] & 0x40000000)) {
       const int idx = ps * 64 + lane;
-      const int row = (int)(((unsigned)idx * bd.mul) >> 7);
-      const int chunk = idx - row * bd.nchunk;
+      const int chunk = (idx >= bd.rows_needed ? 1 : 0) + (idx >= 2 * bd.rows_needed ? 1 : 0);
+      const int row = idx - chunk * bd.rows_needed;
       pf.v[ps] = m4_piece_bytes(img, bd.base + row * width + 16 * chunk, frame_bytes);
       pf.lds[ps] &= ~0x40000000;
     }
@@ -300,13 +347,58 @@ __device__ __forceinline__ float m4_wave_max(float x) {
 }
 
 // per-lane state of one search (raw accumulator values of the best candidate) ...
+// best_ks = ((tile column << 8 | tile row << 2 | accumulator register) << 15) | sum g of the best candidate: which of the
+// lane's candidates it is (the lane itself gives column j and row group g) and its 15-bit pixel sum in one register - one
+// v_add with a wave-uniform constant per candidate, one v_cndmask less per candidate than separate key and sum.
 struct M4State {
   float best_q, second_q;
-  int best_key, best_S1, best_w, best_x;
-  __device__ __forceinline__ void reset() { best_q = -3.0e38f; second_q = -3.0e38f; best_key = 0; best_S1 = best_w = best_x = 0; }
+  int best_ks, best_w, best_x;
+  __device__ __forceinline__ void reset() { best_q = -3.0e38f; second_q = -3.0e38f; best_ks = 0; best_w = best_x = 0; }
 };
+constexpr int kM4MaxTU = 128, kM4MaxTV = 64;     // tile columns / rows the packed key has room for (windows up to 2048 x 1024)
+__device__ __forceinline__ int m4_ks_u(int ks, int j) { return 16 * (ks >> 23) + j; }                       // candidate column in the window
+__device__ __forceinline__ int m4_ks_v(int ks, int g) { return 16 * ((ks >> 17) & 63) + 4 * g + ((ks >> 15) & 3); }
+__device__ __forceinline__ int m4_ks_S1(int ks) { return ks & 0x7fff; }
+// 121 sum g^2 - (sum g)^2 of a stored candidate (exact)
+__device__ __forceinline__ int m4_D1(int S1, int S2) { return __mul24(121, S2) - __mul24(S1, S1); }
+// wave-uniform constants of a search's scoring loop.  c_s1 / c_s2 are the start values of the sum-g and sum-g^2 (low byte
+// plane) accumulators; they live in registers the compiler cannot see through (m4_opaque), or it would rebuild the two
+// quads with eight v_mov in front of every tile.
+struct M4Quads { mf_v4i c_s1, c_s2; };                 // once per wavefront
+struct M4Const { int kS, c121, c_nc; float af, b2f, cf, lo, hi; };   // once per search
+__device__ __forceinline__ void m4_opaque(mf_v4i& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ M4Quads m4_quads() {
+  M4Quads q;
+  q.c_s1 = mf_v4i{15488, 15488, 15488, 15488};
+  q.c_s2 = mf_v4i{15488 * 257, 15488 * 257, 15488 * 257, 15488 * 257};
+  m4_opaque(q.c_s1); m4_opaque(q.c_s2);
+  return q;
+}
+// Ellipse membership is first decided in FP32: val_f = fma(fma(c, dv, 2 b du), dv, (a du) du) differs from the reference's
+// FP64 value by less than 1e-6 R, R = 9 a c / (a c - b^2) >= every |term| (|du| <= halfwidth = floor(3 / sqrt(a - b^2 / c))
+// gives a du^2 <= R, likewise c dv^2, and the cross term is at most their sum): a candidate with val_f outside
+// [9 - tol, 9 + tol], tol = 4e-6 R, is classified for certain; any other candidate sends its tile down the reference's FP64
+// expression (a degenerate S^-1 makes tol infinite or NaN: everything takes the FP64 path).
+__device__ __forceinline__ M4Const m4_const(int Sg0, double a, double b2, double c) {
+  M4Const k;
+  k.kS = 15488 - Sg0;
+  k.c121 = 121;
+  k.c_nc = -15488 * k.kS;                  // |.| <= 15488 * 15367 < 2^31
+  k.af = (float)a; k.b2f = (float)b2; k.cf = (float)c;
+  const float ac = k.af * k.cf, det = ac - 0.25f * k.b2f * k.b2f;
+  const float tol = 3.6e-5f * ac * __builtin_amdgcn_rcpf(det);         // 4e-6 * 9 a c / (a c - b^2)
+  k.lo = 9.0f - tol; k.hi = 9.0f + tol;
+  return k;
+}
+// a * b + c with a, b 24-bit: ONE v_mad_i32_i24 (b in a scalar register, c in a vector register: GFX9's VOP3 takes one
+// scalar source and no literal, and left to itself the compiler splits the constant term off into a separate add)
+__device__ __forceinline__ int m4_mad24(int v_a, int s_b, int v_c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v_a), "s"(s_b), "v"(v_c));
+  return r;
+}
 // ... and its wave-uniform part
-struct M4Uni { int ncand; unsigned long long nx; };
+struct M4Uni { int ncand; };
 
 // Lane predicates as 64-bit masks in scalar registers.  The compiler keeps a predicate that is both selected on and
 // counted (popcount of a ballot) as a 0 / 1 vector register and re-compares it - two more vector instructions per use, in
@@ -317,6 +409,8 @@ __device__ __forceinline__ m4_mask m4_gt_i32(int s_a, int v_b) { m4_mask m; asm(
 __device__ __forceinline__ m4_mask m4_lt_i32(int s_a, int v_b) { m4_mask m; asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }   // a < b
 __device__ __forceinline__ m4_mask m4_eq_i32(int s_a, int v_b) { m4_mask m; asm("v_cmp_eq_u32_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }
 __device__ __forceinline__ m4_mask m4_gt_f64(double s_a, double v_b) { m4_mask m; asm("v_cmp_gt_f64_e64 %0, %1, %2" : "=s"(m) : "s"(s_a), "v"(v_b)); return m; }   // a > b
+__device__ __forceinline__ m4_mask m4_lt_f32s(float v_a, float s_b) { m4_mask m; asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v_a), "s"(s_b)); return m; }   // a < b
+__device__ __forceinline__ m4_mask m4_gt_f32s(float v_a, float s_b) { m4_mask m; asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v_a), "s"(s_b)); return m; }   // a > b
 __device__ __forceinline__ m4_mask m4_gt_f32(float v_a, float v_b) { m4_mask m; asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(v_a), "v"(v_b)); return m; }   // a > b
 __device__ __forceinline__ int m4_sel(m4_mask m, int t, int f) { int r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
 __device__ __forceinline__ float m4_self(m4_mask m, float t, float f) { float r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m)); return r; }
@@ -324,59 +418,82 @@ __device__ __forceinline__ float m4_self(m4_mask m, float t, float f) { float r;
 // the (up to two) 16 x 16 candidate tiles of the band in LDS
 __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* s_T, const mf_v4i b_ones, const mf_v4i b_ones_last,
                                               int up, int vt, int TU, int nu_all, int nv_all, int urelstart, int vrelstart,
-                                              double a, double b2, double c, int kS, float d0f, bool patch_ok, int j, int g,
-                                              M4State& st, M4Uni& un) {
+                                              double a, double b2, double c, const M4Quads& kq, const M4Const& k, bool patch_ok,
+                                              int j, int g, M4State& st, M4Uni& un) {
   const int vi0 = 16 * vt + 4 * g;
-  const int boff = 16 + 16 * (g & 1) - j;                 // 1..32
+  const unsigned* bp = mf_b_base(s_T, g, 16 + 16 * (g & 1) - j);      // this lane's template operands (offset 1..32)
   for (int ut = up; ut < min(up + 2, TU); ++ut) {
-    // ellipse membership: the reference's expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9, same values, same order
+    // ellipse membership: FP32 with a guard band (m4_const), the reference's FP64 expression where that cannot decide
     const int ui = 16 * ut + j;
-    const double du = (double)(urelstart + ui);
-    const double e_uu = a * du * du, e_u = b2 * du;
     const m4_mask m_col = m4_gt_i32(nu_all, ui);
     m4_mask m_cand[4];
+    {
+      const float duf = (float)(urelstart + ui);
+      const float euu = k.af * duf * duf, eu = k.b2f * duf;
+      m4_mask m_amb = 0ull;
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-      int vi = vi0 + reg;
-      asm volatile("" : "+v"(vi));        // (keeps the per-row terms out of registers across the matrix-core section)
-      const double dv = (double)(vrelstart + vi);
-      m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & m4_gt_f64(kNoSigma * kNoSigma, e_uu + e_u * dv + c * dv * dv);
-      un.ncand += __popcll(m_cand[reg]);
+      for (int reg = 0; reg < 4; ++reg) {
+        int vi = vi0 + reg;
+        asm volatile("" : "+v"(vi));        // (keeps the per-row terms out of registers across the matrix-core section)
+        const float dvf = (float)(vrelstart + vi);
+        const float val = __builtin_fmaf(__builtin_fmaf(k.cf, dvf, eu), dvf, euu);
+        const m4_mask in = m4_lt_f32s(val, k.lo);
+        m_amb |= ~(in | m4_gt_f32s(val, k.hi));
+        m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & in;
+      }
+      if (m_amb != 0ull) {
+        // the reference's expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9, same values, same order
+        const double du = (double)(urelstart + ui);
+        const double e_uu = a * du * du, e_u = b2 * du;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          int vi = vi0 + reg;
+          asm volatile("" : "+v"(vi));
+          const double dv = (double)(vrelstart + vi);
+          m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & m4_gt_f64(kNoSigma * kNoSigma, e_uu + e_u * dv + c * dv * dv);
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) un.ncand += __popcll(m_cand[reg]);
     }
     // (a flat template: every candidate is skipped, they are only counted; a corner tile of a tilted ellipse may be empty)
     if (!patch_ok || (m_cand[0] | m_cand[1] | m_cand[2] | m_cand[3]) == 0ull) continue;
     mf_v4i accX, acc1, accH, accL;
     const mf_v4i zero = {0, 0, 0, 0};
-    const char* ap = s_pl + j * kM4Pitch + 16 * ((ut - up) + (g & 1)) + (g >> 1) * kM4Pitch;
+    const char* ap = s_pl + 16 * (j + (g >> 1)) + kM4Chunk * ((ut - up) + (g & 1));
 #pragma unroll
     for (int p = 0; p < 6; ++p) {
-      const mf_v4i aI = *(const mf_v4i*)(ap + 2 * p * kM4Pitch);
-      const mf_v4i aH = *(const mf_v4i*)(ap + 2 * p * kM4Pitch + kM4Plane);
-      const mf_v4i aL = *(const mf_v4i*)(ap + 2 * p * kM4Pitch + 2 * kM4Plane);
-      const mf_v4i bX = mf_load_b(s_T, 2 * p + (g >> 1), boff);
+      const mf_v4i aI = *(const mf_v4i*)(ap + 32 * p);
+      const mf_v4i aH = *(const mf_v4i*)(ap + 32 * p + kM4Plane);
+      const mf_v4i aL = *(const mf_v4i*)(ap + 32 * p + 2 * kM4Plane);
+      const mf_v4i bX = mf_load_b4(bp, p);
       const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
+      // the offsets of the signed byte planes come back through the accumulators' start values: sum g = sum (g - 128) +
+      // 15488 and sum g^2 = 256 sum (H - 128) + sum (L - 128) + 15488 * 257 leave the matrix cores as they are needed
       accX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, p ? accX : zero, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, p ? acc1 : zero, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, p ? acc1 : kq.c_s1, 0, 0, 0);
       accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, p ? accH : zero, 0, 0, 0);
-      accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? accL : zero, 0, 0, 0);
+      accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? accL : kq.c_s2, 0, 0, 0);
     }
-    const int key0 = (ui << 16) | vi0;
+    // Ranking value q = Nc / sqrt(D1) = rho * sqrt(D0) (D0 = 121 sum g0^2 - (sum g0)^2 is the same for every candidate of
+    // a search, so it is left out: one multiply less per candidate; the callers scale the guard band by sqrt(D0) instead).
+    // A candidate whose image sigma is EXACTLY 10 (D1 == 1464100) is ranked like a valid one; whether the reference skips
+    // it is an FP64 matter that only counts if it is the winner or ties with it: then the caller takes the exact walk.
+    const int ks0 = ((ut << 8) | (vt << 2)) << 15;               // wave-uniform: + (reg << 15) + sum g = the packed key | sum
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int s1 = acc1[reg];                                  // sum (g - 128)
-      const int S1 = s1 + 15488;                                 // sum g
-      const int w = (accH[reg] << 8) + accL[reg];                // sum g^2 - 15488 * 257
-      const int D1 = mul24(121, w) - (mul24(S1, S1) - 481630336);   // 121 sum g^2 - (sum g)^2, exact
-      const int Nc = mul24(121, accX[reg]) + mul24(kS, s1);      // 121 sum g0 g - sum g0 sum g, exact (shift invariant)
-      const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1 * d0f);
-      un.nx |= m_cand[reg] & m4_eq_i32(1464100, D1);             // sigma1 == 10 boundary: decided in FP64 only
-      const float qq = m4_self(m_cand[reg] & m4_lt_i32(1464100, D1), q, -3.0e38f);
+      const int S1 = acc1[reg];                                  // sum g
+      const int S2 = (accH[reg] << 8) + accL[reg];               // sum g^2
+      const int D1 = mul24(121, S2) - mul24(S1, S1);             // 121 sum g^2 - (sum g)^2, exact
+      // 121 sum g0 g - sum g0 sum g = 121 x + kS (S1 - 15488), x = the raw cross term of the offset operands (exact)
+      const int Nc = m4_mad24(S1, k.kS, m4_mad24(accX[reg], k.c121, k.c_nc));
+      const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1);
+      const float qq = m4_self(m_cand[reg] & m4_lt_i32(1464099, D1), q, -3.0e38f);
       const m4_mask better = m4_gt_f32(qq, st.best_q);
       st.second_q = __builtin_amdgcn_fmed3f(st.best_q, st.second_q, qq);    // second of {best, second, new}
       st.best_q = m4_self(better, qq, st.best_q);
-      st.best_key = m4_sel(better, key0 + reg, st.best_key);
-      st.best_S1 = m4_sel(better, S1, st.best_S1);
-      st.best_w = m4_sel(better, w, st.best_w);
+      st.best_ks = m4_sel(better, S1 + (ks0 + (reg << 15)), st.best_ks);
+      st.best_w = m4_sel(better, S2, st.best_w);
       st.best_x = m4_sel(better, accX[reg], st.best_x);
     }
   }
@@ -393,16 +510,18 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
   res.code = 0; res.ok = 0; res.found = 0; res.u = 0; res.v = 0; res.ncand = 0; res.score = 1000000.0;
   res.S1 = res.S2 = res.X = 0;
   if (nu_all <= 0 || nv_all <= 0) return res;
-  unsigned tv = 0;
-  if (lane < 33) {
-    const int r = lane / 3, d = lane - 3 * r;
+  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+  if (TU > kM4MaxTU || TV > kM4MaxTV) { res.code = -1; return res; }       // beyond the packed key: the exact walk
+  unsigned tv = 0;                                  // the template in the lane layout of mf_tpl_store
+  const int tr = lane >> 2, tq = lane & 3;
+  if (lane < 44 && tq) {
     for (int kk = 0; kk < 4; ++kk) {
-      const int col = 4 * d + kk;
-      const unsigned byte = (col < 11) ? patch[r * 11 + col] : 0u;
+      const int col = 4 * (tq - 1) + kk;
+      const unsigned byte = (col < 11) ? patch[tr * 11 + col] : 0u;
       tv |= byte << (8 * kk);
     }
   }
-  unsigned s1 = (lane < 33) ? udot4(tv, 0x01010101u, 0u) : 0u, s2 = (lane < 33) ? udot4(tv, tv, 0u) : 0u;
+  unsigned s1 = udot4(tv, 0x01010101u, 0u), s2 = udot4(tv, tv, 0u);
   for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
   const int Sg0 = (int)s1, Sg0sq = (int)s2;
   // patch sigma test, exactly as correlate2_warning + elliptical_search evaluate it
@@ -412,7 +531,10 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
   const bool patch_ok = !(sigmag0 < kCorrelationSigmaThreshold);
   const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
   mf_tpl_init(s_T, lane);
-  mf_tpl_store(tv, s_T, lane);
+  __syncthreads();
+  mf_tpl_ones(s_T, lane);
+  mf_tpl_store(tv, mf_tpl_mask(lane), s_T, lane);
+  __syncthreads();
   const int j = lane & 15, g = lane >> 4;
   const int boff = 16 + 16 * (g & 1) - j;
   const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
@@ -420,8 +542,9 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
   M4State st;
   st.reset();
   M4Uni un;
-  un.ncand = 0; un.nx = 0ull;
-  const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+  un.ncand = 0;
+  const M4Quads kq = m4_quads();
+  const M4Const kc = m4_const(Sg0, a, 2 * b, c);
   for (int vt = 0; vt < TV; ++vt)
     for (int up = 0; up < TU; up += 2) {
       if (vt + up > 0) __syncthreads();                                // the previous band has been consumed
@@ -430,23 +553,24 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
       if (m4_band_loads(image, width, frame_bytes, bd, lane, pf)) m4_band_fix(image, width, frame_bytes, bd, lane, pf);
       m4_band_store(pf, bd, s_pl);
       __syncthreads();
-      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, 15488 - Sg0,
-                    d0f, patch_ok, j, g, st, un);
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, kq, kc,
+                    patch_ok, j, g, st, un);
     }
   res.ncand = un.ncand;
   if (!patch_ok) return res;
   const float gmax = m4_wave_max(st.best_q);
-  if (!(gmax > -1.0e38f)) { if (un.nx) res.code = -1; return res; }       // nothing passed the sigma test
-  const float thr = gmax - 4.0e-6f;
+  if (!(gmax > -1.0e38f)) return res;                                     // nothing passed the sigma test
+  const float thr = gmax - 4.1e-6f * __builtin_amdgcn_sqrtf(d0f);         // q = rho sqrt(D0): the 4e-6 guard band on rho
   const unsigned long long near_mask = __ballot(st.best_q >= thr);
-  if (un.nx != 0ull || __any(st.second_q >= thr) || __popcll(near_mask) > 1) { res.code = -1; return res; }
+  if (__any(st.second_q >= thr) || __popcll(near_mask) > 1) { res.code = -1; return res; }
   const int wl = __ffsll((long long)near_mask) - 1;
-  const int key = __shfl(st.best_key, wl, 64), wS1 = __shfl(st.best_S1, wl, 64), ww = __shfl(st.best_w, wl, 64),
-            wx = __shfl(st.best_x, wl, 64);
-  res.S1 = wS1; res.S2 = ww + 15488 * 257; res.X = wx + 128 * (wS1 - 15488) + 128 * Sg0;
+  const int ks = __shfl(st.best_ks, wl, 64), ww = __shfl(st.best_w, wl, 64), wx = __shfl(st.best_x, wl, 64);
+  const int wS1 = m4_ks_S1(ks);
+  if (m4_D1(wS1, ww) == 1464100) { res.code = -1; return res; }           // image sigma exactly 10: decided in FP64 by the exact walk
+  res.S1 = wS1; res.S2 = ww; res.X = wx + 128 * (wS1 - 15488) + 128 * Sg0;
   res.found = 1;
-  res.u = sb.ucentre + sb.urelstart + (key >> 16);
-  res.v = sb.vcentre + sb.vrelstart + (key & 0xffff);
+  res.u = sb.ucentre + sb.urelstart + m4_ks_u(ks, wl & 15);
+  res.v = sb.vcentre + sb.vrelstart + m4_ks_v(ks, wl >> 4);
   double sd0, sd1;
   const double corr = ncc_score(Sg0, res.S1, res.X, Sg0sq, res.S2, &sd0, &sd1);
   if (sd0 < kCorrelationSigmaThreshold || sd1 < kCorrelationSigmaThreshold) {   // cannot happen (D1 > bound), kept exact
@@ -503,7 +627,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
   if (!xcd_map(nchunks, B, &b, &ch)) return;
   STR(0);
   __shared__ __attribute__((aligned(16))) char s_pl[3 * kM4Plane];
-  __shared__ unsigned s_T[kMfTplDw];
+  __shared__ __attribute__((aligned(16))) unsigned s_T[kMfTplDw];
   const int lane = threadIdx.x;
   const int k0 = ch * chunk;
   const int nsel = n_sel[b];
@@ -523,8 +647,9 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
   };
 
   mf_tpl_init(s_T, lane);
-  const int tslot = (lane < 33) ? (lane / 3) * kMfPitchDw + 4 + lane % 3 : 0;      // where this lane's template dword goes
-  const unsigned tmask = (lane % 3 == 2) ? 0x00ffffffu : 0xffffffffu;
+  const int tidx = mf_tpl_index(lane);               // this lane's dword of a packed template record ...
+  const bool tload = lane < 44 ? (lane & 3) != 0 : (lane >= 48 && lane <= 50);
+  const unsigned tmask = mf_tpl_mask(lane);          // ... and which of its bytes are pixels
   M4Pf pf;
   pf.lds[0] = pf.lds[1] = -1;
   bool pf_over = false;
@@ -534,13 +659,16 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
     if (rc.nu > 0 && rc.nv > 0)
       pf_over = m4_band_loads(img, width, frame_bytes, m4_band(rc.uc, rc.vc, rc.us, rc.vs, rc.nu, rc.nv, 0, 0, width), lane, pf);
     const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rc.f) * kPatchStride + kPatchPackedOffset);
-    pf_tv = tpl[min(lane, 35)];
+    pf_tv = tload ? tpl[tidx] : 0u;
   }
   // operands of the ones matrix: they depend on the lane alone
+  __syncthreads();
+  mf_tpl_ones(s_T, lane);
   __syncthreads();
   const int boff = 16 + 16 * (g & 1) - j;
   const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
   const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
+  const M4Quads kq = m4_quads();
   STR(1);
   for (int i = 0; i < nf; ++i) {
     // the next position's record: scalar loads issued here, consumed after the barrier below (clamped index: the last
@@ -551,12 +679,12 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
     const int nu_all = rc.nu, nv_all = rc.nv;
     const bool geom_ok = nu_all > 0 && nv_all > 0;
     const unsigned tv = pf_tv;
-    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 33), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 34);
-    const bool patch_ok = __builtin_amdgcn_readlane(tv, 35) != 0;
+    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 48), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 49);
+    const bool patch_ok = __builtin_amdgcn_readlane(tv, 50) != 0;
     const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
     if (i > 0) __syncthreads();                       // feature i - 1 is done with the LDS
     if (geom_ok) {
-      if (lane < 33) s_T[tslot] = (tv ^ 0x80808080u) & tmask;
+      mf_tpl_store(tv, tmask, s_T, lane);
       const M4Band bd0 = m4_band(rc.uc, rc.vc, rc.us, rc.vs, nu_all, nv_all, 0, 0, width);
       if (pf_over) m4_band_fix(img, width, frame_bytes, bd0, lane, pf);
       m4_band_store(pf, bd0, s_pl);
@@ -567,20 +695,22 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
       if (rn.nu > 0 && rn.nv > 0)
         pf_over = m4_band_loads(img, width, frame_bytes, m4_band(rn.uc, rn.vc, rn.us, rn.vs, rn.nu, rn.nv, 0, 0, width), lane, pf);
       const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rn.f) * kPatchStride + kPatchPackedOffset);
-      pf_tv = tpl[min(lane, 35)];
+      pf_tv = tload ? tpl[tidx] : 0u;
     }
     int* o = srch_res + ((size_t)b * N + k0 + i) * 8;
     M4State st;
     st.reset();
     M4Uni un;
-    un.ncand = 0; un.nx = 0ull;
+    un.ncand = 0;
     int code = 0;
-    if (geom_ok) {
-      const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
-      const int kS = 15488 - Sg0;
+    const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4;
+    if (geom_ok && (TU > kM4MaxTU || TV > kM4MaxTV)) code = -1;      // a window beyond the packed key: the exact walk
+    else if (geom_ok) {
       const double b2 = 2 * pb;
-      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, 0, 0, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kS, d0f, patch_ok, j, g,
+      const M4Const kc = m4_const(Sg0, pa, b2, pc);
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, 0, 0, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kq, kc, patch_ok, j, g,
                     st, un);
+      if (TU > 2 || TV > 1)                           // (most windows are one band: keep the loop set-up off their path)
       for (int vt = 0; vt < TV; ++vt)                 // the other bands of a large window: staged synchronously
         for (int up = (vt == 0 ? 2 : 0); up < TU; up += 2) {
           __syncthreads();
@@ -589,27 +719,29 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
           if (m4_band_loads(img, width, frame_bytes, bd, lane, p2)) m4_band_fix(img, width, frame_bytes, bd, lane, p2);
           m4_band_store(p2, bd, s_pl);
           __syncthreads();
-          m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kS, d0f, patch_ok,
+          m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kq, kc, patch_ok,
                         j, g, st, un);
         }
       // ---- decision: a unique near-best candidate goes on to k_search_score with its exact sums
       if (patch_ok) {
         const float gmax = m4_wave_max(st.best_q);
         if (gmax > -1.0e38f) {
-          const float thr = gmax - 4.0e-6f;
+          const float thr = gmax - 4.1e-6f * __builtin_amdgcn_sqrtf(d0f);   // q = rho sqrt(D0): the 4e-6 guard band on rho
           const bool near = st.best_q >= thr;
           const unsigned long long near_mask = __ballot(near);
-          if (un.nx != 0ull || __any(st.second_q >= thr) || __popcll(near_mask) > 1) code = -1;
+          const int wS1 = m4_ks_S1(st.best_ks);
+          // several near-best candidates, or the one there is sits on the sigma == 10 boundary: the exact walk decides
+          if (__any(st.second_q >= thr) || __popcll(near_mask) > 1 || __any(near && m4_D1(wS1, st.best_w) == 1464100)) code = -1;
           else {
             code = 1;
             if (near) {                               // the one lane that holds the only possible winner stores its record
               int4 o0, o1;
-              o0.x = 1; o0.y = rc.uc + rc.us + (st.best_key >> 16); o0.z = rc.vc + rc.vs + (st.best_key & 0xffff); o0.w = st.best_S1;
-              o1.x = st.best_w + 15488 * 257; o1.y = st.best_x + 128 * st.best_S1 + 128 * (Sg0 - 15488); o1.z = un.ncand; o1.w = 1;
+              o0.x = 1; o0.y = rc.uc + rc.us + m4_ks_u(st.best_ks, j); o0.z = rc.vc + rc.vs + m4_ks_v(st.best_ks, g); o0.w = wS1;
+              o1.x = st.best_w; o1.y = st.best_x + 128 * wS1 + 128 * (Sg0 - 15488); o1.z = un.ncand; o1.w = 1;
               *(int4*)o = o0; *(int4*)(o + 4) = o1;     // (k_search_score writes this position's score)
             }
           }
-        } else if (un.nx != 0ull) code = -1;
+        }
       }
     }
     if (code < 0) {
@@ -737,7 +869,7 @@ __global__ void __launch_bounds__(64) k_search_batch(const uint8_t* __restrict__
                                                      int* __restrict__ ok, int* __restrict__ uv, double* __restrict__ score) {
   const int i = blockIdx.x;
   __shared__ __attribute__((aligned(16))) char s_pl[VARIANT == 1 ? 3 * kM4Plane : 16];
-  __shared__ unsigned s_tpl[VARIANT == 1 ? kMfTplDw : 1];
+  __shared__ __attribute__((aligned(16))) unsigned s_tpl[VARIANT == 1 ? kMfTplDw : 4];
   const double ce[2] = {centre[i * 2], centre[i * 2 + 1]};
   const double a = puinv[i * 3], b = puinv[i * 3 + 1], c = puinv[i * 3 + 2];
   const SearchBounds sb = search_bounds(ce, a, b, c, width, height);

@@ -44,7 +44,14 @@ def parse_args():
                     help="prior std-dev (m) of every map feature; > 0 makes the covariance dense (0: AddNewKnownFeature zeros)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a HIP graph (small batches are launch-bound)")
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
-    return ap.parse_args()
+    ap.add_argument("--mapping", action="store_true",
+                    help="the reference's DEFAULT workload instead of the headline: --features known features (use 6-12), the shipped "
+                         "parameters (select 10, keep 12 visible, 100 depth particles), a camera that translates past the 0.2 m/s "
+                         "gate, GoOneStep(enable_mapping = true): features are initialised, converted and deleted along the way")
+    a = ap.parse_args()
+    if a.mapping and a.feature_sigma == 0.005:
+        a.feature_sigma = 0.0          # AddNewKnownFeature's zeros, like the shipped scene
+    return a
 
 
 def free_port():
@@ -149,6 +156,82 @@ def per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W,
                 note="every rank: the first %d sequences of its own shard x %d frames; worst over ranks" % (nseq, nframes))
 
 
+def mapping_cpu_and_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render, ncores, sample):
+    """--mapping: CPU baseline and parity of the mapping-on workload.  The reference's feature initialisation draws from the
+    process-global drand48 (monoslam.cpp:986-1021), so reference objects cannot step side by side: the timed baseline is the
+    oracle restatement (kind "port": its generator is per object; it is pinned to the reference frame by frame in
+    tests/test_oracle_vs_ref.py), one object per hardware thread, and ONE sequence is also run through the reference build
+    itself (srand48(0) first, like MonoSLAM::Init) as the parity anchor.  Every frame the engine stepped is followed."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api as oa
+    nseq = max(1, min(sample, B, 64))
+    frames_n = n_render
+    allf = np.stack([d_frames.download((nseq, H, W), np.uint8, offset=k * B * fb) for k in range(frames_n + 1)])
+
+    def build(cls, b):
+        s = cls(cam, params["delta_t"], params["number_of_features_to_select"])
+        s.set_mapping_params(params)
+        s.set_state(specs[b].xv0, specs[b].Pxx0)
+        xo = specs[b].xp_org()
+        for i in range(N):
+            s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
+        return s
+
+    slams = [build(oa.OracleSLAM, b) for b in range(nseq)]
+    traj = np.zeros((nseq, frames_n, 3))
+
+    def run(b):
+        for k in range(frames_n):
+            slams[b].go_one_step(allf[k + 1, b], False, True)
+            traj[b, k] = slams[b].get_state()[0][:3]
+
+    nthreads = min(ncores, nseq)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=nthreads) as ex:
+        list(ex.map(run, range(nseq)))
+    secs = time.perf_counter() - t0
+    cpu = dict(value=nseq * frames_n / secs, unit="frames/s", cores=nthreads, host_hardware_threads=ncores, kind="port",
+               sample="%d sequences x %d frames (%dx%d, %d known features, mapping on) of this run's input, one oracle object per thread"
+                      % (nseq, frames_n, W, H, N), seconds=secs,
+               note="oracle restatement (oracle/*.hpp) stepped from Python threads (ctypes releases the GIL); the reference build "
+                    "cannot run objects side by side with mapping on (process-global drand48)")
+    log = eng.position_log(0, nseq, capacity=n_render)[:, :frames_n]
+    rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
+    parity = dict(traj_rmse_vs_oracle=rmse, checker="oracle", sequences=nseq, frames=frames_n, frames_stepped=n_render,
+                  covers_every_timed_frame=True, position_maxabs=float(np.abs(log - traj).max()))
+    # the maps grew the same way: feature counts, labels, state size and the whole state at the end
+    dx, same_maps = 0.0, True
+    grown = []
+    for b in range(nseq):
+        xo, xg = slams[b].total_state(), eng.total_state(b)
+        same_maps = same_maps and xo.shape == xg.shape
+        if xo.shape == xg.shape:
+            dx = max(dx, float(np.abs(xo - xg).max()))
+        info = slams[b].mapping_info()
+        grown.append((info["initialised"], info["converted"], info["deleted"]))
+    parity["final_state_maxabs"] = dx if same_maps else float("inf")
+    parity["maps_equal"] = bool(same_maps)
+    g = np.array(grown)
+    parity["features_initialised_converted_deleted_per_sequence_mean"] = [float(v) for v in g.mean(axis=0)]
+    if oa.ref_available():
+        try:
+            oa.ref_lib()
+            ctypes.CDLL(None).srand48(0)
+            r = build(oa.RefSLAM, 0)
+            tr = np.zeros((frames_n, 3))
+            for k in range(frames_n):
+                r.go_one_step(allf[k + 1, 0], False, True)
+                tr[k] = r.get_state()[0][:3]
+            parity["reference_build_sequence0"] = dict(traj_rmse=float(np.sqrt(((log[0] - tr) ** 2).sum(axis=1).mean())),
+                                                       final_state_maxabs=float(np.abs(r.total_state() - eng.total_state(0)).max())
+                                                       if r.total_state().shape == eng.total_state(0).shape else float("inf"))
+        except Exception as ex:      # noqa: BLE001 - the anchor is optional, the oracle leg above is the check
+            parity["reference_build_sequence0"] = "not run: %s" % ex
+    return cpu, parity
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -204,13 +287,15 @@ def main():
     n_frames = K + Wm
     n_render = n_frames + E
     cam = synth.default_camera(W, H)
-    params = synth.default_params(N)
+    params = synth.default_params(min(N, 10) if args.mapping else N)      # data/SceneLib2.cfg:60: number_of_features_to_select = 10
+    NCAP = max(32, 2 * N) if args.mapping else N                          # feature slots per sequence (the map grows with mapping on)
+    spec_kw = dict(v_amp=0.45, w_amp=0.05) if args.mapping else {}        # past the 0.2 m/s gate of monoslam.cpp:159
     seq_ids = sharding.global_sequence_ids(B, world, rank)
 
     # ---- synthetic inputs: specs on the host, frames rendered on the device ----
     t_setup = time.time()
     tex = synth.make_texture()
-    specs = [synth.SequenceSpec(cam, N, n_render, synth.BASE_SEED + int(i)) for i in seq_ids]
+    specs = [synth.SequenceSpec(cam, N, n_render, synth.BASE_SEED + int(i), **spec_kw) for i in seq_ids]
     fb = W * H
     d_tex = _lib.DeviceBuffer(tex.nbytes, dev); d_tex.upload(tex)
     # pose k of every sequence, k-major: frames[k][b]
@@ -225,7 +310,7 @@ def main():
     frame0 = d_frames.download((B, H, W), np.uint8)                                  # t = 0 views -> templates
     templates = np.stack([synth.cut_templates(frame0[b], specs[b].feat_px) for b in range(B)])
 
-    eng = Engine(cam, params, B, N, device=dev)
+    eng = Engine(cam, params, B, NCAP, device=dev)
     if args.groups > 0:
         eng.set_groups(args.groups)
     if args.graph:
@@ -238,13 +323,15 @@ def main():
     setup_s = time.time() - t_setup
 
     def step(k):  # frame k (0-based) = pose k+1, resident in HBM
-        eng.go_one_step(d_frames.ptr + (k + 1) * B * fb, on_device=True, seq_stride=fb)
+        eng.go_one_step(d_frames.ptr + (k + 1) * B * fb, on_device=True, seq_stride=fb, enable_mapping=args.mapping)
 
     # ---- warm-up ----  (its last steps, when there are enough, carry a bracket on EVERY launch: they tell which kernel
     # dominates, so that the timed region brackets only that one and the search kernel - each bracket is two event markers
     # on the stream, and bracketing the four large kernels cost 1-3 % of the step)
     # profiling scopes carry the kernel symbols (they join with rocprofv3's kernel_stats.csv on the name)
     MAJOR = ("k_syrk", "k_fwdsub_lds", "k_fwdsub_ksplit", "k_fwd_gemm", "k_build_AS", "k_chol_left", "k_chol_syrk", "k_search_mfma")
+    if args.mapping:
+        MAJOR = MAJOR + ("k_map_detect", "k_map_me_mark", "k_map_me_scores", "k_map_me_argmin", "k_map_particles", "k_map_update")
     SEARCH = "k_search_mfma"
     focus = "k_syrk," + SEARCH
     n_probe = 3 if (not args.no_profile and Wm >= 6) else 0
@@ -308,7 +395,7 @@ def main():
     # ---- N > 1: every rank checks a small sample of ITS OWN sequences against the reference build (values, not shapes);
     # rank 0 reports the worst deviation and how many ranks took part
     rank_parity = None
-    if world > 1 and args.cpu_sample != 0:
+    if world > 1 and args.cpu_sample != 0 and not args.mapping:
         rank_parity = per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render,
                                       tdev if use_dist else None, world)
 
@@ -398,7 +485,9 @@ def main():
         parity = None
         ncores = os.cpu_count() or 1
         sample = args.cpu_sample if args.cpu_sample >= 0 else min(ncores, B)
-        if world == 1 and sample > 0:
+        if world == 1 and sample > 0 and args.mapping:
+            cpu, parity = mapping_cpu_and_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render, ncores, sample)
+        elif world == 1 and sample > 0:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_api as oa
             use_ref = oa.ref_available()
@@ -495,12 +584,17 @@ def main():
                 parity["full_length"]["final_covariance_rel_fro"] = dP
 
         out = {
-            "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)",
+            "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)" if not args.mapping else
+                      "batched MonoSLAM frames/sec (%dx%d, mapping on, %d known features: the reference's default workload)" % (W, H, N),
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload_name(B, W, H, N, world) + ", all features selected, map prior sigma %.3g m (%s covariance)"
-                                   % (args.feature_sigma, "dense" if args.feature_sigma > 0 else "block-sparse"),
+            "config": {"workload": (workload_name(B, W, H, N, world) + ", all features selected, map prior sigma %.3g m (%s covariance)"
+                                    % (args.feature_sigma, "dense" if args.feature_sigma > 0 else "block-sparse")) if not args.mapping else
+                                   ("the reference's default workload (data/SceneLib2.cfg: select 10, keep 12 visible, 100 depth particles, "
+                                    "one feature initialised at a time) on %d independent %dx%d synthetic sequences per GPU, %d known "
+                                    "features each, GoOneStep(enable_mapping = true)" % (B, W, H, N)),
+                       "enable_mapping": bool(args.mapping),
                        "sequences_per_gpu": B, "features": N, "width": W, "height": H,
                        "state_dim": 13 + 3 * N, "feature_prior_sigma_m": args.feature_sigma, "parallelism": "independent sequences sharded across %d GPU(s), no data-path collective" % world},
             # roofline = the dominant kernel of the step; roofline_search = the NCC search kernel the north star names

@@ -757,7 +757,9 @@ __global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, cons
 }
 #endif  // SL2_TESTING
 
-constexpr int kFusedMaxBlocks = 16;   // the one-launch Cholesky is used up to this many 32-blocks
+#ifdef SL2_TESTING
+constexpr int kFusedMaxBlocks = 16;   // k_chol_fused4 (TEST build) is used up to this many 32-blocks
+#endif
 
 // ---------------------------------------------------------------------------
 // k_chol_fused4: the whole blocked Cholesky of one sequence in ONE launch (used when the number
@@ -1102,7 +1104,7 @@ template <int C> __device__ __forceinline__ void d_column(double (&a)[32], DScal
 #pragma unroll
   for (int f = 1; f <= DCol<C>::F; ++f)
     if (C + f < 32) a[C + f] = __builtin_fma(-l, readlane_f64(l, C + f), a[C + f]);
-  if constexpr (C > 0) d_apply_a<C - 1>(t, a, C + 1 < 32 ? a[C + 1] : l);
+  if constexpr (C > 0) d_apply_a<C - 1>(t, a, C + 1 < 32 ? a[C + 1 < 32 ? C + 1 : 31] : l);
   d_read_a<C>(t, colbase, a[DCol<C>::P0 + 2 * DCol<C>::H - 1 < 32 ? DCol<C>::P0 + 2 * DCol<C>::H - 1 : 31]);
   if constexpr (C > 0) d_apply_b<C - 1>(t, a);
   d_read_b<C>(t, colbase, a[31]);
@@ -1394,8 +1396,10 @@ __global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, d
 constexpr int kFwdPitch = 48;   // LDS row pitch (doubles): the two k-rows read by a 32-lane group land on disjoint banks
 
 template <int NB>
-__global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* __restrict__ At, double* __restrict__ Vt,
-                                                    const double* __restrict__ St, const double* __restrict__ LinvT,
+// (At, Vt and St are NOT __restrict__: the panel solve of the large-system Cholesky calls this kernel in place, with all three
+// on the factor's own storage - every element is read by the lane that later overwrites it, before it does.)
+__global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* At, double* Vt,
+                                                    const double* St, const double* __restrict__ LinvT,
                                                     const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B,
                                                     int J0, int col0, int ntile, int nb_cap) {
   // J0: first block row of this launch.  For maps of more than 13 blocks the substitution runs in groups of
@@ -1419,13 +1423,19 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
   const double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
   const double* Lb = LinvT + ((size_t)b * nblk_max + J0) * 1024;
   __shared__ double sL[2][32 * kFwdPitch];
-  // staging role: row `srow` of the tile (contraction index), 4 consecutive doubles at column `sc4`
-  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
-  const int soff = srow * kFwdPitch + sc4;
+  // staging role: row `srow` of the tile (contraction index), two pieces of two doubles at columns sc2 and 16 + sc2.  (The
+  // eight threads of a row used to store four consecutive doubles each: a ds_write_b128 is serviced eight lanes at a time
+  // over 32 banks, and pieces 0 and 4 of a 256-byte row share their banks - SQ_LDS_BANK_CONFLICT 8.6e6 on 8.2e6 LDS
+  // instructions per launch, profiles/r03_final_pmc_summary.txt.  Now a store instruction's eight lanes write 128
+  // consecutive bytes.)
+  const int srow = tid >> 3, sc2 = (tid & 7) * 2;
+  const int soff = srow * kFwdPitch + sc2;
   // tile (J, K): K < J -> L[J][K] from St (k-major), K == J -> LinvT block J
 #define SL2_TILE_PTR(Jv, Kv) \
-  (((Kv) < (Jv)) ? (Sb + (size_t)((Kv) * 32 + srow) * mld + (Jv) * 32 + sc4) : (Lb + (size_t)(Jv) * 1024 + srow * 32 + sc4))
-  double4 pre = *(const double4*)SL2_TILE_PTR(0, 0);
+  (((Kv) < (Jv)) ? (Sb + (size_t)((Kv) * 32 + srow) * mld + (Jv) * 32 + sc2) : (Lb + (size_t)(Jv) * 1024 + srow * 32 + sc2))
+#define SL2_TILE_LOAD(Jv, Kv) do { const double* _p = SL2_TILE_PTR(Jv, Kv); pre_a = *(const double2*)_p; pre_b = *(const double2*)(_p + 16); } while (0)
+  double2 pre_a, pre_b;
+  SL2_TILE_LOAD(0, 0);
   v4d V[NB][2];
   v4d at[2];
   const bool half0 = (16 >= m);
@@ -1445,11 +1455,12 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
 #pragma unroll
       for (int K = 0; K <= J; ++K) {
         double* buf = sL[t & 1];
-        *(double4*)&buf[soff] = pre;
+        *(double2*)&buf[soff] = pre_a;
+        *(double2*)&buf[soff + 16] = pre_b;
         __syncthreads();
         // next tile of the stream (uniform control flow: nblk is per sequence = per workgroup)
-        if (K < J) pre = *(const double4*)SL2_TILE_PTR(J, K + 1);
-        else if (J + 1 < nblk && J + 1 < NB) pre = *(const double4*)SL2_TILE_PTR(J + 1, 0);
+        if (K < J) SL2_TILE_LOAD(J, K + 1);
+        else if (J + 1 < nblk && J + 1 < NB) SL2_TILE_LOAD(J + 1, 0);
         const double* pa = buf + hi * kFwdPitch + lo;
         if (K < J) {
 #pragma unroll
@@ -1493,6 +1504,7 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
     }
   }
 #undef SL2_TILE_PTR
+#undef SL2_TILE_LOAD
 }
 
 // ---------------------------------------------------------------------------
@@ -1859,8 +1871,9 @@ static int launch_fwdsub_grouped(sl2_engine* e, int B) {
 // The two 64-column panels of V^T are streamed through LDS in K-chunks of 16 rows,
 // double-buffered: the global loads of chunk c+1 are in flight while the 16 MFMAs
 // of chunk c run (the kernel was memory-latency-bound with direct fragment loads:
-// SQ_WAIT_ANY 55 %, MFMA pipe 38 % busy).  LDS row pitch 80 doubles: the two
-// k-rows read by one 32-lane group of a ds_read_b64 land on disjoint banks.
+// SQ_WAIT_ANY 55 %, MFMA pipe 38 % busy).  LDS: 32 KB, rows of 64 doubles without padding; the odd k-rows swap their
+// two 16-column halves within each 32-column group (column ^ 16), so that the two k-rows read by one 32-lane group of a
+// ds_read_b64 land on disjoint banks (the first version padded the rows to 80 doubles: 40 KB, three workgroups per CU).
 // ---------------------------------------------------------------------------
 
 __global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, double* __restrict__ P, double* __restrict__ x,
@@ -2108,7 +2121,6 @@ static int launch_update_range(sl2_engine* e) {
     const size_t need = (size_t)e->root->B * e->mld * e->mld;
     if (s_scratch_n < need) { if (s_scratch) (void)hipFree(s_scratch); SL2_HIP(hipMalloc((void**)&s_scratch, sizeof(double) * need)); s_scratch_n = need; }
     LaunchScope ls(e, "k_build_AS_tiles", true);
-    const int nt = e->ld / 64;
     hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
                        e->f_nu, e->f_R, e->f_arow, e->m_count, e->Vt, s_scratch, e->N, e->ld, e->mld, B, e->root->build_split & 255, bt_tiles_per_wg(e));
     SL2_HIP(hipGetLastError());
@@ -2116,7 +2128,6 @@ static int launch_update_range(sl2_engine* e) {
   if (build_variant == 2) {
     // A^T and S from the upper block triangle of P: one workgroup per 64 x 64 tile (measured slower: see the kernel)
     LaunchScope ls(e, "k_build_AS_tiles", true);
-    const int nt = e->ld / 64;
     hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
                        e->f_nu, e->f_R, e->f_arow, e->m_count, e->At, e->St, e->N, e->ld, e->mld, B, 0, bt_tiles_per_wg(e));
     SL2_HIP(hipGetLastError());

@@ -647,6 +647,19 @@ static int enable_feature_initialisation(sl2_engine* e) {
     return SL2_ERR_INVALID;
   }
   if (e->groups.size() > 1) { set_error("feature initialisation: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
+  {   // k_map_update keeps the particle list in dynamic LDS (96 B per particle) next to ~1 KB of static LDS: say so here
+      // rather than fail at the first launch (gfx950 has 160 KB per workgroup; the check is for whatever device this is)
+    hipDeviceProp_t prop;
+    SL2_HIP(hipGetDeviceProperties(&prop, e->device));
+    const size_t need = sizeof(double) * kParticleDoubles * (size_t)e->prm.number_of_particles + 2048;
+    if (need > prop.sharedMemPerBlock) {
+      char buf[200];
+      snprintf(buf, sizeof(buf), "feature initialisation: number_of_particles = %d needs %zu bytes of LDS per workgroup, the device has %zu",
+               e->prm.number_of_particles, need, (size_t)prop.sharedMemPerBlock);
+      set_error(buf);
+      return SL2_ERR_CAPACITY;
+    }
+  }
   if (!e->score_map) {
     const size_t px = (size_t)e->B * e->cam.width * e->cam.height;
     SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));

@@ -262,7 +262,11 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
 // ---------------------------------------------------------------------------
 // k_map_particles: one workgroup per sequence, one thread per particle.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
+// THREADS = the launch's block size (particle slots of the engine, a multiple of 64): the shipped 100 particles run at
+// __launch_bounds__(128) - the thread holds about 130 doubles of covariance blocks and Jacobians, which a 1024-thread bound
+// (128 registers) spills - and only engines created for more particles take the wider, spilling instantiations.
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
                                                                  int* __restrict__ part_i, double* __restrict__ particles,
                                                                  int* __restrict__ me_desc, double* __restrict__ last_r,
                                                                  CameraParams cam, int ld, int ppos, int pcap) {
@@ -552,7 +556,7 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
 struct SlotArrays {
   double *x, *P, *xp_org, *f_h, *f_Hx, *f_Hy, *f_R, *f_S, *f_score, *f_z, *f_nu, *srch_d;
   uint8_t* patch;
-  int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *n_sel, *m_count, *n_slots, *part_i;
+  int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *f_arow, *n_sel, *m_count, *n_slots, *part_i;
 };
 template <typename T>
 __device__ __forceinline__ void slot_move(T* base, int per, int dst, int src, int tid, int nthreads) {
@@ -602,12 +606,14 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
       slot_move(a.f_nu + o * 2, 2, d, f, tid, nt);
       slot_move(a.srch_i + o * 8, 8, d, f, tid, nt);
       slot_move(a.srch_d + o * 4, 4, d, f, tid, nt);
+      slot_move(a.f_arow + o, 1, d, f, tid, nt);      // (slot-indexed like the rest: a squeeze between make_measurements and the update)
       slot_move(a.x + (size_t)b * ld + 13, 3, d, f, tid, nt);
     }
     __syncthreads();
   }
   for (int f = nl + tid; f < ns; f += nt) {                      // the freed slots: unused again
     flags[f] = 0;
+    a.f_arow[o + f] = -1;
     a.attempted[o + f] = 0; a.successful[o + f] = 0;
     for (int k = 0; k < 3; ++k) a.x[(size_t)b * ld + 13 + 3 * f + k] = 0.0;
   }
@@ -677,7 +683,7 @@ int launch_compact_slots(sl2_engine* e, int need) {
   a.x = e->x; a.P = e->P; a.xp_org = e->xp_org; a.f_h = e->f_h; a.f_Hx = e->f_Hx; a.f_Hy = e->f_Hy; a.f_R = e->f_R; a.f_S = e->f_S;
   a.f_score = e->f_score; a.f_z = e->f_z; a.f_nu = e->f_nu; a.srch_d = e->srch_d; a.patch = e->patch; a.patch_sums = e->patch_sums;
   a.f_flags = e->f_flags; a.attempted = e->attempted; a.successful = e->successful; a.f_label = e->f_label; a.srch_i = e->srch_i;
-  a.sel_idx = e->sel_idx; a.succ_idx = e->succ_idx; a.n_sel = e->n_sel; a.m_count = e->m_count; a.n_slots = e->n_slots;
+  a.sel_idx = e->sel_idx; a.succ_idx = e->succ_idx; a.f_arow = e->f_arow; a.n_sel = e->n_sel; a.m_count = e->m_count; a.n_slots = e->n_slots;
   a.part_i = e->part_i;
   hipLaunchKernelGGL(k_map_compact_slots, dim3(e->B), dim3(256), sizeof(int) * 2 * e->N, e->stream, a, e->N, e->ld, e->ppos, need);
   SL2_HIP(hipGetLastError());
@@ -787,8 +793,14 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_particles");
-    hipLaunchKernelGGL(k_map_particles, dim3(B), dim3(e->root->pcap), 0, e->stream, e->x, e->P, e->part_i, e->particles, e->me_desc,
-                       e->last_r, e->cam, e->ld, e->ppos, e->root->pcap);
+    const int pc = e->root->pcap;
+#define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B), dim3(pc), 0, e->stream, e->x, e->P, e->part_i, e->particles, \
+                                            e->me_desc, e->last_r, e->cam, e->ld, e->ppos, pc)
+    if (pc <= 128) SL2_PARTICLES(128);
+    else if (pc <= 256) SL2_PARTICLES(256);
+    else if (pc <= 512) SL2_PARTICLES(512);
+    else SL2_PARTICLES(1024);
+#undef SL2_PARTICLES
     SL2_HIP(hipGetLastError());
   }
   {

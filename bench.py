@@ -289,7 +289,9 @@ def main():
     cam = synth.default_camera(W, H)
     params = synth.default_params(min(N, 10) if args.mapping else N)      # data/SceneLib2.cfg:60: number_of_features_to_select = 10
     NCAP = max(32, 2 * N) if args.mapping else N                          # feature slots per sequence (the map grows with mapping on)
-    spec_kw = dict(v_amp=0.45, w_amp=0.05) if args.mapping else {}        # past the 0.2 m/s gate of monoslam.cpp:159
+    # mapping: a hand-held camera's motion - mostly sideways (templates are not warped: an approaching camera loses its features),
+    # 0.15-0.45 m/s, i.e. past the 0.2 m/s gate of monoslam.cpp:159 most of the time; gentle rotation
+    spec_kw = dict(v_amp=np.array([0.3, 0.3, 0.03]), w_amp=0.03) if args.mapping else {}
     seq_ids = sharding.global_sequence_ids(B, world, rank)
 
     # ---- synthetic inputs: specs on the host, frames rendered on the device ----

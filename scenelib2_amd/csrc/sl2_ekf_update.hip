@@ -1423,19 +1423,17 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
   const double* Sb = St + (size_t)b * mld * mld + (size_t)J0 * 32 * mld + J0 * 32;
   const double* Lb = LinvT + ((size_t)b * nblk_max + J0) * 1024;
   __shared__ double sL[2][32 * kFwdPitch];
-  // staging role: row `srow` of the tile (contraction index), two pieces of two doubles at columns sc2 and 16 + sc2.  (The
-  // eight threads of a row used to store four consecutive doubles each: a ds_write_b128 is serviced eight lanes at a time
-  // over 32 banks, and pieces 0 and 4 of a 256-byte row share their banks - SQ_LDS_BANK_CONFLICT 8.6e6 on 8.2e6 LDS
-  // instructions per launch, profiles/r03_final_pmc_summary.txt.  Now a store instruction's eight lanes write 128
-  // consecutive bytes.)
-  const int srow = tid >> 3, sc2 = (tid & 7) * 2;
-  const int soff = srow * kFwdPitch + sc2;
+  // staging role: row `srow` of the tile (contraction index), 4 consecutive doubles at column `sc4`.  (Lanes 0 and 4 of a
+  // row's eight share their banks in the ds_write_b128: SQ_LDS_BANK_CONFLICT 8.6e6 per launch.  Round 4 tried the cure that
+  // worked in k_syrk - two pieces of two doubles per thread, so that a store's eight lanes write 128 consecutive bytes - and
+  // measured it SLOWER on the same box, 0.331 against 0.322-0.324 ms (profiles/r04_fwdsub_staging_ab.txt): twice the global
+  // load instructions in front of every barrier cost more than the conflict cycles, which sit under the MFMAs here.)
+  const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+  const int soff = srow * kFwdPitch + sc4;
   // tile (J, K): K < J -> L[J][K] from St (k-major), K == J -> LinvT block J
 #define SL2_TILE_PTR(Jv, Kv) \
-  (((Kv) < (Jv)) ? (Sb + (size_t)((Kv) * 32 + srow) * mld + (Jv) * 32 + sc2) : (Lb + (size_t)(Jv) * 1024 + srow * 32 + sc2))
-#define SL2_TILE_LOAD(Jv, Kv) do { const double* _p = SL2_TILE_PTR(Jv, Kv); pre_a = *(const double2*)_p; pre_b = *(const double2*)(_p + 16); } while (0)
-  double2 pre_a, pre_b;
-  SL2_TILE_LOAD(0, 0);
+  (((Kv) < (Jv)) ? (Sb + (size_t)((Kv) * 32 + srow) * mld + (Jv) * 32 + sc4) : (Lb + (size_t)(Jv) * 1024 + srow * 32 + sc4))
+  double4 pre = *(const double4*)SL2_TILE_PTR(0, 0);
   v4d V[NB][2];
   v4d at[2];
   const bool half0 = (16 >= m);
@@ -1455,12 +1453,11 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
 #pragma unroll
       for (int K = 0; K <= J; ++K) {
         double* buf = sL[t & 1];
-        *(double2*)&buf[soff] = pre_a;
-        *(double2*)&buf[soff + 16] = pre_b;
+        *(double4*)&buf[soff] = pre;
         __syncthreads();
         // next tile of the stream (uniform control flow: nblk is per sequence = per workgroup)
-        if (K < J) SL2_TILE_LOAD(J, K + 1);
-        else if (J + 1 < nblk && J + 1 < NB) SL2_TILE_LOAD(J + 1, 0);
+        if (K < J) pre = *(const double4*)SL2_TILE_PTR(J, K + 1);
+        else if (J + 1 < nblk && J + 1 < NB) pre = *(const double4*)SL2_TILE_PTR(J + 1, 0);
         const double* pa = buf + hi * kFwdPitch + lo;
         if (K < J) {
 #pragma unroll
@@ -1504,7 +1501,6 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
     }
   }
 #undef SL2_TILE_PTR
-#undef SL2_TILE_LOAD
 }
 
 // ---------------------------------------------------------------------------

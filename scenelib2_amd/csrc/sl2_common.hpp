@@ -132,6 +132,8 @@ struct sl2_engine {
   int* me_desc = nullptr;                // [B][pcap][8] search ellipses of the particles
   double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
   int* owner_map = nullptr;              // [B][H][W] which particle ellipse scores a position (kOwnerFree between searches)
+  int* me_big_list = nullptr;            // [B] sequences whose multi-ellipse search is too large for the one-workgroup form, this step
+  int* me_big_count = nullptr;           // [1]
   bool mapping_used = false;
   int* init_uv = nullptr;                // [B][2] pixel selections of sl2_initialise_feature (allocated on first use)
   // ---- whole-step HIP graphs (small batches are launch-bound: ~12 kernels per step) ----

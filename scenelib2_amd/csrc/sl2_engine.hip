@@ -436,7 +436,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->f_arow, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->pos_count, e->init_uv, e->f_label, e->next_label};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->me_big_list, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->snap_stage) hipFree(e->snap_stage);
   if (e->snap_host) hipHostFree(e->snap_host);
@@ -665,6 +665,9 @@ static int enable_feature_initialisation(sl2_engine* e) {
     SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));
     SL2_HIP(hipMalloc((void**)&e->owner_map, sizeof(int) * px));
     SL2_HIP(hipMemsetAsync(e->owner_map, 0x7f, sizeof(int) * px, e->stream));   // 0x7f7f7f7f: above every particle index
+    SL2_HIP(hipMalloc((void**)&e->me_big_list, sizeof(int) * (e->B + 1)));
+    e->me_big_count = e->me_big_list + e->B;
+    SL2_HIP(hipMemsetAsync(e->me_big_list, 0, sizeof(int) * (e->B + 1), e->stream));
   }
   e->mapping_used = true;
   return SL2_OK;

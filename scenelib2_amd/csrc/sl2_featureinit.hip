@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(kDetThreads) k_find_best_patch(const uint8_t* 
 }
 
 // ---------------------------------------------------------------------------
-// Multi-ellipse search: describe -> score the union once -> per-ellipse arg-min.
+// Multi-ellipse search: describe, then one workgroup per job (stamp the union, score it once, per-ellipse arg-min).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ puinv, const double* __restrict__ centre, int total,
                                                     int width, int height, int* __restrict__ desc) {
@@ -45,31 +45,29 @@ __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ p
   me_describe(puinv[3 * e], puinv[3 * e + 1], puinv[3 * e + 2], centre[2 * e], centre[2 * e + 1], width, height, desc + 8 * (size_t)e);
 }
 
-__global__ void __launch_bounds__(256) k_me_mark(int width, int height, int total, const int* __restrict__ ell_job,
-                                                 const int* __restrict__ desc, const double* __restrict__ puinv, int* __restrict__ owner) {
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);                       // one ellipse per wavefront
-  if (e >= total) return;
-  me_mark_ellipse_wave(desc + 8 * (size_t)e, puinv + 3 * (size_t)e, width, owner + (size_t)ell_job[e] * width * height, e);
-}
-
-__global__ void __launch_bounds__(256) k_me_scores(const uint8_t* __restrict__ images, int width, int height,
-                                                   const int* __restrict__ image_index, const uint8_t* __restrict__ patches,
-                                                   const int* __restrict__ first, const int* __restrict__ desc,
-                                                   int* __restrict__ owner, double* __restrict__ score_map) {
-  const int job = blockIdx.y;
-  me_score_union_wg(images + (size_t)image_index[job] * width * height, width, patches + (size_t)job * 121,
-                    desc + 8 * (size_t)first[job], first[job + 1] - first[job], owner + (size_t)job * width * height,
-                    score_map + (size_t)job * width * height, blockIdx.x, gridDim.x);
-}
-
-__global__ void __launch_bounds__(256) k_me_argmin(int width, int height, int total, const int* __restrict__ ell_job,
-                                                   const int* __restrict__ desc, const double* __restrict__ puinv,
-                                                   const double* __restrict__ score_map, int* __restrict__ result,
-                                                   double* __restrict__ corrmax) {
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);                       // one ellipse per wavefront
-  if (e >= total) return;
-  me_argmin_wave(width, desc + 8 * (size_t)e, puinv + 3 * (size_t)e, score_map + (size_t)ell_job[e] * width * height,
-                 result + 3 * (size_t)e, corrmax ? corrmax + e : nullptr);
+// one workgroup per job: me_search_fused_wg (stamps and scores of the union's bounding box in LDS); a job whose union exceeds
+// kMeCap positions goes on the list of k_me_big_* (the image-sized owner / score maps are touched by those only)
+struct MeJobsBatch {
+  const uint8_t* images; const int* image_index; const uint8_t* patches; const int* first; const int* desc_base; const double* puinv;
+  int* owner_base; double* map_base; int* result; double* corrmax; int width, height;
+  __device__ const uint8_t* img(int j) const { return images + (size_t)image_index[j] * width * height; }
+  __device__ const uint8_t* patch(int j) const { return patches + (size_t)j * 121; }
+  __device__ const int* desc(int j) const { return desc_base + 8 * (size_t)first[j]; }
+  __device__ int n_ell(int j) const { return first[j + 1] - first[j]; }
+  __device__ const double* pu(int j, int e) const { return puinv + 3 * ((size_t)first[j] + e); }
+  __device__ int* owner(int j) const { return owner_base + (size_t)j * width * height; }
+  __device__ double* map(int j) const { return map_base + (size_t)j * width * height; }
+  __device__ void emit(int j, int e, int flag, int u, int v, double best) const {
+    const size_t k = (size_t)first[j] + e;
+    result[3 * k] = flag; result[3 * k + 1] = u; result[3 * k + 2] = v;
+    if (corrmax) corrmax[k] = best;
+  }
+};
+__global__ void __launch_bounds__(256) k_me_search(MeJobsBatch J, int* __restrict__ big_list, int* __restrict__ big_count) {
+  const int job = blockIdx.x;
+  const bool done = me_search_fused_wg(J.img(job), J.width, J.patch(job), J.desc(job), J.n_ell(job), [&](int e) { return J.pu(job, e); },
+                                       [&](int e, int flag, int u, int v, double best) { J.emit(job, e, flag, u, v, best); });
+  if (!done && threadIdx.x == 0) big_list[atomicAdd(big_count, 1)] = job;
 }
 
 static int check_device(int device) {
@@ -145,13 +143,10 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   if (!puinv || !centre) return SL2_ERR_INVALID;
   int rc = check_device(device);
   if (rc != SL2_OK) return rc;
-  std::vector<int> ell_job(total);
-  for (int j = 0; j < njobs; ++j)
-    for (int e = first[j]; e < first[j + 1]; ++e) ell_job[e] = j;
-  DevBuf d_img, d_idx, d_pat, d_job, d_first, d_pu, d_ce, d_desc, d_map, d_own, d_res, d_corr;
+  DevBuf d_img, d_idx, d_pat, d_first, d_pu, d_ce, d_desc, d_map, d_own, d_res, d_corr, d_big;
   const size_t img_bytes = (size_t)nimages * width * height;
   if (d_img.alloc(img_bytes) || d_idx.alloc(sizeof(int) * njobs) || d_pat.alloc((size_t)njobs * 121) ||
-      d_job.alloc(sizeof(int) * total) || d_first.alloc(sizeof(int) * (njobs + 1)) || d_pu.alloc(sizeof(double) * 3 * total) ||
+      d_big.alloc(sizeof(int) * (njobs + 1)) || d_first.alloc(sizeof(int) * (njobs + 1)) || d_pu.alloc(sizeof(double) * 3 * total) ||
       d_ce.alloc(sizeof(double) * 2 * total) || d_desc.alloc(sizeof(int) * 8 * total) ||
       d_map.alloc(sizeof(double) * (size_t)njobs * width * height) || d_own.alloc(sizeof(int) * (size_t)njobs * width * height) ||
       d_res.alloc(sizeof(int) * 3 * total) ||
@@ -162,7 +157,7 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipMemcpy(d_img.p, images, img_bytes, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_idx.p, image_index, sizeof(int) * njobs, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pat.p, patches, (size_t)njobs * 121, hipMemcpyHostToDevice));
-  SL2_HIP(hipMemcpy(d_job.p, ell_job.data(), sizeof(int) * total, hipMemcpyHostToDevice));
+  SL2_HIP(hipMemset(d_big.p, 0, sizeof(int) * (njobs + 1)));
   SL2_HIP(hipMemcpy(d_first.p, first.data(), sizeof(int) * (njobs + 1), hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pu.p, puinv, sizeof(double) * 3 * total, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_ce.p, centre, sizeof(double) * 2 * total, hipMemcpyHostToDevice));
@@ -173,13 +168,12 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipEventRecord(ev0, 0));
   hipLaunchKernelGGL(k_me_describe, dim3((total + 63) / 64), dim3(64), 0, 0, d_pu.as<double>(), d_ce.as<double>(), total, width,
                      height, d_desc.as<int>());
-  hipLaunchKernelGGL(k_me_mark, dim3((total + 3) / 4), dim3(256), 0, 0, width, height, total, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
-                     d_own.as<int>());
-  const int nslices = njobs >= 512 ? 2 : (njobs >= 64 ? 4 : 16);
-  hipLaunchKernelGGL(k_me_scores, dim3(nslices, njobs), dim3(256), 0, 0, d_img.as<uint8_t>(), width, height, d_idx.as<int>(),
-                     d_pat.as<uint8_t>(), d_first.as<int>(), d_desc.as<int>(), d_own.as<int>(), d_map.as<double>());
-  hipLaunchKernelGGL(k_me_argmin, dim3((total + 3) / 4), dim3(256), 0, 0, width, height, total, d_job.as<int>(), d_desc.as<int>(), d_pu.as<double>(),
-                     d_map.as<double>(), d_res.as<int>(), d_corr.as<double>());
+  MeJobsBatch J;
+  J.images = d_img.as<uint8_t>(); J.image_index = d_idx.as<int>(); J.patches = d_pat.as<uint8_t>(); J.first = d_first.as<int>();
+  J.desc_base = d_desc.as<int>(); J.puinv = d_pu.as<double>(); J.owner_base = d_own.as<int>(); J.map_base = d_map.as<double>();
+  J.result = d_res.as<int>(); J.corrmax = corrmax ? d_corr.as<double>() : nullptr; J.width = width; J.height = height;
+  hipLaunchKernelGGL(k_me_search, dim3(njobs), dim3(256), 0, 0, J, d_big.as<int>(), d_big.as<int>() + njobs);
+  me_big_launch(J, d_big.as<int>(), d_big.as<int>() + njobs, width, 0);
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipEventRecord(ev1, 0));
   SL2_HIP(hipDeviceSynchronize());

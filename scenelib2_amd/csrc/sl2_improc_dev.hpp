@@ -26,25 +26,56 @@ __device__ __forceinline__ void detect_region_wg(const uint8_t* __restrict__ img
   const int nu = ufinish - ustart, nv = vfinish - vstart;
   double best = 0.0;   // *evbest = 0 (:1136): only a strictly positive eigenvalue can win
   int best_idx = -1;
-  for (int idx = tid; idx < nu * nv; idx += kDetThreads) {
-    const int v = vstart + idx / nu, u = ustart + idx % nu;
-    int sxx = 0, syy = 0, sxy = 0;
-    for (int r = v - half; r <= v + half; ++r) {
-      const uint8_t* up = img + (size_t)(r - 1) * width;
-      const uint8_t* mid = img + (size_t)r * width;
-      const uint8_t* dn = img + (size_t)(r + 1) * width;
+  // The three 11 x 11 sums of gradient products are separable, like the reference's own sliding column sums
+  // (monoslam.cpp:1120-1192): per tile of kDetTW x kDetTH positions the image bytes go to LDS once, every (row, column)
+  // gets its three HORIZONTAL 11-sums (33 multiply-adds on bytes from LDS), every position the VERTICAL sum of eleven of
+  // those - ~45 taps per position instead of 121 x 3 (rounds 1-3; 0.15 ms per mapping step at batch 1024).  All integer,
+  // so the order of the sums is immaterial; the eigenvalue is the reference's FP64 expression on exact inputs.
+  constexpr int kDetTW = 80, kDetTH = 20;
+  __shared__ uint8_t s_img[(kDetTH + 12) * (kDetTW + 12)];
+  __shared__ int s_h[3][(kDetTH + 10) * kDetTW];
+  for (int v0 = vstart; v0 < vfinish; v0 += kDetTH)
+    for (int u0 = ustart; u0 < ufinish; u0 += kDetTW) {
+      const int tw = min(kDetTW, ufinish - u0), th = min(kDetTH, vfinish - v0);
+      const int iw = tw + 12, ih = th + 12;                     // image bytes: rows v0 - 6 .. v0 + th + 5, columns u0 - 6 .. u0 + tw + 5
+      __syncthreads();                                          // the previous tile's sums have been consumed
+      for (int i = tid; i < iw * ih; i += kDetThreads) {
+        const int r = i / iw, c = i - r * iw;
+        s_img[r * (kDetTW + 12) + c] = img[(size_t)(v0 - 6 + r) * width + (u0 - 6 + c)];    // inside the frame: the region is clamped 6 px in
+      }
+      __syncthreads();
+      // horizontal sums for rows v0 - 5 .. v0 + th + 4 (local row index 1 .. th + 10 of s_img), columns u0 .. u0 + tw - 1
+      for (int i = tid; i < (th + 10) * tw; i += kDetThreads) {
+        const int rr = i / tw, cu = i - rr * tw;
+        const uint8_t* up = s_img + rr * (kDetTW + 12) + cu + 1;          // row above, at column u - 5
+        const uint8_t* mid = up + (kDetTW + 12);
+        const uint8_t* dn = mid + (kDetTW + 12);
+        int sxx = 0, syy = 0, sxy = 0;
 #pragma unroll
-      for (int c = -5; c <= 5; ++c) {
-        const int gx2 = (int)mid[u + c + 1] - (int)mid[u + c - 1];   // 2 gx
-        const int gy2 = (int)dn[u + c] - (int)up[u + c];             // 2 gy
-        sxx += gx2 * gx2; syy += gy2 * gy2; sxy += gx2 * gy2;
+        for (int c = 0; c < 11; ++c) {
+          const int gx2 = (int)mid[c + 1] - (int)mid[c - 1];              // 2 gx
+          const int gy2 = (int)dn[c] - (int)up[c];                        // 2 gy
+          sxx += gx2 * gx2; syy += gy2 * gy2; sxy += gx2 * gy2;
+        }
+        s_h[0][rr * kDetTW + cu] = sxx; s_h[1][rr * kDetTW + cu] = syy; s_h[2][rr * kDetTW + cu] = sxy;
+      }
+      __syncthreads();
+      for (int i = tid; i < th * tw; i += kDetThreads) {
+        const int rv = i / tw, cu = i - rv * tw;
+        int sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+          sxx += s_h[0][(rv + r) * kDetTW + cu]; syy += s_h[1][(rv + r) * kDetTW + cu]; sxy += s_h[2][(rv + r) * kDetTW + cu];
+        }
+        const double A = sxx / 4.0, Bq = sxy / 4.0, C = syy / 4.0;       // exact
+        const double BB = sqrt((A + C) * (A + C) - 4 * (A * C - Bq * Bq));  // find_eigenvalues, :1194-1205
+        const double e2 = (A + C - BB) / 2.0;
+        // the reference scans v outer / u inner and keeps the FIRST maximum (strict '>'): here positions arrive tile by
+        // tile, so the scan index decides among equals
+        const int idx = (v0 - vstart + rv) * nu + (u0 - ustart + cu);
+        if (e2 > best || (e2 == best && best_idx >= 0 && idx < best_idx)) { best = e2; best_idx = idx; }
       }
     }
-    const double A = sxx / 4.0, Bq = sxy / 4.0, C = syy / 4.0;       // exact
-    const double BB = sqrt((A + C) * (A + C) - 4 * (A * C - Bq * Bq));  // find_eigenvalues, :1194-1205
-    const double e2 = (A + C - BB) / 2.0;
-    if (e2 > best) { best = e2; best_idx = idx; }
-  }
   __shared__ double s_best[kDetThreads];
   __shared__ int s_idx[kDetThreads];
   s_best[tid] = best;
@@ -134,11 +165,11 @@ __device__ __forceinline__ void me_mark_ellipse_wave(const int* __restrict__ d, 
                                                      int* __restrict__ owner, int index) {
   const int nu = d[3], nv = d[5];
   if (nu <= 0 || nv <= 0) return;
-  const float rcp = 1.0f / (float)nv;
+  const float rcp = 1.0f / (float)nu;
   const double a = pu[0], b = pu[1], c = pu[2];
   for (int idx = threadIdx.x & 63; idx < nu * nv; idx += 64) {
-    int q, r;
-    box_divmod(idx, nv, rcp, &q, &r);
+    int q, r;                                       // row r of the box, column q: consecutive lanes walk along an image row
+    box_divmod(idx, nu, rcp, &r, &q);
     const int urel = d[2] + q, vrel = d[4] + r;
     if (!in_ellipse(a, b, c, urel, vrel)) continue;
     owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any visitor's stamp will do
@@ -212,16 +243,17 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
   double best = 1000000.0;   // cpp:156
   int order = -1;
   if (nu > 0 && nv > 0) {
-    const float rcp = 1.0f / (float)nv;
+    const float rcp = 1.0f / (float)nu;
     const double a = pu[0], b = pu[1], c = pu[2];
     for (int idx = lane; idx < nu * nv; idx += 64) {
-      int q, r;
-      box_divmod(idx, nv, rcp, &q, &r);
+      int q, r;                                     // consecutive lanes along an image row (coalesced reads of the score map);
+      box_divmod(idx, nu, rcp, &r, &q);             // the reference's scan order (u outer, v inner) is carried as `o`
       const int urel = d[2] + q, vrel = d[4] + r;
       if (!in_ellipse(a, b, c, urel, vrel)) continue;
       const size_t pos = (size_t)(d[1] + vrel) * width + (d[0] + urel);
       const double corr = map[pos];
-      if (corr <= best) { best = corr; order = idx; }
+      const int o = q * nv + r;
+      if ((corr < best || (corr == best && o > order) || order < 0) && corr <= best) { best = corr; order = o; }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -235,6 +267,170 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
     out[2] = order >= 0 ? d[1] + d[4] + order % nv : 0;
     if (best_out) *best_out = best;
   }
+}
+
+// ---------------------------------------------------------------------------
+// The whole multi-ellipse search of ONE job by ONE workgroup (256 threads), round 4.
+//
+// A job's ellipses - the depth particles of one partially initialised feature - lie along one epipolar line and overlap
+// almost completely: in the mapping workload of bench.py --mapping about 95 ellipses of ~310 positions each (29.6 k box
+// positions per job) cover a union whose BOUNDING BOX has ~480 positions (p90 810, largest seen 2 200).  The three-kernel
+// form walked every ellipse's box twice through image-sized maps in HBM, in the reference's scan order (u outer, v inner:
+// consecutive lanes = consecutive image ROWS, one cache line per lane): 0.46 + 0.40 + 0.45 ms per step at batch 1024.
+// Here the stamps and the scores of the union's bounding box live in LDS (up to kMeCap positions), every box is walked
+// with consecutive lanes along a row, and nothing but the image and the results touches memory.  Order matters to the
+// result in one place only - "corr <= corrmax" lets the LAST minimum in scan order win - and that is carried as an
+// explicit order index (u-major) in the arg-min.  A bounding box beyond kMeCap positions (a freshly created feature under a
+// weak pose estimate can have ellipses as large as the frame: 95 x 71 k box positions) is NOT done here - one workgroup
+// would take milliseconds - : the function returns false and the caller runs the three-pass form, spread over many
+// workgroups, for those jobs (a handful per step).
+//   pu_of(e)  -> pointer to (PuInv(0,0), PuInv(0,1), PuInv(1,1)) of ellipse e
+//   emit(e, flag, u, v, best)   called by one lane per ellipse
+// ---------------------------------------------------------------------------
+constexpr int kMeCap = 4096;
+template <typename PuFn, typename EmitFn>
+__device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
+                                                   const int* __restrict__ desc, int n_ell, PuFn pu_of, EmitFn emit) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int f_patch[121];
+  __shared__ int f_sums[2];
+  __shared__ int f_box[4];
+  __shared__ int f_n;
+  __shared__ unsigned char f_stamp[kMeCap];
+  __shared__ int f_list[kMeCap];
+  __shared__ double f_score[kMeCap];
+  if (tid < 121) f_patch[tid] = patch121[tid];
+  if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; f_n = 0; }
+  __syncthreads();
+  for (int e = tid; e < n_ell; e += 256) {
+    const int* d = desc + 8 * (size_t)e;
+    if (d[3] <= 0 || d[5] <= 0) continue;
+    atomicMin(&f_box[0], d[0] + d[2]);
+    atomicMin(&f_box[1], d[1] + d[4]);
+    atomicMax(&f_box[2], d[0] + d[2] + d[3]);
+    atomicMax(&f_box[3], d[1] + d[4] + d[5]);
+  }
+  if (tid == 0) {
+    int s0 = 0, s0q = 0;
+    for (int p = 0; p < 121; ++p) { s0 += f_patch[p]; s0q += f_patch[p] * f_patch[p]; }
+    f_sums[0] = s0; f_sums[1] = s0q;
+  }
+  __syncthreads();
+  const bool any = f_box[2] >= 0;
+  const int x0 = f_box[0], y0 = f_box[1], bw = any ? f_box[2] - f_box[0] : 0, bh = any ? f_box[3] - f_box[1] : 0;
+  const int area = bw * bh;
+  if (area > kMeCap) return false;      // the caller spreads such a job over many workgroups (me_mark_ellipse_wave / me_score_union_wg / me_argmin_wave)
+  // ---- stamps
+  for (int i = tid; i < (area + 3) / 4; i += 256) ((int*)f_stamp)[i] = 0;
+  __syncthreads();
+  for (int e = wave; e < n_ell; e += 4) {
+    const int* d = desc + 8 * (size_t)e;
+    const int nu = d[3], nv = d[5];
+    if (nu <= 0 || nv <= 0) continue;
+    const double* pu = pu_of(e);
+    const double a = pu[0], b = pu[1], c = pu[2];
+    const float rcp = 1.0f / (float)nu;
+    const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
+    for (int idx = lane; idx < nu * nv; idx += 64) {
+      int r, q;                                       // row r of the box, column q: consecutive lanes along a row
+      box_divmod(idx, nu, rcp, &r, &q);
+      if (in_ellipse(a, b, c, d[2] + q, d[4] + r)) f_stamp[(by + r) * bw + bx + q] = 1;
+    }
+  }
+  __syncthreads();
+  // ---- the stamped positions, each scored once
+  for (int idx = tid; idx < area; idx += 256)
+    if (f_stamp[idx]) f_list[atomicAdd(&f_n, 1)] = idx;
+  __syncthreads();
+  {
+    const int n = f_n, Sg0 = f_sums[0], Sg0sq = f_sums[1];
+    const float rcpw = 1.0f / (float)bw;
+    for (int k = tid; k < n; k += 256) {
+      const int idx = f_list[k];
+      int r, q;
+      box_divmod(idx, bw, rcpw, &r, &q);
+      f_score[idx] = me_score_position(img, width, f_patch, Sg0, Sg0sq, x0 + q, y0 + r);
+    }
+  }
+  __syncthreads();
+  // ---- per-ellipse arg-min: smallest score, among equals the LARGEST scan-order index (u outer, v inner; cpp:151-185)
+  for (int e = wave; e < n_ell; e += 4) {
+    const int* d = desc + 8 * (size_t)e;
+    const int nu = d[3], nv = d[5];
+    double best = 1000000.0;   // cpp:156
+    int order = -1;
+    if (nu > 0 && nv > 0) {
+      const double* pu = pu_of(e);
+      const double a = pu[0], b = pu[1], c = pu[2];
+      const float rcp = 1.0f / (float)nu;
+      const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
+      for (int idx = lane; idx < nu * nv; idx += 64) {
+        int r, q;
+        box_divmod(idx, nu, rcp, &r, &q);
+        if (!in_ellipse(a, b, c, d[2] + q, d[4] + r)) continue;
+        const double corr = f_score[(by + r) * bw + bx + q];
+        const int o = q * nv + r;
+        if (corr < best || (corr == best && o > order) || order < 0) {
+          if (corr <= best) { best = corr; order = o; }       // (a first candidate above 1e6 is not taken: "corr <= corrmax")
+        }
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ob = __shfl_xor(best, off, 64);
+      const int oo = __shfl_xor(order, off, 64);
+      if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
+    }
+    if (lane == 0)
+      emit(e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
+           order >= 0 ? d[1] + d[4] + order % nv : 0, best);
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------
+// The jobs me_search_fused_wg declined (union beyond kMeCap positions), spread over many workgroups: the three passes through
+// the image-sized maps.  `Jobs` describes where a job's data lives (the engine's particle records / the arrays of the
+// stateless operator); list / count = the declined jobs of this step.  Fixed small grids that stride over the list - a
+// step has a handful of such jobs, usually none.
+//   Jobs: img(job), patch(job), desc(job), n_ell(job), pu(job, e), owner(job), map(job), emit(job, e, flag, u, v, best)
+// ---------------------------------------------------------------------------
+template <typename Jobs>
+__global__ void __launch_bounds__(256) k_me_big_mark(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
+  const int n = *count, wave = threadIdx.x >> 6;
+  for (int li = blockIdx.y; li < n; li += gridDim.y) {
+    const int job = list[li], ne = J.n_ell(job);
+    for (int e = blockIdx.x * 4 + wave; e < ne; e += gridDim.x * 4)
+      me_mark_ellipse_wave(J.desc(job) + 8 * (size_t)e, J.pu(job, e), width, J.owner(job), e);
+  }
+}
+template <typename Jobs>
+__global__ void __launch_bounds__(256) k_me_big_scores(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
+  const int n = *count;
+  for (int li = blockIdx.y; li < n; li += gridDim.y) {
+    const int job = list[li];
+    me_score_union_wg(J.img(job), width, J.patch(job), J.desc(job), J.n_ell(job), J.owner(job), J.map(job), blockIdx.x, gridDim.x);
+    __syncthreads();
+  }
+}
+template <typename Jobs>
+__global__ void __launch_bounds__(256) k_me_big_argmin(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
+  const int n = *count, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ int s_res[4][4];
+  __shared__ double s_bst[4];
+  for (int li = blockIdx.y; li < n; li += gridDim.y) {
+    const int job = list[li], ne = J.n_ell(job);
+    for (int e = blockIdx.x * 4 + wave; e < ne; e += gridDim.x * 4) {
+      me_argmin_wave(width, J.desc(job) + 8 * (size_t)e, J.pu(job, e), J.map(job), s_res[wave], &s_bst[wave]);
+      if (lane == 0) J.emit(job, e, s_res[wave][0], s_res[wave][1], s_res[wave][2], s_bst[wave]);
+    }
+  }
+}
+constexpr int kMeBigGridX = 32, kMeBigGridY = 16, kMeBigSlices = 16;
+template <typename Jobs>
+inline void me_big_launch(Jobs J, const int* list, const int* count, int width, hipStream_t st) {
+  hipLaunchKernelGGL(k_me_big_mark<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
+  hipLaunchKernelGGL(k_me_big_scores<Jobs>, dim3(kMeBigSlices, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
+  hipLaunchKernelGGL(k_me_big_argmin<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
 }
 
 }  // namespace sl2

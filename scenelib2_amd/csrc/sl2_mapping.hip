@@ -6,7 +6,7 @@
 //   k_map_detect     set_image_selection_automatically (Shi-Tomasi)         :1043-1205
 //   k_map_create     InitialiseFeature + partially-initialised Feature ctor :1211-1276, feature.cpp:45-104
 //   k_map_particles  predict_partially_initialised_feature_measurements     :1349-1401
-//   k_map_me_*       measure_feature_with_multiple_priors                   :1411-1439 (+ improc/search_multiple...)
+//   k_map_me_search  measure_feature_with_multiple_priors                   :1411-1439 (+ improc/search_multiple...)
 //   k_map_update     update_partially_initialised_feature_probabilities, conversion test,
 //                    convert_from_partially_to_fully_initialised, sell-by deletion, trajectory push
 //                                                                           :1299-1342, 1449-1538, feature.cpp:204-269
@@ -269,9 +269,10 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
                                                                  int* __restrict__ part_i, double* __restrict__ particles,
                                                                  int* __restrict__ me_desc, double* __restrict__ last_r,
-                                                                 CameraParams cam, int ld, int ppos, int pcap) {
+                                                                 int* __restrict__ me_big_count, CameraParams cam, int ld, int ppos, int pcap) {
   const int b = blockIdx.x, tid = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
+  if (b == 0 && tid == 0) *me_big_count = 0;     // the step's list of oversized multi-ellipse searches starts empty
   if (!pi[kPartActive]) return;
   __shared__ int s_making;
   if (tid == 0) {
@@ -310,48 +311,40 @@ __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restr
   me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * pcap + tid) * 8);
 }
 
-__global__ void __launch_bounds__(256) k_map_me_mark(int width, int height, const int* __restrict__ part_i,
-                                                     const int* __restrict__ me_desc, const double* __restrict__ particles,
-                                                     int* __restrict__ owner, int pcap) {
-  const int b = blockIdx.y, p = blockIdx.x * 4 + (threadIdx.x >> 6);      // one particle ellipse per wavefront
-  const int* pi = part_i + (size_t)b * kPartInts;
-  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
-  me_mark_ellipse_wave(me_desc + ((size_t)b * pcap + p) * 8,
-                       particles + ((size_t)b * pcap + p) * kParticleDoubles + 7, width, owner + (size_t)b * width * height, p);
-}
-
-__global__ void __launch_bounds__(256) k_map_me_scores(const uint8_t* __restrict__ frames, size_t seq_stride, int width,
-                                                       const uint8_t* __restrict__ patch, const int* __restrict__ part_i,
-                                                       const int* __restrict__ me_desc, int* __restrict__ owner,
-                                                       double* __restrict__ score_map, int N, int height, int pcap) {
-  const int b = blockIdx.y;
-  const int* pi = part_i + (size_t)b * kPartInts;
-  if (!pi[kPartActive] || !pi[kPartMaking]) return;
-  const size_t fi = (size_t)b * N + pi[kPartLabel];
-  me_score_union_wg(frames + (size_t)b * seq_stride, width, patch + fi * kPatchStride, me_desc + (size_t)b * pcap * 8,
-                    pi[kPartNp], owner + (size_t)b * width * height, score_map + (size_t)b * width * height, blockIdx.x, gridDim.x);
-}
-
-__global__ void __launch_bounds__(256) k_map_me_argmin(int width, int height, const int* __restrict__ part_i,
-                                                       const int* __restrict__ me_desc, double* __restrict__ particles,
-                                                       const double* __restrict__ score_map, int pcap) {
-  const int wave = threadIdx.x >> 6;
-  const int b = blockIdx.y, p = blockIdx.x * 4 + wave;                     // one particle ellipse per wavefront
-  const int* pi = part_i + (size_t)b * kPartInts;
-  if (!pi[kPartActive] || !pi[kPartMaking] || p >= pi[kPartNp]) return;
-  double* o = particles + ((size_t)b * pcap + p) * kParticleDoubles;
-  __shared__ int s_res4[4][4];
-  int* s_res = s_res4[wave];
-  me_argmin_wave(width, me_desc + ((size_t)b * pcap + p) * 8, o + 7, score_map + (size_t)b * width * height, s_res, nullptr);
-  if ((threadIdx.x & 63) == 0) {
-    if (s_res[0]) {       // the measurement is stored only on success (:1429-1437)
-      o[5] = (double)s_res[1];
-      o[6] = (double)s_res[2];
+// measure_feature_with_multiple_priors (monoslam.cpp:1411-1439) + SearchMultipleOverlappingEllipses::search: the whole
+// multi-ellipse search of a sequence's partially initialised feature by one workgroup, stamps and scores of the union's
+// bounding box in LDS (me_search_fused_wg; rounds 1-3 ran three launches - k_map_me_mark, k_map_me_scores, k_map_me_argmin -
+// through image-sized maps in HBM, walking every ellipse's box column by column: 1.3 ms of a 1.35 ms mapping step at batch
+// 1024, profiles/r04_mapping_*).  A sequence whose union is too large for that goes on the list of k_me_big_*.
+struct MeJobsEngine {
+  const uint8_t* frames; size_t seq_stride; const uint8_t* patch_base; const int* part_i; const int* me_desc; double* particles;
+  int* owner_base; double* map_base; int N, pcap, width, height;
+  __device__ const int* pi(int b) const { return part_i + (size_t)b * kPartInts; }
+  __device__ const uint8_t* img(int b) const { return frames + (size_t)b * seq_stride; }
+  __device__ const uint8_t* patch(int b) const { return patch_base + ((size_t)b * N + pi(b)[kPartLabel]) * kPatchStride; }
+  __device__ const int* desc(int b) const { return me_desc + (size_t)b * pcap * 8; }
+  __device__ int n_ell(int b) const { return pi(b)[kPartNp]; }
+  __device__ const double* pu(int b, int e) const { return particles + ((size_t)b * pcap + e) * kParticleDoubles + 7; }
+  __device__ int* owner(int b) const { return owner_base + (size_t)b * width * height; }
+  __device__ double* map(int b) const { return map_base + (size_t)b * width * height; }
+  __device__ void emit(int b, int e, int flag, int u, int v, double) const {
+    double* o = particles + ((size_t)b * pcap + e) * kParticleDoubles;
+    if (flag) {           // the measurement is stored only on success (:1429-1437)
+      o[5] = (double)u;
+      o[6] = (double)v;
       o[11] = 1.0;
     } else {
       o[11] = 0.0;
     }
   }
+};
+__global__ void __launch_bounds__(256) k_map_me_search(MeJobsEngine J, int* __restrict__ big_list, int* __restrict__ big_count) {
+  const int b = blockIdx.x;
+  const int* pi = J.pi(b);
+  if (!pi[kPartActive] || !pi[kPartMaking]) return;
+  const bool done = me_search_fused_wg(J.img(b), J.width, J.patch(b), J.desc(b), J.n_ell(b), [&](int e) { return J.pu(b, e); },
+                                       [&](int e, int flag, int u, int v, double best) { J.emit(b, e, flag, u, v, best); });
+  if (!done && threadIdx.x == 0) big_list[atomicAdd(big_count, 1)] = b;
 }
 
 // ---------------------------------------------------------------------------
@@ -795,7 +788,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
     LaunchScope ls(e, "k_map_particles");
     const int pc = e->root->pcap;
 #define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B), dim3(pc), 0, e->stream, e->x, e->P, e->part_i, e->particles, \
-                                            e->me_desc, e->last_r, e->cam, e->ld, e->ppos, pc)
+                                            e->me_desc, e->last_r, e->me_big_count, e->cam, e->ld, e->ppos, pc)
     if (pc <= 128) SL2_PARTICLES(128);
     else if (pc <= 256) SL2_PARTICLES(256);
     else if (pc <= 512) SL2_PARTICLES(512);
@@ -804,23 +797,20 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
     SL2_HIP(hipGetLastError());
   }
   {
-    LaunchScope ls(e, "k_map_me_mark");
-    hipLaunchKernelGGL(k_map_me_mark, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->owner_map, e->root->pcap);
-    SL2_HIP(hipGetLastError());
-  }
-  {
-    LaunchScope ls(e, "k_map_me_scores");
-    const int nslices = B >= 512 ? 2 : (B >= 64 ? 4 : 16);     // row slices of the union's bounding box per sequence
-    hipLaunchKernelGGL(k_map_me_scores, dim3(nslices, B), dim3(256), 0, e->stream, e->cur_frames, e->cur_stride, W, e->patch,
-                       e->part_i, e->me_desc, e->owner_map, e->score_map, e->N, H, e->root->pcap);
-    SL2_HIP(hipGetLastError());
-  }
-  {
-    LaunchScope ls(e, "k_map_me_argmin");
-    hipLaunchKernelGGL(k_map_me_argmin, dim3((mp.n_particles + 3) / 4, B), dim3(256), 0, e->stream, W, H, e->part_i, e->me_desc, e->particles,
-                       e->score_map, e->root->pcap);
-    SL2_HIP(hipGetLastError());
+    MeJobsEngine J;
+    J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.part_i = e->part_i; J.me_desc = e->me_desc;
+    J.particles = e->particles; J.owner_base = e->owner_map; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
+    J.width = W; J.height = H;
+    {
+      LaunchScope ls(e, "k_map_me_search");
+      hipLaunchKernelGGL(k_map_me_search, dim3(B), dim3(256), 0, e->stream, J, e->me_big_list, e->me_big_count);
+      SL2_HIP(hipGetLastError());
+    }
+    {
+      LaunchScope ls(e, "k_me_big");
+      me_big_launch(J, e->me_big_list, e->me_big_count, W, e->stream);
+      SL2_HIP(hipGetLastError());
+    }
   }
   {
     LaunchScope ls(e, "k_map_update");

@@ -89,3 +89,32 @@ def test_multi_ellipse_class_mirror_and_empty_job():
     res, corr = improc.search_multiple_overlapping_ellipses_batch(img[None], [0, 0, 0], np.stack([patch.reshape(121)] * 3), [1, 0, 2],
                                                                  np.array(s._pu), np.array(s._ce))
     assert (res == want).all()
+
+
+def test_multi_ellipse_search_small_and_frame_sized_unions():
+    """Both forms of the search: a job whose union fits the one-workgroup LDS form (a dozen small ellipses), and jobs whose
+    ellipses are as large as the frame (what a freshly created feature under a weak pose estimate produces) - those are
+    spread over the k_me_big_* kernels.  Same results, exactly."""
+    from scenelib2_amd import improc
+    rng = np.random.default_rng(91)
+    W, H = 320, 240
+    images, patches, counts, pu, ce = [], [], [], [], []
+    for j, (n, sig) in enumerate([(12, 5.0), (95, 9000.0), (40, 2500.0), (7, 3.0), (64, 20000.0)]):
+        img = _texture(rng, H, W)
+        cx, cy = 160 + 10 * j, 120 - 5 * j
+        images.append(img); patches.append(img[cy - 5:cy + 6, cx - 5:cx + 6].reshape(121).copy()); counts.append(n)
+        for t in range(n):
+            r = 0.3 * sig
+            pu.append(oa.sinv_from_S(np.array([[sig * (1 + 0.01 * t), r], [r, sig * (1.2 - 0.002 * t)]])))
+            ce.append([cx + 0.7 * t + 0.25, cy - 0.4 * t + 0.6])
+    images, patches, counts, pu, ce = np.stack(images), np.stack(patches), np.array(counts, np.int32), np.array(pu), np.array(ce)
+    res, corr = improc.search_multiple_overlapping_ellipses_batch(images, np.arange(len(counts)), patches, counts, pu, ce)
+    first = np.concatenate([[0], np.cumsum(counts)])
+    for j in range(len(counts)):
+        sl = slice(first[j], first[j + 1])
+        want, wcorr, ncorr = oa.search_multiple_ellipses(images[j], patches[j], pu[sl], ce[sl])
+        assert (res[sl] == want).all() and (corr[sl] == wcorr).all(), j
+        assert (ncorr > 4096) == (j in (1, 2, 4)), (j, ncorr)      # which form each job took
+    # a second call on the same engine-side maps must start clean (stamps cleared by the big form)
+    res2, corr2 = improc.search_multiple_overlapping_ellipses_batch(images, np.arange(len(counts)), patches, counts, pu, ce)
+    assert (res2 == res).all() and (corr2 == corr).all()

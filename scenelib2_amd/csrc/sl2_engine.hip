@@ -682,7 +682,7 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
   if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
   sl2_engine* g = e->groups.empty() ? e : e->groups[0];
   g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
-  g->score_map = e->score_map; g->owner_map = e->owner_map;
+  g->score_map = e->score_map; g->owner_map = e->owner_map; g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
   if (uv) {
     if (!e->init_uv) SL2_HIP(hipMalloc((void**)&e->init_uv, sizeof(int) * 2 * e->B));
     // the caller's buffer may be pinned or registered memory, for which an asynchronous copy really is asynchronous: the copy
@@ -740,6 +740,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
       g->owner_map = e->owner_map;
+      g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
       r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
     }
     return r;

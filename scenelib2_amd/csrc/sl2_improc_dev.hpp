@@ -245,15 +245,26 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
   if (nu > 0 && nv > 0) {
     const float rcp = 1.0f / (float)nu;
     const double a = pu[0], b = pu[1], c = pu[2];
-    for (int idx = lane; idx < nu * nv; idx += 64) {
-      int q, r;                                     // consecutive lanes along an image row (coalesced reads of the score map);
-      box_divmod(idx, nu, rcp, &r, &q);             // the reference's scan order (u outer, v inner) is carried as `o`
-      const int urel = d[2] + q, vrel = d[4] + r;
-      if (!in_ellipse(a, b, c, urel, vrel)) continue;
-      const size_t pos = (size_t)(d[1] + vrel) * width + (d[0] + urel);
-      const double corr = map[pos];
-      const int o = q * nv + r;
-      if ((corr < best || (corr == best && o > order) || order < 0) && corr <= best) { best = corr; order = o; }
+    // consecutive lanes along an image row (coalesced reads of the score map); the reference's scan order (u outer, v
+    // inner) is carried as `o`.  Four positions per lane and round, their loads issued together: with one ellipse per
+    // wavefront nothing else hides the latency of a load that is consumed at once (a frame-sized ellipse is ~900 rounds; at
+    // one round trip per round that was 0.5 ms, the whole of k_me_big_argmin).
+    const int total = nu * nv, d0 = d[0], d1 = d[1], d2 = d[2], d4 = d[4];
+    for (int base = lane; base < total; base += 256) {
+      double corr[4];
+      int oo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int idx = base + 64 * k;
+        int q, r;
+        box_divmod(idx < total ? idx : 0, nu, rcp, &r, &q);
+        const bool in = idx < total && in_ellipse(a, b, c, d2 + q, d4 + r);
+        oo[k] = in ? q * nv + r : -1;
+        corr[k] = in ? map[(size_t)(d1 + d4 + r) * width + (d0 + d2 + q)] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (oo[k] >= 0 && (corr[k] < best || (corr[k] == best && oo[k] > order) || order < 0) && corr[k] <= best) { best = corr[k]; order = oo[k]; }
     }
   }
   for (int off = 32; off > 0; off >>= 1) {
@@ -288,6 +299,7 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
 //   emit(e, flag, u, v, best)   called by one lane per ellipse
 // ---------------------------------------------------------------------------
 constexpr int kMeCap = 4096;
+constexpr int kMeImgCap = 8192;      // bytes of image under a union's bounding box (+ 5 pixels all round) kept in LDS
 template <typename PuFn, typename EmitFn>
 __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
                                                    const int* __restrict__ desc, int n_ell, PuFn pu_of, EmitFn emit) {
@@ -299,6 +311,7 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
   __shared__ unsigned char f_stamp[kMeCap];
   __shared__ int f_list[kMeCap];
   __shared__ double f_score[kMeCap];
+  __shared__ uint8_t f_img[kMeImgCap];
   if (tid < 121) f_patch[tid] = patch121[tid];
   if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; f_n = 0; }
   __syncthreads();
@@ -343,13 +356,27 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
     if (f_stamp[idx]) f_list[atomicAdd(&f_n, 1)] = idx;
   __syncthreads();
   {
+    // the image under the union (+ 5 pixels all round) goes to LDS once: the 121 taps of a position then cost no memory
+    // round trips (a thread scores one or two positions; from memory its eleven rows were eleven dependent round trips each)
     const int n = f_n, Sg0 = f_sums[0], Sg0sq = f_sums[1];
     const float rcpw = 1.0f / (float)bw;
+    const int iw = bw + 10, ih = bh + 10;
+    const bool tile = area > 0 && iw * ih <= kMeImgCap;      // (area == 0: a job none of whose ellipses has a valid box - x0 / y0 are unset)
+    if (tile) {
+      const float rcpi = 1.0f / (float)iw;
+      for (int i = tid; i < iw * ih; i += 256) {
+        int r, q;
+        box_divmod(i, iw, rcpi, &r, &q);
+        f_img[i] = img[(size_t)(y0 - 5 + r) * width + (x0 - 5 + q)];
+      }
+      __syncthreads();
+    }
     for (int k = tid; k < n; k += 256) {
       const int idx = f_list[k];
       int r, q;
       box_divmod(idx, bw, rcpw, &r, &q);
-      f_score[idx] = me_score_position(img, width, f_patch, Sg0, Sg0sq, x0 + q, y0 + r);
+      f_score[idx] = tile ? me_score_position(f_img, iw, f_patch, Sg0, Sg0sq, q + 5, r + 5)
+                          : me_score_position(img, width, f_patch, Sg0, Sg0sq, x0 + q, y0 + r);
     }
   }
   __syncthreads();

@@ -63,7 +63,7 @@ struct MeJobsBatch {
     if (corrmax) corrmax[k] = best;
   }
 };
-__global__ void __launch_bounds__(256) k_me_search(MeJobsBatch J, int* __restrict__ big_list, int* __restrict__ big_count) {
+__global__ void __launch_bounds__(1024) k_me_search(MeJobsBatch J, int* __restrict__ big_list, int* __restrict__ big_count) {
   const int job = blockIdx.x;
   const bool done = me_search_fused_wg(J.img(job), J.width, J.patch(job), J.desc(job), J.n_ell(job), [&](int e) { return J.pu(job, e); },
                                        [&](int e, int flag, int u, int v, double best) { J.emit(job, e, flag, u, v, best); });
@@ -172,7 +172,7 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   J.images = d_img.as<uint8_t>(); J.image_index = d_idx.as<int>(); J.patches = d_pat.as<uint8_t>(); J.first = d_first.as<int>();
   J.desc_base = d_desc.as<int>(); J.puinv = d_pu.as<double>(); J.owner_base = d_own.as<int>(); J.map_base = d_map.as<double>();
   J.result = d_res.as<int>(); J.corrmax = corrmax ? d_corr.as<double>() : nullptr; J.width = width; J.height = height;
-  hipLaunchKernelGGL(k_me_search, dim3(njobs), dim3(256), 0, 0, J, d_big.as<int>(), d_big.as<int>() + njobs);
+  hipLaunchKernelGGL(k_me_search, dim3(njobs), dim3(1024), 0, 0, J, d_big.as<int>(), d_big.as<int>() + njobs);
   me_big_launch(J, d_big.as<int>(), d_big.as<int>() + njobs, width, 0);
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipEventRecord(ev1, 0));

@@ -161,13 +161,16 @@ __device__ __forceinline__ void box_divmod(int idx, int n, float rcp, int* q, in
 }
 
 // One wavefront stamps one ellipse.
+// (part = this wavefront's share of the box's rows, of `parts`: a frame-sized ellipse is split over a workgroup's waves)
 __device__ __forceinline__ void me_mark_ellipse_wave(const int* __restrict__ d, const double* __restrict__ pu, int width,
-                                                     int* __restrict__ owner, int index) {
+                                                     int* __restrict__ owner, int index, int part = 0, int parts = 1) {
   const int nu = d[3], nv = d[5];
   if (nu <= 0 || nv <= 0) return;
   const float rcp = 1.0f / (float)nu;
   const double a = pu[0], b = pu[1], c = pu[2];
-  for (int idx = threadIdx.x & 63; idx < nu * nv; idx += 64) {
+  const int rows_per = (nv + parts - 1) / parts;
+  const int i0 = part * rows_per * nu, i1 = min((part + 1) * rows_per, nv) * nu;
+  for (int idx = i0 + (threadIdx.x & 63); idx < i1; idx += 64) {
     int q, r;                                       // row r of the box, column q: consecutive lanes walk along an image row
     box_divmod(idx, nu, rcp, &r, &q);
     const int urel = d[2] + q, vrel = d[4] + r;
@@ -236,8 +239,9 @@ __device__ __forceinline__ void me_score_union_wg(const uint8_t* __restrict__ im
 
 // Arg-min of ellipse e over its positions in scan order (u outer, v inner), "corr <= corrmax" => last minimum
 // wins.  One wavefront.  out = (flag, u, v); returns the best score in *best_out (lane 0).
-__device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict__ d, const double* __restrict__ pu,
-                                               const double* __restrict__ map, int* __restrict__ out, double* best_out) {
+// me_argmin_part: the wave-reduced (best, order) of rows part * ceil(nv / parts) ... of the box, valid on every lane
+__device__ __forceinline__ void me_argmin_part(int width, const int* __restrict__ d, const double* __restrict__ pu,
+                                               const double* __restrict__ map, int part, int parts, double* best_o, int* order_o) {
   const int lane = threadIdx.x & 63;
   const int nu = d[3], nv = d[5];
   double best = 1000000.0;   // cpp:156
@@ -249,8 +253,9 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
     // inner) is carried as `o`.  Four positions per lane and round, their loads issued together: with one ellipse per
     // wavefront nothing else hides the latency of a load that is consumed at once (a frame-sized ellipse is ~900 rounds; at
     // one round trip per round that was 0.5 ms, the whole of k_me_big_argmin).
-    const int total = nu * nv, d0 = d[0], d1 = d[1], d2 = d[2], d4 = d[4];
-    for (int base = lane; base < total; base += 256) {
+    const int rows_per = (nv + parts - 1) / parts;
+    const int first = part * rows_per * nu, total = min((part + 1) * rows_per, nv) * nu, d0 = d[0], d1 = d[1], d2 = d[2], d4 = d[4];
+    for (int base = first + lane; base < total; base += 256) {
       double corr[4];
       int oo[4];
 #pragma unroll
@@ -272,7 +277,16 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
     const int oo = __shfl_xor(order, off, 64);
     if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
   }
-  if (lane == 0) {
+  *best_o = best;
+  *order_o = order;
+}
+__device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict__ d, const double* __restrict__ pu,
+                                               const double* __restrict__ map, int* __restrict__ out, double* best_out) {
+  double best;
+  int order;
+  me_argmin_part(width, d, pu, map, 0, 1, &best, &order);
+  if ((threadIdx.x & 63) == 0) {
+    const int nv = d[5];
     out[0] = (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0;           // cpp:187-191
     out[1] = order >= 0 ? d[0] + d[2] + order / nv : 0;                  // result_u_ / result_v_ start at 0 (cpp:45-46)
     out[2] = order >= 0 ? d[1] + d[4] + order % nv : 0;
@@ -281,7 +295,7 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
 }
 
 // ---------------------------------------------------------------------------
-// The whole multi-ellipse search of ONE job by ONE workgroup (256 threads), round 4.
+// The whole multi-ellipse search of ONE job by ONE workgroup (any multiple of 64 threads; the callers use 1024), round 4.
 //
 // A job's ellipses - the depth particles of one partially initialised feature - lie along one epipolar line and overlap
 // almost completely: in the mapping workload of bench.py --mapping about 95 ellipses of ~310 positions each (29.6 k box
@@ -298,24 +312,22 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
 //   pu_of(e)  -> pointer to (PuInv(0,0), PuInv(0,1), PuInv(1,1)) of ellipse e
 //   emit(e, flag, u, v, best)   called by one lane per ellipse
 // ---------------------------------------------------------------------------
-constexpr int kMeCap = 4096;
-constexpr int kMeImgCap = 8192;      // bytes of image under a union's bounding box (+ 5 pixels all round) kept in LDS
+constexpr int kMeCap = 2048;
+constexpr int kMeImgCap = 6144;      // bytes of image under a union's bounding box (+ 5 pixels all round) kept in LDS
 template <typename PuFn, typename EmitFn>
 __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
                                                    const int* __restrict__ desc, int n_ell, PuFn pu_of, EmitFn emit) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = (int)blockDim.x, nwave = nthr >> 6;
   __shared__ int f_patch[121];
   __shared__ int f_sums[2];
   __shared__ int f_box[4];
-  __shared__ int f_n;
   __shared__ unsigned char f_stamp[kMeCap];
-  __shared__ int f_list[kMeCap];
   __shared__ double f_score[kMeCap];
   __shared__ uint8_t f_img[kMeImgCap];
   if (tid < 121) f_patch[tid] = patch121[tid];
-  if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; f_n = 0; }
+  if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; }
   __syncthreads();
-  for (int e = tid; e < n_ell; e += 256) {
+  for (int e = tid; e < n_ell; e += nthr) {
     const int* d = desc + 8 * (size_t)e;
     if (d[3] <= 0 || d[5] <= 0) continue;
     atomicMin(&f_box[0], d[0] + d[2]);
@@ -323,10 +335,11 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
     atomicMax(&f_box[2], d[0] + d[2] + d[3]);
     atomicMax(&f_box[3], d[1] + d[4] + d[5]);
   }
-  if (tid == 0) {
+  if (wave == 0) {
     int s0 = 0, s0q = 0;
-    for (int p = 0; p < 121; ++p) { s0 += f_patch[p]; s0q += f_patch[p] * f_patch[p]; }
-    f_sums[0] = s0; f_sums[1] = s0q;
+    for (int p = lane; p < 121; p += 64) { s0 += f_patch[p]; s0q += f_patch[p] * f_patch[p]; }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s0q += __shfl_xor(s0q, off, 64); }
+    if (lane == 0) { f_sums[0] = s0; f_sums[1] = s0q; }
   }
   __syncthreads();
   const bool any = f_box[2] >= 0;
@@ -334,9 +347,9 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
   const int area = bw * bh;
   if (area > kMeCap) return false;      // the caller spreads such a job over many workgroups (me_mark_ellipse_wave / me_score_union_wg / me_argmin_wave)
   // ---- stamps
-  for (int i = tid; i < (area + 3) / 4; i += 256) ((int*)f_stamp)[i] = 0;
+  for (int i = tid; i < (area + 3) / 4; i += nthr) ((int*)f_stamp)[i] = 0;
   __syncthreads();
-  for (int e = wave; e < n_ell; e += 4) {
+  for (int e = wave; e < n_ell; e += nwave) {
     const int* d = desc + 8 * (size_t)e;
     const int nu = d[3], nv = d[5];
     if (nu <= 0 || nv <= 0) continue;
@@ -351,28 +364,26 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
     }
   }
   __syncthreads();
-  // ---- the stamped positions, each scored once
-  for (int idx = tid; idx < area; idx += 256)
-    if (f_stamp[idx]) f_list[atomicAdd(&f_n, 1)] = idx;
-  __syncthreads();
+  // ---- the stamped positions, each scored once (no compaction into a list: with up to sixteen waves on at most kMeCap
+  // positions a thread meets four of them at most, and the atomic counter of a list serialises)
   {
     // the image under the union (+ 5 pixels all round) goes to LDS once: the 121 taps of a position then cost no memory
     // round trips (a thread scores one or two positions; from memory its eleven rows were eleven dependent round trips each)
-    const int n = f_n, Sg0 = f_sums[0], Sg0sq = f_sums[1];
+    const int Sg0 = f_sums[0], Sg0sq = f_sums[1];
     const float rcpw = 1.0f / (float)bw;
     const int iw = bw + 10, ih = bh + 10;
     const bool tile = area > 0 && iw * ih <= kMeImgCap;      // (area == 0: a job none of whose ellipses has a valid box - x0 / y0 are unset)
     if (tile) {
       const float rcpi = 1.0f / (float)iw;
-      for (int i = tid; i < iw * ih; i += 256) {
+      for (int i = tid; i < iw * ih; i += nthr) {
         int r, q;
         box_divmod(i, iw, rcpi, &r, &q);
         f_img[i] = img[(size_t)(y0 - 5 + r) * width + (x0 - 5 + q)];
       }
       __syncthreads();
     }
-    for (int k = tid; k < n; k += 256) {
-      const int idx = f_list[k];
+    for (int idx = tid; idx < area; idx += nthr) {
+      if (!f_stamp[idx]) continue;
       int r, q;
       box_divmod(idx, bw, rcpw, &r, &q);
       f_score[idx] = tile ? me_score_position(f_img, iw, f_patch, Sg0, Sg0sq, q + 5, r + 5)
@@ -381,7 +392,7 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
   }
   __syncthreads();
   // ---- per-ellipse arg-min: smallest score, among equals the LARGEST scan-order index (u outer, v inner; cpp:151-185)
-  for (int e = wave; e < n_ell; e += 4) {
+  for (int e = wave; e < n_ell; e += nwave) {
     const int* d = desc + 8 * (size_t)e;
     const int nu = d[3], nv = d[5];
     double best = 1000000.0;   // cpp:156
@@ -426,8 +437,8 @@ __global__ void __launch_bounds__(256) k_me_big_mark(Jobs J, const int* __restri
   const int n = *count, wave = threadIdx.x >> 6;
   for (int li = blockIdx.y; li < n; li += gridDim.y) {
     const int job = list[li], ne = J.n_ell(job);
-    for (int e = blockIdx.x * 4 + wave; e < ne; e += gridDim.x * 4)
-      me_mark_ellipse_wave(J.desc(job) + 8 * (size_t)e, J.pu(job, e), width, J.owner(job), e);
+    for (int e = blockIdx.x; e < ne; e += gridDim.x)              // one ellipse per workgroup, its rows split over the four waves
+      me_mark_ellipse_wave(J.desc(job) + 8 * (size_t)e, J.pu(job, e), width, J.owner(job), e, wave, 4);
   }
 }
 template <typename Jobs>
@@ -442,17 +453,29 @@ __global__ void __launch_bounds__(256) k_me_big_scores(Jobs J, const int* __rest
 template <typename Jobs>
 __global__ void __launch_bounds__(256) k_me_big_argmin(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
   const int n = *count, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ int s_res[4][4];
+  __shared__ int s_ord[4];
   __shared__ double s_bst[4];
   for (int li = blockIdx.y; li < n; li += gridDim.y) {
     const int job = list[li], ne = J.n_ell(job);
-    for (int e = blockIdx.x * 4 + wave; e < ne; e += gridDim.x * 4) {
-      me_argmin_wave(width, J.desc(job) + 8 * (size_t)e, J.pu(job, e), J.map(job), s_res[wave], &s_bst[wave]);
-      if (lane == 0) J.emit(job, e, s_res[wave][0], s_res[wave][1], s_res[wave][2], s_bst[wave]);
+    for (int e = blockIdx.x; e < ne; e += gridDim.x) {            // one ellipse per workgroup, its rows split over the four waves
+      const int* d = J.desc(job) + 8 * (size_t)e;
+      double best;
+      int order;
+      me_argmin_part(width, d, J.pu(job, e), J.map(job), wave, 4, &best, &order);
+      if (lane == 0) { s_bst[wave] = best; s_ord[wave] = order; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+          if (s_ord[w] >= 0 && (order < 0 || s_bst[w] < best || (s_bst[w] == best && s_ord[w] > order))) { best = s_bst[w]; order = s_ord[w]; }
+        const int nv = d[5];
+        J.emit(job, e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
+               order >= 0 ? d[1] + d[4] + order % nv : 0, best);
+      }
+      __syncthreads();
     }
   }
 }
-constexpr int kMeBigGridX = 32, kMeBigGridY = 16, kMeBigSlices = 16;
+constexpr int kMeBigGridX = 128, kMeBigGridY = 8, kMeBigSlices = 16;
 template <typename Jobs>
 inline void me_big_launch(Jobs J, const int* list, const int* count, int width, hipStream_t st) {
   hipLaunchKernelGGL(k_me_big_mark<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);

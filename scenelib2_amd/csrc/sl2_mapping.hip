@@ -338,7 +338,7 @@ struct MeJobsEngine {
     }
   }
 };
-__global__ void __launch_bounds__(256) k_map_me_search(MeJobsEngine J, int* __restrict__ big_list, int* __restrict__ big_count) {
+__global__ void __launch_bounds__(1024) k_map_me_search(MeJobsEngine J, int* __restrict__ big_list, int* __restrict__ big_count) {
   const int b = blockIdx.x;
   const int* pi = J.pi(b);
   if (!pi[kPartActive] || !pi[kPartMaking]) return;
@@ -803,7 +803,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
     J.width = W; J.height = H;
     {
       LaunchScope ls(e, "k_map_me_search");
-      hipLaunchKernelGGL(k_map_me_search, dim3(B), dim3(256), 0, e->stream, J, e->me_big_list, e->me_big_count);
+      hipLaunchKernelGGL(k_map_me_search, dim3(B), dim3(1024), 0, e->stream, J, e->me_big_list, e->me_big_count);
       SL2_HIP(hipGetLastError());
     }
     {

@@ -114,7 +114,7 @@ def test_multi_ellipse_search_small_and_frame_sized_unions():
         sl = slice(first[j], first[j + 1])
         want, wcorr, ncorr = oa.search_multiple_ellipses(images[j], patches[j], pu[sl], ce[sl])
         assert (res[sl] == want).all() and (corr[sl] == wcorr).all(), j
-        assert (ncorr > 4096) == (j in (1, 2, 4)), (j, ncorr)      # which form each job took
+        assert (ncorr > 2048) == (j in (1, 2, 4)), (j, ncorr)      # which form each job took (kMeCap positions of bounding box)
     # a second call on the same engine-side maps must start clean (stamps cleared by the big form)
     res2, corr2 = improc.search_multiple_overlapping_ellipses_batch(images, np.arange(len(counts)), patches, counts, pu, ce)
     assert (res2 == res).all() and (corr2 == corr).all()

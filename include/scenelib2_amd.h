@@ -108,6 +108,9 @@ int sl2_device_count(void);
 /* Replaces `new MonoSLAM` + the object wiring of MonoSLAM::Init (monoslam.cpp:1852-1885)
  * for `batch` sequences with room for `max_features` features each.  `stream` is a
  * hipStream_t (NULL => the engine creates its own). */
+/* Limits (SL2_ERR_CAPACITY): at most 676 feature slots per sequence (2048 state columns: one k_build_AS workgroup holds a
+ * sequence's row of A^T) and 512 features measured per frame (number_of_features_to_select); the reference's feature_list_ is
+ * unbounded.  BASELINE's largest configuration (500 features, 1513 states) is inside. */
 int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int max_features, int device,
                void* stream, sl2_engine** out);
 void sl2_destroy(sl2_engine* e);
@@ -144,10 +147,12 @@ int sl2_set_feature_covariances(sl2_engine* e, int seq0, int nseq, int nfeat, co
  * sequences' frames.  frames_on_device != 0 => `frames` is a device pointer
  * (zero-copy); otherwise host memory, copied H2D on the engine's stream.
  * enable_mapping != 0 runs the feature-initialisation tail (monoslam.cpp:152-170: AutoInitialiseFeature behind the
- * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) for the shipped max_features_to_init_at_once = 1 and up to
- * 1024 depth particles (params.number_of_particles; the shipped value is 100); other settings are rejected with
- * SL2_ERR_INVALID.  SL2_STATUS_LABELS_EXHAUSTED = a sequence could not take a
- * new feature because all max_features slots hold live features. */
+ * 0.2 m/s speed gate, MatchPartiallyInitialisedFeatures) with up to params.max_features_to_init_at_once <= 4 partially
+ * initialised features in flight per sequence (the shipped value is 1; the six state columns of each are reserved at
+ * sl2_create) and up to 1024 depth particles (params.number_of_particles; the shipped value is 100); other settings are
+ * rejected with SL2_ERR_INVALID.  With more than one feature in flight the reference's own arithmetic is kept, including the
+ * position it records for later features after a conversion (feature.cpp:254).  SL2_STATUS_LABELS_EXHAUSTED = a sequence could
+ * not take a new feature because all max_features slots hold live features. */
 int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device,
                     int save_trajectory, int enable_mapping);
 
@@ -289,13 +294,15 @@ int sl2_get_total_covariance(sl2_engine* e, int seq, double* P, int capacity_n);
 /* feature_list_ of one sequence in list order (deleted features skipped unless
  * include_deleted).  Returns the number written through *count. */
 int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity, int include_deleted, int* count);
-/* The partially initialised feature of one sequence (FeatureInitInfo + its particles, feature_init_info.h:46-118).
- * ints [16] = active, label, number_of_match_attempts_, #particles, making_measurement_on_this_step_flag_, uu_, vv_,
- * region_defined (this step), init_feature_search_{ustart,vstart,ufinish,vfinish}_, #initialised, #converted, #deleted
- * (totals for this sequence), created (this step); dbl [9] = mean_, covariance_, y_(0..5), evbest of the last detection;
- * particles [capacity][12] = lambda_, probability_, cumulative_probability_, m_h_(2), m_z_(2), m_SInv_(00,01,11), m_detS_,
- * m_successful_measurement_flag_ (may be NULL). */
-int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, double* particles, int capacity);
+/* Entry `index` of feature_init_info_vector_ of one sequence (FeatureInitInfo + its particles, feature_init_info.h:46-118;
+ * up to params.max_features_to_init_at_once <= 4 entries, in the vector's order).
+ * ints [16] = feature_init_info_vector_.size(), label, number_of_match_attempts_, #particles,
+ * making_measurement_on_this_step_flag_, uu_, vv_, region_defined (this step), init_feature_search_{ustart,vstart,ufinish,vfinish}_,
+ * #initialised, #converted, #deleted (totals for this sequence), created (this step); dbl [9] = mean_, covariance_, y_(0..5),
+ * evbest of the last detection; particles [capacity][12] = lambda_, probability_, cumulative_probability_, m_h_(2), m_z_(2),
+ * m_SInv_(00,01,11), m_detS_, m_successful_measurement_flag_ (may be NULL).  ints [0] and the sequence-level entries (5..15,
+ * dbl [8]) are filled for any index; the feature's own entries are zero when index >= ints [0]. */
+int sl2_get_partial_feature(sl2_engine* e, int seq, int index, int32_t* ints, double* dbl, double* particles, int capacity);
 /* Feature::patch_ (feature.h:118; 11x11, row-major) of the feature with this label: the template given to
  * sl2_add_known_features, or the one copy_into_patch cut from the frame when the feature was initialised
  * (monoslam.cpp:1236-1250).  Labels of deleted features keep their last template. */

@@ -145,7 +145,7 @@ def _bind(L):
     L.sl2_find_best_patch_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sl2_search_multiple_overlapping_ellipses_batch.argtypes = [C.c_int, c_u8p, C.c_int, C.c_int, C.c_int, C.c_int, c_ip, c_u8p,
                                                                  c_ip, c_dp, c_dp, c_ip, c_dp, c_dp]
-    L.sl2_get_partial_feature.argtypes = [vp, C.c_int, c_ip, c_dp, c_dp, C.c_int]
+    L.sl2_get_partial_feature.argtypes = [vp, C.c_int, C.c_int, c_ip, c_dp, c_dp, C.c_int]
     L.sl2_list_frames.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, c_ip]
     L.sl2_read_pgm.argtypes = [C.c_char_p, c_u8p, C.c_size_t, c_ip, c_ip]
     L.sl2_read_image.argtypes = [C.c_char_p, c_u8p, C.c_size_t, c_ip, c_ip]

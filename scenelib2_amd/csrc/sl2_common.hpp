@@ -37,16 +37,23 @@ enum : int {
   FF_SUCCESS = 8,     // successful_measurement_flag_
   FF_VISIBLE = 16,    // passed visibility_test in the last selection
   FF_USED = 32,       // slot was ever used (deleted features keep FF_USED)
-  FF_PARTIAL = 64,    // label reserved by a partially initialised feature (its 6 states live at ppos)
+  FF_PARTIAL = 64,    // label reserved by a partially initialised feature (its 6 states live at ppos + 6 k, k = its partial slot)
 };
 
 constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
 // feature initialisation (one partially initialised feature per sequence)
 constexpr int kMaxParticles = 1024;      // upper bound of params.number_of_particles (k_map_particles: one thread per particle)
 constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2], z[2], SInv(00,01,11), detS, success
-constexpr int kPartInts = 16, kPartDoubles = 4;   // per-sequence record of the partial feature (part_i / part_d)
-enum : int { kPartActive = 0, kPartLabel, kPartAttempts, kPartNp, kPartMaking, kPartUU, kPartVV, kPartRegionValid,
+// Partially initialised features: up to kMaxPartial per sequence (params.max_features_to_init_at_once, monoslam.cpp:163-167).
+// part_i / part_d = the per-SEQUENCE record: feature_init_info_vector_.size(), the partial slots in the vector's order (a
+// conversion or deletion erases an entry, the later ones move up), the image selection and the counters; ps_i / ps_d = one
+// record per PARTIAL SLOT k (FeatureInitInfo): its six states live in columns ppos + 6 k of x / P.
+constexpr int kMaxPartial = 4;
+constexpr int kPartInts = 16, kPartDoubles = 4;
+enum : int { kPartCount = 0, kPartOrder /* kMaxPartial ints */, kPartUU = 5, kPartVV, kPartRegionValid,
              kPartRegion /* 4 ints */, kPartInitialised = 12, kPartConverted, kPartDeleted, kPartCreated };
+constexpr int kPsInts = 8, kPsDoubles = 4;          // ps_d: mean, covariance of lambda
+enum : int { kPsActive = 0, kPsLabel /* the feature SLOT that holds its label */, kPsAttempts, kPsNp, kPsMaking };
 constexpr int kWorkDoubles = 5;     // per-sequence work counters of a step (work[]): window bytes, searches, candidates, exact
                                     // fallbacks, 16 x 16 candidate tiles of the matrix-core search
 constexpr int kCholBlock = 32;       // block size of the blocked Cholesky / forward substitution
@@ -122,17 +129,27 @@ struct sl2_engine {
   int build_variant = 1;      // 1 = k_build_AS (A and S in one pass over the measured features' rows of P; the product's only path); TEST build: 2 = k_build_AS_tiles (upper block triangle of P), 0 = k_build_A then k_build_S
   int fwd_variant = 1;        // forward substitution: 1 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory (any size)
   // ---- feature initialisation ----
-  int ppos = 0;                          // first column of the partial feature's six states (13 + 3N)
+  int ppos = 0;                          // first column of the partial features' states (13 + 3N); slot k at ppos + 6 k
+  int kpart = 1;                         // partial slots per sequence: params.max_features_to_init_at_once, 1 .. kMaxPartial
   int* part_i = nullptr;                 // [B][kPartInts]
-  double* part_d = nullptr;              // [B][kPartDoubles]  mean, covariance of lambda, evbest of the last detection
-  int pcap = 128;                        // particle slots per sequence: roundup(params.number_of_particles, 64)
-  double* particles = nullptr;           // [B][pcap][kParticleDoubles]
+  double* part_d = nullptr;              // [B][kPartDoubles]  [2] = evbest of the last detection
+  int* ps_i = nullptr;                   // [B][kpart][kPsInts]
+  double* ps_d = nullptr;                // [B][kpart][kPsDoubles]
+  int pcap = 128;                        // particle slots per partial feature: roundup(params.number_of_particles, 64)
+  double* particles = nullptr;           // [B][kpart][pcap][kParticleDoubles]
+  // Q28 (feature.cpp:254): a conversion moves the LATER features' position_in_total_state_vector_ by 6 instead of 3, and the
+  // reference then places their dh_by_dy blocks three columns early in H (monoslam.cpp:564).  pos_err = how far a slot's
+  // recorded position lies below its true one; f_hcol = the engine column its H block therefore lands on (k_search_score
+  // recomputes it for sequences that carry such an error; every other sequence uses 13 + 3 slot).
+  int* pos_err = nullptr;                // [B][N]
+  int* pos_err_any = nullptr;            // [B]
+  int* f_hcol = nullptr;                 // [B][N]
   unsigned long long* rand48 = nullptr;  // [B]  drand48 state (srand48(0) at Init, monoslam.cpp:1968)
   double* prev_r = nullptr;              // [B][3] camera position before the prediction (speed estimate, :121-124)
-  int* me_desc = nullptr;                // [B][pcap][8] search ellipses of the particles
-  double* score_map = nullptr;           // [B][H][W] correlation cache of the multi-ellipse search (allocated on first use)
-  int* owner_map = nullptr;              // [B][H][W] which particle ellipse scores a position (kOwnerFree between searches)
-  int* me_big_list = nullptr;            // [B] sequences whose multi-ellipse search is too large for the one-workgroup form, this step
+  int* me_desc = nullptr;                // [B][kpart][pcap][8] search ellipses of the particles
+  double* score_map = nullptr;           // [B][kpart][H][W] score cache of an OVERSIZED multi-ellipse search (allocated on first use)
+  int* owner_map = nullptr;              // [B][kpart][H][W] its stamps (kOwnerFree between searches)
+  int* me_big_list = nullptr;            // [B * kpart] (sequence, partial slot) jobs too large for the one-workgroup form, this step
   int* me_big_count = nullptr;           // [1]
   bool mapping_used = false;
   int* init_uv = nullptr;                // [B][2] pixel selections of sl2_initialise_feature (allocated on first use)

@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
                                                   const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
                                                   const int* __restrict__ m_count, double* __restrict__ At,
-                                                  double* __restrict__ St, int N, int ld, int mld) {
+                                                  double* __restrict__ St, const int* __restrict__ f_hcol,
+                                                  const int* __restrict__ pos_err_any, int N, int ld, int mld) {
   extern __shared__ double sAt[];   // [2 * BATCH][ld]
   const int b = blockIdx.x;
   const int cnt = m_count[b];
@@ -107,6 +108,9 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   double* Sb = St + (size_t)b * mld * mld;
   const double* Pb = P + (size_t)b * ld * ld;
   const int* sidx = succ_idx + (size_t)b * N;
+  // the state columns feature f's dh_by_dy multiplies: its own, 13 + 3 f - unless the sequence carries the reference's
+  // misplaced position_in_total_state_vector_ (Q28, feature.cpp:254 / monoslam.cpp:564): then what k_search_score looked up
+  const int* hcol = (pos_err_any[b] != 0) ? f_hcol + (size_t)b * N : nullptr;
   // role "columns i of At"
   double pc[NQ][7];
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   if (t < m) {
     const int fa = sidx[t >> 1];
     const size_t fia = (size_t)b * N + fa;
-    posa = 13 + 3 * fa;
+    posa = hcol ? hcol[fa] : 13 + 3 * fa;
 #pragma unroll
     for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fia * 14 + (t & 1) * 7 + c];
 #pragma unroll
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
       if (jj < nb) {
         const int f = sidx[j0 + jj];
         const size_t fi = (size_t)b * N + f;
-        const int pos = 13 + 3 * f;
+        const int pos = hcol ? hcol[f] : 13 + 3 * f;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           const int i = t + q * (int)blockDim.x;
@@ -2159,17 +2163,17 @@ static int launch_update_range(sl2_engine* e) {
     if (build_variant == 4 && e->ld <= 1024) {
       const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch, true>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     } else
 #endif
     if (e->ld <= 1024) {
       const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     } else {
       const size_t shm = sizeof(double) * 2 * 2 * e->ld;      // <= 64 KB
       hipLaunchKernelGGL((k_build_AS<2, 2>), dim3(B, nsplit), dim3(1024), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->N, e->ld, e->mld);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     }
     SL2_HIP(hipGetLastError());
   }

@@ -162,7 +162,7 @@ static int build_groups(sl2_engine* e, int G) {
     sl2_engine* g = new sl2_engine();
     g->device = e->device; g->cam = e->cam; g->prm = e->prm;
     g->B = count; g->N = e->N; g->ld = e->ld; g->nsel_max = e->nsel_max; g->mld = e->mld; g->nblk_max = e->nblk_max;
-    g->ppos = e->ppos; g->pcap = e->pcap;
+    g->ppos = e->ppos; g->pcap = e->pcap; g->kpart = e->kpart;
     g->root = e; g->group_first = first;
     if (G == 1) g->stream = e->stream; else SL2_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
     const size_t f = first;
@@ -180,8 +180,10 @@ static int build_groups(sl2_engine* e, int G) {
     g->work = e->work + f * kWorkDoubles; g->At = e->At + f * mld * ld; g->Vt = e->Vt + f * mld * ld; g->St = e->St + f * mld * mld;
     g->LinvT = e->LinvT + f * (size_t)e->nblk_max * 1024;
     g->part_i = e->part_i + f * kPartInts; g->part_d = e->part_d + f * kPartDoubles;
-    g->particles = e->particles + f * e->pcap * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
-    g->me_desc = e->me_desc + f * e->pcap * 8;
+    g->ps_i = e->ps_i + f * e->kpart * kPsInts; g->ps_d = e->ps_d + f * e->kpart * kPsDoubles;
+    g->particles = e->particles + f * e->kpart * e->pcap * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
+    g->me_desc = e->me_desc + f * e->kpart * e->pcap * 8;
+    g->pos_err = e->pos_err + f * N; g->pos_err_any = e->pos_err_any + f; g->f_hcol = e->f_hcol + f * N;
     e->groups.push_back(g);
   }
   return SL2_OK;
@@ -302,8 +304,10 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (e->prm.minimum_attempted_measurements_of_feature <= 0) e->prm.minimum_attempted_measurements_of_feature = 10;
   if (!(e->prm.successful_match_fraction > 0.0)) e->prm.successful_match_fraction = 0.5;
   e->B = batch; e->N = max_features;
-  // columns: xv(13), 3 per feature slot, 6 for one partially initialised feature, 1 for the innovation (At / Vt)
-  e->ld = round_up(13 + 3 * max_features + 6 + 1, 64);
+  // columns: xv(13), 3 per feature slot, 6 per partially initialised feature in flight (params.max_features_to_init_at_once of
+  // them, the shipped value is 1), 1 for the innovation (At / Vt)
+  e->kpart = params->max_features_to_init_at_once < 1 ? 1 : (params->max_features_to_init_at_once > kMaxPartial ? kMaxPartial : params->max_features_to_init_at_once);
+  e->ld = round_up(13 + 3 * max_features + 6 * e->kpart + 1, 64);
   e->ppos = 13 + 3 * max_features;
   int nsel = params->number_of_features_to_select;
   if (nsel < 1) nsel = 1;
@@ -374,10 +378,15 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->LinvT, B * (size_t)e->nblk_max * 1024));
   A(dmalloc(&e->part_i, B * kPartInts));
   A(dmalloc(&e->part_d, B * kPartDoubles));
-  A(dmalloc(&e->particles, B * (size_t)e->pcap * kParticleDoubles));
+  A(dmalloc(&e->ps_i, B * (size_t)e->kpart * kPsInts));
+  A(dmalloc(&e->ps_d, B * (size_t)e->kpart * kPsDoubles));
+  A(dmalloc(&e->pos_err, B * N));
+  A(dmalloc(&e->pos_err_any, B));
+  A(dmalloc(&e->f_hcol, B * N));
+  A(dmalloc(&e->particles, B * (size_t)e->kpart * e->pcap * kParticleDoubles));
   A(dmalloc(&e->rand48, B));
   A(dmalloc(&e->prev_r, B * 3));
-  A(dmalloc(&e->me_desc, B * (size_t)e->pcap * 8));
+  A(dmalloc(&e->me_desc, B * (size_t)e->kpart * e->pcap * 8));
 #undef A
   {  // srand48(0) in MonoSLAM::Init (monoslam.cpp:1968), one generator per sequence
     std::vector<unsigned long long> seeds(B, kRand48Seed0);
@@ -436,7 +445,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->f_arow, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->me_big_list, e->pos_count, e->init_uv, e->f_label, e->next_label};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->me_big_list, e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->f_hcol, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->snap_stage) hipFree(e->snap_stage);
   if (e->snap_host) hipHostFree(e->snap_host);
@@ -641,9 +650,11 @@ static void drop_step_graphs_of(sl2_engine* e) {
 // what this engine supports and allocates the per-pixel maps of the multi-ellipse search.
 static int enable_feature_initialisation(sl2_engine* e) {
   if (e->mapping_used) return SL2_OK;
-  // what this engine supports is the shipped configuration (data/SceneLib2.cfg:62 max_features_to_init_at_once = 1)
-  if (e->prm.max_features_to_init_at_once != 1 || e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
-    set_error("feature initialisation: needs max_features_to_init_at_once == 1 (the shipped value) and 1 <= number_of_particles <= 1024");
+  // data/SceneLib2.cfg:62 ships max_features_to_init_at_once = 1; up to kMaxPartial partially initialised features per sequence
+  // are carried (six state columns each, reserved at sl2_create)
+  if (e->prm.max_features_to_init_at_once < 1 || e->prm.max_features_to_init_at_once > kMaxPartial ||
+      e->prm.number_of_particles < 1 || e->prm.number_of_particles > kMaxParticles) {
+    set_error("feature initialisation: needs 1 <= max_features_to_init_at_once <= 4 and 1 <= number_of_particles <= 1024");
     return SL2_ERR_INVALID;
   }
   if (e->groups.size() > 1) { set_error("feature initialisation: not available with sequence groups (sl2_set_groups > 1)"); return SL2_ERR_INVALID; }
@@ -661,13 +672,13 @@ static int enable_feature_initialisation(sl2_engine* e) {
     }
   }
   if (!e->score_map) {
-    const size_t px = (size_t)e->B * e->cam.width * e->cam.height;
+    const size_t px = (size_t)e->B * e->kpart * e->cam.width * e->cam.height;
     SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));
     SL2_HIP(hipMalloc((void**)&e->owner_map, sizeof(int) * px));
     SL2_HIP(hipMemsetAsync(e->owner_map, 0x7f, sizeof(int) * px, e->stream));   // 0x7f7f7f7f: above every particle index
-    SL2_HIP(hipMalloc((void**)&e->me_big_list, sizeof(int) * (e->B + 1)));
-    e->me_big_count = e->me_big_list + e->B;
-    SL2_HIP(hipMemsetAsync(e->me_big_list, 0, sizeof(int) * (e->B + 1), e->stream));
+    SL2_HIP(hipMalloc((void**)&e->me_big_list, sizeof(int) * ((size_t)e->B * e->kpart + 1)));
+    e->me_big_count = e->me_big_list + (size_t)e->B * e->kpart;
+    SL2_HIP(hipMemsetAsync(e->me_big_list, 0, sizeof(int) * ((size_t)e->B * e->kpart + 1), e->stream));
   }
   e->mapping_used = true;
   return SL2_OK;
@@ -799,9 +810,15 @@ int sl2_set_graph_mode(sl2_engine* e, int enabled) {
 
 struct HostSeq {
   std::vector<double> x, P;
-  std::vector<int> flags, labels;
+  std::vector<int> flags, labels, pos_err, ps;     // ps: [kpart][kPsInts]
   int n_slots = 0;
   int part[kPartInts] = {0};
+  // partial slot (0 .. kpart - 1) of the partially initialised feature whose label sits in feature slot f; -1: none
+  int pslot_of(int f, int kpart) const {
+    for (int k = 0; k < kpart; ++k)
+      if (ps[(size_t)k * kPsInts + kPsActive] && ps[(size_t)k * kPsInts + kPsLabel] == f) return k;
+    return -1;
+  }
 };
 
 static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
@@ -813,6 +830,10 @@ static int fetch_seq(sl2_engine* e, int seq, bool want_P, HostSeq& hs) {
   SL2_HIP(hipMemcpy(hs.flags.data(), e->f_flags + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
   hs.labels.resize(e->N);
   SL2_HIP(hipMemcpy(hs.labels.data(), e->f_label + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  hs.pos_err.resize(e->N);
+  SL2_HIP(hipMemcpy(hs.pos_err.data(), e->pos_err + (size_t)seq * e->N, sizeof(int) * e->N, hipMemcpyDeviceToHost));
+  hs.ps.resize((size_t)e->kpart * kPsInts);
+  SL2_HIP(hipMemcpy(hs.ps.data(), e->ps_i + (size_t)seq * e->kpart * kPsInts, sizeof(int) * hs.ps.size(), hipMemcpyDeviceToHost));
   hs.x.resize(e->ld);
   SL2_HIP(hipMemcpy(hs.x.data(), e->x + (size_t)seq * e->ld, sizeof(double) * e->ld, hipMemcpyDeviceToHost));
   if (want_P) {
@@ -845,7 +866,10 @@ static std::vector<int> live_index(const sl2_engine* e, const HostSeq& hs) {
   for (int f = 0; f < hs.n_slots; ++f) {
     if (hs.flags[f] & FF_ACTIVE) for (int k = 0; k < 3; ++k) idx.push_back(13 + 3 * f + k);
     // a partially initialised feature sits at its label's place in feature_list_ with six states
-    if (hs.flags[f] & FF_PARTIAL) for (int k = 0; k < 6; ++k) idx.push_back(e->ppos + k);
+    if (hs.flags[f] & FF_PARTIAL) {
+      const int ks = hs.pslot_of(f, e->kpart);
+      if (ks >= 0) for (int k = 0; k < 6; ++k) idx.push_back(e->ppos + 6 * ks + k);
+    }
   }
   return idx;
 }
@@ -926,12 +950,13 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
     fi.visible = (fl & FF_VISIBLE) ? 1 : 0;
     fi.attempted_measurements_of_feature = att[f];
     fi.successful_measurements_of_feature = suc[f];
-    fi.position_in_total_state_vector = active ? pos : -1;
+    fi.position_in_total_state_vector = active ? pos - hs.pos_err[f] : -1;      // (Q28: what the reference has on record)
     fi.fully_initialised_flag = partial ? 0 : 1;
     fi.state_size = partial ? 6 : 3;
     if (active) pos += fi.state_size;
-    for (int k = 0; k < 3; ++k) fi.y[k] = partial ? hs.x[e->ppos + k] : hs.x[13 + 3 * f + k];
-    for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? hs.x[e->ppos + 3 + k] : 0.0;
+    const int pcol = partial ? e->ppos + 6 * (hs.pslot_of(f, e->kpart) < 0 ? 0 : hs.pslot_of(f, e->kpart)) : 0;
+    for (int k = 0; k < 3; ++k) fi.y[k] = partial ? hs.x[pcol + k] : hs.x[13 + 3 * f + k];
+    for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? hs.x[pcol + 3 + k] : 0.0;
     for (int k = 0; k < 2; ++k) { fi.h[k] = h[f * 2 + k]; fi.z[k] = z[f * 2 + k]; fi.nu[k] = nu[f * 2 + k]; }
     fi.R = R[f];
     for (int k = 0; k < 4; ++k) fi.S[k] = S[f * 4 + k];
@@ -943,27 +968,39 @@ int sl2_get_features(sl2_engine* e, int seq, sl2_feature_info* out, int capacity
   return SL2_OK;
 }
 
-int sl2_get_partial_feature(sl2_engine* e, int seq, int32_t* ints, double* dbl, double* particles, int capacity) {
-  if (!range_ok(e, seq, 1) || !ints || !dbl) return SL2_ERR_INVALID;
+int sl2_get_partial_feature(sl2_engine* e, int seq, int index, int32_t* ints, double* dbl, double* particles, int capacity) {
+  if (!range_ok(e, seq, 1) || !ints || !dbl || index < 0) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   int pi[kPartInts];
   double pd[kPartDoubles];
   SL2_HIP(hipMemcpy(pi, e->part_i + (size_t)seq * kPartInts, sizeof(pi), hipMemcpyDeviceToHost));
   SL2_HIP(hipMemcpy(pd, e->part_d + (size_t)seq * kPartDoubles, sizeof(pd), hipMemcpyDeviceToHost));
-  for (int k = 0; k < kPartInts; ++k) ints[k] = pi[k];
-  if (pi[kPartActive] && pi[kPartLabel] >= 0 && pi[kPartLabel] < e->N)     // the record holds the SLOT: report the label
-    SL2_HIP(hipMemcpy(&ints[kPartLabel], e->f_label + (size_t)seq * e->N + pi[kPartLabel], sizeof(int), hipMemcpyDeviceToHost));
-  dbl[0] = pd[0]; dbl[1] = pd[1];
-  std::vector<double> y(6, 0.0);
-  if (pi[kPartActive]) SL2_HIP(hipMemcpy(y.data(), e->x + (size_t)seq * e->ld + e->ppos, sizeof(double) * 6, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 6; ++k) dbl[2 + k] = y[k];
+  for (int k = 0; k < 16; ++k) ints[k] = 0;
+  for (int k = 0; k < 9; ++k) dbl[k] = 0.0;
+  const int count = pi[kPartCount];
+  ints[0] = count;
+  ints[5] = pi[kPartUU]; ints[6] = pi[kPartVV]; ints[7] = pi[kPartRegionValid];
+  for (int k = 0; k < 4; ++k) ints[8 + k] = pi[kPartRegion + k];
+  ints[12] = pi[kPartInitialised]; ints[13] = pi[kPartConverted]; ints[14] = pi[kPartDeleted]; ints[15] = pi[kPartCreated];
   dbl[8] = pd[2];
-  if (particles && pi[kPartActive]) {
-    const int n = pi[kPartNp] < capacity ? pi[kPartNp] : capacity;
+  if (index >= count) return SL2_OK;
+  const int ks = pi[kPartOrder + index];           // the partial slot of the index-th entry of feature_init_info_vector_
+  int ps[kPsInts];
+  double psd[kPsDoubles];
+  SL2_HIP(hipMemcpy(ps, e->ps_i + ((size_t)seq * e->kpart + ks) * kPsInts, sizeof(ps), hipMemcpyDeviceToHost));
+  SL2_HIP(hipMemcpy(psd, e->ps_d + ((size_t)seq * e->kpart + ks) * kPsDoubles, sizeof(psd), hipMemcpyDeviceToHost));
+  ints[1] = -1;
+  if (ps[kPsLabel] >= 0 && ps[kPsLabel] < e->N)     // the record holds the SLOT: report the label
+    SL2_HIP(hipMemcpy(&ints[1], e->f_label + (size_t)seq * e->N + ps[kPsLabel], sizeof(int), hipMemcpyDeviceToHost));
+  ints[2] = ps[kPsAttempts]; ints[3] = ps[kPsNp]; ints[4] = ps[kPsMaking];
+  dbl[0] = psd[0]; dbl[1] = psd[1];
+  SL2_HIP(hipMemcpy(dbl + 2, e->x + (size_t)seq * e->ld + e->ppos + 6 * ks, sizeof(double) * 6, hipMemcpyDeviceToHost));
+  if (particles) {
+    const int n = ps[kPsNp] < capacity ? ps[kPsNp] : capacity;
     if (n > 0)
-      SL2_HIP(hipMemcpy(particles, e->particles + (size_t)seq * e->pcap * kParticleDoubles, sizeof(double) * n * kParticleDoubles,
-                        hipMemcpyDeviceToHost));
+      SL2_HIP(hipMemcpy(particles, e->particles + ((size_t)seq * e->kpart + ks) * e->pcap * kParticleDoubles,
+                        sizeof(double) * n * kParticleDoubles, hipMemcpyDeviceToHost));
   }
   return SL2_OK;
 }

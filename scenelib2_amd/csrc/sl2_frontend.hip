@@ -23,7 +23,7 @@ __device__ long long* g_front_trace = nullptr;     // development only: 8 cycle 
 // (static map): Pxx <- (F Pxx) F^T + Q, strip P[0:13, j] <- F P[0:13, j], mirrored.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
-                                                 double* __restrict__ prev_r, const int* __restrict__ part_i, int ppos, int ld,
+                                                 double* __restrict__ prev_r, const int* __restrict__ part_i, int pend, int ld,
                                                  double dt) {
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -31,8 +31,8 @@ __global__ void __launch_bounds__(256) k_predict(double* __restrict__ x, double*
   double* Pb = P + (size_t)b * ld * ld;
   FTR(0, 0);
   if (tid < 3) prev_r[b * 3 + tid] = xb[tid];   // prev_xp_pos (monoslam.cpp:121-124); xb is rewritten at the very end
-  // columns of the map: the 3-D features, and the six states of a partially initialised one at ppos
-  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * n_slots[b];
+  // columns of the map: the 3-D features, and the six states of every partial slot (pend = ppos + 6 kpart) while any is in use
+  const int n_used = part_i[(size_t)b * kPartInts + kPartCount] ? pend : 13 + 3 * n_slots[b];
   // the first batch of strip columns is fetched now: its memory latency hides behind the serial motion model
   double v0[13];
   for (int k = 0; k < 13; ++k) v0[k] = (13 + tid < n_used) ? Pb[(size_t)k * ld + 13 + tid] : 0.0;
@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
                                                   int* __restrict__ status, double* __restrict__ pos_log, int* __restrict__ pos_count, int N, int ld,
                                                   int min_attempts, double match_fraction, int save_trajectory,
-                                                  const int* __restrict__ part_i, int ppos) {
+                                                  const int* __restrict__ part_i, int pend) {
   extern __shared__ int s_del[];  // [N] slots deleted this frame, then [N] flags
   __shared__ double s_N[16], s_P[169], s_T[169];
   __shared__ int s_ndel;
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
   const int ns = n_slots[b];
-  const int n_used = part_i[(size_t)b * kPartInts + kPartActive] ? ppos + 6 : 13 + 3 * ns;
+  const int n_used = part_i[(size_t)b * kPartInts + kPartCount] ? pend : 13 + 3 * ns;
   const bool updated = (n_sel[b] > 0) && (m_count[b] > 0);
   // Everything this kernel reads that does not depend on its own results is requested NOW, in one round trip: the vehicle
   // block, this thread's strip columns (rows 3..6), its feature's flags and counters.  (Phase by phase the kernel was a
@@ -470,7 +470,7 @@ namespace sl2 {
 
 int launch_predict(sl2_engine* e) {
   LaunchScope ls(e, "k_predict");
-  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(256), 0, e->stream, e->x, e->P, e->n_slots, e->prev_r, e->part_i, e->ppos, e->ld,
+  hipLaunchKernelGGL(k_predict, dim3(e->B), dim3(256), 0, e->stream, e->x, e->P, e->n_slots, e->prev_r, e->part_i, e->ppos + 6 * e->kpart, e->ld,
                      e->prm.delta_t);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
@@ -501,7 +501,7 @@ int launch_finalize(sl2_engine* e, int save_trajectory) {
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
                      e->pos_count, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
-                     e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos);
+                     e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos + 6 * e->kpart);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

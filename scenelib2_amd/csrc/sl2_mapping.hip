@@ -1,6 +1,6 @@
 // Feature initialisation inside the per-frame step: the tail of
-// MonoSLAM::GoOneStep (monoslam.cpp:152-170) for the whole batch, one partially initialised
-// feature per sequence (the shipped max_features_to_init_at_once = 1):
+// MonoSLAM::GoOneStep (monoslam.cpp:152-170) for the whole batch, up to kMaxPartial partially initialised
+// features per sequence (params.max_features_to_init_at_once; the shipped value is 1):
 //
 //   k_map_region     speed gate + AutoInitialiseFeature's region choice     monoslam.cpp:159-165, 823-1032
 //   k_map_detect     set_image_selection_automatically (Shi-Tomasi)         :1043-1205
@@ -11,10 +11,12 @@
 //                    convert_from_partially_to_fully_initialised, sell-by deletion, trajectory push
 //                                                                           :1299-1342, 1449-1538, feature.cpp:204-269
 //
-// State layout: the partial feature's six states (r_W, hhat_W) live in columns ppos = 13 + 3N .. ppos + 5
-// of x / P (it is always the last feature of feature_list_, so this IS the reference's order); its label
-// slot is reserved at creation (next_free_label_++) and receives the 3-D point at conversion.  A deleted
-// or converted partial feature leaves its six rows / columns zero.
+// State layout: the six states (r_W, hhat_W) of the partial feature in partial slot k live in columns ppos + 6 k ..
+// ppos + 6 k + 5 of x / P, ppos = 13 + 3N (behind the map: the update's algebra does not care where a state sits, and the
+// accessors put them back at their feature's place in feature_list_ order); its label slot is reserved at creation
+// (next_free_label_++) and receives the 3-D point at conversion.  A deleted or converted partial feature leaves its six
+// rows / columns zero.  feature_init_info_vector_'s order (creation order, entries erased on conversion / deletion) is the
+// list part_i[kPartOrder ..]: the reference walks that vector with its erase-inside-the-loop quirks, and so do we.
 #include "sl2_improc_dev.hpp"
 #include "sl2_mapmath.hpp"
 
@@ -25,7 +27,8 @@ struct MapParams {
   int force;      // InitialiseAutoFeature (monoslam.cpp:1535-1541): no speed gate, no visible-feature count
   int keep_visible, n_particles, min_particles, erase_after;
   double min_lambda, max_lambda, sd_ratio, prune_threshold, dt;
-  int pcap;       // particle slots per sequence in `particles` / `me_desc` (sl2_engine::pcap)
+  int pcap;       // particle slots per partial feature in `particles` / `me_desc` (sl2_engine::pcap)
+  int kpart;      // partial slots per sequence (sl2_engine::kpart)
 };
 
 // ---------------------------------------------------------------------------
@@ -51,7 +54,9 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
     const double vx = (xb[0] - prev_r[b * 3 + 0]) / mp.dt, vy = (xb[1] - prev_r[b * 3 + 1]) / mp.dt,
                  vz = (xb[2] - prev_r[b * 3 + 2]) / mp.dt;
     const double speed = sqrt(vx * vx + vy * vy + vz * vz);
-    if ((mp.force || (speed > 0.2 && mp.enable_mapping && n_vis[b] < mp.keep_visible)) && !pi[kPartActive]) {
+    // feature_init_info_vector_.size() < kMaxFeaturesToInitAtOnce_ (monoslam.cpp:163-165; the buttons have no such gate in the
+    // reference, but a sequence has only kpart partial slots here)
+    if ((mp.force || (speed > 0.2 && mp.enable_mapping && n_vis[b] < mp.keep_visible)) && pi[kPartCount] < mp.kpart) {
       if (ns >= N) {
         status[b] |= 2;            // the map is full: cannot reserve a label (capacity chosen at sl2_create)
       } else {
@@ -148,19 +153,27 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
                                                    int* __restrict__ attempted, int* __restrict__ successful,
                                                    int* __restrict__ f_label, int* __restrict__ next_label,
                                                    int* __restrict__ part_i, double* __restrict__ part_d,
+                                                   int* __restrict__ ps_i, double* __restrict__ ps_d, int* __restrict__ pos_err,
                                                    double* __restrict__ particles, double* __restrict__ last_r, CameraParams cam,
-                                                   MapParams mp, int N, int ld, int ppos) {
+                                                   MapParams mp, int N, int ld, int ppos0) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   double* pd = part_d + (size_t)b * kPartDoubles;
   if (!pi[kPartRegionValid]) return;
   if (!(pd[2] > 20000)) return;        // SUITABLE_PATCH_SCORE_THRESHOLD (:837, 850-858)
+  // the partial slot this feature takes: the first free one (k_map_region / k_map_manual checked that there is one)
+  int* psb = ps_i + (size_t)b * mp.kpart * kPsInts;
+  int ks = 0;
+  while (ks < mp.kpart - 1 && psb[ks * kPsInts + kPsActive]) ++ks;
+  if (psb[ks * kPsInts + kPsActive]) return;
+  const int ppos = ppos0 + 6 * ks;
   // (`label` below is the SLOT the feature takes - the end of the list; its Feature::label_ comes from next_label)
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
   const int label = n_slots[b];
   const int uu = pi[kPartUU], vv = pi[kPartVV];
   __shared__ double s_T[6 * 13], s_D[12], s_col[6 * 13], s_y[6], s_Ri;
+  __shared__ int s_extra[6 * kMaxPartial], s_nextra;
   if (lane == 0) {
     double xp[7], ypi[6], Tq[12], Dh[6], Ri;
     for (int i = 0; i < 7; ++i) xp[i] = xb[i];
@@ -174,11 +187,18 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     for (int k = 0; k < 3; ++k) { s_D[(3 + k) * 2 + 0] = Dh[k * 2 + 0]; s_D[(3 + k) * 2 + 1] = Dh[k * 2 + 1]; }
     for (int i = 0; i < 6; ++i) s_y[i] = ypi[i];
     s_Ri = Ri;
+    // the other partially initialised features are earlier entries of feature_list_ too: their six columns get cross terms
+    int ne = 0;
+    for (int j = 0; j < mp.kpart; ++j)
+      if (j != ks && psb[j * kPsInts + kPsActive])
+        for (int k = 0; k < 6; ++k) s_extra[ne++] = ppos0 + 6 * j + k;
+    s_nextra = ne;
   }
   __syncthreads();
   // new columns: P[c][ppos + k] = sum_i T[k][i] P[i][c]  (Pxy = Pxx T^T and (T Pxy_j)^T, feature.cpp:82-103)
   const int n_rows = 13 + 3 * label;
-  for (int c = lane; c < n_rows; c += 64) {
+  for (int cc = lane; cc < n_rows + s_nextra; cc += 64) {
+    const int c = cc < n_rows ? cc : s_extra[cc - n_rows];
     double pc[13];
     for (int i = 0; i < 13; ++i) pc[i] = (c < 13) ? Pb[(size_t)c * ld + i] : Pb[(size_t)i * ld + c];
     for (int k = 0; k < 6; ++k) {
@@ -207,6 +227,7 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     xp_org[fi * 8 + 7] = 0.0;
     f_flags[fi] = FF_USED | FF_PARTIAL;
     attempted[fi] = 0; successful[fi] = 0;
+    pos_err[fi] = 0;
     f_label[fi] = next_label[b];           // label_ = next_free_label_++ (monoslam.cpp:1306-1307)
     next_label[b] += 1;
     n_slots[b] = label + 1;
@@ -244,17 +265,20 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     const double lambda_step = (1.0 / double(mp.n_particles)) * (mp.max_lambda - mp.min_lambda);
     const double uniform_probability = 1.0 / double(mp.n_particles);
     double lambda = mp.min_lambda;
-    double* pp = particles + (size_t)b * mp.pcap * kParticleDoubles;
+    double* pp = particles + ((size_t)b * mp.kpart + ks) * mp.pcap * kParticleDoubles;
     for (int i = 0; i < mp.n_particles; ++i) {
       double* o = pp + (size_t)i * kParticleDoubles;
       for (int k = 0; k < kParticleDoubles; ++k) o[k] = 0.0;
       o[0] = lambda; o[1] = uniform_probability;
       lambda += lambda_step;
     }
-    pi[kPartActive] = 1; pi[kPartLabel] = label; pi[kPartAttempts] = 0; pi[kPartNp] = mp.n_particles; pi[kPartMaking] = 0;
+    int* ps = psb + ks * kPsInts;
+    ps[kPsActive] = 1; ps[kPsLabel] = label; ps[kPsAttempts] = 0; ps[kPsNp] = mp.n_particles; ps[kPsMaking] = 0;
+    pi[kPartOrder + pi[kPartCount]] = ks;          // feature_init_info_vector_.push_back
+    pi[kPartCount] += 1;
     pi[kPartCreated] = 1;
     pi[kPartInitialised] += 1;
-    pd[0] = 0.0; pd[1] = 0.0;
+    ps_d[((size_t)b * mp.kpart + ks) * kPsDoubles + 0] = 0.0; ps_d[((size_t)b * mp.kpart + ks) * kPsDoubles + 1] = 0.0;
     for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xb[k];
   }
 }
@@ -267,32 +291,34 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
 // (128 registers) spills - and only engines created for more particles take the wider, spilling instantiations.
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
-                                                                 int* __restrict__ part_i, double* __restrict__ particles,
+                                                                 int* __restrict__ ps_i, double* __restrict__ particles,
                                                                  int* __restrict__ me_desc, double* __restrict__ last_r,
-                                                                 int* __restrict__ me_big_count, CameraParams cam, int ld, int ppos, int pcap) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  int* pi = part_i + (size_t)b * kPartInts;
-  if (b == 0 && tid == 0) *me_big_count = 0;     // the step's list of oversized multi-ellipse searches starts empty
-  if (!pi[kPartActive]) return;
+                                                                 int* __restrict__ me_big_count, CameraParams cam, int ld, int ppos0, int pcap,
+                                                                 int kpart) {
+  const int b = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x;       // one workgroup per (sequence, partial slot)
+  int* ps = ps_i + ((size_t)b * kpart + ks) * kPsInts;
+  if (b == 0 && ks == 0 && tid == 0) *me_big_count = 0;     // the step's list of oversized multi-ellipse searches starts empty
+  if (!ps[kPsActive]) return;
   __shared__ int s_making;
   if (tid == 0) {
-    const int att = pi[kPartAttempts];
-    pi[kPartAttempts] = att + 1;                 // number_of_match_attempts_++ != 0  (Q29)
+    const int att = ps[kPsAttempts];
+    ps[kPsAttempts] = att + 1;                  // number_of_match_attempts_++ != 0  (Q29)
     s_making = (att != 0) ? 1 : 0;
-    pi[kPartMaking] = s_making;
+    ps[kPsMaking] = s_making;
   }
   __syncthreads();
   if (!s_making) return;
+  const int ppos = ppos0 + 6 * ks;
   const double* xb = x + (size_t)b * ld;
   const double* Pb = P + (size_t)b * ld * ld;
   if (tid == 0)
     for (int k = 0; k < 3; ++k) last_r[b * 3 + k] = xb[k];   // func_zeroedyi -> func_r(xp), Q12
-  const int np = pi[kPartNp];
+  const int np = ps[kPsNp];
   if (tid >= np) return;
   double xp[7], ypi[6];
   for (int i = 0; i < 7; ++i) xp[i] = xb[i];
   for (int i = 0; i < 6; ++i) ypi[i] = xb[ppos + i];
-  double* o = particles + ((size_t)b * pcap + tid) * kParticleDoubles;
+  double* o = particles + (((size_t)b * kpart + ks) * pcap + tid) * kParticleDoubles;
   double h[2], Hx[14], Hy[12], Rn;
   part_measurement_model(cam, xp, ypi, o[0], h, Hx, Hy, &Rn);
   double Pxx7[49], Pxy7[42], Pyy[36], S[4];
@@ -308,7 +334,7 @@ __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restr
   o[3] = h[0]; o[4] = h[1];
   o[7] = a; o[8] = bq; o[9] = c;
   o[10] = det2_partial_pivot_lu(S);
-  me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + ((size_t)b * pcap + tid) * 8);
+  me_describe(a, bq, c, h[0], h[1], cam.width, cam.height, me_desc + (((size_t)b * kpart + ks) * pcap + tid) * 8);
 }
 
 // measure_feature_with_multiple_priors (monoslam.cpp:1411-1439) + SearchMultipleOverlappingEllipses::search: the whole
@@ -316,19 +342,19 @@ __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restr
 // bounding box in LDS (me_search_fused_wg; rounds 1-3 ran three launches - k_map_me_mark, k_map_me_scores, k_map_me_argmin -
 // through image-sized maps in HBM, walking every ellipse's box column by column: 1.3 ms of a 1.35 ms mapping step at batch
 // 1024, profiles/r04_mapping_*).  A sequence whose union is too large for that goes on the list of k_me_big_*.
-struct MeJobsEngine {
-  const uint8_t* frames; size_t seq_stride; const uint8_t* patch_base; const int* part_i; const int* me_desc; double* particles;
-  int* owner_base; double* map_base; int N, pcap, width, height;
-  __device__ const int* pi(int b) const { return part_i + (size_t)b * kPartInts; }
-  __device__ const uint8_t* img(int b) const { return frames + (size_t)b * seq_stride; }
-  __device__ const uint8_t* patch(int b) const { return patch_base + ((size_t)b * N + pi(b)[kPartLabel]) * kPatchStride; }
-  __device__ const int* desc(int b) const { return me_desc + (size_t)b * pcap * 8; }
-  __device__ int n_ell(int b) const { return pi(b)[kPartNp]; }
-  __device__ const double* pu(int b, int e) const { return particles + ((size_t)b * pcap + e) * kParticleDoubles + 7; }
-  __device__ int* owner(int b) const { return owner_base + (size_t)b * width * height; }
-  __device__ double* map(int b) const { return map_base + (size_t)b * width * height; }
-  __device__ void emit(int b, int e, int flag, int u, int v, double) const {
-    double* o = particles + ((size_t)b * pcap + e) * kParticleDoubles;
+struct MeJobsEngine {      // job = sequence * kpart + partial slot
+  const uint8_t* frames; size_t seq_stride; const uint8_t* patch_base; const int* ps_i; const int* me_desc; double* particles;
+  int* owner_base; double* map_base; int N, pcap, width, height, kpart;
+  __device__ const int* ps(int j) const { return ps_i + (size_t)j * kPsInts; }
+  __device__ const uint8_t* img(int j) const { return frames + (size_t)(j / kpart) * seq_stride; }
+  __device__ const uint8_t* patch(int j) const { return patch_base + ((size_t)(j / kpart) * N + ps(j)[kPsLabel]) * kPatchStride; }
+  __device__ const int* desc(int j) const { return me_desc + (size_t)j * pcap * 8; }
+  __device__ int n_ell(int j) const { return ps(j)[kPsNp]; }
+  __device__ const double* pu(int j, int e) const { return particles + ((size_t)j * pcap + e) * kParticleDoubles + 7; }
+  __device__ int* owner(int j) const { return owner_base + (size_t)j * width * height; }
+  __device__ double* map(int j) const { return map_base + (size_t)j * width * height; }
+  __device__ void emit(int j, int e, int flag, int u, int v, double) const {
+    double* o = particles + ((size_t)j * pcap + e) * kParticleDoubles;
     if (flag) {           // the measurement is stored only on success (:1429-1437)
       o[5] = (double)u;
       o[6] = (double)v;
@@ -339,44 +365,95 @@ struct MeJobsEngine {
   }
 };
 __global__ void __launch_bounds__(1024) k_map_me_search(MeJobsEngine J, int* __restrict__ big_list, int* __restrict__ big_count) {
-  const int b = blockIdx.x;
-  const int* pi = J.pi(b);
-  if (!pi[kPartActive] || !pi[kPartMaking]) return;
-  const bool done = me_search_fused_wg(J.img(b), J.width, J.patch(b), J.desc(b), J.n_ell(b), [&](int e) { return J.pu(b, e); },
-                                       [&](int e, int flag, int u, int v, double best) { J.emit(b, e, flag, u, v, best); });
-  if (!done && threadIdx.x == 0) big_list[atomicAdd(big_count, 1)] = b;
+  const int j = blockIdx.x;
+  const int* ps = J.ps(j);
+  if (!ps[kPsActive] || !ps[kPsMaking]) return;
+  const bool done = me_search_fused_wg(J.img(j), J.width, J.patch(j), J.desc(j), J.n_ell(j), [&](int e) { return J.pu(j, e); },
+                                       [&](int e, int flag, int u, int v, double best) { J.emit(j, e, flag, u, v, best); });
+  if (!done && threadIdx.x == 0) big_list[atomicAdd(big_count, 1)] = j;
 }
 
 // ---------------------------------------------------------------------------
-// k_map_update: one wavefront per sequence.  Lane 0 walks the particle list exactly like the reference
-// (Bayes update, normalise, prune, normalise, mean / covariance, conversion and sell-by tests); the
-// covariance surgery of a conversion / deletion is done by all lanes.
+// k_map_update: one wavefront per sequence; the rest of MatchPartiallyInitialisedFeatures (monoslam.cpp:1299-1342) over the
+// sequence's partially initialised features IN THE ORDER OF feature_init_info_vector_ (part_i[kPartOrder ..]):
+//   A  update_partially_initialised_feature_probabilities (:1449-1497): Bayes update, normalise, prune, normalise, mean /
+//      covariance per feature; a feature whose matches all failed is deleted - inside a `for (; feat < end; ++feat)` loop, so
+//      the entry that slides into its place is SKIPPED in this pass (it keeps last frame's weights, mean and covariance);
+//   B  the conversion test (:1316-1333) on every entry that was measured, erase(feat--) + ++feat: nothing is skipped;
+//   C  delete_partially_initialised_features_past_sell_by_date (:1506-1521).
+// Per feature the particle list lives in LDS: the per-particle arithmetic (likelihood, division by the total, pruning test,
+// compaction) runs on all lanes; every SUM is formed by lane 0 in list order, which is the reference's order (the sums
+// decide the bits of the weights, and through them pruning and conversion).  The covariance surgery of a conversion /
+// deletion is done by all lanes.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, double* __restrict__ P, int* __restrict__ f_flags,
                                                    const int* __restrict__ n_slots, int* __restrict__ part_i,
-                                                   double* __restrict__ part_d, double* __restrict__ particles,
+                                                   int* __restrict__ ps_i, double* __restrict__ ps_d, int* __restrict__ pos_err,
+                                                   int* __restrict__ pos_err_any, double* __restrict__ particles,
                                                    double* __restrict__ traj, int* __restrict__ traj_count,
-                                                   const double* __restrict__ last_r, MapParams mp, int N, int ld, int ppos) {
+                                                   const double* __restrict__ last_r, MapParams mp, int N, int ld, int ppos0) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
-  double* pd = part_d + (size_t)b * kPartDoubles;
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
-  __shared__ int s_action;         // 0 none, 1 convert, 2 delete
+  const int ns = n_slots[b];
+  __shared__ int s_count, s_order[kMaxPartial];
+  __shared__ int s_flag;           // scratch decision of lane 0
   __shared__ int s_np;
-  __shared__ double s_lambda, s_plambda, s_total;
+  __shared__ double s_total;
   extern __shared__ double s_p[];        // [number_of_particles][kParticleDoubles]
-  // The particle list lives in LDS for the duration of the update: the per-particle arithmetic (likelihood, division
-  // by the total, pruning test, compaction) runs on all lanes; every SUM is formed by lane 0 in list order, which is
-  // the reference's order (the sums decide the bits of the weights, and through them pruning and conversion).
-  const bool active = pi[kPartActive] != 0, making = active && pi[kPartMaking] != 0;
-  double* pp = particles + (size_t)b * mp.pcap * kParticleDoubles;
-  int np = active ? pi[kPartNp] : 0;
-  if (lane == 0) { s_action = 0; s_np = np; }
-  if (making) {
-    for (int idx = lane; idx < np * kParticleDoubles; idx += 64) s_p[idx] = pp[idx];
+  if (lane == 0) {
+    s_count = pi[kPartCount];
+    for (int k = 0; k < kMaxPartial; ++k) s_order[k] = pi[kPartOrder + k];
+  }
+  __syncthreads();
+
+  // vector::erase(begin + idx)
+  auto erase_entry = [&](int idx) {
+    if (lane == 0) {
+      for (int k = idx; k + 1 < s_count; ++k) s_order[k] = s_order[k + 1];
+      s_count -= 1;
+    }
     __syncthreads();
-    // update_partially_initialised_feature_probabilities (:1449-1497)
+  };
+  // the six rows / columns of partial slot ks are released (zero = absent), its record cleared
+  auto release_slot = [&](int ks) {
+    const int ppos = ppos0 + 6 * ks;
+    for (int c = lane; c < ld; c += 64)
+      for (int k = 0; k < 6; ++k) {
+        Pb[(size_t)c * ld + ppos + k] = 0.0;
+        Pb[(size_t)(ppos + k) * ld + c] = 0.0;
+      }
+    if (lane == 0) {
+      for (int k = 0; k < 6; ++k) xb[ppos + k] = 0.0;
+      int* ps = ps_i + ((size_t)b * mp.kpart + ks) * kPsInts;
+      ps[kPsActive] = 0; ps[kPsMaking] = 0; ps[kPsNp] = 0;
+    }
+    __syncthreads();
+  };
+  // delete_partially_initialised_feature (:1523-1538): delete_feature() consumes the label, the entry leaves the vector
+  auto delete_partial = [&](int idx) {
+    const int ks = s_order[idx];
+    if (lane == 0) {
+      const int label = ps_i[((size_t)b * mp.kpart + ks) * kPsInts + kPsLabel];
+      f_flags[(size_t)b * N + label] = FF_USED;
+      pi[kPartDeleted] += 1;
+    }
+    release_slot(ks);
+    erase_entry(idx);
+  };
+
+  // ---- A: update_partially_initialised_feature_probabilities
+  for (int idx = 0; idx < s_count; ++idx) {
+    const int ks = s_order[idx];
+    int* ps = ps_i + ((size_t)b * mp.kpart + ks) * kPsInts;
+    double* pd = ps_d + ((size_t)b * mp.kpart + ks) * kPsDoubles;
+    if (!ps[kPsMaking]) continue;
+    double* pp = particles + ((size_t)b * mp.kpart + ks) * mp.pcap * kParticleDoubles;
+    int np = ps[kPsNp];
+    __syncthreads();                               // (the previous feature is done with s_p)
+    for (int i = lane; i < np * kParticleDoubles; i += 64) s_p[i] = pp[i];
+    __syncthreads();
     for (int i = lane; i < np; i += 64) {
       double* o = s_p + i * kParticleDoubles;
       double likelihood = 0.0;
@@ -388,151 +465,167 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
       double total = 0.0;
       for (int i = 0; i < np; ++i) total += s_p[i * kParticleDoubles + 1];
       s_total = total;
-      if (total == 0.0) s_action = 2;   // every match failed: the feature goes (:1490-1494)
+      s_flag = (total == 0.0) ? 1 : 0;             // every match failed: the feature goes (:1490-1494)
     }
     __syncthreads();
-    if (s_action == 0) {
-      double total = s_total;
-      for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
-      __syncthreads();
-      // (the cumulative column is rewritten after pruning; only its final values are ever read)
-      // prune_particle_vector (feature_init_info.cpp:131-147): order-preserving compaction, 64 particles per round; a
-      // round's destinations lie below its own sources and below every later round's sources
-      const double prune_threshold = mp.prune_threshold / double(np);
-      int kept = 0;
-      for (int i0 = 0; i0 < np; i0 += 64) {
-        const int i = i0 + lane;
-        double v[kParticleDoubles];
-        bool keep = false;
-        if (i < np) {
-#pragma unroll
-          for (int k = 0; k < kParticleDoubles; ++k) v[k] = s_p[i * kParticleDoubles + k];
-          keep = !(v[1] < prune_threshold);
-        }
-        const unsigned long long mask = __ballot(keep);
-        __syncthreads();
-        if (keep) {
-          const int dst = kept + __popcll(mask & ((1ull << lane) - 1ull));
-#pragma unroll
-          for (int k = 0; k < kParticleDoubles; ++k) s_p[dst * kParticleDoubles + k] = v[k];
-        }
-        kept += __popcll(mask);
-        __syncthreads();
-      }
-      np = kept;
-      if (lane == 0) {
-        double tot2 = 0.0;
-        for (int i = 0; i < np; ++i) tot2 += s_p[i * kParticleDoubles + 1];
-        s_total = tot2;
-      }
-      __syncthreads();
-      total = s_total;
-      if (total != 0.0)
-        for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
-      __syncthreads();
-      if (lane == 0) {
-        double cum = 0.0;
-        for (int i = 0; i < np; ++i) {
-          cum += s_p[i * kParticleDoubles + 1];
-          s_p[i * kParticleDoubles + 2] = cum;
-        }
-        // (a zero total after pruning would need a zero pruning threshold, which prunes nothing: not reachable)
-        // calculate_mean_and_covariance (feature_init_info.cpp:157-174)
-        double mean = 0.0, e2 = 0.0;
-        for (int i = 0; i < np; ++i) {
-          const double* o = s_p + i * kParticleDoubles;
-          mean += o[1] * o[0];
-          e2 += o[1] * (o[0] * o[0]);
-        }
-        pd[0] = mean;
-        pd[1] = e2 - (mean * mean);
-        pi[kPartNp] = np;
-        s_np = np;
-        // conversion test (:1320-1332)
-        const double mean_sd_ratio = sqrt(pd[1]) / pd[0];
-        if (mean_sd_ratio < mp.sd_ratio && np > mp.min_particles) s_action = 1;
-      }
-      __syncthreads();
-      for (int idx = lane; idx < np * kParticleDoubles; idx += 64) pp[idx] = s_p[idx];
+    if (s_flag) {
+      delete_partial(idx);                         // the loop's ++idx now steps over the entry that moved into this place
+      continue;
     }
-  }
-  if (lane == 0) {
-    // delete_partially_initialised_features_past_sell_by_date (:1506-1521)
-    if (active && s_action == 0 && (pi[kPartAttempts] > mp.erase_after || s_np <= mp.min_particles)) s_action = 2;
-    s_lambda = pd[0];
-    s_plambda = pd[1];
+    double total = s_total;
+    for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
+    __syncthreads();
+    // (the cumulative column is rewritten after pruning; only its final values are ever read)
+    // prune_particle_vector (feature_init_info.cpp:131-147): order-preserving compaction, 64 particles per round; a
+    // round's destinations lie below its own sources and below every later round's sources
+    const double prune_threshold = mp.prune_threshold / double(np);
+    int kept = 0;
+    for (int i0 = 0; i0 < np; i0 += 64) {
+      const int i = i0 + lane;
+      double v[kParticleDoubles];
+      bool keep = false;
+      if (i < np) {
+#pragma unroll
+        for (int k = 0; k < kParticleDoubles; ++k) v[k] = s_p[i * kParticleDoubles + k];
+        keep = !(v[1] < prune_threshold);
+      }
+      const unsigned long long mask = __ballot(keep);
+      __syncthreads();
+      if (keep) {
+        const int dst = kept + __popcll(mask & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int k = 0; k < kParticleDoubles; ++k) s_p[dst * kParticleDoubles + k] = v[k];
+      }
+      kept += __popcll(mask);
+      __syncthreads();
+    }
+    np = kept;
+    if (lane == 0) {
+      double tot2 = 0.0;
+      for (int i = 0; i < np; ++i) tot2 += s_p[i * kParticleDoubles + 1];
+      s_total = tot2;
+    }
+    __syncthreads();
+    total = s_total;
+    if (total != 0.0)
+      for (int i = lane; i < np; i += 64) s_p[i * kParticleDoubles + 1] = s_p[i * kParticleDoubles + 1] / total;
+    __syncthreads();
+    if (lane == 0) {
+      double cum = 0.0;
+      for (int i = 0; i < np; ++i) {
+        cum += s_p[i * kParticleDoubles + 1];
+        s_p[i * kParticleDoubles + 2] = cum;
+      }
+      // (a zero total after pruning would need a zero pruning threshold, which prunes nothing: not reachable)
+      // calculate_mean_and_covariance (feature_init_info.cpp:157-174)
+      double mean = 0.0, e2 = 0.0;
+      for (int i = 0; i < np; ++i) {
+        const double* o = s_p + i * kParticleDoubles;
+        mean += o[1] * o[0];
+        e2 += o[1] * (o[0] * o[0]);
+      }
+      pd[0] = mean;
+      pd[1] = e2 - (mean * mean);
+      ps[kPsNp] = np;
+    }
+    __syncthreads();
+    for (int i = lane; i < np * kParticleDoubles; i += 64) pp[i] = s_p[i];
   }
   __syncthreads();
-  const int action = s_action;
-  if (action != 0) {
-    const int label = pi[kPartLabel];
+
+  // ---- B: conversion (:1316-1333)
+  for (int idx = 0; idx < s_count;) {
+    const int ks = s_order[idx];
+    int* ps = ps_i + ((size_t)b * mp.kpart + ks) * kPsInts;
+    double* pd = ps_d + ((size_t)b * mp.kpart + ks) * kPsDoubles;
+    if (lane == 0) {
+      s_flag = 0;
+      if (ps[kPsMaking]) {
+        const double mean_sd_ratio = sqrt(pd[1]) / pd[0];
+        if (mean_sd_ratio < mp.sd_ratio && ps[kPsNp] > mp.min_particles) s_flag = 1;
+      }
+    }
+    __syncthreads();
+    if (!s_flag) { ++idx; continue; }
+    // convert_from_partially_to_fully_initialised (feature.cpp:204-269): J = [I3 | lambda I3], d = hhat
+    const int ppos = ppos0 + 6 * ks;
+    const int label = ps[kPsLabel];
     const int fpos = 13 + 3 * label;
-    const int n_rows = 13 + 3 * n_slots[b];
-    if (action == 1) {
-      // convert_from_partially_to_fully_initialised (feature.cpp:204-269): J = [I3 | lambda I3], d = hhat
-      const double lam = s_lambda;
-      for (int c = lane; c < n_rows; c += 64) {
-        if (c >= fpos && c < fpos + 3) continue;
-        for (int k = 0; k < 3; ++k) {
-          // sum over the six partial states; only m = k and m = 3 + k are non-zero in J
+    const double lam = pd[0], plam = pd[1];
+    // every column that holds state: the pose, the feature slots, the other partial slots (their rows / columns are zero
+    // when unused, so they need no test)
+    const int n_rows = 13 + 3 * ns;
+    for (int cc = lane; cc < n_rows + 6 * mp.kpart; cc += 64) {
+      const int c = cc < n_rows ? cc : ppos0 + (cc - n_rows);
+      if ((c >= fpos && c < fpos + 3) || (c >= ppos && c < ppos + 6)) continue;
+      for (int k = 0; k < 3; ++k) {
+        // sum over the six partial states; only m = k and m = 3 + k are non-zero in J
+        double acc = 0.0;
+        for (int m = 0; m < 6; ++m) {
+          const double j = (m == k) ? 1.0 : ((m == 3 + k) ? lam : 0.0);
+          acc += Pb[(size_t)c * ld + ppos + m] * j;
+        }
+        Pb[(size_t)c * ld + fpos + k] = acc;
+        Pb[(size_t)(fpos + k) * ld + c] = acc;
+      }
+    }
+    if (lane == 0) {
+      double Pyy6[36], JP[18], d[3], y3[3];
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) Pyy6[r * 6 + c] = Pb[(size_t)(ppos + r) * ld + ppos + c];
+      for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 6; ++c) {
           double acc = 0.0;
           for (int m = 0; m < 6; ++m) {
             const double j = (m == k) ? 1.0 : ((m == 3 + k) ? lam : 0.0);
-            acc += Pb[(size_t)c * ld + ppos + m] * j;
+            acc += j * Pyy6[m * 6 + c];
           }
-          Pb[(size_t)c * ld + fpos + k] = acc;
-          Pb[(size_t)(fpos + k) * ld + c] = acc;
+          JP[k * 6 + c] = acc;
         }
-      }
-      if (lane == 0) {
-        double Pyy6[36], JP[18], d[3], y3[3];
-        for (int r = 0; r < 6; ++r)
-          for (int c = 0; c < 6; ++c) Pyy6[r * 6 + c] = Pb[(size_t)(ppos + r) * ld + ppos + c];
-        for (int k = 0; k < 3; ++k)
-          for (int c = 0; c < 6; ++c) {
-            double acc = 0.0;
-            for (int m = 0; m < 6; ++m) {
-              const double j = (m == k) ? 1.0 : ((m == 3 + k) ? lam : 0.0);
-              acc += j * Pyy6[m * 6 + c];
-            }
-            JP[k * 6 + c] = acc;
+      for (int k = 0; k < 3; ++k) { d[k] = xb[ppos + 3 + k]; y3[k] = xb[ppos + k] + lam * xb[ppos + 3 + k]; }
+      for (int k = 0; k < 3; ++k)
+        for (int l = 0; l < 3; ++l) {
+          double a1 = 0.0;
+          for (int m = 0; m < 6; ++m) {
+            const double j = (m == l) ? 1.0 : ((m == 3 + l) ? lam : 0.0);
+            a1 += JP[k * 6 + m] * j;
           }
-        for (int k = 0; k < 3; ++k) { d[k] = xb[ppos + 3 + k]; y3[k] = xb[ppos + k] + lam * xb[ppos + 3 + k]; }
-        for (int k = 0; k < 3; ++k)
-          for (int l = 0; l < 3; ++l) {
-            double a1 = 0.0;
-            for (int m = 0; m < 6; ++m) {
-              const double j = (m == l) ? 1.0 : ((m == 3 + l) ? lam : 0.0);
-              a1 += JP[k * 6 + m] * j;
-            }
-            const double a2 = (d[k] * s_plambda) * d[l];
-            Pb[(size_t)(fpos + k) * ld + fpos + l] = a1 + a2;
-          }
-        for (int k = 0; k < 3; ++k) xb[fpos + k] = y3[k];
-        f_flags[(size_t)b * N + label] = FF_USED | FF_ACTIVE;
-        pi[kPartConverted] += 1;
-      }
-    } else if (lane == 0) {
-      f_flags[(size_t)b * N + label] = FF_USED;     // delete_feature(): the label is consumed
-      pi[kPartDeleted] += 1;
+          const double a2 = (d[k] * plam) * d[l];
+          Pb[(size_t)(fpos + k) * ld + fpos + l] = a1 + a2;
+        }
+      for (int k = 0; k < 3; ++k) xb[fpos + k] = y3[k];
+      f_flags[(size_t)b * N + label] = FF_USED | FF_ACTIVE;
+      pi[kPartConverted] += 1;
+    }
+    // Q28 (feature.cpp:254): every LATER feature of feature_list_ has its position_in_total_state_vector_ moved by 6, the
+    // partial model's size, where the state shrank by 3: from now on its dh_by_dy lands three columns early in H
+    {
+      bool any = false;
+      for (int f = label + 1 + lane; f < ns; f += 64)
+        if (f_flags[(size_t)b * N + f] & (FF_ACTIVE | FF_PARTIAL)) { pos_err[(size_t)b * N + f] += 3; any = true; }
+      if (__any(any) && lane == 0) pos_err_any[b] = 1;
     }
     __syncthreads();
-    // the six partial rows / columns are released (zero = absent)
-    for (int c = lane; c < ld; c += 64)
-      for (int k = 0; k < 6; ++k) {
-        Pb[(size_t)c * ld + ppos + k] = 0.0;
-        Pb[(size_t)(ppos + k) * ld + c] = 0.0;
-      }
-    if (lane == 0) {
-      for (int k = 0; k < 6; ++k) xb[ppos + k] = 0.0;
-      pi[kPartActive] = 0; pi[kPartMaking] = 0; pi[kPartNp] = 0;
-    }
+    release_slot(ks);
+    erase_entry(idx);                    // erase(feat--) then ++feat: the entry that moved up is examined next
   }
-  if (lane == 0 && mp.save_trajectory) {   // monoslam.cpp:172-177, after the mapping tail (stale rRES_, Q12)
-    const int c = traj_count[b];
-    double* t = traj + ((size_t)b * kTrajCapacity + (c % kTrajCapacity)) * 3;
-    for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
-    traj_count[b] = c + 1;
+
+  // ---- C: delete_partially_initialised_features_past_sell_by_date (:1506-1521)
+  for (int idx = 0; idx < s_count;) {
+    const int ks = s_order[idx];
+    const int* ps = ps_i + ((size_t)b * mp.kpart + ks) * kPsInts;
+    if (ps[kPsAttempts] > mp.erase_after || ps[kPsNp] <= mp.min_particles) delete_partial(idx);
+    else ++idx;
+  }
+  if (lane == 0) {
+    pi[kPartCount] = s_count;
+    for (int k = 0; k < kMaxPartial; ++k) pi[kPartOrder + k] = s_order[k];
+    if (mp.save_trajectory) {   // monoslam.cpp:172-177, after the mapping tail (stale rRES_, Q12)
+      const int c = traj_count[b];
+      double* t = traj + ((size_t)b * kTrajCapacity + (c % kTrajCapacity)) * 3;
+      for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
+      traj_count[b] = c + 1;
+    }
   }
 }
 
@@ -549,7 +642,8 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
 struct SlotArrays {
   double *x, *P, *xp_org, *f_h, *f_Hx, *f_Hy, *f_R, *f_S, *f_score, *f_z, *f_nu, *srch_d;
   uint8_t* patch;
-  int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *f_arow, *n_sel, *m_count, *n_slots, *part_i;
+  int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *f_arow, *n_sel, *m_count, *n_slots, *ps_i, *pos_err;
+  int kpart;
 };
 template <typename T>
 __device__ __forceinline__ void slot_move(T* base, int per, int dst, int src, int tid, int nthreads) {
@@ -600,6 +694,7 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
       slot_move(a.srch_i + o * 8, 8, d, f, tid, nt);
       slot_move(a.srch_d + o * 4, 4, d, f, tid, nt);
       slot_move(a.f_arow + o, 1, d, f, tid, nt);      // (slot-indexed like the rest: a squeeze between make_measurements and the update)
+      slot_move(a.pos_err + o, 1, d, f, tid, nt);
       slot_move(a.x + (size_t)b * ld + 13, 3, d, f, tid, nt);
     }
     __syncthreads();
@@ -607,15 +702,16 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
   for (int f = nl + tid; f < ns; f += nt) {                      // the freed slots: unused again
     flags[f] = 0;
     a.f_arow[o + f] = -1;
+    a.pos_err[o + f] = 0;
     a.attempted[o + f] = 0; a.successful[o + f] = 0;
     for (int k = 0; k < 3; ++k) a.x[(size_t)b * ld + 13 + 3 * f + k] = 0.0;
   }
   // slot numbers held elsewhere
   for (int k = tid; k < a.n_sel[b]; k += nt) { const int f = a.sel_idx[o + k]; a.sel_idx[o + k] = (f >= 0 && f < ns) ? s_new[f] : -1; }
   for (int k = tid; k < a.m_count[b]; k += nt) { const int f = a.succ_idx[o + k]; a.succ_idx[o + k] = (f >= 0 && f < ns) ? s_new[f] : -1; }
-  if (tid == 0) {
-    int* pi = a.part_i + (size_t)b * kPartInts;
-    if (pi[kPartActive] && pi[kPartLabel] >= 0 && pi[kPartLabel] < ns) pi[kPartLabel] = s_new[pi[kPartLabel]];
+  if (tid < a.kpart) {
+    int* ps = a.ps_i + ((size_t)b * a.kpart + tid) * kPsInts;
+    if (ps[kPsActive] && ps[kPsLabel] >= 0 && ps[kPsLabel] < ns) ps[kPsLabel] = s_new[ps[kPsLabel]];
   }
   // ---- P: new index i <- old index src(i); pose rows and the partial feature's six rows / the innovation row stay where
   // they are, the vacated feature rows / columns become zero.  Row by row in increasing i: src(i) >= i, so a source row is
@@ -677,7 +773,7 @@ int launch_compact_slots(sl2_engine* e, int need) {
   a.f_score = e->f_score; a.f_z = e->f_z; a.f_nu = e->f_nu; a.srch_d = e->srch_d; a.patch = e->patch; a.patch_sums = e->patch_sums;
   a.f_flags = e->f_flags; a.attempted = e->attempted; a.successful = e->successful; a.f_label = e->f_label; a.srch_i = e->srch_i;
   a.sel_idx = e->sel_idx; a.succ_idx = e->succ_idx; a.f_arow = e->f_arow; a.n_sel = e->n_sel; a.m_count = e->m_count; a.n_slots = e->n_slots;
-  a.part_i = e->part_i;
+  a.ps_i = e->ps_i; a.pos_err = e->pos_err; a.kpart = e->kpart;
   hipLaunchKernelGGL(k_map_compact_slots, dim3(e->B), dim3(256), sizeof(int) * 2 * e->N, e->stream, a, e->N, e->ld, e->ppos, need);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
@@ -687,7 +783,7 @@ int launch_compact_slots(sl2_engine* e, int need) {
 // per sequence, publish the selection for k_map_create exactly as k_map_region + k_map_detect would have.
 __global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, const int* __restrict__ n_slots, int* __restrict__ part_i,
                                                    double* __restrict__ part_d, int* __restrict__ status, int N, int width,
-                                                   int height, int B) {
+                                                   int height, int B, int kpart) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
   int* pi = part_i + (size_t)b * kPartInts;
@@ -696,7 +792,7 @@ __global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, c
   const int u = uv[2 * b], v = uv[2 * b + 1];
   if (u < 0) return;                                                   // this sequence is left alone
   if (u < 5 || v < 5 || u > width - 6 || v > height - 6) return;       // the 11 x 11 patch must lie inside the frame
-  if (pi[kPartActive]) return;                                         // one partially initialised feature at a time
+  if (pi[kPartCount] >= kpart) return;                                 // every partial slot of the sequence is taken
   if (n_slots[b] >= N) { status[b] |= 2; return; }
   status[b] &= ~2;
   pi[kPartUU] = u; pi[kPartVV] = v;
@@ -715,6 +811,7 @@ static MapParams map_params(const sl2_engine* e, int enable_mapping, int save_tr
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
   mp.pcap = e->root->pcap;
+  mp.kpart = e->root->kpart;
   return mp;
 }
 
@@ -722,7 +819,7 @@ static int launch_create(sl2_engine* e, const MapParams& mp) {
   LaunchScope ls(e, "k_map_create");
   hipLaunchKernelGGL(k_map_create, dim3(e->B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch,
                      e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
-                     e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+                     e->ps_i, e->ps_d, e->pos_err, e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }
@@ -732,7 +829,7 @@ int launch_manual_init(sl2_engine* e, const int* d_uv) {
   const MapParams mp = map_params(e, 1, 0, 1);
   { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   hipLaunchKernelGGL(k_map_manual, dim3((e->B + 63) / 64), dim3(64), 0, e->stream, d_uv, e->n_slots, e->part_i, e->part_d, e->status,
-                     e->N, e->cam.width, e->cam.height, e->B);
+                     e->N, e->cam.width, e->cam.height, e->B, e->kpart);
   SL2_HIP(hipGetLastError());
   return launch_create(e, mp);
 }
@@ -763,6 +860,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.sd_ratio = e->prm.standard_deviation_depth_ratio; mp.prune_threshold = e->prm.prune_probability_threshold;
   mp.dt = e->prm.delta_t;
   mp.pcap = e->root->pcap;
+  mp.kpart = e->root->kpart;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
   if (enable_mapping) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
@@ -781,14 +879,14 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
     LaunchScope ls(e, "k_map_create");
     hipLaunchKernelGGL(k_map_create, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch, e->patch_sums,
                        e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
-                       e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+                       e->ps_i, e->ps_d, e->pos_err, e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }
   {
     LaunchScope ls(e, "k_map_particles");
     const int pc = e->root->pcap;
-#define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B), dim3(pc), 0, e->stream, e->x, e->P, e->part_i, e->particles, \
-                                            e->me_desc, e->last_r, e->me_big_count, e->cam, e->ld, e->ppos, pc)
+#define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B, mp.kpart), dim3(pc), 0, e->stream, e->x, e->P, e->ps_i, e->particles, \
+                                            e->me_desc, e->last_r, e->me_big_count, e->cam, e->ld, e->ppos, pc, mp.kpart)
     if (pc <= 128) SL2_PARTICLES(128);
     else if (pc <= 256) SL2_PARTICLES(256);
     else if (pc <= 512) SL2_PARTICLES(512);
@@ -798,12 +896,12 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     MeJobsEngine J;
-    J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.part_i = e->part_i; J.me_desc = e->me_desc;
+    J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.ps_i = e->ps_i; J.me_desc = e->me_desc;
     J.particles = e->particles; J.owner_base = e->owner_map; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
-    J.width = W; J.height = H;
+    J.width = W; J.height = H; J.kpart = mp.kpart;
     {
       LaunchScope ls(e, "k_map_me_search");
-      hipLaunchKernelGGL(k_map_me_search, dim3(B), dim3(1024), 0, e->stream, J, e->me_big_list, e->me_big_count);
+      hipLaunchKernelGGL(k_map_me_search, dim3(B * mp.kpart), dim3(1024), 0, e->stream, J, e->me_big_list, e->me_big_count);
       SL2_HIP(hipGetLastError());
     }
     {
@@ -814,8 +912,8 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   }
   {
     LaunchScope ls(e, "k_map_update");
-    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), sizeof(double) * kParticleDoubles * (size_t)mp.n_particles, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i, e->part_d,
-                       e->particles, e->traj, e->traj_count, e->last_r, mp, e->N, e->ld, e->ppos);
+    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), sizeof(double) * kParticleDoubles * (size_t)mp.n_particles, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i,
+                       e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->particles, e->traj, e->traj_count, e->last_r, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

@@ -778,7 +778,10 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        int* __restrict__ successful, int* __restrict__ meas_ok,
                                                        double* __restrict__ meas_score, double* __restrict__ work,
                                                        int* __restrict__ succ_idx, int* __restrict__ f_arow,
-                                                       int* __restrict__ m_count, int N) {
+                                                       int* __restrict__ m_count, const int* __restrict__ n_slots,
+                                                       const int* __restrict__ pos_err, const int* __restrict__ pos_err_any,
+                                                       int* __restrict__ f_hcol, const int* __restrict__ ps_i, int kpart, int ppos0,
+                                                       int N) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   extern __shared__ int s_flag[];        // [N] successful measurement of slot i in this frame
   __shared__ int s_wcnt[16];
@@ -859,6 +862,33 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
     for (int w = 0; w < nwave; ++w) acc += s_red[w][tid];
     work[b * kWorkDoubles + tid] = acc;
   }
+  // Q28 (feature.cpp:254, monoslam.cpp:564): a sequence in which a feature's recorded position_in_total_state_vector_ lies
+  // below its true one gets, per slot, the engine column its dh_by_dy block therefore lands on - the reference's position
+  // minus the error, looked up in the reference's state order (feature_list_ order, partial features with six states)
+  if (pos_err_any[b] && tid == 0) {
+    int* chunk_col = s_flag;                   // (s_flag has done its work) [N + 8]: the three-state chunks of the reference's state
+    const int ns = n_slots[b];
+    const int* psb = ps_i + (size_t)b * kpart * kPsInts;
+    int c = 0;
+    for (int f = 0; f < ns && c < N + 6; ++f) {
+      const int fl = f_flags[(size_t)b * N + f];
+      if (fl & FF_ACTIVE) chunk_col[c++] = 13 + 3 * f;
+      else if (fl & FF_PARTIAL) {
+        int ks = 0;
+        for (int k = 0; k < kpart; ++k) if (psb[k * kPsInts + kPsActive] && psb[k * kPsInts + kPsLabel] == f) ks = k;
+        chunk_col[c++] = ppos0 + 6 * ks;
+        chunk_col[c++] = ppos0 + 6 * ks + 3;
+      }
+    }
+    c = 0;
+    for (int f = 0; f < ns; ++f) {
+      const int fl = f_flags[(size_t)b * N + f];
+      if (!(fl & (FF_ACTIVE | FF_PARTIAL))) continue;
+      const int t = c - pos_err[(size_t)b * N + f] / 3;
+      f_hcol[(size_t)b * N + f] = t >= 0 ? chunk_col[t < N + 7 ? t : N + 7] : 13 + 3 * t;     // (t < 0: inside the vehicle state, same columns here)
+      c += (fl & FF_PARTIAL) ? 2 : 1;
+    }
+  }
 }
 
 // Stateless batch kernel (C-ABI seam S1): grid (count), one wave per search.  VARIANT 0 = exact, 1 = matrix-core walk.
@@ -925,9 +955,9 @@ int launch_search(sl2_engine* e) {
     if (threads > 1024) threads = 1024;
     if (e->B >= 256) threads = 64;
     if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
-    hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * e->N, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
+    hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * (e->N + 8), e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
-                       e->succ_idx, e->f_arow, e->m_count, e->N);
+                       e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos, e->N);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

@@ -12,9 +12,9 @@
 namespace sl2 {
 
 struct SnapArrays {
-  const double *x, *P, *xp_org, *f_h, *f_z, *f_nu, *f_R, *f_S, *f_Hx, *f_Hy, *traj, *part_d, *particles;
+  const double *x, *P, *xp_org, *f_h, *f_z, *f_nu, *f_R, *f_S, *f_Hx, *f_Hy, *traj, *ps_d, *particles;
   const int *f_flags, *f_label, *n_slots, *next_label, *attempted, *successful, *sel_idx, *n_sel, *n_vis, *m_count, *traj_count,
-      *status, *part_i;
+      *status, *part_i, *ps_i, *pos_err;
   const uint8_t* patch;
 };
 
@@ -29,7 +29,7 @@ __device__ __forceinline__ int up8(int v) { return (v + 7) & ~7; }
 
 // One workgroup.  LDS: per slot flags, label, list index (-1: not in feature_list_), state size, first double of its
 // covariance record, patch index (-1: not included); then the selection's labels.
-__global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq, int N, int ld, int ppos, int pcap, int traj_cursor,
+__global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq, int N, int ld, int ppos, int pcap, int kpart, int traj_cursor,
                                                            int patch_from_label, long long steps_done, unsigned char* __restrict__ stage,
                                                            uint4* __restrict__ host_out) {
   extern __shared__ int sm[];
@@ -46,6 +46,11 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
   const int ns = a.n_slots[seq];
   const int nsel_raw = a.n_sel[seq];
   const int* pi = a.part_i + (size_t)seq * kPartInts;
+  const int* psb = a.ps_i + (size_t)seq * kpart * kPsInts;
+  __shared__ int s_ps[kMaxPartial][kPsInts];
+  if (tid < kpart * kPsInts) s_ps[tid / kPsInts][tid % kPsInts] = psb[tid];
+  // the partial slot whose label sits in feature slot f (-1: none)
+  auto pslot_of = [&](int f) { int r = -1; for (int k = 0; k < kpart; ++k) if (s_ps[k][kPsActive] && s_ps[k][kPsLabel] == f) r = k; return r; };
   for (int f = tid; f < ns; f += kSnapThreads) { s_flags[f] = a.f_flags[o + f]; s_label[f] = a.f_label[o + f]; }
   for (int k = tid; k < nsel_raw; k += kSnapThreads) s_sel[k] = a.sel_idx[o + k];
   __syncthreads();
@@ -71,8 +76,9 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     if (first < 0) first = 0;
     if (first < traj_cursor) first = traj_cursor;
     if (first > total) first = total;
-    const int n_partial = pi[kPartActive] ? 1 : 0;
-    const int n_particles = n_partial ? pi[kPartNp] : 0;
+    const int n_partial = pi[kPartCount];
+    int n_particles = 0;                       // of all entries of feature_init_info_vector_ together
+    for (int q = 0; q < n_partial; ++q) n_particles += s_ps[pi[kPartOrder + q]][kPsNp];
     int* h = reinterpret_cast<int*>(&hd);
     for (int k = 0; k < 64; ++k) h[k] = 0;
     hd.magic = kSnapMagic; hd.api_version = SL2_API_VERSION; hd.seq = seq;
@@ -96,7 +102,7 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     hd.off_cov = off; off += cov * 8;
     hd.off_selection = off; off += up8(kept * 4);
     hd.off_traj = off; off += (total - first) * 24;
-    hd.off_partial = off; off += n_partial * ((int)sizeof(sl2_partial_info) + n_particles * kParticleDoubles * 8);
+    hd.off_partial = off; off += n_partial * (int)sizeof(sl2_partial_info) + n_particles * kParticleDoubles * 8;
     hd.off_patches = off; off += np * 128;
     hd.bytes = off;
   }
@@ -116,7 +122,7 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     const int fl = s_flags[f];
     const bool partial = (fl & FF_PARTIAL) != 0;
     const int d = partial ? 6 : 3;
-    const int col = partial ? ppos : 13 + 3 * f;
+    const int col = partial ? ppos + 6 * (pslot_of(f) < 0 ? 0 : pslot_of(f)) : 13 + 3 * f;
     sl2_feature_info fi;
     fi.label = s_label[f];
     fi.active = 1;
@@ -124,7 +130,7 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     fi.successful_measurement_flag = (fl & FF_SUCCESS) ? 1 : 0;
     fi.attempted_measurements_of_feature = a.attempted[o + f];
     fi.successful_measurements_of_feature = a.successful[o + f];
-    fi.position_in_total_state_vector = s_pos[f];
+    fi.position_in_total_state_vector = s_pos[f] - a.pos_err[o + f];      // (Q28: what the reference has on record)
     fi.visible = (fl & FF_VISIBLE) ? 1 : 0;
     for (int k = 0; k < 3; ++k) fi.y[k] = xb[col + k];
     for (int k = 0; k < 2; ++k) { fi.h[k] = a.f_h[(o + f) * 2 + k]; fi.z[k] = a.f_z[(o + f) * 2 + k]; fi.nu[k] = a.f_nu[(o + f) * 2 + k]; }
@@ -135,7 +141,7 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     for (int k = 0; k < 7; ++k) fi.xp_org[k] = a.xp_org[(o + f) * 8 + k];
     fi.fully_initialised_flag = partial ? 0 : 1;
     fi.state_size = d;
-    for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? xb[ppos + 3 + k] : 0.0;
+    for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? xb[col + 3 + k] : 0.0;
     *reinterpret_cast<sl2_feature_info*>(stage + hd.off_features + (size_t)li * kFeatureInfoBytes) = fi;
     double* oc = reinterpret_cast<double*>(stage + hd.off_cov) + s_cov[f];
     for (int r = 0; r < 13; ++r)
@@ -162,22 +168,27 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     const int logical = hd.traj_first + k / 3;
     o_tr[k] = a.traj[((size_t)seq * kTrajCapacity + (logical % kTrajCapacity)) * 3 + (k % 3)];
   }
-  // feature_init_info_vector_
-  if (hd.n_partial) {
-    sl2_partial_info* pinfo = reinterpret_cast<sl2_partial_info*>(stage + hd.off_partial);
-    const int npart = pi[kPartNp];
-    if (tid == 0) {
-      const int slot = pi[kPartLabel];
-      pinfo->label = (slot >= 0 && slot < ns) ? s_label[slot] : -1;
-      pinfo->number_of_match_attempts = pi[kPartAttempts];
-      pinfo->n_particles = npart;
-      pinfo->making_measurement_on_this_step_flag = pi[kPartMaking];
-      pinfo->mean = a.part_d[(size_t)seq * kPartDoubles + 0];
-      pinfo->covariance = a.part_d[(size_t)seq * kPartDoubles + 1];
+  // feature_init_info_vector_, in the vector's order
+  {
+    unsigned char* out = stage + hd.off_partial;
+    for (int q = 0; q < hd.n_partial; ++q) {
+      const int ks = pi[kPartOrder + q];
+      const int npart = s_ps[ks][kPsNp];
+      sl2_partial_info* pinfo = reinterpret_cast<sl2_partial_info*>(out);
+      if (tid == 0) {
+        const int slot = s_ps[ks][kPsLabel];
+        pinfo->label = (slot >= 0 && slot < ns) ? s_label[slot] : -1;
+        pinfo->number_of_match_attempts = s_ps[ks][kPsAttempts];
+        pinfo->n_particles = npart;
+        pinfo->making_measurement_on_this_step_flag = s_ps[ks][kPsMaking];
+        pinfo->mean = a.ps_d[((size_t)seq * kpart + ks) * kPsDoubles + 0];
+        pinfo->covariance = a.ps_d[((size_t)seq * kpart + ks) * kPsDoubles + 1];
+      }
+      double* opp = reinterpret_cast<double*>(pinfo + 1);
+      const double* src = a.particles + ((size_t)seq * kpart + ks) * pcap * kParticleDoubles;
+      for (int k = tid; k < npart * kParticleDoubles; k += kSnapThreads) opp[k] = src[k];
+      out += sizeof(sl2_partial_info) + (size_t)npart * kParticleDoubles * 8;
     }
-    double* opp = reinterpret_cast<double*>(pinfo + 1);
-    const double* src = a.particles + (size_t)seq * pcap * kParticleDoubles;
-    for (int k = tid; k < npart * kParticleDoubles; k += kSnapThreads) opp[k] = src[k];
   }
   // the blob leaves for the host: the workgroup's own stores above are visible to it after the barrier
   __threadfence();
@@ -195,8 +206,8 @@ using namespace sl2;
 extern "C" size_t sl2_snapshot_capacity(const sl2_engine* e) {
   if (!e) return 0;
   const size_t N = e->N;
-  size_t b = sizeof(sl2_snapshot_header) + 13 * 8 + 169 * 8 + N * sizeof(sl2_feature_info) + (N * (13 * 3 + 9) + (13 * 6 + 36)) * 8 +
-             ((N * 4 + 7) & ~(size_t)7) + (size_t)kTrajCapacity * 24 + sizeof(sl2_partial_info) + (size_t)e->pcap * kParticleDoubles * 8 +
+  size_t b = sizeof(sl2_snapshot_header) + 13 * 8 + 169 * 8 + N * sizeof(sl2_feature_info) + (N * (13 * 3 + 9) + (size_t)e->kpart * (13 * 6 + 36)) * 8 +
+             ((N * 4 + 7) & ~(size_t)7) + (size_t)kTrajCapacity * 24 + (size_t)e->kpart * (sizeof(sl2_partial_info) + (size_t)e->pcap * kParticleDoubles * 8) +
              N * 128;
   return (b + 15) & ~(size_t)15;
 }
@@ -214,11 +225,11 @@ extern "C" int sl2_snapshot(sl2_engine* e, int seq, int traj_cursor, int patch_f
   // queued behind them
   SnapArrays a;
   a.x = e->x; a.P = e->P; a.xp_org = e->xp_org; a.f_h = e->f_h; a.f_z = e->f_z; a.f_nu = e->f_nu; a.f_R = e->f_R; a.f_S = e->f_S;
-  a.f_Hx = e->f_Hx; a.f_Hy = e->f_Hy; a.traj = e->traj; a.part_d = e->part_d; a.particles = e->particles;
+  a.f_Hx = e->f_Hx; a.f_Hy = e->f_Hy; a.traj = e->traj; a.ps_d = e->ps_d; a.particles = e->particles;
   a.f_flags = e->f_flags; a.f_label = e->f_label; a.n_slots = e->n_slots; a.next_label = e->next_label; a.attempted = e->attempted;
   a.successful = e->successful; a.sel_idx = e->sel_idx; a.n_sel = e->n_sel; a.n_vis = e->n_vis; a.m_count = e->m_count;
-  a.traj_count = e->traj_count; a.status = e->status; a.part_i = e->part_i; a.patch = e->patch;
-  hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(kSnapThreads), sizeof(int) * 7 * e->N, e->stream, a, seq, e->N, e->ld, e->ppos, e->pcap,
+  a.traj_count = e->traj_count; a.status = e->status; a.part_i = e->part_i; a.ps_i = e->ps_i; a.pos_err = e->pos_err; a.patch = e->patch;
+  hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(kSnapThreads), sizeof(int) * 7 * e->N, e->stream, a, seq, e->N, e->ld, e->ppos, e->pcap, e->kpart,
                      traj_cursor, patch_from_label, e->steps_done, (unsigned char*)e->snap_stage, (uint4*)e->snap_host_dev);
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipStreamSynchronize(e->stream));

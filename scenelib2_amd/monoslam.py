@@ -198,22 +198,30 @@ class Engine:
                             y_direction=np.array(f.y_direction[:])))
         return out
 
-    def partial_feature(self, seq, capacity=1024):
-        """The partially initialised feature of a sequence (FeatureInitInfo + particles), or None; plus the mapping
-        counters of the sequence under key 'info' either way."""
+    def partial_feature(self, seq, index=0, capacity=1024):
+        """Entry `index` of feature_init_info_vector_ of a sequence (FeatureInitInfo + particles), or None; plus the mapping
+        counters of the sequence under key 'info' either way (info['n_partial'] = the vector's size)."""
         ints = np.zeros(16, dtype=np.int32)
         dbl = np.zeros(9)
         parts = np.zeros((capacity, 12))
-        self._ck(self.L.sl2_get_partial_feature(self.h, seq, _lib.ip(ints), _lib.dp(dbl), _lib.dp(parts), capacity))
+        self._ck(self.L.sl2_get_partial_feature(self.h, seq, int(index), _lib.ip(ints), _lib.dp(dbl), _lib.dp(parts), capacity))
         info = dict(n_partial=int(ints[0]), initialised=int(ints[12]), converted=int(ints[13]), deleted=int(ints[14]),
                     uu=int(ints[5]), vv=int(ints[6]), region_defined=int(ints[7]), ustart=int(ints[8]), vstart=int(ints[9]),
                     ufinish=int(ints[10]), vfinish=int(ints[11]), created=int(ints[15]), evbest=float(dbl[8]))
-        if not ints[0]:
+        if index >= ints[0]:
             return dict(info=info, pf=None)
         n = int(ints[3])
         return dict(info=info, pf=dict(label=int(ints[1]), n_particles=n, attempts=int(ints[2]), making=bool(ints[4]),
                                        mean=float(dbl[0]), covariance=float(dbl[1]), y=dbl[2:8].copy(),
                                        particles=parts[:n].copy()))
+
+    def partial_features(self, seq, capacity=1024):
+        """All entries of feature_init_info_vector_, in the vector's order."""
+        first = self.partial_feature(seq, 0, capacity)
+        out = [first["pf"]] if first["pf"] is not None else []
+        for k in range(1, first["info"]["n_partial"]):
+            out.append(self.partial_feature(seq, k, capacity)["pf"])
+        return out
 
     def selection(self, seq):
         labels = np.zeros(self.max_features, dtype=np.int32)

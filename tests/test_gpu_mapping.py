@@ -102,7 +102,7 @@ def test_mapping_with_300_depth_particles():
 def test_mapping_rejects_unsupported_settings_and_needs_flag():
     from scenelib2_amd import _lib
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=3)
-    p2 = dict(params); p2["max_features_to_init_at_once"] = 2
+    p2 = dict(params); p2["max_features_to_init_at_once"] = 5          # the engine carries up to four partial features per sequence
     eng = _engine(cam, p2, spec, templates)
     with pytest.raises(_lib.Sl2Error):
         eng.go_one_step(frames[1][None], enable_mapping=True)
@@ -394,3 +394,78 @@ def test_slot_squeeze_at_100_features_moves_state_covariance_and_templates_exact
             x0, x1 = pr.oracles[b].total_state(), eng.total_state(b)
             assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
             assert rel_fro(eng.total_covariance(b), pr.oracles[b].total_covariance()) < 1e-8, (k, b)
+
+
+@pytest.mark.parametrize("checker", ["reference", "oracle"])
+def test_two_features_initialised_at_once_against_the_reference(checker):
+    """params.max_features_to_init_at_once = 2 with 200 depth particles (data/SceneLib2.cfg:62 ships 1; the gate is
+    monoslam.cpp:163-167): two partially initialised features in flight - twelve extra states, each matched with its own
+    particle set - through conversions while the other is still partial.  The reference then moves the LATER feature's
+    position_in_total_state_vector_ by 6 instead of 3 (feature.cpp:254, Q28) and from then on stacks that feature's dh_by_dy
+    three columns early in H (monoslam.cpp:564): the engine reproduces the recorded positions AND the filter that results,
+    frame by frame, against the reference's own translation units (oracle/_ref/libref.so) and against the oracle."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60, v_amp=0.5)
+    params = dict(params)
+    params["max_features_to_init_at_once"] = 2
+    params["number_of_particles"] = 200
+    params["number_of_features_to_keep_visible"] = 14
+    if checker == "reference" and oa.ref_available():
+        import ctypes
+        oa.ref_lib()
+        ctypes.CDLL(None).srand48(0)                 # MonoSLAM::Init (monoslam.cpp:1968): the reference's generator is the process's
+        s = oa.RefSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
+        s.set_mapping_params(params)
+        s.set_state(spec.xv0, spec.Pxx0)
+        for i in range(spec.n_features):
+            s.add_known_feature(spec.feat_y[i], spec.xp_org()[i], templates[i])
+    else:
+        s = oracle_for(cam, params, spec, templates, oa)
+    eng = _engine(cam, params, spec, templates, max_features=40)
+    max_partial, q28, measured_with_q28 = 0, 0, 0
+    for k in range(1, 61):
+        s.go_one_step(frames[k], True, True)
+        eng.go_one_step(frames[k][None], save_trajectory=True, enable_mapping=True)
+        info = s.mapping_info()
+        got = eng.partial_feature(0, capacity=256)["info"]
+        keys = ("initialised", "converted", "deleted", "n_partial") if not isinstance(s, oa.RefSLAM) else ("n_partial",)   # (the reference keeps no event counters)
+        assert [got[key] for key in keys] == [info[key] for key in keys], (k, got, info)
+        max_partial = max(max_partial, info["n_partial"])
+        mine = eng.partial_features(0, capacity=256)
+        assert len(mine) == info["n_partial"]
+        for j, g in enumerate(mine):
+            pf = s.partial_feature(j, max_particles=256)
+            assert (g["label"], g["n_particles"], g["attempts"], g["making"]) == \
+                   (pf["label"], pf["n_particles"], pf["attempts"], pf["making"]), (k, j)
+            a, b = g["particles"], pf["particles"]
+            assert np.array_equal(a[:, 0], b[:, 0]) and np.allclose(a[:, 1], b[:, 1], rtol=1e-8, atol=1e-300), (k, j)
+            if pf["making"]:
+                assert np.array_equal(a[:, 11], b[:, 11]), (k, j)
+                ok = b[:, 11] != 0
+                assert np.array_equal(a[ok, 5:7], b[ok, 5:7]), (k, j)
+        x0, P0 = s.total_state(), s.total_covariance()
+        x1, P1 = eng.total_state(0), eng.total_covariance(0)
+        assert x0.size == x1.size, k
+        assert np.abs(x1 - x0).max() < 1e-9, (k, np.abs(x1 - x0).max())
+        assert np.linalg.norm(P1 - P0) <= 1e-8 * max(np.linalg.norm(P0), 1e-12), k
+        kinds = s.feature_kinds()
+        feats = eng.features(0)
+        assert [f["label"] for f in feats] == list(kinds[:, 2]) and [f["state_size"] for f in feats] == list(kinds[:, 0]), k
+        pos = 13
+        for i, fe in enumerate(feats):
+            fo = s.feature(i)
+            assert fe["pos"] == fo["pos"], (k, i, fe["pos"], fo["pos"])                 # the position ON RECORD, Q28 included
+            if fo["pos"] != pos:
+                q28 += 1
+                measured_with_q28 += int(fe["selected"] and fe["success"])
+            assert fe["selected"] == fo["selected"] and fe["attempted"] == fo["attempted"] and fe["successful"] == fo["successful"]
+            pos += int(kinds[i][0])
+        snap = eng.snapshot(0)
+        assert snap["header"].n_partial == info["n_partial"]
+        assert [f["info"].position_in_total_state_vector for f in snap["features"]] == [fe["pos"] for fe in feats]
+        for j, rec in enumerate(snap["partial"]):
+            assert rec["info"].label == mine[j]["label"] and np.array_equal(rec["particles"], mine[j]["particles"])
+    assert max_partial == 2, "the scene never had two partially initialised features in flight"
+    assert q28 > 0, "Q28 never showed: no conversion happened next to a later feature"
+    assert measured_with_q28 > 0, "no feature with a misplaced position was ever measured: the H placement went untested"
+    t0, t1 = s.trajectory(), eng.trajectory(0)
+    assert t0.shape == t1.shape and np.abs(t0 - t1).max() < 1e-9

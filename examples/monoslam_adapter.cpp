@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
     try {
       auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
       auto mean = [](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return v.empty() ? 0.0 : s / v.size(); };
-      std::vector<double> loop_us, call_us, step_us, refresh_us;
+      std::vector<double> loop_us, call_us, step_us, refresh_us, snap_us;
       size_t n_features = 0, n_frames = 0, snap_cap = 0;
       for (int pass = 0; pass < 2; ++pass) {
         SceneLib2Amd::MonoSLAM slam;
@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
           } else {
             step_us.push_back(slam.last_step_us_);
             refresh_us.push_back(slam.last_refresh_us_);
+            snap_us.push_back(slam.last_snapshot_us_);
           }
         }
         n_features = slam.feature_list_.size();
@@ -73,10 +74,10 @@ int main(int argc, char** argv) {
       if (!f) { fprintf(stderr, "cannot write %s\n", latency.c_str()); return 5; }
       fprintf(f, "{\"frames\": %zu, \"timed_frames\": %zu, \"features_at_end\": %zu, \"mapping\": %s, "
                  "\"frame_us_median\": %.2f, \"frame_us_mean\": %.2f, \"go_one_step_us_median\": %.2f, \"go_one_step_us_mean\": %.2f, "
-                 "\"step_us_median\": %.2f, \"step_us_mean\": %.2f, \"readback_us_median\": %.2f, \"readback_us_mean\": %.2f, "
+                 "\"step_us_median\": %.2f, \"step_us_mean\": %.2f, \"readback_us_median\": %.2f, \"readback_us_mean\": %.2f, \"snapshot_call_us_median\": %.2f, "
                  "\"blocking_copies_per_frame\": 0, \"synchronisations_per_frame\": 1, \"snapshot_capacity_bytes\": %zu}\n",
               n_frames, loop_us.size(), n_features, enable_mapping ? "true" : "false", median(loop_us), mean(loop_us), median(call_us),
-              mean(call_us), median(step_us), mean(step_us), median(refresh_us), mean(refresh_us), snap_cap);
+              mean(call_us), median(step_us), mean(step_us), median(refresh_us), mean(refresh_us), median(snap_us), snap_cap);
       fclose(f);
     } catch (const std::exception& e) {
       fprintf(stderr, "error: %s\n", e.what());

@@ -292,7 +292,7 @@ class MonoSLAM {
   // wait for the GPU; with measure_timing_ = true a synchronisation is inserted between the two and they are the step and
   // the read-back proper (examples/monoslam_adapter --latency).
   bool measure_timing_ = false;
-  double last_step_us_ = 0.0, last_refresh_us_ = 0.0;
+  double last_step_us_ = 0.0, last_refresh_us_ = 0.0, last_snapshot_us_ = 0.0;   // (the last: the sl2_snapshot call inside the read-back)
 
   // ---- public data members, names as in monoslam.h:158-218 ----
   std::unique_ptr<Camera> camera_;
@@ -359,7 +359,9 @@ class MonoSLAM {
   void refresh_public_members() {
     const void* blob = nullptr;
     size_t nbytes = 0;
+    const auto ts0 = std::chrono::steady_clock::now();
     check(sl2_snapshot(eng_, 0, traj_seen_, patch_seen_, &blob, &nbytes), "sl2_snapshot");
+    last_snapshot_us_ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ts0).count();
     const unsigned char* base = static_cast<const unsigned char*>(blob);
     const sl2_snapshot_header& hd = *reinterpret_cast<const sl2_snapshot_header*>(base);
     if (hd.api_version != SL2_API_VERSION) throw std::runtime_error("scenelib2_amd: library / header version mismatch");
@@ -422,9 +424,11 @@ class MonoSLAM {
     }
     const int32_t* sel = reinterpret_cast<const int32_t*>(base + hd.off_selection);
     selected_feature_list_.clear();
-    for (int k = 0; k < hd.n_selected; ++k)
-      for (auto& f : feature_list_)
-        if (f->label_ == sel[k]) { selected_feature_list_.push_back(f.get()); break; }
+    for (int k = 0; k < hd.n_selected; ++k) {          // feature_list_ is in label order (labels are handed out in creation order)
+      size_t lo = 0, hi = feature_list_.size();
+      while (lo < hi) { const size_t mid = (lo + hi) / 2; if (feature_list_[mid]->label_ < sel[k]) lo = mid + 1; else hi = mid; }
+      if (lo < feature_list_.size() && feature_list_[lo]->label_ == sel[k]) selected_feature_list_.push_back(feature_list_[lo].get());
+    }
     // trajectory_store_: append what is new, keep at most 1000 entries (monoslam.cpp:172-177)
     const double* tr = reinterpret_cast<const double*>(base + hd.off_traj);
     if (hd.traj_first > traj_seen_) trajectory_store_.clear();     // (more than 1000 pushes between two calls)

@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
   int* s_pi = sm + 4 * N;
   int* s_pos = sm + 5 * N;
   int* s_sel = sm + 6 * N;
+  int* s_col = sm + 7 * N;                     // first state column of a live slot's feature
   __shared__ sl2_snapshot_header hd;
   const int tid = threadIdx.x;
   const size_t o = (size_t)seq * N;
@@ -54,23 +55,43 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
   for (int f = tid; f < ns; f += kSnapThreads) { s_flags[f] = a.f_flags[o + f]; s_label[f] = a.f_label[o + f]; }
   for (int k = tid; k < nsel_raw; k += kSnapThreads) s_sel[k] = a.sel_idx[o + k];
   __syncthreads();
-  if (tid == 0) {
-    int nf = 0, pos = 13, cov = 0, np = 0;
-    for (int f = 0; f < ns; ++f) {
-      const int fl = s_flags[f];
-      const int d = (fl & FF_PARTIAL) ? 6 : ((fl & FF_ACTIVE) ? 3 : 0);
-      s_li[f] = d ? nf : -1;
-      s_pos[f] = pos;
-      s_cov[f] = cov;
-      s_pi[f] = (d && s_label[f] >= patch_from_label) ? np : -1;
-      if (d) { ++nf; pos += d; cov += 13 * d + d * d; if (s_label[f] >= patch_from_label) ++np; }
+  // list positions, state positions, covariance offsets and the compacted selection: one wavefront, ballots and popcounts
+  // (a single thread walking the slots through LDS was 15 us of a 40 us kernel at 100 features)
+  __shared__ int s_tot[5];                     // nf, total state size, covariance doubles, patches, kept selection entries
+  if (tid < 64) {
+    int nfull = 0, npart = 0, npatch = 0;      // running counts in front of the current 64 slots (wave-uniform)
+    for (int base = 0; base < ns; base += 64) {
+      const int f = base + tid;
+      const int fl = f < ns ? s_flags[f] : 0;
+      const bool part = (fl & FF_PARTIAL) != 0, full = !part && (fl & FF_ACTIVE) != 0;
+      const bool wants_patch = (part || full) && s_label[f < ns ? f : 0] >= patch_from_label;
+      const unsigned long long m_full = __ballot(full), m_part = __ballot(part), m_pat = __ballot(wants_patch);
+      const unsigned long long below = (1ull << tid) - 1ull;
+      const int cf = nfull + __popcll(m_full & below), cp = npart + __popcll(m_part & below);
+      if (f < ns) {
+        s_li[f] = (part || full) ? cf + cp : -1;
+        s_pos[f] = 13 + 3 * cf + 6 * cp;
+        s_cov[f] = (13 * 3 + 9) * cf + (13 * 6 + 36) * cp;
+        s_pi[f] = wants_patch ? npatch + __popcll(m_pat & below) : -1;
+      }
+      nfull += __popcll(m_full); npart += __popcll(m_part); npatch += __popcll(m_pat);
     }
     // delete_feature() deselects the feature it removes (monoslam.cpp:800-801)
     int kept = 0;
-    for (int k = 0; k < nsel_raw; ++k) {
-      const int f = s_sel[k];
-      if (f >= 0 && f < ns && (s_flags[f] & FF_ACTIVE)) s_sel[kept++] = s_label[f];
+    for (int base = 0; base < nsel_raw; base += 64) {
+      const int k = base + tid;
+      const int f = k < nsel_raw ? s_sel[k] : -1;
+      const bool ok = f >= 0 && f < ns && (s_flags[f] & FF_ACTIVE);
+      const int lab = ok ? s_label[f] : 0;
+      const unsigned long long m = __ballot(ok);
+      if (ok) s_sel[kept + __popcll(m & ((1ull << tid) - 1ull))] = lab;      // (destinations lie at or below this round's sources)
+      kept += __popcll(m);
     }
+    if (tid == 0) { s_tot[0] = nfull + npart; s_tot[1] = 13 + 3 * nfull + 6 * npart; s_tot[2] = 48 * nfull + 114 * npart; s_tot[3] = npatch; s_tot[4] = kept; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int nf = s_tot[0], pos = s_tot[1], cov = s_tot[2], np = s_tot[3], kept = s_tot[4];
     const int total = a.traj_count[seq];
     int first = total - kTrajCapacity;
     if (first < 0) first = 0;
@@ -143,21 +164,30 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
     fi.state_size = d;
     for (int k = 0; k < 3; ++k) fi.y_direction[k] = partial ? xb[col + 3 + k] : 0.0;
     *reinterpret_cast<sl2_feature_info*>(stage + hd.off_features + (size_t)li * kFeatureInfoBytes) = fi;
-    double* oc = reinterpret_cast<double*>(stage + hd.off_cov) + s_cov[f];
-    for (int r = 0; r < 13; ++r)
-      for (int c = 0; c < d; ++c) oc[r * d + c] = Pb[(size_t)r * ld + col + c];
-    oc += 13 * d;
-    for (int r = 0; r < d; ++r)
-      for (int c = 0; c < d; ++c) oc[r * d + c] = Pb[(size_t)(col + r) * ld + col + c];
-    const int pidx = s_pi[f];
-    if (pidx >= 0) {
-      unsigned char* op = stage + hd.off_patches + (size_t)pidx * 128;
-      *reinterpret_cast<int*>(op) = s_label[f];
-      const uint8_t* src = a.patch + (o + f) * kPatchStride;
-      for (int k = 0; k < SL2_PATCH_BYTES; ++k) op[4 + k] = src[k];
-      op[125] = op[126] = op[127] = 0;
-    }
+    s_col[f] = col;
   }
+  __syncthreads();
+  // Pxy_ / Pyy_ blocks and the new templates: one (feature, element) pair per thread and round, so that the ~50 loads of a
+  // feature's blocks are spread over lanes instead of queued on one
+  for (int idx = tid; idx < ns * 128; idx += kSnapThreads) {
+    const int f = idx >> 7, el = idx & 127;
+    if (s_li[f] < 0) continue;
+    const int d = (s_flags[f] & FF_PARTIAL) ? 6 : 3, col = s_col[f];
+    if (el >= 13 * d + d * d) continue;
+    double* oc = reinterpret_cast<double*>(stage + hd.off_cov) + s_cov[f];
+    if (el < 13 * d) oc[el] = Pb[(size_t)(el / d) * ld + col + el % d];
+    else { const int q = el - 13 * d; oc[el] = Pb[(size_t)(col + q / d) * ld + col + q % d]; }
+  }
+  if (hd.n_patches)
+    for (int idx = tid; idx < ns * 128; idx += kSnapThreads) {
+      const int f = idx >> 7, el = idx & 127;
+      const int pidx = s_li[f] >= 0 ? s_pi[f] : -1;
+      if (pidx < 0) continue;
+      unsigned char* op = stage + hd.off_patches + (size_t)pidx * 128;
+      if (el < 4) op[el] = (unsigned char)((unsigned)s_label[f] >> (8 * el));            // int32 label, little endian
+      else if (el < 4 + SL2_PATCH_BYTES) op[el] = a.patch[(o + f) * kPatchStride + el - 4];
+      else op[el] = 0;
+    }
   // selected_feature_list_ as labels
   int* o_sel = reinterpret_cast<int*>(stage + hd.off_selection);
   for (int k = tid; k < hd.n_selected; k += kSnapThreads) o_sel[k] = s_sel[k];
@@ -229,7 +259,7 @@ extern "C" int sl2_snapshot(sl2_engine* e, int seq, int traj_cursor, int patch_f
   a.f_flags = e->f_flags; a.f_label = e->f_label; a.n_slots = e->n_slots; a.next_label = e->next_label; a.attempted = e->attempted;
   a.successful = e->successful; a.sel_idx = e->sel_idx; a.n_sel = e->n_sel; a.n_vis = e->n_vis; a.m_count = e->m_count;
   a.traj_count = e->traj_count; a.status = e->status; a.part_i = e->part_i; a.ps_i = e->ps_i; a.pos_err = e->pos_err; a.patch = e->patch;
-  hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(kSnapThreads), sizeof(int) * 7 * e->N, e->stream, a, seq, e->N, e->ld, e->ppos, e->pcap, e->kpart,
+  hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(kSnapThreads), sizeof(int) * 8 * e->N, e->stream, a, seq, e->N, e->ld, e->ppos, e->pcap, e->kpart,
                      traj_cursor, patch_from_label, e->steps_done, (unsigned char*)e->snap_stage, (uint4*)e->snap_host_dev);
   SL2_HIP(hipGetLastError());
   SL2_HIP(hipStreamSynchronize(e->stream));

@@ -262,10 +262,13 @@ int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count);
 /* One binary PGM (P5, maxval <= 255) -> 8-bit grey, row-major, step == width (the frame contract of GoOneStep;
  * the reference decodes with cv::imread(path, 0), filegrabber.cpp:105-108).  out may be NULL to query the size.  Host only. */
 int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
-/* FileGrabber::GetImageFile (filegrabber.cpp:106-109: cv::imread(path, 0)) for the two containers this library decodes,
- * chosen by the file's magic bytes: binary PGM as above, or PNG (non-interlaced; 8-bit grey / grey+alpha / RGB / RGBA /
- * palette, 1-2-4-bit grey / palette).  Grey PNGs are byte-exact; colour is reduced like libpng's rgb_to_gray, which is what
- * imread(.., 0) uses: (9797 R + 19234 G + 3737 B + 16384) >> 15.  out may be NULL to query the size.  Host only. */
+/* FileGrabber::GetImageFile (filegrabber.cpp:106-109: cv::imread(path, 0)) for the three containers this library decodes,
+ * chosen by the file's magic bytes: binary PGM as above; PNG (non-interlaced; 8-bit grey / grey+alpha / RGB / RGBA /
+ * palette, 1-2-4-bit grey / palette) - grey PNGs are byte-exact, colour is reduced like libpng's rgb_to_gray, which is what
+ * imread(.., 0) uses: (9797 R + 19234 G + 3737 B + 16384) >> 15; JPEG (sequential DCT, Huffman, 8 bits, one or three
+ * components) - the luminance component through libjpeg's integer inverse DCT (jpeg_idct_islow), which is what imread(.., 0)
+ * gets from libjpeg with out_color_space = JCS_GRAYSCALE; progressive / arithmetic / 12-bit / four-component files are
+ * refused with an error.  out may be NULL to query the size.  Host only. */
 int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
 /* FileGrabber + FrameGrabber for a batch: dirs[s] is the frame directory of sequence s.  A producer thread decodes
  * (sl2_read_image: PGM or PNG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of

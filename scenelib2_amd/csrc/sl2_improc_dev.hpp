@@ -23,7 +23,7 @@ __device__ __forceinline__ void detect_region_wg(const uint8_t* __restrict__ img
     if (tid == 0) { uv[0] = ustart; uv[1] = vstart; *ev = 0.0; }
     return;
   }
-  const int nu = ufinish - ustart, nv = vfinish - vstart;
+  const int nu = ufinish - ustart;
   double best = 0.0;   // *evbest = 0 (:1136): only a strictly positive eigenvalue can win
   int best_idx = -1;
   // The three 11 x 11 sums of gradient products are separable, like the reference's own sliding column sums

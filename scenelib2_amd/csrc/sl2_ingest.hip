@@ -6,12 +6,14 @@
 //     (byte-wise std::sort on the path strings, filegrabber.cpp:63-83);
 //   * decode: 8-bit single-channel, row-major, step == width — the only contract GoOneStep relies on
 //     (SURVEY 2, row 14).  The reference decodes through cv::imread(path, 0) (filegrabber.cpp:106-109), a third-party
-//     call that is not re-implemented in general; two containers are read here, chosen by the file's magic bytes:
+//     call that is not re-implemented in general; three containers are read here, chosen by the file's magic bytes:
 //       - binary PGM (P5, maxval <= 255), the format of the reference's own fixtures;
 //       - PNG (the format of the MonoSLAM test sequences): non-interlaced, 8 bits per sample (grey, grey + alpha, RGB,
 //         RGBA, palette) or 1/2/4-bit grey / palette; IDAT inflated with zlib, the five scan-line filters undone here.
 //         Grey PNGs are delivered byte for byte.  Colour goes to grey the way cv::imread(.., 0) gets it from libpng
 //         (png_set_rgb_to_gray, 8-bit path): (9797 R + 19234 G + 3737 B + 16384) >> 15; alpha is dropped;
+//       - JPEG (round 4; sl2_jpeg.hpp): sequential DCT, Huffman, 8 bits, grey or YCbCr - the luminance component through
+//         libjpeg's integer inverse DCT, which is what imread(.., 0) delivers (out_color_space = JCS_GRAYSCALE);
 //   * a producer thread decodes ahead into pinned host buffers (the reference queues <= 50 frames,
 //     framegrabber.cpp:93-104; here `depth` batches), the consumer uploads one batch per call with an
 //     asynchronous copy into one of two device buffers, so the copy of frame k+1 overlaps the step on
@@ -30,6 +32,7 @@
 #include <vector>
 
 #include "sl2_common.hpp"
+#include "sl2_jpeg.hpp"
 
 namespace sl2 {
 
@@ -199,6 +202,23 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, 
   return true;
 }
 
+// JPEG (sequential DCT, Huffman): the luminance component through libjpeg's integer inverse DCT - what cv::imread(path, 0) delivers
+static bool read_jpeg(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) { set_error(("cannot open " + path).c_str()); return false; }
+  std::vector<uint8_t> file;
+  uint8_t buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof(buf), f)) > 0) {
+    file.insert(file.end(), buf, buf + got);
+    if (file.size() > ((size_t)256 << 20)) break;
+  }
+  fclose(f);
+  std::string err;
+  if (!jpeg::decode_grey(file, px, w, h, &err, kMaxFramePixels)) { set_error((path + ": " + err).c_str()); return false; }
+  return true;
+}
+
 // container chosen by the magic bytes
 static bool read_image(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
   FILE* f = fopen(path.c_str(), "rb");
@@ -207,6 +227,7 @@ static bool read_image(const std::string& path, std::vector<uint8_t>& px, int* w
   const size_t n = fread(m, 1, 2, f);
   fclose(f);
   if (n == 2 && m[0] == 0x89 && m[1] == 'P') return read_png(path, px, w, h);
+  if (n == 2 && m[0] == 0xFF && m[1] == 0xD8) return read_jpeg(path, px, w, h);
   return read_pgm(path, px, w, h);
 }
 

@@ -399,7 +399,6 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   const int ns = n_slots[b];
   __shared__ int s_count, s_order[kMaxPartial];
   __shared__ int s_flag;           // scratch decision of lane 0
-  __shared__ int s_np;
   __shared__ double s_total;
   extern __shared__ double s_p[];        // [number_of_particles][kParticleDoubles]
   if (lane == 0) {

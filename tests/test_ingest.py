@@ -203,3 +203,72 @@ def test_decoders_survive_random_corruption(tmp_path):
     with pytest.raises(_lib.Sl2Error):
         ingest.read_image(os.path.join(d, "huge.pgm"))
     assert outcomes["err"] > 50 and outcomes["ok"] + outcomes["err"] == 300
+
+
+def _pil():
+    try:
+        import PIL.Image as Image
+        from PIL import features
+        return Image if features.check("jpg") else None
+    except ImportError:
+        return None
+
+
+@pytest.mark.skipif(_pil() is None, reason="Pillow with libjpeg is the independent checker")
+def test_read_jpeg_gives_libjpeg_grey_bytes(tmp_path):
+    """cv::imread(path, 0) on a JPEG (filegrabber.cpp:106-109) = libjpeg with out_color_space = JCS_GRAYSCALE: the luminance
+    component as the integer inverse DCT leaves it.  An independent libjpeg build (Pillow, draft('L')) must give the same
+    bytes as sl2_read_image for grey and colour files, every chroma subsampling, optimised Huffman tables, restart
+    intervals, sizes that are not multiples of the MCU, 16-bit-free quantisation at qualities 30 .. 100."""
+    Image = _pil()
+    rng = np.random.default_rng(12)
+
+    def scene(h, w, c):
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = 128 + 60 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 40 * ((xx // 16 + yy // 12) % 2)
+        img = np.stack([base + rng.normal(0, 12, (h, w)) + 20 * k for k in range(c)], axis=-1)
+        return np.clip(img, 0, 255).astype(np.uint8)
+
+    n = 0
+    for (h, w) in ((240, 320), (37, 53), (8, 8), (17, 129)):
+        for c in (1, 3):
+            img = scene(h, w, c)
+            pil = Image.fromarray(img[..., 0] if c == 1 else img)
+            variants = [dict(quality=q) for q in (30, 75, 92, 100)] + [dict(quality=85, optimize=True)]
+            if c == 3:
+                variants += [dict(quality=80, subsampling=s) for s in (0, 1, 2)]
+            variants += [dict(quality=70, restart_marker_blocks=3), dict(quality=88, restart_marker_rows=1)]
+            for kw in variants:
+                path = os.path.join(str(tmp_path), "t.jpg")
+                pil.save(path, "JPEG", **kw)
+                ref = Image.open(path)
+                ref.draft("L", ref.size)                  # libjpeg itself outputs grey: no RGB -> grey conversion by Pillow
+                want = np.array(ref.convert("L") if ref.mode != "L" else ref)
+                got = ingest.read_image(path)
+                assert got.shape == want.shape == (h, w), (kw, got.shape, want.shape)
+                assert np.array_equal(got, want), (h, w, c, kw, int(np.abs(got.astype(int) - want.astype(int)).max()))
+                n += 1
+    assert n >= 50
+
+
+@pytest.mark.skipif(_pil() is None, reason="Pillow writes the files")
+def test_read_jpeg_rejects_what_it_does_not_decode(tmp_path):
+    Image = _pil()
+    img = (np.arange(64 * 64).reshape(64, 64) % 251).astype(np.uint8)
+    path = os.path.join(str(tmp_path), "p.jpg")
+    Image.fromarray(img).save(path, "JPEG", progressive=True)
+    with pytest.raises(_lib.Sl2Error, match="progressive"):
+        ingest.read_image(path)
+    Image.fromarray(np.stack([img] * 4, axis=-1), "CMYK").save(path, "JPEG")
+    with pytest.raises(_lib.Sl2Error, match="component"):
+        ingest.read_image(path)
+    Image.fromarray(img).save(path, "JPEG", quality=80)
+    raw = open(path, "rb").read()
+    for cut in (len(raw) // 2, 30, 3):
+        with open(path, "wb") as f:
+            f.write(raw[:cut])
+        try:
+            out = ingest.read_image(path)                 # a truncated scan decodes to something (libjpeg pads too) or is refused ...
+            assert out.shape == (64, 64)
+        except _lib.Sl2Error:
+            pass                                          # ... but never crashes

@@ -1,6 +1,8 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
 // GoOneStep restatement + a flat C interface for ctypes (tests, smoke(), and the
 // cpu_baseline leg of bench.py).  See slam_oracle.hpp for the parity status.
+#include <cstdlib>
+#include <malloc.h>
 #include "slam_oracle.hpp"
 #include "feature_init_oracle.hpp"
 
@@ -77,6 +79,16 @@ using oracle::Feature;
 using oracle::Mat;
 using oracle::MonoSLAM;
 using oracle::Vec;
+
+// Every dense temporary of the filter (n x n doubles, several per frame) is above glibc's mmap threshold: left alone each is
+// an mmap / munmap pair plus a page fault per 4 KB, and with one MonoSLAM object per hardware thread those take the process's
+// address-space lock in turn.  The timing harness keeps such blocks on the heap instead (set at load time, before any object
+// is built).  Timing infrastructure only: the arithmetic is untouched.  SL2_HARNESS_NO_MALLOPT=1 leaves glibc's defaults.
+__attribute__((constructor)) static void sl2_harness_malloc_setup() {
+  if (getenv("SL2_HARNESS_NO_MALLOPT")) return;
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+}
 
 extern "C" {
 

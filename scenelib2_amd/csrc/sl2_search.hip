@@ -423,7 +423,10 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
   const int vi0 = 16 * vt + 4 * g;
   const unsigned* bp = mf_b_base(s_T, g, 16 + 16 * (g & 1) - j);      // this lane's template operands (offset 1..32)
   for (int ut = up; ut < min(up + 2, TU); ++ut) {
-    // ellipse membership: FP32 with a guard band (m4_const), the reference's FP64 expression where that cannot decide
+    // ellipse membership: FP32 with a guard band (m4_const), the reference's FP64 expression where that cannot decide.
+    // (Round 4 also tried the matrix-core work FIRST and this classification behind it, to fill the MFMAs' ~400 cycles with
+    // vector work of the same wavefront: 0.0947 against 0.0865 ms on the same box - the operand reads' LDS latency is then
+    // exposed in front of the first MFMA, where this code used to cover it.  profiles/r04_search_ab_pmc.txt.)
     const int ui = 16 * ut + j;
     const m4_mask m_col = m4_gt_i32(nu_all, ui);
     m4_mask m_cand[4];

@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--batch", type=int, default=1024, help="sequences per GPU")
-    ap.add_argument("--features", type=int, default=100)
+    ap.add_argument("--features", type=int, default=None, help="known features per sequence (default: 100; 12 with --mapping)")
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--height", type=int, default=240)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="sequences of the CPU-baseline sample (-1: one per hardware thread of the host; 0: skip)")
@@ -44,11 +44,15 @@ def parse_args():
                     help="prior std-dev (m) of every map feature; > 0 makes the covariance dense (0: AddNewKnownFeature zeros)")
     ap.add_argument("--graph", action="store_true", help="replay the step as a HIP graph (small batches are launch-bound)")
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
+    ap.add_argument("--search-split", type=int, default=-1,
+                    help="bands from which a search window is shared out over wavefronts (sl2_set_search_split; -1: engine default, 0: never)")
     ap.add_argument("--mapping", action="store_true",
                     help="the reference's DEFAULT workload instead of the headline: --features known features (use 6-12), the shipped "
                          "parameters (select 10, keep 12 visible, 100 depth particles), a camera that translates past the 0.2 m/s "
                          "gate, GoOneStep(enable_mapping = true): features are initialised, converted and deleted along the way")
     a = ap.parse_args()
+    if a.features is None:
+        a.features = 12 if a.mapping else 100
     if a.mapping and a.feature_sigma == 0.005:
         a.feature_sigma = 0.0          # AddNewKnownFeature's zeros, like the shipped scene
     return a
@@ -313,6 +317,8 @@ def main():
     templates = np.stack([synth.cut_templates(frame0[b], specs[b].feat_px) for b in range(B)])
 
     eng = Engine(cam, params, B, NCAP, device=dev)
+    if args.search_split >= 0:
+        eng.set_search_split(args.search_split)
     if args.groups > 0:
         eng.set_groups(args.groups)
     if args.graph:

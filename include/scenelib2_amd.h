@@ -197,6 +197,14 @@ int sl2_set_graph_mode(sl2_engine* e, int enabled);
 /* Which search kernel sl2_make_measurements / sl2_go_one_step use: 1 = int8 matrix-core walk (k_search_mfma, default),
  * 0 = the exact kernel with one candidate per lane (k_search_exact, the cross-check).  Identical results, bit for bit. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
+/* Search windows of at least `min_bands` bands (a band = 32 x 16 candidate positions; a window of nu x nv positions has
+ * ceil(ceil(nu / 16) / 2) * ceil(nv / 16) of them) are not walked by one wavefront but cut into units of four bands that
+ * 2048 extra workgroups at the end of the search launch work off - the window of a poorly constrained feature can be the
+ * whole frame (150 bands at 320 x 240), and one wavefront walking it alone was the tail of the search.  Default 8; 0 =
+ * never (and no extra workgroups: they cost the headline step 0.06 %).  Results are identical either way: the parts' best
+ * and second-best candidates are combined into the decision a single wavefront takes.  (An addition within SL2_API_VERSION 4: no existing entry point
+ * changed; sl2_get_step_work has a 13th value.) */
+int sl2_set_search_split(sl2_engine* e, int min_bands);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
  * chol_variant 1 = one-launch left-looking Cholesky (k_chol_left; default), 2 = one-launch right-looking (k_chol_fused4),
  *              0 = three launches per block column;
@@ -421,8 +429,9 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
  * out[5] = sum of m^3, out[6] = sum of n (state size) , out[7] = sum n*m, out[8] = sum n*n*m, out[9] = sum n*m*m,
  * out[10] = searches that took the exact fallback kernel path,
  * out[11] = 16 x 16 candidate tiles of the search windows, sum_f ceil(nu / 16) ceil(nv / 16): the matrix-core work of
- * k_search_mfma (24 v_mfma_i32_16x16x64_i8 per tile) */
-#define SL2_STEP_WORK_COUNT 12
+ * k_search_mfma (24 v_mfma_i32_16x16x64_i8 per tile),
+ * out[12] = search windows that were shared out over the wavefronts of the launch (sl2_set_search_split) */
+#define SL2_STEP_WORK_COUNT 13
 /* capacity = length of the caller's array: min(capacity, SL2_STEP_WORK_COUNT) values are written (a caller built against a
  * header with fewer entries is never overrun; one built against more sees the extra entries untouched). */
 int sl2_get_step_work(sl2_engine* e, double* out, int capacity);

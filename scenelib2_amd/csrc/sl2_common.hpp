@@ -44,6 +44,21 @@ constexpr int kTrajCapacity = 1000;  // monoslam.cpp:174
 // feature initialisation (one partially initialised feature per sequence)
 constexpr int kMaxParticles = 1024;      // upper bound of params.number_of_particles (k_map_particles: one thread per particle)
 constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2], z[2], SInv(00,01,11), detS, success
+// Large search windows are cut into UNITS of a few bands (32 x 16 candidate positions each) that any wavefront of the search
+// launch may take (sl2_search.hip: m4_big_windows).  sl2_engine::srch_big, ints: [0] units allocated this step (k_select),
+// [1] windows shared out in the last completed step (sl2_get_step_work), [2] next unit to hand out, [3] windows shared out this
+// step; then per unit: its entry (sequence, selected position, first unit of its window, units of its window), the count
+// of finished units of the window (kept at the window's first unit) and its partial result (8 ints).
+constexpr int kSrchSplitDefault = 8;                  // bands from which a window is shared out (mapping workload, step: 0.734 ms never, 0.687 at 24, 0.665 at 8, 0.661 at 4)
+constexpr int kSrchBigUnits = 16384;                  // units per step and sequence group (a 320 x 240 window: 38); windows beyond stay with their own wavefront
+constexpr int kSrchBigSlots = 64;                     // units per window at most: its partial results are combined by one wavefront, a lane each
+constexpr int kSrchBigMinBands = 4;                   // bands per unit at least
+constexpr int kSrchSharedNu = -(1 << 30);             // the width a shared window's record carries (srch_sel[..][4]; the true one: [14])
+constexpr int kSrchBigEntries = 4;                    // int offsets into srch_big
+constexpr int kSrchBigDone = kSrchBigEntries + 4 * kSrchBigUnits;
+constexpr int kSrchBigParts = kSrchBigDone + kSrchBigUnits;
+constexpr int kSrchBigInts = kSrchBigParts + 8 * kSrchBigUnits;
+__host__ __device__ inline int srch_unit_bands(int bands) { const int g = (bands + kSrchBigSlots - 1) / kSrchBigSlots; return g > kSrchBigMinBands ? g : kSrchBigMinBands; }
 // Partially initialised features: up to kMaxPartial per sequence (params.max_features_to_init_at_once, monoslam.cpp:163-167).
 // part_i / part_d = the per-SEQUENCE record: feature_init_info_vector_.size(), the partial slots in the vector's order (a
 // conversion or deletion erases an entry, the later ones move up), the image selection and the counters; ps_i / ps_d = one
@@ -167,6 +182,9 @@ struct sl2_engine {
                               // 512 x n = 1513, profiles/r03_c5_chol_panel_ab.txt); TEST build: SL2_CHOL_PANEL = 4 | 8
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice
   int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)
+  int search_split = sl2::kSrchSplitDefault;   // windows of at least this many 32 x 16 bands are shared out over wavefronts (0 = never); sl2_set_search_split
+  // ---- large search windows (round 4): the step's units of work for every wavefront of k_search_mfma (layout: kSrchBig* above) ----
+  int* srch_big = nullptr;    // per sequence GROUP (allocated by build_groups)
 
   // ---- per-frame feature scratch (device), indexed [B][N] ----
   double* f_h = nullptr;      // [..][2]

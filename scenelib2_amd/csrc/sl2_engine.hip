@@ -150,6 +150,7 @@ using namespace sl2;
 static int build_groups(sl2_engine* e, int G) {
   for (sl2_engine* g : e->groups) {
     if (g->stream != e->stream) hipStreamDestroy(g->stream);
+    if (g->srch_big) hipFree(g->srch_big);
     delete g;
   }
   e->groups.clear();
@@ -184,6 +185,9 @@ static int build_groups(sl2_engine* e, int G) {
     g->particles = e->particles + f * e->kpart * e->pcap * kParticleDoubles; g->rand48 = e->rand48 + f; g->prev_r = e->prev_r + f * 3;
     g->me_desc = e->me_desc + f * e->kpart * e->pcap * 8;
     g->pos_err = e->pos_err + f * N; g->pos_err_any = e->pos_err_any + f; g->f_hcol = e->f_hcol + f * N;
+    // the group's list of large search windows: count and counters start at zero and are returned to zero by k_search_score
+    SL2_HIP(hipMalloc((void**)&g->srch_big, sizeof(int) * kSrchBigInts));
+    SL2_HIP(hipMemsetAsync(g->srch_big, 0, sizeof(int) * kSrchBigParts, e->stream));      // (everything but the partial results)
     e->groups.push_back(g);
   }
   return SL2_OK;
@@ -437,6 +441,7 @@ void sl2_destroy(sl2_engine* e) {
   for (sl2_engine* g : e->groups) {
     if (g->stream != e->stream) hipStreamDestroy(g->stream);
     if (g->fork_event) hipEventDestroy(g->fork_event);
+    if (g->srch_big) hipFree(g->srch_big);
     delete g;
   }
   if (e->fork_event) hipEventDestroy(e->fork_event);
@@ -569,6 +574,14 @@ int sl2_set_search_variant(sl2_engine* e, int variant) {
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   e->step_graphs.clear();
   e->search_variant = variant;
+  return SL2_OK;
+}
+
+int sl2_set_search_split(sl2_engine* e, int min_bands) {
+  if (!e || min_bands < 0) return SL2_ERR_INVALID;
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);        // the threshold is a kernel argument of the captured k_select
+  e->step_graphs.clear();
+  e->search_split = min_bands;
   return SL2_OK;
 }
 
@@ -1220,6 +1233,12 @@ int sl2_get_step_work(sl2_engine* e, double* out_caller, int capacity) {
     const double m = 2.0 * mc[b];
     out[3] += m; out[4] += m * m; out[5] += m * m * m; out[6] += n; out[7] += n * m; out[8] += n * n * m; out[9] += n * m * m;
   }
+  for (sl2_engine* g : e->groups)
+    if (g->srch_big) {
+      int last = 0;
+      SL2_HIP(hipMemcpy(&last, g->srch_big + 1, sizeof(int), hipMemcpyDeviceToHost));     // (k_search_score leaves the step's count there)
+      out[12] += last;
+    }
   for (int k = 0; k < capacity && k < SL2_STEP_WORK_COUNT; ++k) out_caller[k] = out[k];   // never beyond the caller's array
   return SL2_OK;
 }

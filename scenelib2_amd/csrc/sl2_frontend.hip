@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
                                                 int* __restrict__ sel_idx, int* __restrict__ n_sel, int* __restrict__ n_vis,
                                                 double* __restrict__ last_r, const int* __restrict__ srch_i,
                                                 const double* __restrict__ srch_d, int* __restrict__ srch_sel, int N,
-                                                int n_want) {
+                                                int n_want, int* __restrict__ srch_big, int split_bands) {
   extern __shared__ double s_dyn[];
   double* s_score = s_dyn;                 // [N]
   int* s_vis = (int*)(s_dyn + N);          // [N]
@@ -254,6 +254,34 @@ __global__ void __launch_bounds__(256) k_select(const double* __restrict__ f_sco
       const double* sd = srch_d + ((size_t)b * N + i) * 4;
       double* recd = (double*)(rec + 8);
       recd[0] = sd[0]; recd[1] = sd[1]; recd[2] = sd[2];
+      // A window of many bands (a poorly constrained feature: up to the whole frame) would keep ONE wavefront of the search
+      // kernel busy long after every other one has finished: it is cut into units of a few bands that go on the step's list,
+      // and the trailing workgroups of the search launch take units (sl2_search.hip, m4_big_windows).  The record then carries
+      // nu = kSrchSharedNu - an empty window for the position's own wavefront, which leaves the result alone - and the true
+      // width in rec[14].
+      int shared = 0;
+      if (split_bands > 0 && si[3] > 0 && si[5] > 0) {
+        const int TU = (si[3] + 15) >> 4, TV = (si[5] + 15) >> 4;
+        const int bands = ((TU + 1) >> 1) * TV;
+        if (bands >= split_bands && TU <= 128 && TV <= 64) {            // (kM4MaxTU / kM4MaxTV: beyond them the exact walk)
+          const int per = srch_unit_bands(bands), units = (bands + per - 1) / per;
+          const int u0 = atomicAdd(srch_big, units);
+          if (u0 + units <= kSrchBigUnits) {
+            int4 en;
+            en.x = b; en.y = rank; en.z = u0; en.w = units;
+            for (int q = 0; q < units; ++q) *(int4*)(srch_big + kSrchBigEntries + 4 * (u0 + q)) = en;
+            atomicAdd(srch_big + 3, 1);
+            shared = 1;
+          } else {
+            // no room: the window stays with its own wavefront; what was allocated below the capacity reads as "nothing"
+            int4 en;
+            en.x = -1; en.y = 0; en.z = 0; en.w = 0;
+            for (int q = u0; q < min(u0 + units, kSrchBigUnits); ++q) *(int4*)(srch_big + kSrchBigEntries + 4 * q) = en;
+          }
+        }
+      }
+      rec[14] = shared ? si[3] : 0;
+      if (shared) rec[4] = kSrchSharedNu;
     }
   }
   FTR(1, 3);
@@ -490,7 +518,8 @@ int launch_select(sl2_engine* e, int n) {
   if (n > e->nsel_max) n = e->nsel_max;
   const size_t shm = (size_t)e->N * (sizeof(double) + 3 * sizeof(int));
   hipLaunchKernelGGL(k_select, dim3(e->B), dim3(256), shm, e->stream, e->f_score, e->f_flags, e->n_slots, e->xp_org,
-                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->N, n);
+                     e->sel_idx, e->n_sel, e->n_vis, e->last_r, e->srch_i, e->srch_d, e->srch_sel, e->N, n, e->srch_big,
+                     (e->srch_big && e->root->search_variant == 1) ? e->root->search_split : 0);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

@@ -613,10 +613,167 @@ __global__ void __launch_bounds__(64) k_search_exact(const uint8_t* __restrict__
   }
 }
 
-constexpr int kMfChunk = 4;
 #ifndef SL2_MF_WAVES
 #define SL2_MF_WAVES 4
 #endif
+
+// ---------------------------------------------------------------------------
+// Large windows (round 4).  A feature whose position is poorly constrained - a fresh one under a weak pose estimate - has
+// a window of up to the whole frame: 150 bands at 320 x 240, each a synchronous round trip for the one wavefront that owns
+// it.  In the mapping workload that tail WAS the kernel: 0.12 ms per launch on average and 0.55 at worst for 0.03 ms of
+// typical work (profiles/r04_mapping_kernel_stats.csv).  k_select therefore cuts every window of at least
+// sl2_engine::search_split bands into UNITS of a few bands (srch_unit_bands: four, more for windows beyond 256 bands, so
+// that a window has at most kSrchBigSlots units), puts them on the step's list (srch_big) and marks the window's record;
+// the position's own wavefront skips it, and the last workgroups of the launch, which own no positions, take units off
+// the list - one atomic counter for the whole list, a unit per grab:
+//   * a unit leaves a partial result: the best ranking value among its candidates, the second best, the best
+//     candidate's position and sums, the number of candidates inside the ellipse;
+//   * the wavefront that finishes a window's LAST unit (a counter per window) combines the partial results.  The decision
+//     is the one a single wavefront takes - a unique candidate within the guard band of the maximum is the reference's
+//     winner, anything else goes to the exact walk: "unique" is "the second largest ranking value of the whole window lies
+//     below the band", and the second largest of a union follows from each part's two largest.
+// Nobody waits for anybody; the counters are returned to zero by k_search_score (the next launch).  Partial results cross
+// XCDs: they are written and read with agent-scope atomics around __threadfence().
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int m4_wave_atomic_add(int* p, int v, int lane) {
+  int r = 0;
+  if (lane == 0) r = atomicAdd(p, v);
+  return __builtin_amdgcn_readfirstlane(r);
+}
+__device__ __forceinline__ int m4_coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void m4_coherent_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int frame_bytes,
+                                               const uint8_t* __restrict__ patch, const int* __restrict__ srch_sel,
+                                               int* __restrict__ srch_res, double* __restrict__ meas_score, int N,
+                                               int* __restrict__ big, int nunits, char* s_pl, unsigned* s_T) {
+  const int lane = threadIdx.x;
+  const int j = lane & 15, g = lane >> 4;
+  int u = m4_wave_atomic_add(big + 2, 1, lane);
+  if (u >= nunits) return;                            // (the usual end of a wavefront when a list exists: everything is handed out)
+  __syncthreads();                                    // whatever the caller was doing with the LDS is over
+  mf_tpl_init(s_T, lane);
+  __syncthreads();
+  mf_tpl_ones(s_T, lane);
+  __syncthreads();
+  const int boff = 16 + 16 * (g & 1) - j;
+  const mf_v4i b_ones = mf_load_b(s_T, 12, boff);
+  const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);
+  const M4Quads kq = m4_quads();
+  const int tidx = mf_tpl_index(lane);
+  const bool tload = lane < 44 ? (lane & 3) != 0 : (lane >= 48 && lane <= 50);
+  const unsigned tmask = mf_tpl_mask(lane);
+  for (; u < nunits; u = m4_wave_atomic_add(big + 2, 1, lane)) {
+    const int4 en = *(const int4*)(big + kSrchBigEntries + 4 * u);       // sequence, selected position, the window's first unit, its units
+    const int b = en.x, k = en.y, u0 = en.z, units = en.w;
+    if (b < 0) continue;                                                   // (allocated for a window that found no room)
+    const int* rec = srch_sel + ((size_t)b * N + k) * 16;
+    const int f = rec[0], uc = rec[1], vc = rec[2], us = rec[3], nu_all = rec[14], vs = rec[5], nv_all = rec[6];   // (rec[4] = kSrchSharedNu: see k_select)
+    const int TU = (nu_all + 15) >> 4, TV = (nv_all + 15) >> 4, nbu = (TU + 1) >> 1, nbands = nbu * TV;
+    const int per = srch_unit_bands(nbands);
+    // (an entry that no longer describes its record - the selection ran twice before a search - is nobody's work: the
+    // record's own entries, or its own wavefront, cover it)
+    if (rec[4] != kSrchSharedNu || nu_all <= 0 || nv_all <= 0 || (nbands + per - 1) / per != units) continue;
+    const double* recd = (const double*)(rec + 8);
+    const double pa = recd[0], b2 = 2 * recd[1], pc = recd[2];
+    const uint8_t* img = frames + (size_t)b * seq_stride;
+    const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + f) * kPatchStride + kPatchPackedOffset);
+    const unsigned tv = tload ? tpl[tidx] : 0u;
+    const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 48), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 49);
+    const bool patch_ok = __builtin_amdgcn_readlane(tv, 50) != 0;
+    __syncthreads();                                  // the previous unit's last tile has been read
+    mf_tpl_store(tv, tmask, s_T, lane);
+    const M4Const kc = m4_const(Sg0, pa, b2, pc);
+    M4State st;
+    st.reset();
+    M4Uni un;
+    un.ncand = 0;
+    const int band0 = (u - u0) * per, band1 = min(band0 + per, nbands);
+    for (int bi = band0; bi < band1; ++bi) {
+      const int vt = bi / nbu, up = 2 * (bi - vt * nbu);
+      __syncthreads();
+      const M4Band bd = m4_band(uc, vc, us, vs, nu_all, nv_all, up, vt, width);
+      M4Pf pf;
+      if (m4_band_loads(img, width, frame_bytes, bd, lane, pf)) m4_band_fix(img, width, frame_bytes, bd, lane, pf);
+      m4_band_store(pf, bd, s_pl);
+      __syncthreads();
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, us, vs, pa, b2, pc, kq, kc, patch_ok, j, g, st, un);
+    }
+    // ---- the unit's partial result: maximum, runner-up, the best candidate's position and sums, candidate count
+    const float gmax = m4_wave_max(st.best_q);
+    const int wl = __ffsll((long long)__ballot(st.best_q == gmax)) - 1;  // (every lane holds -3e38 if nothing qualified: lane 0)
+    const float top2 = m4_wave_max(lane == wl ? st.second_q : st.best_q);
+    const int w_ks = __builtin_amdgcn_readlane(st.best_ks, wl), w_S2 = __builtin_amdgcn_readlane(st.best_w, wl);
+    const int w_x = __builtin_amdgcn_readlane(st.best_x, wl);
+    const int w_S1 = m4_ks_S1(w_ks);
+    if (lane == 0) {
+      int* pr = big + kSrchBigParts + 8 * u;
+      m4_coherent_store(pr + 0, __float_as_int(gmax));
+      m4_coherent_store(pr + 1, __float_as_int(top2));
+      m4_coherent_store(pr + 2, uc + us + m4_ks_u(w_ks, wl & 15));
+      m4_coherent_store(pr + 3, vc + vs + m4_ks_v(w_ks, wl >> 4));
+      m4_coherent_store(pr + 4, w_S1);
+      m4_coherent_store(pr + 5, w_S2);
+      m4_coherent_store(pr + 6, w_x + 128 * w_S1 + 128 * (Sg0 - 15488));
+      m4_coherent_store(pr + 7, un.ncand);
+    }
+    __threadfence();                                                     // the partial result is visible before the count says so
+    if (m4_wave_atomic_add(big + kSrchBigDone + u0, 1, lane) != units - 1) continue;
+    // ---- this was the window's last unit: combine (a lane per unit)
+    __threadfence();
+    float pg = -3.0e38f, pt = -3.0e38f;
+    int pu = 0, pv = 0, pS1 = 0, pS2 = 0, pX = 0, pn = 0;
+    if (lane < units) {
+      const int* pr = big + kSrchBigParts + 8 * (u0 + lane);
+      pg = __int_as_float(m4_coherent_load(pr + 0)); pt = __int_as_float(m4_coherent_load(pr + 1));
+      pu = m4_coherent_load(pr + 2); pv = m4_coherent_load(pr + 3); pS1 = m4_coherent_load(pr + 4);
+      pS2 = m4_coherent_load(pr + 5); pX = m4_coherent_load(pr + 6); pn = m4_coherent_load(pr + 7);
+    }
+    int ncand = pn;
+    for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
+    int* o = srch_res + ((size_t)b * N + k) * 8;
+    int code = 0;
+    if (patch_ok) {
+      const float wmax = m4_wave_max(pg);
+      if (wmax > -1.0e38f) {
+        const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+        const float thr = wmax - 4.1e-6f * __builtin_amdgcn_sqrtf(d0f);  // q = rho sqrt(D0): the 4e-6 guard band on rho
+        const int hl = __ffsll((long long)__ballot(pg == wmax)) - 1;
+        const float second = m4_wave_max(lane == hl ? pt : pg);          // second largest ranking value of the whole window
+        const bool boundary = __builtin_amdgcn_readlane(m4_D1(pS1, pS2), hl) == 1464100;
+        if (second >= thr || boundary) code = -1;                          // several near-best candidates, or sigma == 10: the exact walk
+        else {
+          code = 1;
+          if (lane == hl) {
+            int4 o0, o1;
+            o0.x = 1; o0.y = pu; o0.z = pv; o0.w = pS1;
+            o1.x = pS2; o1.y = pX; o1.z = ncand; o1.w = 1;
+            *(int4*)o = o0; *(int4*)(o + 4) = o1;                          // (k_search_score writes this position's score)
+          }
+        }
+      }
+    }
+    if (code < 0) {
+      SearchBounds sb;
+      sb.ucentre = uc; sb.vcentre = vc; sb.urelstart = us; sb.urelfinish = us + nu_all - 1;
+      sb.vrelstart = vs; sb.vrelfinish = vs + nv_all - 1; sb.halfwidth = sb.halfheight = 0;
+      const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + f) * kPatchStride, sb, recd[0], recd[1], recd[2]);
+      if (lane == 0) {
+        o[0] = r.code; o[1] = r.u; o[2] = r.v; o[3] = r.S1; o[4] = r.S2; o[5] = r.X; o[6] = r.ncand;
+        o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
+        meas_score[(size_t)b * N + k] = r.score;
+      }
+    } else if (code == 0 && lane == 0) {                                   // nothing found
+      int4 o0, o1;
+      o0.x = 0; o0.y = 0; o0.z = 0; o0.w = 0; o1.x = 0; o1.y = 0; o1.z = ncand; o1.w = 0;
+      *(int4*)o = o0; *(int4*)(o + 4) = o1;
+      meas_score[(size_t)b * N + k] = 1000000.0;
+    }
+  }
+}
+
+constexpr int kMfChunk = 4;
+constexpr int kSearchBigWaves = 2048;   // workgroups of k_search_mfma that work off the large windows' units: two per SIMD of the chip
 // Engine kernel.  One wavefront works through `chunk` consecutive selected positions of one sequence (XCD-mapped: a
 // sequence's frame stays in one XCD's L2).  A feature's search is a chain of dependent memory round trips - record,
 // template + window, LDS - so the loop is software-pipelined: while position i is in the matrix cores and being scored,
@@ -625,12 +782,25 @@ constexpr int kMfChunk = 4;
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SL2_MF_WAVES, 8)))
 k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int frame_bytes, const uint8_t* __restrict__ patch,
             const int* __restrict__ srch_sel, const int* __restrict__ n_sel, int* __restrict__ srch_res,
-            double* __restrict__ meas_score, int N, int nchunks, int B, int chunk) {
+            double* __restrict__ meas_score, int N, int nchunks, int B, int chunk, int* __restrict__ srch_big) {
+  __shared__ __attribute__((aligned(16))) char s_pl[3 * kM4Plane];
+  __shared__ __attribute__((aligned(16))) unsigned s_T[kMfTplDw];
+  // The last kSearchBigWaves workgroups of the grid own no positions: they work off the units of the step's large windows
+  // (m4_big_windows above; with no window on the list - the usual step of a well-constrained map - they read the list's
+  // length and end).  Being the last to be dispatched they run while the launch drains.  Measured alternatives
+  // (profiles/r04_search_shared_ab.txt): the same work at the END of every wavefront costs the common path 5-9 % (the
+  // arguments' scalar registers stay alive across the wavefront's own positions, the list length is read at the start or
+  // at the end) and ran the units slower (0.134 against 0.082 ms in the mapping workload); a launch of its own costs ~3 us
+  // and moved the placement of the launches behind it (k_build_AS + 13 us at the headline shape).
+  if (srch_big && (int)blockIdx.x >= nchunks * ((B + kXcds - 1) / kXcds * kXcds)) {      // (= xcd_grid(nchunks, B), the workgroups that own positions)
+    const int nunits = min(srch_big[0], kSrchBigUnits);
+    if (nunits > 0)
+      m4_big_windows(frames, seq_stride, width, frame_bytes, patch, srch_sel, srch_res, meas_score, N, srch_big, nunits, s_pl, s_T);
+    return;
+  }
   int b, ch;
   if (!xcd_map(nchunks, B, &b, &ch)) return;
   STR(0);
-  __shared__ __attribute__((aligned(16))) char s_pl[3 * kM4Plane];
-  __shared__ __attribute__((aligned(16))) unsigned s_T[kMfTplDw];
   const int lane = threadIdx.x;
   const int k0 = ch * chunk;
   const int nsel = n_sel[b];
@@ -641,6 +811,9 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
 
   // the record k_select wrote for selected position k (one 64-byte line; uniform address: scalar loads).  The window
   // integers are fetched one position ahead (the prefetch needs them), PuInv when its position is worked on.
+  // (A window that k_select put on the step's list of large windows has nu = kSrchSharedNu in its record - its true width
+  // sits in rec[14] - and reads as an empty window here: nothing is loaded for it, and the position's result is left to
+  // the workgroups that work off the list.)
   struct Rec { int f, uc, vc, us, nu, vs, nv; };
   auto record = [&](int i) {
     const int* rec = srch_sel + ((size_t)b * N + k0 + i) * 16;
@@ -758,7 +931,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
         o[7] = (r.found ? 1 : 0) | (r.ok ? 2 : 0) | 4;
         meas_score[(size_t)b * N + k0 + i] = r.score;
       }
-    } else if (code == 0 && lane == 0) {              // nothing found (or nothing to search)
+    } else if (code == 0 && lane == 0 && nu_all != kSrchSharedNu) {      // nothing found (or nothing to search)
       int4 o0, o1;
       o0.x = 0; o0.y = 0; o0.z = 0; o0.w = 0; o1.x = 0; o1.y = 0; o1.z = un.ncand; o1.w = 0;
       *(int4*)o = o0; *(int4*)(o + 4) = o1;
@@ -784,15 +957,23 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        int* __restrict__ m_count, const int* __restrict__ n_slots,
                                                        const int* __restrict__ pos_err, const int* __restrict__ pos_err_any,
                                                        int* __restrict__ f_hcol, const int* __restrict__ ps_i, int kpart, int ppos0,
-                                                       int N) {
+                                                       int N, int* __restrict__ srch_big) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   extern __shared__ int s_flag[];        // [N] successful measurement of slot i in this frame
   __shared__ int s_wcnt[16];
   __shared__ double s_red[16][kWorkDoubles];
   const int ns = n_sel[b];
+  // the step's list of large windows has been worked off by the search kernel: its counters and its length return to zero
+  const int nunits_done = (b == 0 && srch_big) ? min(srch_big[0], kSrchBigUnits) : 0;
+  const int nshared_done = (b == 0 && srch_big) ? srch_big[3] : 0;
+  for (int i = tid; i < nunits_done; i += (int)blockDim.x) srch_big[kSrchBigDone + i] = 0;
   double w_win = 0.0, w_n = 0.0, w_cand = 0.0, w_fb = 0.0, w_tiles = 0.0;
   for (int i = tid; i < N; i += (int)blockDim.x) s_flag[i] = 0;
   __syncthreads();
+  if (b == 0 && srch_big && tid == 0) {                         // (every thread has read them: the barrier above)
+    srch_big[1] = nshared_done;                                 // sl2_get_step_work
+    srch_big[0] = 0; srch_big[2] = 0; srch_big[3] = 0;
+  }
   for (int k0 = 0; k0 < ns; k0 += (int)blockDim.x) {
     const int k = k0 + tid;
     if (k < ns) {
@@ -941,9 +1122,10 @@ int launch_search(sl2_engine* e) {
       chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
       if (e->root->search_chunk > 0) chunk = e->root->search_chunk;        // experiments (TEST build: SL2_SEARCH_CHUNK)
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
-      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+      const bool shared = e->srch_big && e->root->search_split > 0;       // (k_select only lists windows under the same condition)
+      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B) + (shared ? kSearchBigWaves : 0)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,
-                         e->N, nchunks, e->B, chunk);
+                         e->N, nchunks, e->B, chunk, shared ? e->srch_big : nullptr);
     }
     SL2_HIP(hipGetLastError());
   }
@@ -960,7 +1142,7 @@ int launch_search(sl2_engine* e) {
     if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
     hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * (e->N + 8), e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
-                       e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos, e->N);
+                       e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos, e->N, e->srch_big);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

@@ -102,6 +102,10 @@ class Engine:
     def set_search_variant(self, variant):
         self._ck(self.L.sl2_set_search_variant(self.h, int(variant)))
 
+    def set_search_split(self, min_bands):
+        """Windows of at least `min_bands` 32 x 16 bands are shared out over the wavefronts of the search launch (0 = never)."""
+        self._ck(self.L.sl2_set_search_split(self.h, int(min_bands)))
+
     def set_update_variant(self, chol_variant=1, fwd_variant=1):
         self._ck(self.L.sl2_set_update_variant(self.h, int(chol_variant), int(fwd_variant)))
 
@@ -309,10 +313,10 @@ class Engine:
         return out
 
     def step_work(self):
-        w = np.zeros(12)
+        w = np.zeros(13)
         self._ck(self.L.sl2_get_step_work(self.h, _lib.dp(w), w.size))
         keys = ["window_bytes", "searched", "candidates", "sum_m", "sum_m2", "sum_m3", "sum_n", "sum_nm", "sum_nnm",
-                "sum_nmm", "search_fallbacks", "search_tiles"]
+                "sum_nmm", "search_fallbacks", "search_tiles", "search_shared"]
         return dict(zip(keys, w.tolist()))
 
 

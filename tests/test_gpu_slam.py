@@ -142,19 +142,25 @@ def _sigma_ten_block():
     return np.random.default_rng(5).permutation(vals).reshape(11, 11).astype(np.uint8)
 
 
-@pytest.mark.parametrize("variant", [1, 0])
-def test_engine_search_kernel_on_adversarial_frames(variant):
+@pytest.mark.parametrize("variant,split", [(1, None), (0, None), (1, 1), (1, 2), (1, 0)])
+def test_engine_search_kernel_on_adversarial_frames(variant, split):
     """The ENGINE's pipelined search kernel (sl2_go_one_step -> k_search_mfma: packed template records, first
     band prefetched, later bands staged in the loop) on crafted frames, against the oracle: around the last measured
     position of every feature the frame gets, in turn, two copies of the template that differ by k and k + 1 one-level
     pixel flips (scores inside the FP32 guard band), two identical copies (exact tie: the last in scan order wins), a
     flat patch of image (every candidate fails the sigma test), and a block whose sigma is exactly 10.  The first frames
     have 3-sigma windows of several bands.  The exact fallback must have run (and still
-    everything - measurements, counters, state, covariance - equals the reference's)."""
+    everything - measurements, counters, state, covariance - equals the reference's).
+    split = 1 / 2: every window of at least that many bands is cut into units that the wavefronts of a second launch
+    work off (sl2_set_search_split; the default shares out windows of 8 bands, 0 none): the same crafted ties, near ties
+    and flat patches then meet the combination of partial results instead of one wavefront's decision."""
     rng = np.random.default_rng(77)
     B, N, F = 4, 24, 7
     pr = Pair(N, F, batch=B)
     pr.engine.set_search_variant(variant)
+    if split is not None:
+        pr.engine.set_search_split(split)
+    shared = 0
     H, W = pr.cam["height"], pr.cam["width"]
     ten = _sigma_ten_block()
     fallbacks, multi_band, pasted = 0, 0, 0
@@ -189,6 +195,7 @@ def test_engine_search_kernel_on_adversarial_frames(variant):
         pr.compare_state(TOL_X, TOL_P)
         w = pr.engine.step_work()
         fallbacks += int(w["search_fallbacks"])
+        shared += int(w["search_shared"])
         for b in range(B):
             for i in range(N):
                 S = pr.oracles[b].feature(i)["S"]
@@ -197,6 +204,48 @@ def test_engine_search_kernel_on_adversarial_frames(variant):
     assert pasted > 100 and multi_band > 50
     if variant == 1:
         assert fallbacks > 20, "the exact fallback of the matrix-core walk never ran: the crafted frames missed their purpose"
+    if split == 1:
+        assert shared > 0.9 * B * N * F, "with a threshold of one band every search is a shared one"
+    elif split == 2:
+        assert 50 < shared < B * N * F
+    elif split == 0 or variant == 0:
+        assert shared == 0
+
+
+@pytest.mark.parametrize("split", [None, 1, 0])
+def test_frame_sized_windows_are_shared_out_over_the_launch(split):
+    """A camera position known to 0.3 m only: the 3-sigma windows of the first frame are the whole frame (150 bands of
+    32 x 16 positions at 320 x 240).  One wavefront used to walk such a window alone; now k_select cuts it into units of four
+    bands and the wavefronts of k_search_big take units, the last one combining the partial results (m4_big_windows).  The
+    measurements are the reference's, pixel for pixel, with the default threshold, with a threshold of one band, and
+    with sharing switched off; so are the candidate counts the work counters carry.  (Tolerances on state and covariance
+    are 1e-7 here: the first update shrinks a prior 10^4 times larger than the posterior.)"""
+    B, N, F = 3, 24, 4
+    pr = Pair(N, F, batch=B)
+    if split is not None:
+        pr.engine.set_search_split(split)
+    xv, Pxx = [], []
+    for b in range(B):
+        P0 = pr.specs[b].Pxx0.copy()
+        P0[0, 0] = P0[1, 1] = P0[2, 2] = 0.09
+        pr.oracles[b].set_state(pr.specs[b].xv0, P0)
+        xv.append(pr.specs[b].xv0)
+        Pxx.append(P0)
+    pr.engine.set_vehicle_state(np.stack(xv), np.stack(Pxx))
+    seen = 0
+    for k in range(F):
+        pr.step_both(k)
+        pr.compare_state(1e-7, 1e-7)
+        w = pr.engine.step_work()
+        total = sum(o.diag()["candidates"] for o in pr.oracles)      # (the oracle's count runs on from step to step)
+        ncand, seen = total - seen, total
+        if k == 0:
+            assert w["search_tiles"] > 100 * w["searched"] > 0, "the windows of the first frame are not frame-sized"
+            if split == 0:
+                assert w["search_shared"] == 0
+            else:
+                assert w["search_shared"] >= 0.9 * w["searched"]
+        assert w["candidates"] == ncand, "in-ellipse candidates of frame %d: %d against the oracle's %d" % (k, w["candidates"], ncand)
 
 
 def test_uncertain_map_dense_covariance():
@@ -210,6 +259,19 @@ def test_uncertain_map_dense_covariance():
     P = pr.engine.total_covariance(0)
     assert np.count_nonzero(np.abs(P) > 1e-12) > 0.9 * P.size          # dense
     assert np.abs(pr.engine.total_state(0)[13:] - y0).max() > 1e-6      # the map moved
+
+
+def test_map_much_smaller_than_its_capacity():
+    """An engine with room for 60 features (256 state columns, four tiles of 64) that holds 9 and 14: k_syrk leaves the tiles
+    of the never-used slots alone (P and V^T are zero there), and the filter is the reference's all the same - with a
+    dense covariance (feature priors), so that every live tile changes."""
+    pr = Pair(14, 8, batch=2, max_features=60, feature_counts=[9, 14], feature_sigma=0.01)
+    for k in range(8):
+        pr.step_both(k)
+        pr.compare_state(TOL_X, TOL_P)
+    for b in range(2):
+        P = pr.engine.total_covariance(b)
+        assert np.count_nonzero(np.abs(P) > 1e-12) > 0.9 * P.size
 
 
 @pytest.mark.parametrize("groups", [1, 3])

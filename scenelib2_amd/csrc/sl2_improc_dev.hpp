@@ -141,6 +141,39 @@ __device__ __forceinline__ double me_score_position(const uint8_t* __restrict__ 
   return corr;
 }
 
+// The same score with the window in LDS (a byte tile of pitch iw whose allocation runs at least 16 bytes past the last
+// byte a window can touch) and the template as 33 packed dwords (11 rows x 12 bytes, byte 11 = 0): a window row is twelve
+// bytes out of four aligned dwords (v_alignbyte), the three sums are v_dot4_u32_u8 - 20 instructions a row instead of 66
+// for eleven byte taps.  Integer sums: identical.
+__device__ __forceinline__ double me_score_position_lds(const uint8_t* s_img, int iw, const unsigned* s_tpl, int Sg0, int Sg0sq,
+                                                        int x, int y) {
+  unsigned Sg1 = 0, Sg0g1 = 0, Sg1sq = 0;
+  int addr = (y - 5) * iw + (x - 5);
+#pragma unroll
+  for (int r = 0; r < 11; ++r) {
+    const unsigned* base = (const unsigned*)(s_img + (addr & ~3));
+    const unsigned sh = (unsigned)addr & 3u;
+    const unsigned d0 = base[0], d1 = base[1], d2 = base[2], d3 = base[3];
+    const unsigned w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    const unsigned w2 = __builtin_amdgcn_alignbyte(d3, d2, sh) & 0x00ffffffu;
+    const unsigned t0 = s_tpl[3 * r], t1 = s_tpl[3 * r + 1], t2 = s_tpl[3 * r + 2];
+    Sg1 = __builtin_amdgcn_udot4(w0, 0x01010101u, Sg1, false);
+    Sg1 = __builtin_amdgcn_udot4(w1, 0x01010101u, Sg1, false);
+    Sg1 = __builtin_amdgcn_udot4(w2, 0x01010101u, Sg1, false);
+    Sg0g1 = __builtin_amdgcn_udot4(w0, t0, Sg0g1, false);
+    Sg0g1 = __builtin_amdgcn_udot4(w1, t1, Sg0g1, false);
+    Sg0g1 = __builtin_amdgcn_udot4(w2, t2, Sg0g1, false);
+    Sg1sq = __builtin_amdgcn_udot4(w0, w0, Sg1sq, false);
+    Sg1sq = __builtin_amdgcn_udot4(w1, w1, Sg1sq, false);
+    Sg1sq = __builtin_amdgcn_udot4(w2, w2, Sg1sq, false);
+    addr += iw;
+  }
+  double sd0, sd1;
+  double corr = ncc_score(Sg0, (int)Sg1, (int)Sg0g1, Sg0sq, (int)Sg1sq, &sd0, &sd1);
+  if (sd1 < kCorrelationSigmaThreshold) corr += 5.0;     // LOW_SIGMA_PENALTY, h:56 / cpp:173-175
+  return corr;
+}
+
 // The union of a job's ellipses is scored once (the reference's per-call score cache, cpp:114,160-181).  Pass 1: every
 // ellipse stamps the positions it visits in an int map (plain stores - the stamp only says "somebody visits this",
 // so which store lands last is irrelevant; an atomicMin here cost 0.75 ms per search at batch 1024: the ellipses overlap
@@ -312,60 +345,119 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
 //   pu_of(e)  -> pointer to (PuInv(0,0), PuInv(0,1), PuInv(1,1)) of ellipse e
 //   emit(e, flag, u, v, best)   called by one lane per ellipse
 // ---------------------------------------------------------------------------
+// Every position (column q, row r) of an ellipse's nu x nv bounding box that lies inside the ellipse, one wavefront:
+// use(fetch(q, r), q, r).  A lane keeps ONE column (or one per block of 64 columns) and walks rows, 64 / W rows of W columns
+// per step, W the power of two that holds nu: the column's terms of the reference's expression ((a u) u, (2 b) u) are formed
+// once, a position costs the row's terms and the compare - twelve instructions where the flat index walk (position = step *
+// 64 + lane, divided by nu) took 35.  Four rows are worked on together: a job has a workgroup to itself and the chip is
+// mostly idle (~300 jobs a step), so what counts is the length of a wavefront's dependent chain - four predicates and four
+// fetches (unconditional, from a row clamped into the box) in flight instead of one.  Same operations in the same order as
+// in_ellipse; use() is called in increasing row order.
+template <typename Fetch, typename Use>
+__device__ __forceinline__ void me_for_each_inside(double a, double b, double c, int us, int nu, int vs, int nv, int lane, Fetch fetch,
+                                                   Use use) {
+  const int lg = nu <= 16 ? 4 : (nu <= 32 ? 5 : 6);
+  const int ql = lane & ((1 << lg) - 1), rs = lane >> lg, rp = 64 >> lg;
+  const double b2 = 2 * b;
+  for (int cb = 0; cb < nu; cb += 64) {
+    const int q = cb + ql;
+    if (q >= nu) continue;
+    const double du = (double)(us + q);
+    const double t1 = a * du * du, bu = b2 * du;
+    for (int r0 = rs; r0 < nv; r0 += 4 * rp) {
+      bool in[4];
+      decltype(fetch(0, 0)) val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * rp;
+        const double dv = (double)(vs + r);
+        in[k] = r < nv && (t1 + bu * dv + c * dv * dv < kNoSigma * kNoSigma);
+        val[k] = fetch(q, min(r, nv - 1));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (in[k]) use(val[k], q, r0 + k * rp);
+    }
+  }
+}
+
+#ifdef SL2_ME_TRACE   // development build (scripts/me_trace.py): cycles per phase of me_search_fused_wg, summed over workgroups
+__device__ unsigned long long g_me_trace[16];
+#define METR(slot) do { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); atomicAdd(&g_me_trace[slot], (unsigned long long)(now_ - t_me_)); t_me_ = now_; } } while (0)
+#define METR_BEGIN long long t_me_ = (long long)__builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_me_trace[15], 1ull)
+#else
+#define METR(slot) do { } while (0)
+#define METR_BEGIN do { } while (0)
+#endif
 constexpr int kMeCap = 2048;
+constexpr int kMeEllCap = 256;       // ellipses of a job whose records fit the one-workgroup form
 constexpr int kMeImgCap = 6144;      // bytes of image under a union's bounding box (+ 5 pixels all round) kept in LDS
 template <typename PuFn, typename EmitFn>
 __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
                                                    const int* __restrict__ desc, int n_ell, PuFn pu_of, EmitFn emit) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthr = (int)blockDim.x, nwave = nthr >> 6;
+  METR_BEGIN;
   __shared__ int f_patch[121];
   __shared__ int f_sums[2];
   __shared__ int f_box[4];
-  __shared__ unsigned char f_stamp[kMeCap];
   __shared__ double f_score[kMeCap];
-  __shared__ uint8_t f_img[kMeImgCap];
-  if (tid < 121) f_patch[tid] = patch121[tid];
-  if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; }
-  __syncthreads();
-  for (int e = tid; e < n_ell; e += nthr) {
-    const int* d = desc + 8 * (size_t)e;
-    if (d[3] <= 0 || d[5] <= 0) continue;
-    atomicMin(&f_box[0], d[0] + d[2]);
-    atomicMin(&f_box[1], d[1] + d[4]);
-    atomicMax(&f_box[2], d[0] + d[2] + d[3]);
-    atomicMax(&f_box[3], d[1] + d[4] + d[5]);
+  __shared__ __attribute__((aligned(16))) uint8_t f_img[kMeImgCap + 16];      // (+ 16: me_score_position_lds reads whole dwords)
+  __shared__ unsigned f_tpl[33];
+  // A job has a workgroup to itself on a chip that is mostly idle (~300 jobs a step): what counts is the length of its
+  // chain of memory round trips.  Everything the search reads besides the image - template, the ellipses' boxes and S^-1 -
+  // is requested HERE, by all threads at once, and parked in LDS: the passes below walk ~7 ellipses per wavefront twice,
+  // and fetching each one's record when its turn came was two dependent round trips per ellipse and pass; loading the
+  // template, the packed template, the boxes and S^-1 in four separate blocks was four round trips in a row (10 us of a
+  // 40 us job, scripts/me_trace.py).  (More ellipses than kMeEllCap, or a workgroup of another size: the job takes the
+  // path of the oversized unions, which has neither limit.)
+  if (n_ell > kMeEllCap || nthr != 1024) return false;
+  __shared__ int f_desc[kMeEllCap * 8];
+  __shared__ double f_pu[kMeEllCap * 3];
+  {
+    const int nd = n_ell * 8, np = n_ell * 3;
+    const int ip = max(min(tid, np - 1), 0);            // (clamped: every thread loads, only the owners store)
+    const int pv = patch121[min(tid, 120)];
+    const int dA = desc[max(min(tid, nd - 1), 0)], dB = desc[max(min(tid + 1024, nd - 1), 0)];
+    const double puv = pu_of(ip / 3)[ip % 3];
+    if (tid < 121) f_patch[tid] = pv;
+    if (tid < nd) f_desc[tid] = dA;
+    if (tid + 1024 < nd) f_desc[tid + 1024] = dB;
+    if (tid < np) f_pu[tid] = puv;
+    if (tid == 0) { f_box[0] = 0x7fffffff; f_box[1] = 0x7fffffff; f_box[2] = -1; f_box[3] = -1; }
   }
-  if (wave == 0) {
+  __syncthreads();
+  if (tid < kMeEllCap) {                                 // waves 0-3: the union's bounding box, one ellipse per thread
+    int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = -1, hi_y = -1;
+    if (tid < n_ell) {
+      const int* d = f_desc + 8 * tid;
+      if (d[3] > 0 && d[5] > 0) { lo_x = d[0] + d[2]; lo_y = d[1] + d[4]; hi_x = lo_x + d[3]; hi_y = lo_y + d[5]; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+      hi_x = max(hi_x, __shfl_xor(hi_x, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+    }
+    if (lane == 0 && hi_x >= 0) { atomicMin(&f_box[0], lo_x); atomicMin(&f_box[1], lo_y); atomicMax(&f_box[2], hi_x); atomicMax(&f_box[3], hi_y); }
+  } else if (wave == 4) {                                // the template's sums
     int s0 = 0, s0q = 0;
     for (int p = lane; p < 121; p += 64) { s0 += f_patch[p]; s0q += f_patch[p] * f_patch[p]; }
     for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s0q += __shfl_xor(s0q, off, 64); }
     if (lane == 0) { f_sums[0] = s0; f_sums[1] = s0q; }
+  } else if (wave == 5 && lane < 33) {                   // the template packed for me_score_position_lds
+    const int row = lane / 3, k = lane % 3;
+    unsigned w = 0;
+    for (int e = 0; e < 4; ++e) { const int col = 4 * k + e; if (col < 11) w |= (unsigned)f_patch[row * 11 + col] << (8 * e); }
+    f_tpl[lane] = w;
   }
   __syncthreads();
+  METR(0);
   const bool any = f_box[2] >= 0;
   const int x0 = f_box[0], y0 = f_box[1], bw = any ? f_box[2] - f_box[0] : 0, bh = any ? f_box[3] - f_box[1] : 0;
   const int area = bw * bh;
   if (area > kMeCap) return false;      // the caller spreads such a job over many workgroups (me_mark_ellipse_wave / me_score_union_wg / me_argmin_wave)
-  // ---- stamps
-  for (int i = tid; i < (area + 3) / 4; i += nthr) ((int*)f_stamp)[i] = 0;
-  __syncthreads();
-  for (int e = wave; e < n_ell; e += nwave) {
-    const int* d = desc + 8 * (size_t)e;
-    const int nu = d[3], nv = d[5];
-    if (nu <= 0 || nv <= 0) continue;
-    const double* pu = pu_of(e);
-    const double a = pu[0], b = pu[1], c = pu[2];
-    const float rcp = 1.0f / (float)nu;
-    const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
-    for (int idx = lane; idx < nu * nv; idx += 64) {
-      int r, q;                                       // row r of the box, column q: consecutive lanes along a row
-      box_divmod(idx, nu, rcp, &r, &q);
-      if (in_ellipse(a, b, c, d[2] + q, d[4] + r)) f_stamp[(by + r) * bw + bx + q] = 1;
-    }
-  }
-  __syncthreads();
-  // ---- the stamped positions, each scored once (no compaction into a list: with up to sixteen waves on at most kMeCap
-  // positions a thread meets four of them at most, and the atomic counter of a list serialises)
+  // ---- every position of the union's bounding box is scored, whether an ellipse visits it or not: finding out which ones
+  // are visited (a pass of all ellipses over their boxes that stamped them) cost 9 us of a 32 us job, scoring the unvisited
+  // third of at most kMeCap positions costs ~1 (scripts/me_trace.py); nobody reads a score outside its ellipse.
+  METR(1);
   {
     // the image under the union (+ 5 pixels all round) goes to LDS once: the 121 taps of a position then cost no memory
     // round trips (a thread scores one or two positions; from memory its eleven rows were eleven dependent round trips each)
@@ -382,36 +474,32 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
       }
       __syncthreads();
     }
+    METR(2);
     for (int idx = tid; idx < area; idx += nthr) {
-      if (!f_stamp[idx]) continue;
       int r, q;
       box_divmod(idx, bw, rcpw, &r, &q);
-      f_score[idx] = tile ? me_score_position(f_img, iw, f_patch, Sg0, Sg0sq, q + 5, r + 5)
+      f_score[idx] = tile ? me_score_position_lds(f_img, iw, f_tpl, Sg0, Sg0sq, q + 5, r + 5)
                           : me_score_position(img, width, f_patch, Sg0, Sg0sq, x0 + q, y0 + r);
     }
   }
   __syncthreads();
-  // ---- per-ellipse arg-min: smallest score, among equals the LARGEST scan-order index (u outer, v inner; cpp:151-185)
+  METR(3);
+  // ---- per-ellipse arg-min: smallest score, among equals the LARGEST scan-order index (u outer, v inner; cpp:151-185).
+  // A lane meets its candidates in increasing scan order (its column, or columns 64 apart, rows upwards), so "corr <=
+  // best: take it" is the whole rule inside a lane (a first candidate above 1e6 is not taken: "corr <= corrmax", cpp:156);
+  // the order index only decides between lanes.
   for (int e = wave; e < n_ell; e += nwave) {
-    const int* d = desc + 8 * (size_t)e;
+    const int* d = f_desc + 8 * e;
     const int nu = d[3], nv = d[5];
     double best = 1000000.0;   // cpp:156
     int order = -1;
     if (nu > 0 && nv > 0) {
-      const double* pu = pu_of(e);
-      const double a = pu[0], b = pu[1], c = pu[2];
-      const float rcp = 1.0f / (float)nu;
+      const double* pu = f_pu + 3 * e;
       const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
-      for (int idx = lane; idx < nu * nv; idx += 64) {
-        int r, q;
-        box_divmod(idx, nu, rcp, &r, &q);
-        if (!in_ellipse(a, b, c, d[2] + q, d[4] + r)) continue;
-        const double corr = f_score[(by + r) * bw + bx + q];
-        const int o = q * nv + r;
-        if (corr < best || (corr == best && o > order) || order < 0) {
-          if (corr <= best) { best = corr; order = o; }       // (a first candidate above 1e6 is not taken: "corr <= corrmax")
-        }
-      }
+      me_for_each_inside(pu[0], pu[1], pu[2], d[2], nu, d[4], nv, lane, [&](int q, int r) { return f_score[(by + r) * bw + bx + q]; },
+                         [&](double corr, int q, int r) {
+        if (corr <= best) { best = corr; order = q * nv + r; }
+      });
     }
     for (int off = 32; off > 0; off >>= 1) {
       const double ob = __shfl_xor(best, off, 64);
@@ -422,6 +510,7 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
       emit(e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
            order >= 0 ? d[1] + d[4] + order % nv : 0, best);
   }
+  METR(4);
   return true;
 }
 

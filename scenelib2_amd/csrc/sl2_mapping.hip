@@ -919,3 +919,11 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
 }
 
 }  // namespace sl2
+
+#ifdef SL2_ME_TRACE
+extern "C" int sl2_debug_me_trace(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(sl2::g_me_trace), sizeof(unsigned long long) * 16) != hipSuccess) return 2;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(sl2::g_me_trace), z, sizeof(z)) != hipSuccess) return 2; }
+  return 0;
+}
+#endif

@@ -163,7 +163,6 @@ struct sl2_engine {
   double* prev_r = nullptr;              // [B][3] camera position before the prediction (speed estimate, :121-124)
   int* me_desc = nullptr;                // [B][kpart][pcap][8] search ellipses of the particles
   double* score_map = nullptr;           // [B][kpart][H][W] score cache of an OVERSIZED multi-ellipse search (allocated on first use)
-  int* owner_map = nullptr;              // [B][kpart][H][W] its stamps (kOwnerFree between searches)
   int* me_big_list = nullptr;            // [B * kpart] (sequence, partial slot) jobs too large for the one-workgroup form, this step
   int* me_big_count = nullptr;           // [1]
   bool mapping_used = false;

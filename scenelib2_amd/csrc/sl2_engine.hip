@@ -450,7 +450,7 @@ void sl2_destroy(sl2_engine* e) {
                   e->traj, e->traj_count, e->last_r, e->status, e->f_h, e->f_Hx, e->f_Hy, e->f_R, e->f_S, e->f_score,
                   e->f_z, e->f_nu, e->sel_idx, e->n_sel, e->n_vis, e->meas_ok, e->meas_score, e->succ_idx, e->f_arow, e->m_count,
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
-                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->owner_map, e->me_big_list, e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->f_hcol, e->pos_count, e->init_uv, e->f_label, e->next_label};
+                  e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->me_big_list, e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->f_hcol, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
   if (e->snap_stage) hipFree(e->snap_stage);
   if (e->snap_host) hipHostFree(e->snap_host);
@@ -687,8 +687,6 @@ static int enable_feature_initialisation(sl2_engine* e) {
   if (!e->score_map) {
     const size_t px = (size_t)e->B * e->kpart * e->cam.width * e->cam.height;
     SL2_HIP(hipMalloc((void**)&e->score_map, sizeof(double) * px));
-    SL2_HIP(hipMalloc((void**)&e->owner_map, sizeof(int) * px));
-    SL2_HIP(hipMemsetAsync(e->owner_map, 0x7f, sizeof(int) * px, e->stream));   // 0x7f7f7f7f: above every particle index
     SL2_HIP(hipMalloc((void**)&e->me_big_list, sizeof(int) * ((size_t)e->B * e->kpart + 1)));
     e->me_big_count = e->me_big_list + (size_t)e->B * e->kpart;
     SL2_HIP(hipMemsetAsync(e->me_big_list, 0, sizeof(int) * ((size_t)e->B * e->kpart + 1), e->stream));
@@ -706,7 +704,7 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
   if ((rc = bind_frames(e, frames, seq_stride, frames_on_device)) != SL2_OK) return rc;
   sl2_engine* g = e->groups.empty() ? e : e->groups[0];
   g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
-  g->score_map = e->score_map; g->owner_map = e->owner_map; g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
+  g->score_map = e->score_map; g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
   if (uv) {
     if (!e->init_uv) SL2_HIP(hipMalloc((void**)&e->init_uv, sizeof(int) * 2 * e->B));
     // the caller's buffer may be pinned or registered memory, for which an asynchronous copy really is asynchronous: the copy
@@ -763,7 +761,6 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       sl2_engine* g = e->groups.empty() ? e : e->groups[0];
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
-      g->owner_map = e->owner_map;
       g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
       r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
     }

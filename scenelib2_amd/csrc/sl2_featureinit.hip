@@ -46,16 +46,15 @@ __global__ void __launch_bounds__(64) k_me_describe(const double* __restrict__ p
 }
 
 // one workgroup per job: me_search_fused_wg (stamps and scores of the union's bounding box in LDS); a job whose union exceeds
-// kMeCap positions goes on the list of k_me_big_* (the image-sized owner / score maps are touched by those only)
+// kMeCap positions goes on the list of k_me_big_* (the image-sized score maps are touched by those only)
 struct MeJobsBatch {
   const uint8_t* images; const int* image_index; const uint8_t* patches; const int* first; const int* desc_base; const double* puinv;
-  int* owner_base; double* map_base; int* result; double* corrmax; int width, height;
+  double* map_base; int* result; double* corrmax; int width, height;
   __device__ const uint8_t* img(int j) const { return images + (size_t)image_index[j] * width * height; }
   __device__ const uint8_t* patch(int j) const { return patches + (size_t)j * 121; }
   __device__ const int* desc(int j) const { return desc_base + 8 * (size_t)first[j]; }
   __device__ int n_ell(int j) const { return first[j + 1] - first[j]; }
   __device__ const double* pu(int j, int e) const { return puinv + 3 * ((size_t)first[j] + e); }
-  __device__ int* owner(int j) const { return owner_base + (size_t)j * width * height; }
   __device__ double* map(int j) const { return map_base + (size_t)j * width * height; }
   __device__ void emit(int j, int e, int flag, int u, int v, double best) const {
     const size_t k = (size_t)first[j] + e;
@@ -143,12 +142,12 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   if (!puinv || !centre) return SL2_ERR_INVALID;
   int rc = check_device(device);
   if (rc != SL2_OK) return rc;
-  DevBuf d_img, d_idx, d_pat, d_first, d_pu, d_ce, d_desc, d_map, d_own, d_res, d_corr, d_big;
+  DevBuf d_img, d_idx, d_pat, d_first, d_pu, d_ce, d_desc, d_map, d_res, d_corr, d_big;
   const size_t img_bytes = (size_t)nimages * width * height;
   if (d_img.alloc(img_bytes) || d_idx.alloc(sizeof(int) * njobs) || d_pat.alloc((size_t)njobs * 121) ||
       d_big.alloc(sizeof(int) * (njobs + 1)) || d_first.alloc(sizeof(int) * (njobs + 1)) || d_pu.alloc(sizeof(double) * 3 * total) ||
       d_ce.alloc(sizeof(double) * 2 * total) || d_desc.alloc(sizeof(int) * 8 * total) ||
-      d_map.alloc(sizeof(double) * (size_t)njobs * width * height) || d_own.alloc(sizeof(int) * (size_t)njobs * width * height) ||
+      d_map.alloc(sizeof(double) * (size_t)njobs * width * height) ||
       d_res.alloc(sizeof(int) * 3 * total) ||
       d_corr.alloc(sizeof(double) * total)) {
     set_error("hipMalloc failed");
@@ -161,7 +160,6 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
   SL2_HIP(hipMemcpy(d_first.p, first.data(), sizeof(int) * (njobs + 1), hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_pu.p, puinv, sizeof(double) * 3 * total, hipMemcpyHostToDevice));
   SL2_HIP(hipMemcpy(d_ce.p, centre, sizeof(double) * 2 * total, hipMemcpyHostToDevice));
-  SL2_HIP(hipMemset(d_own.p, 0x7f, sizeof(int) * (size_t)njobs * width * height));   // = kOwnerFree
   hipEvent_t ev0, ev1;
   SL2_HIP(hipEventCreate(&ev0));
   SL2_HIP(hipEventCreate(&ev1));
@@ -170,7 +168,7 @@ extern "C" int sl2_search_multiple_overlapping_ellipses_batch(int device, const 
                      height, d_desc.as<int>());
   MeJobsBatch J;
   J.images = d_img.as<uint8_t>(); J.image_index = d_idx.as<int>(); J.patches = d_pat.as<uint8_t>(); J.first = d_first.as<int>();
-  J.desc_base = d_desc.as<int>(); J.puinv = d_pu.as<double>(); J.owner_base = d_own.as<int>(); J.map_base = d_map.as<double>();
+  J.desc_base = d_desc.as<int>(); J.puinv = d_pu.as<double>(); J.map_base = d_map.as<double>();
   J.result = d_res.as<int>(); J.corrmax = corrmax ? d_corr.as<double>() : nullptr; J.width = width; J.height = height;
   hipLaunchKernelGGL(k_me_search, dim3(njobs), dim3(1024), 0, 0, J, d_big.as<int>(), d_big.as<int>() + njobs);
   me_big_launch(J, d_big.as<int>(), d_big.as<int>() + njobs, width, 0);

@@ -174,14 +174,12 @@ __device__ __forceinline__ double me_score_position_lds(const uint8_t* s_img, in
   return corr;
 }
 
-// The union of a job's ellipses is scored once (the reference's per-call score cache, cpp:114,160-181).  Pass 1: every
-// ellipse stamps the positions it visits in an int map (plain stores - the stamp only says "somebody visits this",
-// so which store lands last is irrelevant; an atomicMin here cost 0.75 ms per search at batch 1024: the ellipses overlap
-// heavily and the atomics serialise).  Pass 2: ONE scan over the union's bounding box per job finds the stamped
-// positions, clears the stamps and scores each position once.  Pass 3: per-ellipse arg-min over the score map.
+// The union of a job's ellipses is scored once (the reference's per-call score cache, cpp:114,160-181): every position of
+// the union's bounding box gets its score, then every ellipse takes the arg-min over the positions it visits.
 // (History: testing every earlier ellipse of the job for every position - 90 % of the search with 100 particle ellipses;
-// then one workgroup per ellipse scoring the positions it owned - each re-scanned its own box, 0.31 ms of 0.55.)
-constexpr int kOwnerFree = 0x7f7f7f7f;    // = memset(0x7f): above every ellipse index
+// one workgroup per ellipse scoring the positions it owned - each re-scanned its own box, 0.31 ms of 0.55; ellipses
+// stamping the positions they visit in an int map, one scan per job compacting the stamped positions into lists - round 4
+// dropped the stamps: scoring a position nobody visits is cheaper than finding out that nobody does.)
 
 // idx = q * n + r for 0 <= idx < 2^22, 0 < n: a float reciprocal estimate, corrected (the integer division sequence is ~40
 // instructions, and the box scans below do little else)
@@ -193,49 +191,49 @@ __device__ __forceinline__ void box_divmod(int idx, int n, float rcp, int* q, in
   *q = qq; *r = rr;
 }
 
-// One wavefront stamps one ellipse.
-// (part = this wavefront's share of the box's rows, of `parts`: a frame-sized ellipse is split over a workgroup's waves)
-__device__ __forceinline__ void me_mark_ellipse_wave(const int* __restrict__ d, const double* __restrict__ pu, int width,
-                                                     int* __restrict__ owner, int index, int part = 0, int parts = 1) {
-  const int nu = d[3], nv = d[5];
-  if (nu <= 0 || nv <= 0) return;
-  const float rcp = 1.0f / (float)nu;
-  const double a = pu[0], b = pu[1], c = pu[2];
-  const int rows_per = (nv + parts - 1) / parts;
-  const int i0 = part * rows_per * nu, i1 = min((part + 1) * rows_per, nv) * nu;
-  for (int idx = i0 + (threadIdx.x & 63); idx < i1; idx += 64) {
-    int q, r;                                       // row r of the box, column q: consecutive lanes walk along an image row
-    box_divmod(idx, nu, rcp, &r, &q);
-    const int urel = d[2] + q, vrel = d[4] + r;
-    if (!in_ellipse(a, b, c, urel, vrel)) continue;
-    owner[(size_t)(d[1] + vrel) * width + (d[0] + urel)] = index;     // racy on purpose: any visitor's stamp will do
-  }
-}
-
-// Workgroup-collective (256 threads): score every stamped position of rows slice / nslices of the bounding box of the
-// job's n_ell ellipses (descriptors desc[8 e]), clearing the stamps on the way.
-__device__ __forceinline__ void me_score_union_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
-                                                  const int* __restrict__ desc, int n_ell, int* __restrict__ owner,
-                                                  double* __restrict__ map, int slice, int nslices) {
-  const int tid = threadIdx.x;
+// Workgroup-collective (256 threads): the scores of rows slice / nslices of the bounding box of the job's n_ell ellipses
+// (descriptors desc[8 e]) go to the job's image-sized score map - EVERY position of the box, whether an ellipse visits it
+// or not (round 4 stamped the visited ones first, a launch of its own over every ellipse's box, and compacted them into
+// lists: a frame-sized box is 77 k positions of ~250 instructions, nothing for the chip once it is spread over workgroups;
+// nobody reads a score outside its ellipse).  The image under a band of rows goes through LDS (me_score_position_lds).
+constexpr int kMeBandBytes = 16384;
+__device__ __forceinline__ void me_score_box_wg(const uint8_t* __restrict__ img, int width, const uint8_t* __restrict__ patch121,
+                                                const int* __restrict__ desc, int n_ell, double* __restrict__ map, int slice,
+                                                int nslices) {
+  const int tid = threadIdx.x, lane = tid & 63;
   __shared__ int s_patch[121];
+  __shared__ unsigned s_tpl[33];
   __shared__ int s_sums[2];
   __shared__ int s_box[4];
-  if (tid < 121) s_patch[tid] = patch121[tid];
-  if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) uint8_t s_band[kMeBandBytes + 16];
+  const int pv = patch121[min(tid, 120)];
+  int lo_x = 0x7fffffff, lo_y = 0x7fffffff, hi_x = -1, hi_y = -1;
   for (int e = tid; e < n_ell; e += 256) {
     const int* d = desc + 8 * (size_t)e;
-    if (d[3] <= 0 || d[5] <= 0) continue;
-    atomicMin(&s_box[0], d[0] + d[2]);
-    atomicMin(&s_box[1], d[1] + d[4]);
-    atomicMax(&s_box[2], d[0] + d[2] + d[3]);
-    atomicMax(&s_box[3], d[1] + d[4] + d[5]);
+    const int nu = d[3], nv = d[5];
+    if (nu <= 0 || nv <= 0) continue;
+    lo_x = min(lo_x, d[0] + d[2]); lo_y = min(lo_y, d[1] + d[4]);
+    hi_x = max(hi_x, d[0] + d[2] + nu); hi_y = max(hi_y, d[1] + d[4] + nv);
   }
-  if (tid == 0) {
+  if (tid < 121) s_patch[tid] = pv;
+  if (tid == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -1; s_box[3] = -1; }
+  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = min(lo_x, __shfl_xor(lo_x, off, 64)); lo_y = min(lo_y, __shfl_xor(lo_y, off, 64));
+    hi_x = max(hi_x, __shfl_xor(hi_x, off, 64)); hi_y = max(hi_y, __shfl_xor(hi_y, off, 64));
+  }
+  if (lane == 0 && hi_x >= 0) { atomicMin(&s_box[0], lo_x); atomicMin(&s_box[1], lo_y); atomicMax(&s_box[2], hi_x); atomicMax(&s_box[3], hi_y); }
+  if (tid >= 64 && tid < 64 + 33) {                      // the template packed for me_score_position_lds
+    const int row = (tid - 64) / 3, k = (tid - 64) % 3;
+    unsigned w = 0;
+    for (int e = 0; e < 4; ++e) { const int col = 4 * k + e; if (col < 11) w |= (unsigned)s_patch[row * 11 + col] << (8 * e); }
+    s_tpl[tid - 64] = w;
+  }
+  if (tid >= 128 && tid < 192) {                         // the template's sums
     int s0 = 0, s0q = 0;
-    for (int p = 0; p < 121; ++p) { s0 += s_patch[p]; s0q += s_patch[p] * s_patch[p]; }
-    s_sums[0] = s0; s_sums[1] = s0q;
+    for (int p = lane; p < 121; p += 64) { s0 += s_patch[p]; s0q += s_patch[p] * s_patch[p]; }
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s0q += __shfl_xor(s0q, off, 64); }
+    if (lane == 0) { s_sums[0] = s0; s_sums[1] = s0q; }
   }
   __syncthreads();
   if (s_box[2] < 0) return;
@@ -244,29 +242,61 @@ __device__ __forceinline__ void me_score_union_wg(const uint8_t* __restrict__ im
   const int rows = s_box[3] - s_box[1], per = (rows + nslices - 1) / nslices;
   const int ys = s_box[1] + slice * per;
   const int ye = (ys + per < s_box[3]) ? ys + per : s_box[3];
-  const int total = bw * (ye - ys);
-  // Stamped positions are first compacted into an LDS list so that the 121-tap correlations run on full wavefronts.
-  constexpr int kListCap = 1024;
-  __shared__ int s_list[kListCap];
-  __shared__ int s_n;
-  for (int base = 0; base < total; base += kListCap) {
-    if (tid == 0) s_n = 0;
-    __syncthreads();
-    const int end = (base + kListCap < total) ? base + kListCap : total;
-    for (int idx = base + tid; idx < end; idx += 256) {
-      const int y = ys + idx / bw, x = x0 + idx % bw;
-      const size_t pos = (size_t)y * width + x;
-      if (owner[pos] >= kOwnerFree) continue;
-      owner[pos] = kOwnerFree;          // the stamp map is clean again for the next search
-      s_list[atomicAdd(&s_n, 1)] = (y << 16) | x;
+  const int iw = bw + 10;
+  const int band = kMeBandBytes / iw - 10;               // rows of positions whose windows fit the LDS band (iw <= width + 10)
+  if (band <= 0) return;                                 // (a frame wider than ~1600 pixels: not reachable, me_big is bounded by sl2_create's checks)
+  const float rcpi = 1.0f / (float)iw, rcpw = 1.0f / (float)bw;
+  for (int yb = ys; yb < ye; yb += band) {
+    const int nr = min(band, ye - yb);
+    __syncthreads();                                     // the previous band has been scored
+    for (int i = tid; i < iw * (nr + 10); i += 256) {
+      int r, q;
+      box_divmod(i, iw, rcpi, &r, &q);
+      s_band[i] = img[(size_t)(yb - 5 + r) * width + (x0 - 5 + q)];
     }
     __syncthreads();
-    const int n = s_n;
-    for (int k = tid; k < n; k += 256) {
-      const int x = s_list[k] & 0xffff, y = s_list[k] >> 16;
-      map[(size_t)y * width + x] = me_score_position(img, width, s_patch, Sg0, Sg0sq, x, y);
+    for (int idx = tid; idx < bw * nr; idx += 256) {
+      int r, q;
+      box_divmod(idx, bw, rcpw, &r, &q);
+      map[(size_t)(yb + r) * width + (x0 + q)] = me_score_position_lds(s_band, iw, s_tpl, Sg0, Sg0sq, q + 5, r + 5);
     }
-    __syncthreads();
+  }
+}
+
+// Every position (column q, row r) of an ellipse's nu x nv bounding box that lies inside the ellipse, one wavefront:
+// use(fetch(q, r), q, r).  A lane keeps ONE column (or one per block of 64 columns) and walks rows, 64 / W rows of W columns
+// per step, W the power of two that holds nu: the column's terms of the reference's expression ((a u) u, (2 b) u) are formed
+// once, a position costs the row's terms and the compare - twelve instructions where the flat index walk (position = step *
+// 64 + lane, divided by nu) took 35.  Four rows are worked on together: a job has a workgroup to itself and the chip is
+// mostly idle (~300 jobs a step), so what counts is the length of a wavefront's dependent chain - four predicates and four
+// fetches (unconditional, from a row clamped into the box) in flight instead of one.  Same operations in the same order as
+// in_ellipse; use() is called in increasing row order.
+template <typename Fetch, typename Use>
+__device__ __forceinline__ void me_for_each_inside(double a, double b, double c, int us, int nu, int vs, int nv, int lane, Fetch fetch,
+                                                   Use use, int r_first = 0, int r_end = 0x7fffffff) {
+  const int lg = nu <= 16 ? 4 : (nu <= 32 ? 5 : 6);
+  const int ql = lane & ((1 << lg) - 1), rs = lane >> lg, rp = 64 >> lg;
+  const double b2 = 2 * b;
+  for (int cb = 0; cb < nu; cb += 64) {
+    const int q = cb + ql;
+    if (q >= nu) continue;
+    const double du = (double)(us + q);
+    const double t1 = a * du * du, bu = b2 * du;
+    const int rend = min(nv, r_end);                      // (rows r_first .. r_end - 1 only: a tall box shared by several wavefronts)
+    for (int r0 = r_first + rs; r0 < rend; r0 += 4 * rp) {
+      bool in[4];
+      decltype(fetch(0, 0)) val[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + k * rp;
+        const double dv = (double)(vs + r);
+        in[k] = r < rend && (t1 + bu * dv + c * dv * dv < kNoSigma * kNoSigma);
+        val[k] = fetch(q, min(r, rend - 1));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (in[k]) use(val[k], q, r0 + k * rp);
+    }
   }
 }
 
@@ -280,30 +310,14 @@ __device__ __forceinline__ void me_argmin_part(int width, const int* __restrict_
   double best = 1000000.0;   // cpp:156
   int order = -1;
   if (nu > 0 && nv > 0) {
-    const float rcp = 1.0f / (float)nu;
-    const double a = pu[0], b = pu[1], c = pu[2];
-    // consecutive lanes along an image row (coalesced reads of the score map); the reference's scan order (u outer, v
-    // inner) is carried as `o`.  Four positions per lane and round, their loads issued together: with one ellipse per
-    // wavefront nothing else hides the latency of a load that is consumed at once (a frame-sized ellipse is ~900 rounds; at
-    // one round trip per round that was 0.5 ms, the whole of k_me_big_argmin).
+    // A lane keeps a column and walks rows (me_for_each_inside: consecutive lanes along an image row = coalesced reads of the
+    // score map, four rows' loads in flight); it meets its candidates in increasing scan order (u outer, v inner), so "corr <=
+    // best: take it" is the whole rule inside a lane and the order index only decides between lanes.
     const int rows_per = (nv + parts - 1) / parts;
-    const int first = part * rows_per * nu, total = min((part + 1) * rows_per, nv) * nu, d0 = d[0], d1 = d[1], d2 = d[2], d4 = d[4];
-    for (int base = first + lane; base < total; base += 256) {
-      double corr[4];
-      int oo[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int idx = base + 64 * k;
-        int q, r;
-        box_divmod(idx < total ? idx : 0, nu, rcp, &r, &q);
-        const bool in = idx < total && in_ellipse(a, b, c, d2 + q, d4 + r);
-        oo[k] = in ? q * nv + r : -1;
-        corr[k] = in ? map[(size_t)(d1 + d4 + r) * width + (d0 + d2 + q)] : 0.0;
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (oo[k] >= 0 && (corr[k] < best || (corr[k] == best && oo[k] > order) || order < 0) && corr[k] <= best) { best = corr[k]; order = oo[k]; }
-    }
+    const double* m0 = map + (size_t)(d[1] + d[4]) * width + (d[0] + d[2]);
+    me_for_each_inside(pu[0], pu[1], pu[2], d[2], nu, d[4], nv, lane, [&](int q, int r) { return m0[(size_t)r * width + q]; },
+                       [&](double corr, int q, int r) { if (corr <= best) { best = corr; order = q * nv + r; } },
+                       part * rows_per, (part + 1) * rows_per);
   }
   for (int off = 32; off > 0; off >>= 1) {
     const double ob = __shfl_xor(best, off, 64);
@@ -345,42 +359,6 @@ __device__ __forceinline__ void me_argmin_wave(int width, const int* __restrict_
 //   pu_of(e)  -> pointer to (PuInv(0,0), PuInv(0,1), PuInv(1,1)) of ellipse e
 //   emit(e, flag, u, v, best)   called by one lane per ellipse
 // ---------------------------------------------------------------------------
-// Every position (column q, row r) of an ellipse's nu x nv bounding box that lies inside the ellipse, one wavefront:
-// use(fetch(q, r), q, r).  A lane keeps ONE column (or one per block of 64 columns) and walks rows, 64 / W rows of W columns
-// per step, W the power of two that holds nu: the column's terms of the reference's expression ((a u) u, (2 b) u) are formed
-// once, a position costs the row's terms and the compare - twelve instructions where the flat index walk (position = step *
-// 64 + lane, divided by nu) took 35.  Four rows are worked on together: a job has a workgroup to itself and the chip is
-// mostly idle (~300 jobs a step), so what counts is the length of a wavefront's dependent chain - four predicates and four
-// fetches (unconditional, from a row clamped into the box) in flight instead of one.  Same operations in the same order as
-// in_ellipse; use() is called in increasing row order.
-template <typename Fetch, typename Use>
-__device__ __forceinline__ void me_for_each_inside(double a, double b, double c, int us, int nu, int vs, int nv, int lane, Fetch fetch,
-                                                   Use use) {
-  const int lg = nu <= 16 ? 4 : (nu <= 32 ? 5 : 6);
-  const int ql = lane & ((1 << lg) - 1), rs = lane >> lg, rp = 64 >> lg;
-  const double b2 = 2 * b;
-  for (int cb = 0; cb < nu; cb += 64) {
-    const int q = cb + ql;
-    if (q >= nu) continue;
-    const double du = (double)(us + q);
-    const double t1 = a * du * du, bu = b2 * du;
-    for (int r0 = rs; r0 < nv; r0 += 4 * rp) {
-      bool in[4];
-      decltype(fetch(0, 0)) val[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = r0 + k * rp;
-        const double dv = (double)(vs + r);
-        in[k] = r < nv && (t1 + bu * dv + c * dv * dv < kNoSigma * kNoSigma);
-        val[k] = fetch(q, min(r, nv - 1));
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (in[k]) use(val[k], q, r0 + k * rp);
-    }
-  }
-}
-
 #ifdef SL2_ME_TRACE   // development build (scripts/me_trace.py): cycles per phase of me_search_fused_wg, summed over workgroups
 __device__ unsigned long long g_me_trace[16];
 #define METR(slot) do { if (threadIdx.x == 0) { const long long now_ = (long long)__builtin_readcyclecounter(); atomicAdd(&g_me_trace[slot], (unsigned long long)(now_ - t_me_)); t_me_ = now_; } } while (0)
@@ -453,7 +431,7 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
   const bool any = f_box[2] >= 0;
   const int x0 = f_box[0], y0 = f_box[1], bw = any ? f_box[2] - f_box[0] : 0, bh = any ? f_box[3] - f_box[1] : 0;
   const int area = bw * bh;
-  if (area > kMeCap) return false;      // the caller spreads such a job over many workgroups (me_mark_ellipse_wave / me_score_union_wg / me_argmin_wave)
+  if (area > kMeCap) return false;      // the caller spreads such a job over many workgroups (me_score_box_wg / me_argmin_part)
   // ---- every position of the union's bounding box is scored, whether an ellipse visits it or not: finding out which ones
   // are visited (a pass of all ellipses over their boxes that stamped them) cost 9 us of a 32 us job, scoring the unvisited
   // third of at most kMeCap positions costs ~1 (scripts/me_trace.py); nobody reads a score outside its ellipse.
@@ -519,23 +497,14 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
 // the image-sized maps.  `Jobs` describes where a job's data lives (the engine's particle records / the arrays of the
 // stateless operator); list / count = the declined jobs of this step.  Fixed small grids that stride over the list - a
 // step has a handful of such jobs, usually none.
-//   Jobs: img(job), patch(job), desc(job), n_ell(job), pu(job, e), owner(job), map(job), emit(job, e, flag, u, v, best)
+//   Jobs: img(job), patch(job), desc(job), n_ell(job), pu(job, e), map(job), emit(job, e, flag, u, v, best)
 // ---------------------------------------------------------------------------
-template <typename Jobs>
-__global__ void __launch_bounds__(256) k_me_big_mark(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
-  const int n = *count, wave = threadIdx.x >> 6;
-  for (int li = blockIdx.y; li < n; li += gridDim.y) {
-    const int job = list[li], ne = J.n_ell(job);
-    for (int e = blockIdx.x; e < ne; e += gridDim.x)              // one ellipse per workgroup, its rows split over the four waves
-      me_mark_ellipse_wave(J.desc(job) + 8 * (size_t)e, J.pu(job, e), width, J.owner(job), e, wave, 4);
-  }
-}
 template <typename Jobs>
 __global__ void __launch_bounds__(256) k_me_big_scores(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
   const int n = *count;
   for (int li = blockIdx.y; li < n; li += gridDim.y) {
     const int job = list[li];
-    me_score_union_wg(J.img(job), width, J.patch(job), J.desc(job), J.n_ell(job), J.owner(job), J.map(job), blockIdx.x, gridDim.x);
+    me_score_box_wg(J.img(job), width, J.patch(job), J.desc(job), J.n_ell(job), J.map(job), blockIdx.x, gridDim.x);
     __syncthreads();
   }
 }
@@ -564,10 +533,9 @@ __global__ void __launch_bounds__(256) k_me_big_argmin(Jobs J, const int* __rest
     }
   }
 }
-constexpr int kMeBigGridX = 128, kMeBigGridY = 8, kMeBigSlices = 16;
+constexpr int kMeBigGridX = 128, kMeBigGridY = 8, kMeBigSlices = 64;
 template <typename Jobs>
 inline void me_big_launch(Jobs J, const int* list, const int* count, int width, hipStream_t st) {
-  hipLaunchKernelGGL(k_me_big_mark<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
   hipLaunchKernelGGL(k_me_big_scores<Jobs>, dim3(kMeBigSlices, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
   hipLaunchKernelGGL(k_me_big_argmin<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
 }

@@ -344,14 +344,13 @@ __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restr
 // 1024, profiles/r04_mapping_*).  A sequence whose union is too large for that goes on the list of k_me_big_*.
 struct MeJobsEngine {      // job = sequence * kpart + partial slot
   const uint8_t* frames; size_t seq_stride; const uint8_t* patch_base; const int* ps_i; const int* me_desc; double* particles;
-  int* owner_base; double* map_base; int N, pcap, width, height, kpart;
+  double* map_base; int N, pcap, width, height, kpart;
   __device__ const int* ps(int j) const { return ps_i + (size_t)j * kPsInts; }
   __device__ const uint8_t* img(int j) const { return frames + (size_t)(j / kpart) * seq_stride; }
   __device__ const uint8_t* patch(int j) const { return patch_base + ((size_t)(j / kpart) * N + ps(j)[kPsLabel]) * kPatchStride; }
   __device__ const int* desc(int j) const { return me_desc + (size_t)j * pcap * 8; }
   __device__ int n_ell(int j) const { return ps(j)[kPsNp]; }
   __device__ const double* pu(int j, int e) const { return particles + ((size_t)j * pcap + e) * kParticleDoubles + 7; }
-  __device__ int* owner(int j) const { return owner_base + (size_t)j * width * height; }
   __device__ double* map(int j) const { return map_base + (size_t)j * width * height; }
   __device__ void emit(int j, int e, int flag, int u, int v, double) const {
     double* o = particles + ((size_t)j * pcap + e) * kParticleDoubles;
@@ -861,7 +860,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.pcap = e->root->pcap;
   mp.kpart = e->root->kpart;
   const int W = e->cam.width, H = e->cam.height;
-  if (!e->score_map || !e->owner_map) { set_error("launch_mapping: score / ownership map not allocated"); return SL2_ERR_INVALID; }
+  if (!e->score_map) { set_error("launch_mapping: score map not allocated"); return SL2_ERR_INVALID; }
   if (enable_mapping) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   {
     LaunchScope ls(e, "k_map_region");
@@ -896,7 +895,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   {
     MeJobsEngine J;
     J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.ps_i = e->ps_i; J.me_desc = e->me_desc;
-    J.particles = e->particles; J.owner_base = e->owner_map; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
+    J.particles = e->particles; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
     J.width = W; J.height = H; J.kpart = mp.kpart;
     {
       LaunchScope ls(e, "k_map_me_search");

@@ -49,7 +49,16 @@ constexpr int kParticleDoubles = 12;     // lambda, probability, cumulative, h[2
 // [1] windows shared out in the last completed step (sl2_get_step_work), [2] next unit to hand out, [3] windows shared out this
 // step; then per unit: its entry (sequence, selected position, first unit of its window, units of its window), the count
 // of finished units of the window (kept at the window's first unit) and its partial result (8 ints).
-constexpr int kSrchSplitDefault = 8;                  // bands from which a window is shared out (mapping workload, step: 0.734 ms never, 0.687 at 24, 0.665 at 8, 0.661 at 4)
+// Default threshold: 8 bands at 320 x 240 (150 bands a frame; mapping workload, step: 0.734 ms never, 0.687 at 24, 0.665 at 8,
+// 0.661 at 4), the same twentieth of the frame at other sizes - what is shared out must be the rare window that is far larger
+// than the rest, not the typical one: at 1280 x 720 x 500 features a threshold of 8 bands listed 8192 windows a step and
+// the 2048 trailing workgroups became the search (2.19 against 1.24 ms, profiles/r04_search_shared_ab.txt).
+constexpr int kSrchSplitDefault = 8;
+__host__ __device__ inline int srch_split_default(int width, int height) {
+  const int frame_bands = ((width + 31) / 32) * ((height + 15) / 16);
+  const int t = frame_bands * kSrchSplitDefault / 150;
+  return t > kSrchSplitDefault ? t : kSrchSplitDefault;
+}
 constexpr int kSrchBigUnits = 16384;                  // units per step and sequence group (a 320 x 240 window: 38); windows beyond stay with their own wavefront
 constexpr int kSrchBigSlots = 64;                     // units per window at most: its partial results are combined by one wavefront, a lane each
 constexpr int kSrchBigMinBands = 4;                   // bands per unit at least
@@ -181,7 +190,7 @@ struct sl2_engine {
                               // 512 x n = 1513, profiles/r03_c5_chol_panel_ab.txt); TEST build: SL2_CHOL_PANEL = 4 | 8
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice
   int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)
-  int search_split = sl2::kSrchSplitDefault;   // windows of at least this many 32 x 16 bands are shared out over wavefronts (0 = never); sl2_set_search_split
+  int search_split = sl2::kSrchSplitDefault;   // windows of at least this many 32 x 16 bands are shared out over wavefronts (0 = never); sl2_create: srch_split_default, then sl2_set_search_split
   // ---- large search windows (round 4): the step's units of work for every wavefront of k_search_mfma (layout: kSrchBig* above) ----
   int* srch_big = nullptr;    // per sequence GROUP (allocated by build_groups)
 

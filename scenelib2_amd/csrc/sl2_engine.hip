@@ -311,6 +311,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   // columns: xv(13), 3 per feature slot, 6 per partially initialised feature in flight (params.max_features_to_init_at_once of
   // them, the shipped value is 1), 1 for the innovation (At / Vt)
   e->kpart = params->max_features_to_init_at_once < 1 ? 1 : (params->max_features_to_init_at_once > kMaxPartial ? kMaxPartial : params->max_features_to_init_at_once);
+  e->search_split = srch_split_default(e->cam.width, e->cam.height);
   e->ld = round_up(13 + 3 * max_features + 6 * e->kpart + 1, 64);
   e->ppos = 13 + 3 * max_features;
   int nsel = params->number_of_features_to_select;

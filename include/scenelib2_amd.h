@@ -199,7 +199,7 @@ int sl2_set_graph_mode(sl2_engine* e, int enabled);
 int sl2_set_search_variant(sl2_engine* e, int variant);
 /* Search windows of at least `min_bands` bands (a band = 32 x 16 candidate positions; a window of nu x nv positions has
  * ceil(ceil(nu / 16) / 2) * ceil(nv / 16) of them) are not walked by one wavefront but cut into units of four bands that
- * 2048 extra workgroups at the end of the search launch work off - the window of a poorly constrained feature can be the
+ * extra workgroups at the end of the search launch (a quarter of it, at most 2048) work off - the window of a poorly constrained feature can be the
  * whole frame (150 bands at 320 x 240), and one wavefront walking it alone was the tail of the search.  Default: a twentieth
  * of the frame's bands (8 at 320 x 240, 96 at 1280 x 720: what is shared out should be the rare oversized window); 0 =
  * never (and no extra workgroups: they cost the headline step 0.06 %).  Results are identical either way: the parts' best

@@ -773,7 +773,7 @@ __device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frame
 }
 
 constexpr int kMfChunk = 4;
-constexpr int kSearchBigWaves = 2048;   // workgroups of k_search_mfma that work off the large windows' units: two per SIMD of the chip
+constexpr int kSearchBigWaves = 2048;   // workgroups of k_search_mfma that work off the large windows' units, at most: two per SIMD of the chip
 // Engine kernel.  One wavefront works through `chunk` consecutive selected positions of one sequence (XCD-mapped: a
 // sequence's frame stays in one XCD's L2).  A feature's search is a chain of dependent memory round trips - record,
 // template + window, LDS - so the loop is software-pipelined: while position i is in the matrix cores and being scored,
@@ -785,7 +785,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
             double* __restrict__ meas_score, int N, int nchunks, int B, int chunk, int* __restrict__ srch_big) {
   __shared__ __attribute__((aligned(16))) char s_pl[3 * kM4Plane];
   __shared__ __attribute__((aligned(16))) unsigned s_T[kMfTplDw];
-  // The last kSearchBigWaves workgroups of the grid own no positions: they work off the units of the step's large windows
+  // The last workgroups of the grid (launch_search: up to kSearchBigWaves) own no positions: they work off the units of the step's large windows
   // (m4_big_windows above; with no window on the list - the usual step of a well-constrained map - they read the list's
   // length and end).  Being the last to be dispatched they run while the launch drains.  Measured alternatives
   // (profiles/r04_search_shared_ab.txt): the same work at the END of every wavefront costs the common path 5-9 % (the
@@ -1123,7 +1123,11 @@ int launch_search(sl2_engine* e) {
       if (e->root->search_chunk > 0) chunk = e->root->search_chunk;        // experiments (TEST build: SL2_SEARCH_CHUNK)
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
       const bool shared = e->srch_big && e->root->search_split > 0;       // (k_select only lists windows under the same condition)
-      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B) + (shared ? kSearchBigWaves : 0)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+      // trailing workgroups for the large windows' units: a quarter of the launch, 128 to kSearchBigWaves (a single sequence
+      // should not pay for dispatching two thousand empty wavefronts; its frame-sized window is 38 units)
+      int helpers = xcd_grid(nchunks, e->B) / 4;
+      helpers = helpers < 128 ? 128 : (helpers > kSearchBigWaves ? kSearchBigWaves : helpers);
+      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B) + (shared ? helpers : 0)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,
                          e->N, nchunks, e->B, chunk, shared ? e->srch_big : nullptr);
     }

@@ -712,54 +712,42 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
     if (ps[kPsActive] && ps[kPsLabel] >= 0 && ps[kPsLabel] < ns) ps[kPsLabel] = s_new[ps[kPsLabel]];
   }
   // ---- P: new index i <- old index src(i); pose rows and the partial feature's six rows / the innovation row stay where
-  // they are, the vacated feature rows / columns become zero.  Row by row in increasing i: src(i) >= i, so a source row is
-  // never one already rewritten; within a row all reads complete (barrier) before the writes.
+  // they are, the vacated feature rows / columns become zero.  In blocks of rows, increasing: src(i) >= i, so a block's
+  // source rows are never rows already rewritten; within a block every read completes (barrier) before the writes.  A
+  // block is as many rows as sixteen elements per thread hold (32 rows of 128 columns: a squeeze used to walk the rows one
+  // by one, two barriers each - 145 us for the worst launch of the mapping workload, profiles/r04_mapping_kernel_stats.csv).
   double* Pb = a.P + (size_t)b * ld * ld;
   auto src_index = [&](int i) -> int {
     if (i < 13 || i >= 13 + 3 * N) return i;
     const int d = (i - 13) / 3, c = (i - 13) % 3;
     return d < nl ? 13 + 3 * s_src[d] + c : -1;
   };
-  const int n_end = 13 + 3 * ns;                                  // (rows of never-used slots beyond ns are zero and stay zero)
-  constexpr int kMaxCols = 8;                                     // columns per thread: ld <= 2048
-  for (int i = 13; i < ld; ++i) {
-    const int si = src_index(i);
-    double v[kMaxCols];
+  constexpr int kPerThread = 16;
+  const int rows_per = max(1, (kPerThread * nt) / ld);            // (ld <= 2048 = 8 * 256: at least two rows)
+  const float rcp_ld = 1.0f / (float)ld;
+  for (int i0 = 0; i0 < ld; i0 += rows_per) {
+    const int nelem = min(rows_per, ld - i0) * ld;
+    double v[kPerThread];
 #pragma unroll
-    for (int q = 0; q < kMaxCols; ++q) {
-      const int j = tid + q * nt;
+    for (int q = 0; q < kPerThread; ++q) {
+      const int e = tid + q * nt;
       v[q] = 0.0;
-      if (j < ld) {
-        const int sj = src_index(j);
+      if (e < nelem) {
+        int r = (int)((float)e * rcp_ld), j = e - r * ld;           // e = r * ld + j, e < 2^12: the float estimate is off by one at most
+        if (j < 0) { --r; j += ld; }
+        if (j >= ld) { ++r; j -= ld; }
+        const int si = src_index(i0 + r), sj = src_index(j);
         if (si >= 0 && sj >= 0) v[q] = Pb[(size_t)si * ld + sj];
       }
     }
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kMaxCols; ++q) {
-      const int j = tid + q * nt;
-      if (j < ld) Pb[(size_t)i * ld + j] = v[q];
+    for (int q = 0; q < kPerThread; ++q) {
+      const int e = tid + q * nt;
+      if (e < nelem) Pb[(size_t)i0 * ld + e] = v[q];
     }
-    // (no second barrier: the next row reads row src(i + 1) >= i + 1, never the row just written)
+    // (no second barrier: the next block reads rows >= its own first row, none of which this block wrote)
   }
-  // the pose rows: only their feature columns move
-  for (int i = 0; i < 13; ++i) {
-    double v[kMaxCols];
-#pragma unroll
-    for (int q = 0; q < kMaxCols; ++q) {
-      const int j = tid + q * nt;
-      v[q] = 0.0;
-      if (j < ld) { const int sj = src_index(j); if (sj >= 0) v[q] = Pb[(size_t)i * ld + sj]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kMaxCols; ++q) {
-      const int j = tid + q * nt;
-      if (j < ld) Pb[(size_t)i * ld + j] = v[q];
-    }
-    __syncthreads();
-  }
-  (void)n_end;
   if (tid == 0) a.n_slots[b] = nl;
 }
 

@@ -7,7 +7,7 @@
 
 namespace sl2 {
 
-constexpr int kDetThreads = 256;
+constexpr int kDetThreads = 1024;     // (round 4: 256 until the mapping step showed that a region's job has a CU to itself - what counts is its latency)
 
 // Shi-Tomasi detector over one region, executed by a whole workgroup of kDetThreads threads
 // (MonoSLAM::find_best_patch_inside_region, monoslam.cpp:1070-1205).  uv: in/out (ubest, vbest); ev: evbest.
@@ -31,7 +31,7 @@ __device__ __forceinline__ void detect_region_wg(const uint8_t* __restrict__ img
   // gets its three HORIZONTAL 11-sums (33 multiply-adds on bytes from LDS), every position the VERTICAL sum of eleven of
   // those - ~45 taps per position instead of 121 x 3 (rounds 1-3; 0.15 ms per mapping step at batch 1024).  All integer,
   // so the order of the sums is immaterial; the eigenvalue is the reference's FP64 expression on exact inputs.
-  constexpr int kDetTW = 80, kDetTH = 20;
+  constexpr int kDetTW = 80, kDetTH = 60;       // (the engine's regions are 80 x 60: one tile, one round trip for its image; 20 rows until round 4)
   __shared__ uint8_t s_img[(kDetTH + 12) * (kDetTW + 12)];
   __shared__ int s_h[3][(kDetTH + 10) * kDetTW];
   for (int v0 = vstart; v0 < vfinish; v0 += kDetTH)
@@ -39,9 +39,22 @@ __device__ __forceinline__ void detect_region_wg(const uint8_t* __restrict__ img
       const int tw = min(kDetTW, ufinish - u0), th = min(kDetTH, vfinish - v0);
       const int iw = tw + 12, ih = th + 12;                     // image bytes: rows v0 - 6 .. v0 + th + 5, columns u0 - 6 .. u0 + tw + 5
       __syncthreads();                                          // the previous tile's sums have been consumed
-      for (int i = tid; i < iw * ih; i += kDetThreads) {
-        const int r = i / iw, c = i - r * iw;
-        s_img[r * (kDetTW + 12) + c] = img[(size_t)(v0 - 6 + r) * width + (u0 - 6 + c)];    // inside the frame: the region is clamped 6 px in
+      {
+        // every byte of the tile is requested before the first one is parked (a load - store - load chain was one memory
+        // round trip per byte and thread: 18 us of a 35 us job)
+        constexpr int kPer = ((kDetTH + 12) * (kDetTW + 12) + kDetThreads - 1) / kDetThreads;
+        uint8_t pix[kPer];
+        int at[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+          const int i = tid + q * kDetThreads;
+          const int r = i / iw, c = i - r * iw;
+          at[q] = i < iw * ih ? r * (kDetTW + 12) + c : -1;
+          pix[q] = img[(size_t)(v0 - 6 + min(r, ih - 1)) * width + (u0 - 6 + c)];              // inside the frame: the region is clamped 6 px in
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q)
+          if (at[q] >= 0) s_img[at[q]] = pix[q];
       }
       __syncthreads();
       // horizontal sums for rows v0 - 5 .. v0 + th + 4 (local row index 1 .. th + 10 of s_img), columns u0 .. u0 + tw - 1
@@ -76,21 +89,22 @@ __device__ __forceinline__ void detect_region_wg(const uint8_t* __restrict__ img
         if (e2 > best || (e2 == best && best_idx >= 0 && idx < best_idx)) { best = e2; best_idx = idx; }
       }
     }
-  __shared__ double s_best[kDetThreads];
-  __shared__ int s_idx[kDetThreads];
-  s_best[tid] = best;
-  s_idx[tid] = best_idx;
+  // larger eigenvalue wins; among equals the earlier scan position (a lane without a candidate has idx -1)
+  for (int off = 32; off > 0; off >>= 1) {
+    const double ob = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(best_idx, off, 64);
+    if (oi >= 0 && (best_idx < 0 || ob > best || (ob == best && oi < best_idx))) { best = ob; best_idx = oi; }
+  }
+  __shared__ double s_best[kDetThreads / 64];
+  __shared__ int s_idx[kDetThreads / 64];
+  if ((tid & 63) == 0) { s_best[tid >> 6] = best; s_idx[tid >> 6] = best_idx; }
   __syncthreads();
-  for (int off = kDetThreads / 2; off > 0; off >>= 1) {
-    if (tid < off) {
-      const double ob = s_best[tid + off];
-      const int oi = s_idx[tid + off];
-      const double mb = s_best[tid];
-      const int mi = s_idx[tid];
-      // larger eigenvalue wins; among equals the earlier scan position (a lane without a candidate has idx -1)
-      if (oi >= 0 && (mi < 0 || ob > mb || (ob == mb && oi < mi))) { s_best[tid] = ob; s_idx[tid] = oi; }
+  if (tid == 0) {
+    for (int w = 1; w < kDetThreads / 64; ++w) {
+      const double ob = s_best[w];
+      const int oi = s_idx[w];
+      if (oi >= 0 && (s_idx[0] < 0 || ob > s_best[0] || (ob == s_best[0] && oi < s_idx[0]))) { s_best[0] = ob; s_idx[0] = oi; }
     }
-    __syncthreads();
   }
   if (tid == 0) {
     *ev = s_idx[0] >= 0 ? s_best[0] : 0.0;

@@ -1906,8 +1906,9 @@ __global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, 
   // and the partially initialised features at ppos - are zero in P and in V^T, and a tile that lies in them has nothing to
   // subtract: with mapping on, a map that has grown to a third of its capacity pays for a ninth of the tiles (at 84-100
   // live features of 200: 21 tiles of 55, k_syrk 1.04 -> 0.43 ms, profiles/r04_live_tiles.txt).
+  const int n_live = 13 + 3 * n_slots[b];
   {
-    const int t_lo = (13 + 3 * n_slots[b] + 63) >> 6, t_hi = ppos >> 6;
+    const int t_lo = (n_live + 63) >> 6, t_hi = ppos >> 6;
     if ((ti >= t_lo && ti < t_hi) || (tj >= t_lo && tj < t_hi)) return;
   }
   const int tid = threadIdx.x;
@@ -1945,9 +1946,13 @@ __global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, 
     *(double2*)&sAB[buf][1][kr * 64 + 32 + cs] = r.b1;
   };
   Stage r0 = stage_load(0);
-  // In a diagonal tile the sub-block (wi = 32, wj = 0) is the mirror of (0, 32): that wave only stages.
-  const bool idle = (ti == tj) && (wi > wj);
+  // In a diagonal tile the sub-block (wi = 32, wj = 0) is the mirror of (0, 32): that wave only stages.  So does a wave whose
+  // 32 rows or 32 columns lie in never-used slots (the same rule as for whole tiles above, at the wavefront's granularity:
+  // in the mapping workload - 128 columns of capacity, ~55 live, the partially initialised feature at 109 - nine of the
+  // sixteen 32 x 32 blocks are live).
   const int i0 = ti * 64 + wi, j0 = tj * 64 + wj;
+  const int b_lo = (n_live + 31) >> 5, b_hi = ppos >> 5;
+  const bool idle = ((ti == tj) && (wi > wj)) || ((i0 >> 5) >= b_lo && (i0 >> 5) < b_hi) || ((j0 >> 5) >= b_lo && (j0 >> 5) < b_hi);
   v4d acc[2][2];
   for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
   const int nchunk = mp / kSyrkKC;

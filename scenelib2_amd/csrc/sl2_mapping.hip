@@ -643,10 +643,6 @@ struct SlotArrays {
   int *patch_sums, *f_flags, *attempted, *successful, *f_label, *srch_i, *sel_idx, *succ_idx, *f_arow, *n_sel, *m_count, *n_slots, *ps_i, *pos_err;
   int kpart;
 };
-template <typename T>
-__device__ __forceinline__ void slot_move(T* base, int per, int dst, int src, int tid, int nthreads) {
-  for (int k = tid; k < per; k += nthreads) base[(size_t)dst * per + k] = base[(size_t)src * per + k];
-}
 __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, int ld, int ppos, int need) {
   extern __shared__ int s_map[];        // [N] new slot -> old slot, then [N] old slot -> new slot (-1: retired)
   int* s_src = s_map;
@@ -669,34 +665,75 @@ __global__ void __launch_bounds__(256) k_map_compact_slots(SlotArrays a, int N, 
   const int nl = s_live;
   if (nl == ns) return;                                          // no retired slot to give back
   const size_t o = (size_t)b * N;
-  // ---- per-slot records: in increasing new slot (src >= dst, every earlier move wrote below dst); a barrier per slot
-  // because the source of one move can be the destination of the next
-  for (int d = 0; d < nl; ++d) {
-    const int f = s_src[d];
-    if (f != d) {
-      slot_move(a.patch + o * kPatchStride, kPatchStride, d, f, tid, nt);
-      slot_move(a.patch_sums + o * 2, 2, d, f, tid, nt);
-      slot_move(a.xp_org + o * 8, 8, d, f, tid, nt);
-      slot_move(a.f_flags + o, 1, d, f, tid, nt);
-      slot_move(a.attempted + o, 1, d, f, tid, nt);
-      slot_move(a.successful + o, 1, d, f, tid, nt);
-      slot_move(a.f_label + o, 1, d, f, tid, nt);
-      slot_move(a.f_h + o * 2, 2, d, f, tid, nt);
-      slot_move(a.f_Hx + o * 14, 14, d, f, tid, nt);
-      slot_move(a.f_Hy + o * 6, 6, d, f, tid, nt);
-      slot_move(a.f_R + o, 1, d, f, tid, nt);
-      slot_move(a.f_S + o * 4, 4, d, f, tid, nt);
-      slot_move(a.f_score + o, 1, d, f, tid, nt);
-      slot_move(a.f_z + o * 2, 2, d, f, tid, nt);
-      slot_move(a.f_nu + o * 2, 2, d, f, tid, nt);
-      slot_move(a.srch_i + o * 8, 8, d, f, tid, nt);
-      slot_move(a.srch_d + o * 4, 4, d, f, tid, nt);
-      slot_move(a.f_arow + o, 1, d, f, tid, nt);      // (slot-indexed like the rest: a squeeze between make_measurements and the update)
-      slot_move(a.pos_err + o, 1, d, f, tid, nt);
-      slot_move(a.x + (size_t)b * ld + 13, 3, d, f, tid, nt);
+  // ---- per-slot records: new slot d <- old slot s_src[d] >= d.  A thread takes one slot and holds its whole record (63
+  // numbers) between ONE barrier's reads and writes; slots go in rounds of nt, increasing, so a round's sources are never
+  // slots an earlier round rewrote.  The templates (288 bytes a slot) move as dwords, sixteen a thread and round.  (Until
+  // round 4 every slot was moved by the whole workgroup with a barrier behind it: 20 small dependent copies per slot.)
+  for (int d0 = 0; d0 < nl; d0 += nt) {
+    const int d = d0 + tid;
+    const bool mine = d < nl;
+    const int f = mine ? s_src[d] : 0;
+    int r_sums[2], r_flags, r_att, r_succ, r_label, r_si[8], r_arow, r_perr;
+    double r_xo[8], r_h[2], r_Hx[14], r_Hy[6], r_R, r_S[4], r_score, r_z[2], r_nu[2], r_sd[4], r_x[3];
+    if (mine) {
+      for (int k = 0; k < 2; ++k) r_sums[k] = a.patch_sums[(o + f) * 2 + k];
+      for (int k = 0; k < 8; ++k) r_xo[k] = a.xp_org[(o + f) * 8 + k];
+      r_flags = a.f_flags[o + f]; r_att = a.attempted[o + f]; r_succ = a.successful[o + f]; r_label = a.f_label[o + f];
+      for (int k = 0; k < 2; ++k) r_h[k] = a.f_h[(o + f) * 2 + k];
+      for (int k = 0; k < 14; ++k) r_Hx[k] = a.f_Hx[(o + f) * 14 + k];
+      for (int k = 0; k < 6; ++k) r_Hy[k] = a.f_Hy[(o + f) * 6 + k];
+      r_R = a.f_R[o + f];
+      for (int k = 0; k < 4; ++k) r_S[k] = a.f_S[(o + f) * 4 + k];
+      r_score = a.f_score[o + f];
+      for (int k = 0; k < 2; ++k) { r_z[k] = a.f_z[(o + f) * 2 + k]; r_nu[k] = a.f_nu[(o + f) * 2 + k]; }
+      for (int k = 0; k < 8; ++k) r_si[k] = a.srch_i[(o + f) * 8 + k];
+      for (int k = 0; k < 4; ++k) r_sd[k] = a.srch_d[(o + f) * 4 + k];
+      r_arow = a.f_arow[o + f];      // (slot-indexed like the rest: a squeeze between make_measurements and the update)
+      r_perr = a.pos_err[o + f];
+      for (int k = 0; k < 3; ++k) r_x[k] = a.x[(size_t)b * ld + 13 + 3 * f + k];
     }
     __syncthreads();
+    if (mine && f != d) {
+      for (int k = 0; k < 2; ++k) a.patch_sums[(o + d) * 2 + k] = r_sums[k];
+      for (int k = 0; k < 8; ++k) a.xp_org[(o + d) * 8 + k] = r_xo[k];
+      a.f_flags[o + d] = r_flags; a.attempted[o + d] = r_att; a.successful[o + d] = r_succ; a.f_label[o + d] = r_label;
+      for (int k = 0; k < 2; ++k) a.f_h[(o + d) * 2 + k] = r_h[k];
+      for (int k = 0; k < 14; ++k) a.f_Hx[(o + d) * 14 + k] = r_Hx[k];
+      for (int k = 0; k < 6; ++k) a.f_Hy[(o + d) * 6 + k] = r_Hy[k];
+      a.f_R[o + d] = r_R;
+      for (int k = 0; k < 4; ++k) a.f_S[(o + d) * 4 + k] = r_S[k];
+      a.f_score[o + d] = r_score;
+      for (int k = 0; k < 2; ++k) { a.f_z[(o + d) * 2 + k] = r_z[k]; a.f_nu[(o + d) * 2 + k] = r_nu[k]; }
+      for (int k = 0; k < 8; ++k) a.srch_i[(o + d) * 8 + k] = r_si[k];
+      for (int k = 0; k < 4; ++k) a.srch_d[(o + d) * 4 + k] = r_sd[k];
+      a.f_arow[o + d] = r_arow;
+      a.pos_err[o + d] = r_perr;
+      for (int k = 0; k < 3; ++k) a.x[(size_t)b * ld + 13 + 3 * d + k] = r_x[k];
+    }
+    // (no second barrier: the next round reads slots >= its own first slot, none of which this round wrote)
   }
+  {
+    static_assert(kPatchStride % 4 == 0, "templates move as dwords");
+    constexpr int kDw = kPatchStride / 4, kPer = 16;
+    unsigned* pw = (unsigned*)(a.patch + o * kPatchStride);          // (hipMalloc'ed base, stride 288: dword aligned)
+    const int total = nl * kDw;
+    for (int c0 = 0; c0 < total; c0 += kPer * nt) {
+      unsigned v[kPer];
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int e = c0 + tid + q * nt;
+        if (e < total) { const int d = e / kDw, k = e - d * kDw; v[q] = pw[(size_t)s_src[d] * kDw + k]; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int e = c0 + tid + q * nt;
+        if (e < total) pw[e] = v[q];
+      }
+      // (a round's last slot may be half written: the next round reads the other half of it, or slots above it)
+    }
+  }
+  __syncthreads();
   for (int f = nl + tid; f < ns; f += nt) {                      // the freed slots: unused again
     flags[f] = 0;
     a.f_arow[o + f] = -1;

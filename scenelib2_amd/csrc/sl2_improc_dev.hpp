@@ -287,9 +287,10 @@ __device__ __forceinline__ void me_score_box_wg(const uint8_t* __restrict__ img,
 // in_ellipse; use() is called in increasing row order.
 template <typename Fetch, typename Use>
 __device__ __forceinline__ void me_for_each_inside(double a, double b, double c, int us, int nu, int vs, int nv, int lane, Fetch fetch,
-                                                   Use use, int r_first = 0, int r_end = 0x7fffffff) {
+                                                   Use use, int r_first = 0, int r_end = 0x7fffffff, int lanes = 64) {
+  // (lanes = 32, lane = 0 .. 31: HALF a wavefront walks the box - two small ellipses side by side; needs nu <= 32)
   const int lg = nu <= 16 ? 4 : (nu <= 32 ? 5 : 6);
-  const int ql = lane & ((1 << lg) - 1), rs = lane >> lg, rp = 64 >> lg;
+  const int ql = lane & ((1 << lg) - 1), rs = lane >> lg, rp = lanes >> lg;
   const double b2 = 2 * b;
   for (int cb = 0; cb < nu; cb += 64) {
     const int q = cb + ql;
@@ -480,27 +481,55 @@ __device__ __forceinline__ bool me_search_fused_wg(const uint8_t* __restrict__ i
   // A lane meets its candidates in increasing scan order (its column, or columns 64 apart, rows upwards), so "corr <=
   // best: take it" is the whole rule inside a lane (a first candidate above 1e6 is not taken: "corr <= corrmax", cpp:156);
   // the order index only decides between lanes.
-  for (int e = wave; e < n_ell; e += nwave) {
+  // Two ellipses per wavefront, a half each, when both boxes are at most 32 columns wide (they nearly always are: ~20 x 15):
+  // fetching an ellipse's record, forming its column terms and the cross-lane reduction are as long as the walk itself, and
+  // the two halves share them.
+  for (int e0 = 2 * wave; e0 < n_ell; e0 += 2 * nwave) {
+    const int half = lane >> 5, l32 = lane & 31;
+    const bool have = e0 + half < n_ell;
+    const int e = have ? e0 + half : e0;
     const int* d = f_desc + 8 * e;
     const int nu = d[3], nv = d[5];
-    double best = 1000000.0;   // cpp:156
-    int order = -1;
-    if (nu > 0 && nv > 0) {
-      const double* pu = f_pu + 3 * e;
-      const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
-      me_for_each_inside(pu[0], pu[1], pu[2], d[2], nu, d[4], nv, lane, [&](int q, int r) { return f_score[(by + r) * bw + bx + q]; },
-                         [&](double corr, int q, int r) {
-        if (corr <= best) { best = corr; order = q * nv + r; }
-      });
+    if (!__any(nu > 32)) {
+      double best = 1000000.0;   // cpp:156
+      int order = -1;
+      if (have && nu > 0 && nv > 0) {
+        const double* pu = f_pu + 3 * e;
+        const int bx = d[0] + d[2] - x0, by = d[1] + d[4] - y0;
+        me_for_each_inside(pu[0], pu[1], pu[2], d[2], nu, d[4], nv, l32, [&](int q, int r) { return f_score[(by + r) * bw + bx + q]; },
+                           [&](double corr, int q, int r) { if (corr <= best) { best = corr; order = q * nv + r; } }, 0, 0x7fffffff, 32);
+      }
+      for (int off = 16; off > 0; off >>= 1) {              // (stays inside the halves)
+        const double ob = __shfl_xor(best, off, 64);
+        const int oo = __shfl_xor(order, off, 64);
+        if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
+      }
+      if (l32 == 0 && have)
+        emit(e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
+             order >= 0 ? d[1] + d[4] + order % nv : 0, best);
+      continue;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ob = __shfl_xor(best, off, 64);
-      const int oo = __shfl_xor(order, off, 64);
-      if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
+    for (int h = 0; h < 2 && e0 + h < n_ell; ++h) {          // a wide box: the whole wavefront, one ellipse after the other
+      const int ee = e0 + h;
+      const int* dd = f_desc + 8 * ee;
+      const int nuu = dd[3], nvv = dd[5];
+      double best = 1000000.0;
+      int order = -1;
+      if (nuu > 0 && nvv > 0) {
+        const double* pu = f_pu + 3 * ee;
+        const int bx = dd[0] + dd[2] - x0, by = dd[1] + dd[4] - y0;
+        me_for_each_inside(pu[0], pu[1], pu[2], dd[2], nuu, dd[4], nvv, lane, [&](int q, int r) { return f_score[(by + r) * bw + bx + q]; },
+                           [&](double corr, int q, int r) { if (corr <= best) { best = corr; order = q * nvv + r; } });
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64);
+        const int oo = __shfl_xor(order, off, 64);
+        if (oo >= 0 && (order < 0 || ob < best || (ob == best && oo > order))) { best = ob; order = oo; }
+      }
+      if (lane == 0)
+        emit(ee, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? dd[0] + dd[2] + order / nvv : 0,
+             order >= 0 ? dd[1] + dd[4] + order % nvv : 0, best);
     }
-    if (lane == 0)
-      emit(e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
-           order >= 0 ? d[1] + d[4] + order % nv : 0, best);
   }
   METR(4);
   return true;

@@ -62,12 +62,9 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
       } else {
         status[b] &= ~2;           // (the bit tells about the LAST attempt: room again after deletions / the slot squeeze)
         // FindNonOverlappingRegion (:867-943): where will the image centre be in ten steps?
-        double xv[13], f[13], A44[16], B43[12];
-        for (int i = 0; i < 13; ++i) xv[i] = xb[i];
-        for (int it = 0; it < 10; ++it) {
-          motion_f_and_blocks(xv, mp.dt, f, A44, B43);
-          for (int i = 0; i < 13; ++i) xv[i] = f[i];
-        }
+        double x0[13], xv[13];
+        for (int i = 0; i < 13; ++i) x0[i] = xb[i];
+        motion_f_repeated(x0, mp.dt, 10, xv);
         double R[9], yW[3], xp[7], zeroed[3], h[2], Hx[14], Hy[6], Rn;
         quat_to_rot(&xv[3], R);
         for (int i = 0; i < 3; ++i) {
@@ -210,19 +207,73 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     }
   }
   __syncthreads();
-  if (lane == 0) {
+  // (From here on lane 0 used to work alone - 121 template pixels one dependent load after the other, 1200 particle
+  // numbers, the 36 entries of Pyy: 20 of the kernel's 26 us.  Every piece is spread over the lanes now, each entry still
+  // formed by one lane in the reference's order.)
+  const size_t fi = (size_t)b * N + label;
+  if (lane < 36) {
     // Pyy = (T Pxx) T^T + (D Ri) D^T
-    for (int k = 0; k < 6; ++k)
-      for (int l = 0; l < 6; ++l) {
-        double a1 = 0.0;
-        for (int j = 0; j < 13; ++j) a1 += s_col[k * 13 + j] * s_T[l * 13 + j];
-        double a2 = 0.0;
-        for (int c = 0; c < 2; ++c) a2 += (s_D[k * 2 + c] * s_Ri) * s_D[l * 2 + c];
-        Pb[(size_t)(ppos + k) * ld + ppos + l] = a1 + a2;
+    const int k = lane / 6, l = lane % 6;
+    double a1 = 0.0;
+    for (int j = 0; j < 13; ++j) a1 += s_col[k * 13 + j] * s_T[l * 13 + j];
+    double a2 = 0.0;
+    for (int c = 0; c < 2; ++c) a2 += (s_D[k * 2 + c] * s_Ri) * s_D[l * 2 + c];
+    Pb[(size_t)(ppos + k) * ld + ppos + l] = a1 + a2;
+  }
+  // template: copy_into_patch (:1240-1251) + the packed form the search kernels read
+  __shared__ int s_pix[121];
+  __shared__ double s_lambda[kMaxParticles];
+  {
+    const uint8_t* img = frames + (size_t)b * seq_stride;
+    uint8_t* pt = patch + fi * kPatchStride;
+    const int p0 = lane, p1 = lane + 64;
+    const int g0 = img[(size_t)(p0 / 11 + vv - 5) * cam.width + p0 % 11 + uu - 5];
+    const int g1 = p1 < 121 ? img[(size_t)(p1 / 11 + vv - 5) * cam.width + p1 % 11 + uu - 5] : 0;
+    pt[p0] = (uint8_t)g0; s_pix[p0] = g0;
+    if (p1 < 121) { pt[p1] = (uint8_t)g1; s_pix[p1] = g1; }
+    if (lane < kPatchPackedOffset - 121) pt[121 + lane] = 0;
+    int s0 = g0 + g1, s0sq = g0 * g0 + g1 * g1;             // (integer sums: the order is immaterial)
+    for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s0sq += __shfl_xor(s0sq, off, 64); }
+    if (lane == 0) {
+      // particle depths: lambda_i by repeated addition, as the reference forms them (:1222-1236)
+      const double lambda_step = (1.0 / double(mp.n_particles)) * (mp.max_lambda - mp.min_lambda);
+      double lambda = mp.min_lambda;
+      for (int i = 0; i < mp.n_particles; ++i) { s_lambda[i] = lambda; lambda += lambda_step; }
+    }
+    __syncthreads();
+    unsigned* packed = (unsigned*)(pt + kPatchPackedOffset);
+    if (lane < 33) {
+      const int r = lane / 3, d = lane % 3;
+      unsigned v = 0;
+      for (int k = 0; k < 4; ++k) {
+        const int col = 4 * d + k;
+        if (col < 11) v |= (unsigned)s_pix[r * 11 + col] << (8 * k);
       }
+      packed[lane] = v;
+    } else if (lane >= 36 && lane < (kPatchStride - kPatchPackedOffset) / 4) {
+      packed[lane] = 0u;
+    }
+    if (lane == 0) {
+      const double g0bar = (double)s0 / 121.0;
+      const double varg0 = (double)s0sq / 121.0 - (g0bar * g0bar);
+      const double sigmag0 = sqrt(varg0);
+      packed[33] = (unsigned)s0; packed[34] = (unsigned)s0sq;
+      packed[35] = (sigmag0 < kCorrelationSigmaThreshold) ? 0u : 1u;
+      patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
+    }
+  }
+  {
+    // particle set: uniform prior over [min_lambda, max_lambda) (:1222-1236)
+    const double uniform_probability = 1.0 / double(mp.n_particles);
+    double* pp = particles + ((size_t)b * mp.kpart + ks) * mp.pcap * kParticleDoubles;
+    for (int e = lane; e < mp.n_particles * kParticleDoubles; e += 64) {
+      const int i = e / kParticleDoubles, k = e - i * kParticleDoubles;
+      pp[e] = k == 0 ? s_lambda[i] : (k == 1 ? uniform_probability : 0.0);
+    }
+  }
+  if (lane == 0) {
     for (int i = 0; i < 6; ++i) xb[ppos + i] = s_y[i];
     // label slot: reserved, not yet a 3-D point
-    const size_t fi = (size_t)b * N + label;
     for (int k = 0; k < 7; ++k) xp_org[fi * 8 + k] = xb[k];
     xp_org[fi * 8 + 7] = 0.0;
     f_flags[fi] = FF_USED | FF_PARTIAL;
@@ -231,47 +282,6 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     f_label[fi] = next_label[b];           // label_ = next_free_label_++ (monoslam.cpp:1306-1307)
     next_label[b] += 1;
     n_slots[b] = label + 1;
-    // template: copy_into_patch (:1240-1251) + the packed form the search kernels read
-    const uint8_t* img = frames + (size_t)b * seq_stride;
-    uint8_t* pt = patch + fi * kPatchStride;
-    int s0 = 0, s0sq = 0;
-    for (int r = 0; r < 11; ++r)
-      for (int c = 0; c < 11; ++c) {
-        const int g = img[(size_t)(r + vv - 5) * cam.width + c + uu - 5];
-        pt[r * 11 + c] = (uint8_t)g;
-        s0 += g; s0sq += g * g;
-      }
-    for (int p = 121; p < kPatchPackedOffset; ++p) pt[p] = 0;
-    unsigned* packed = (unsigned*)(pt + kPatchPackedOffset);
-    for (int r = 0; r < 11; ++r)
-      for (int d = 0; d < 3; ++d) {
-        unsigned v = 0;
-        for (int k = 0; k < 4; ++k) {
-          const int col = 4 * d + k;
-          if (col < 11) v |= (unsigned)pt[r * 11 + col] << (8 * k);
-        }
-        packed[r * 3 + d] = v;
-      }
-    {
-      const double g0bar = (double)s0 / 121.0;
-      const double varg0 = (double)s0sq / 121.0 - (g0bar * g0bar);
-      const double sigmag0 = sqrt(varg0);
-      packed[33] = (unsigned)s0; packed[34] = (unsigned)s0sq;
-      packed[35] = (sigmag0 < kCorrelationSigmaThreshold) ? 0u : 1u;
-      for (int k = 36; k < (kPatchStride - kPatchPackedOffset) / 4; ++k) packed[k] = 0u;
-    }
-    patch_sums[fi * 2] = s0; patch_sums[fi * 2 + 1] = s0sq;
-    // particle set: uniform prior over [min_lambda, max_lambda) (:1222-1236)
-    const double lambda_step = (1.0 / double(mp.n_particles)) * (mp.max_lambda - mp.min_lambda);
-    const double uniform_probability = 1.0 / double(mp.n_particles);
-    double lambda = mp.min_lambda;
-    double* pp = particles + ((size_t)b * mp.kpart + ks) * mp.pcap * kParticleDoubles;
-    for (int i = 0; i < mp.n_particles; ++i) {
-      double* o = pp + (size_t)i * kParticleDoubles;
-      for (int k = 0; k < kParticleDoubles; ++k) o[k] = 0.0;
-      o[0] = lambda; o[1] = uniform_probability;
-      lambda += lambda_step;
-    }
     int* ps = psb + ks * kPsInts;
     ps[kPsActive] = 1; ps[kPsLabel] = label; ps[kPsAttempts] = 0; ps[kPsNp] = mp.n_particles; ps[kPsMaking] = 0;
     pi[kPartOrder + pi[kPartCount]] = ks;          // feature_init_info_vector_.push_back

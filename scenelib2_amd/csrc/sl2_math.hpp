@@ -117,6 +117,32 @@ SL2_HD void motion_f_and_blocks(const double xv[13], double dt, double f[13], do
   }
 }
 
+// f applied `steps` times (FindNonOverlappingRegion predicts ten steps ahead, monoslam.cpp:888-893): the velocities do not
+// change under f (u = 0), so q(omega dt) - a square root, a sine and a cosine - is the SAME quaternion in every step and is
+// formed once; every step then is the position update and the quaternion product, in the expressions of
+// motion_f_and_blocks.  Bit-identical to calling that `steps` times (k_map_region did: ten serial sin / cos on one lane).
+SL2_HD void motion_f_repeated(const double xv[13], double dt, int steps, double out[13]) {
+  for (int i = 0; i < 13; ++i) out[i] = xv[i];
+  const double om[3] = {xv[10], xv[11], xv[12]};
+  const double av[3] = {om[0] * dt, om[1] * dt, om[2] * dt};
+  const double angle = sqrt(av[0] * av[0] + av[1] * av[1] + av[2] * av[2]);
+  double qw, qx, qy, qz;
+  if (angle > 0.0) {
+    const double s = sin(angle / 2.0) / angle;
+    const double c = cos(angle / 2.0);
+    qx = s * av[0]; qy = s * av[1]; qz = s * av[2]; qw = c;
+  } else { qx = qy = qz = 0.0; qw = 1.0; }
+  for (int it = 0; it < steps; ++it) {
+    for (int i = 0; i < 3; ++i) out[i] = out[i] + out[7 + i] * dt;
+    const double aw = out[3], ax = out[4], ay = out[5], az = out[6];
+    out[3] = aw * qw - ax * qx - ay * qy - az * qz;
+    out[4] = aw * qx + ax * qw + ay * qz - az * qy;
+    out[5] = aw * qy + ay * qw + az * qx - ax * qz;
+    out[6] = aw * qz + az * qw + ax * qy - ay * qx;
+    for (int i = 0; i < 3; ++i) out[7 + i] = out[7 + i] + 0.0 * dt;
+  }
+}
+
 // One row of F applied to a 13-vector: sum_k F[i][k] v[k], nonzero terms only,
 // in increasing k (== the dense product's rounding, zeros add exactly).
 SL2_HD double frow_dot(int i, double dt, const double A44[16], const double B43[12], const double v[13]) {

@@ -61,6 +61,7 @@ def devmath():
                                  C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int)]
     L.dm_motion.argtypes = [C.POINTER(C.c_double), C.c_double] + [C.POINTER(C.c_double)] * 3
+    L.dm_motion_repeated.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_int] + [C.POINTER(C.c_double)] * 2
     L.dm_predict_cov.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                  C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dm_innovation_cov.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double] + \

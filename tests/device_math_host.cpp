@@ -51,6 +51,18 @@ void dm_predict_cov(const double* xv, double dt, const double* Pxx, const double
   }
 }
 
+// f applied `steps` times: by repeated calls of motion_f_and_blocks (out_a) and by motion_f_repeated (out_b)
+void dm_motion_repeated(const double* xv, double dt, int steps, double* out_a, double* out_b) {
+  double cur[13], f[13], A44[16], B43[12];
+  for (int i = 0; i < 13; ++i) cur[i] = xv[i];
+  for (int it = 0; it < steps; ++it) {
+    motion_f_and_blocks(cur, dt, f, A44, B43);
+    for (int i = 0; i < 13; ++i) cur[i] = f[i];
+  }
+  for (int i = 0; i < 13; ++i) out_a[i] = cur[i];
+  motion_f_repeated(xv, dt, steps, out_b);
+}
+
 void dm_dqnorm(const double* q, double* N16) { dqnorm_by_dq(q, N16); }
 
 // out: h[2], Hx[14], Hy[6], R, vis  (24 doubles)

@@ -35,6 +35,21 @@ def test_motion_model_matches_oracle(oracle, devmath):
         assert np.array_equal(Q, Q0)
 
 
+def test_ten_step_prediction_with_the_rotation_formed_once_is_bit_identical(devmath):
+    """k_map_region predicts ten steps ahead (FindNonOverlappingRegion, monoslam.cpp:888-893): f keeps the velocities, so
+    q(omega dt) is the same quaternion in every step and motion_f_repeated forms it once - same bits as ten calls."""
+    rng = np.random.default_rng(12)
+    for trial in range(50):
+        xv = _rand_xv(rng)
+        if trial == 0:
+            xv[10:] = 0.0                      # omega == 0: the unit quaternion branch
+        if trial == 1:
+            xv[7:10] = -0.0
+        a, b = np.zeros(13), np.zeros(13)
+        devmath.dm_motion_repeated(_dp(xv), 1 / 30.0, 10, _dp(a), _dp(b))
+        assert np.array_equal(a, b), (trial, a - b)
+
+
 def test_predict_covariance_matches_dense_product(oracle, devmath):
     rng = np.random.default_rng(11)
     xv = _rand_xv(rng)

@@ -551,22 +551,23 @@ __global__ void __launch_bounds__(256) k_me_big_scores(Jobs J, const int* __rest
     __syncthreads();
   }
 }
+constexpr int kMeBigArgWaves = 16;      // wavefronts per ellipse (a step has a handful of such jobs on an idle chip: a frame-sized box is 240 rows)
 template <typename Jobs>
-__global__ void __launch_bounds__(256) k_me_big_argmin(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
+__global__ void __launch_bounds__(64 * kMeBigArgWaves) k_me_big_argmin(Jobs J, const int* __restrict__ list, const int* __restrict__ count, int width) {
   const int n = *count, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ int s_ord[4];
-  __shared__ double s_bst[4];
+  __shared__ int s_ord[kMeBigArgWaves];
+  __shared__ double s_bst[kMeBigArgWaves];
   for (int li = blockIdx.y; li < n; li += gridDim.y) {
     const int job = list[li], ne = J.n_ell(job);
-    for (int e = blockIdx.x; e < ne; e += gridDim.x) {            // one ellipse per workgroup, its rows split over the four waves
+    for (int e = blockIdx.x; e < ne; e += gridDim.x) {            // one ellipse per workgroup, its rows split over the waves
       const int* d = J.desc(job) + 8 * (size_t)e;
       double best;
       int order;
-      me_argmin_part(width, d, J.pu(job, e), J.map(job), wave, 4, &best, &order);
+      me_argmin_part(width, d, J.pu(job, e), J.map(job), wave, kMeBigArgWaves, &best, &order);
       if (lane == 0) { s_bst[wave] = best; s_ord[wave] = order; }
       __syncthreads();
       if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < kMeBigArgWaves; ++w)
           if (s_ord[w] >= 0 && (order < 0 || s_bst[w] < best || (s_bst[w] == best && s_ord[w] > order))) { best = s_bst[w]; order = s_ord[w]; }
         const int nv = d[5];
         J.emit(job, e, (order >= 0 && !(best > kCorrThresh2)) ? 1 : 0, order >= 0 ? d[0] + d[2] + order / nv : 0,
@@ -580,7 +581,7 @@ constexpr int kMeBigGridX = 128, kMeBigGridY = 8, kMeBigSlices = 64;
 template <typename Jobs>
 inline void me_big_launch(Jobs J, const int* list, const int* count, int width, hipStream_t st) {
   hipLaunchKernelGGL(k_me_big_scores<Jobs>, dim3(kMeBigSlices, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
-  hipLaunchKernelGGL(k_me_big_argmin<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(256), 0, st, J, list, count, width);
+  hipLaunchKernelGGL(k_me_big_argmin<Jobs>, dim3(kMeBigGridX, kMeBigGridY), dim3(64 * kMeBigArgWaves), 0, st, J, list, count, width);
 }
 
 }  // namespace sl2

@@ -17,5 +17,7 @@ assert L.sl2_debug_me_trace(out, 0) == 0
 n = out[15]
 names = ["records + box", "stamps", "image tile", "scores", "arg-min"]
 tot = sum(out[k] for k in range(5))
-print("workgroups that searched: %d; cycles per workgroup (100 MHz counter): %s; total %.1f" % (
+print("workgroups that searched: %d; cycles per workgroup: %s; total %.1f" % (
     n, ", ".join("%s %.1f" % (names[k], out[k] / max(n, 1)) for k in range(5)), tot / max(n, 1)))
+# the detector's phases (slots 5-8; slot 15 counts both kinds of jobs, so per-job figures need the detector's own count: slot 14)
+print("detector cycles in total: image %d, horizontal sums %d, vertical sums + eigenvalue %d, reduction %d" % (out[5], out[6], out[7], out[8]))

@@ -310,8 +310,11 @@ def main():
     d_pose = _lib.DeviceBuffer(poses.nbytes, dev); d_pose.upload(poses)
     d_org = _lib.DeviceBuffer(origins.nbytes, dev); d_org.upload(origins)
     d_frames = _lib.DeviceBuffer((n_render + 1) * B * fb, dev)
-    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr, d_pose.ptr, (n_render + 1) * B,
-                        d_frames.ptr, device=dev)
+    # the t = 0 views now (the templates are cut from them on the host); the frames behind them are rendered at the END of the
+    # set-up, so that the device does not sit idle for the seconds of host work between its one heavy set-up kernel and the
+    # warm-up steps (with --warmup 5 the first timed steps otherwise run on a device still settling: 1.51 / 1.56 -> 1.48 /
+    # 1.53 ms per step in back-to-back pairs, gpurun r04_bc)
+    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr, d_pose.ptr, B, d_frames.ptr, device=dev)
     torch.cuda.synchronize()
     frame0 = d_frames.download((B, H, W), np.uint8)                                  # t = 0 views -> templates
     templates = np.stack([synth.cut_templates(frame0[b], specs[b].feat_px) for b in range(B)])
@@ -327,7 +330,10 @@ def main():
     eng.add_known_features(np.stack([s.feat_y for s in specs]), np.stack([s.xp_org() for s in specs]), templates)
     if args.feature_sigma > 0.0:
         eng.set_feature_covariances(np.tile(np.eye(3) * args.feature_sigma ** 2, (B, N, 1, 1)))
+    synth.render_device(cam, d_tex.ptr, tex.shape[0], specs[0].tex_extent, d_org.ptr + origins[0].nbytes, d_pose.ptr + poses[0].nbytes,
+                        n_render * B, d_frames.ptr + B * fb, device=dev)
     eng.synchronize()
+    torch.cuda.synchronize()
     setup_s = time.time() - t_setup
 
     def step(k):  # frame k (0-based) = pose k+1, resident in HBM

@@ -216,7 +216,7 @@ def test_engine_search_kernel_on_adversarial_frames(variant, split):
 def test_frame_sized_windows_are_shared_out_over_the_launch(split):
     """A camera position known to 0.3 m only: the 3-sigma windows of the first frame are the whole frame (150 bands of
     32 x 16 positions at 320 x 240).  One wavefront used to walk such a window alone; now k_select cuts it into units of four
-    bands and the wavefronts of k_search_big take units, the last one combining the partial results (m4_big_windows).  The
+    bands and the trailing workgroups of the search launch take units, the last one combining the partial results (m4_big_windows).  The
     measurements are the reference's, pixel for pixel, with the default threshold, with a threshold of one band, and
     with sharing switched off; so are the candidate counts the work counters carry.  (Tolerances on state and covariance
     are 1e-7 here: the first update shrinks a prior 10^4 times larger than the posterior.)"""

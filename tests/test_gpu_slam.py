@@ -636,6 +636,44 @@ def test_zero_angular_velocity_raises_the_status_flag_for_that_sequence_only():
     assert rel_fro(pr.engine.total_covariance(0), o.total_covariance()) <= TOL_P
 
 
+def test_shared_windows_under_contention_are_bit_identical_to_the_unshared_search():
+    """The unit protocol of the large-window search with many sequences at once: 256 sequences x 60 features, a camera known to
+    0.3 m (every first-frame window is the whole frame: ~15 000 windows, the list's 16384 units full and the overflow walked in
+    place), a threshold of ONE band afterwards (every window a job: thousands of small jobs contending for one counter) -
+    against an engine that never shares.  Same measurements and therefore bit-identical states and covariances, every
+    frame; run twice to give a race more than one chance."""
+    B, N, F = 256, 60, 6
+    pr = Pair(N, F, batch=B, make_engine=False)
+    xv = np.stack([s.xv0 for s in pr.specs])
+    Pxx = np.stack([s.Pxx0 for s in pr.specs]).copy()
+    Pxx[:, 0, 0] = Pxx[:, 1, 1] = Pxx[:, 2, 2] = 0.09
+
+    def make(split):
+        e = Engine(pr.cam, pr.params, B, N)
+        e.set_search_split(split)
+        e.set_vehicle_state(xv, Pxx)
+        for b in range(B):
+            e.add_known_features(pr.specs[b].feat_y[None], np.tile(pr.specs[b].poses[0], (1, N, 1)), pr.templates[b][None], seq0=b)
+        return e
+
+    for attempt in range(2):
+        plain, shared = make(0), make(1)
+        total_shared = 0
+        for k in range(F):
+            fr = pr.frame_batch(k)
+            plain.go_one_step(fr, False)
+            shared.go_one_step(fr, False)
+            w0, w1 = plain.step_work(), shared.step_work()
+            total_shared += int(w1["search_shared"])
+            assert w0["search_shared"] == 0 and w1["candidates"] == w0["candidates"] and w1["sum_m"] == w0["sum_m"]
+            for b in range(0, B, 7):
+                assert np.array_equal(shared.total_state(b), plain.total_state(b)), (attempt, k, b)
+                assert np.array_equal(shared.total_covariance(b), plain.total_covariance(b)), (attempt, k, b)
+        assert total_shared > 0.5 * B * N * F
+        for b in range(B):
+            assert np.array_equal(shared.total_state(b), plain.total_state(b)), (attempt, b)
+
+
 def test_two_engines_on_two_host_threads_do_not_interfere():
     """Threading contract of the ABI (include/scenelib2_amd.h: one engine per host thread / stream, no global mutable
     state): two engines stepped concurrently from two threads give exactly what each gives alone."""

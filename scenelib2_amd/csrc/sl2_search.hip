@@ -733,6 +733,7 @@ __device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frame
     for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off, 64);
     int* o = srch_res + ((size_t)b * N + k) * 8;
     int code = 0;
+    unsigned long long near_units = 0ull;                                  // units that hold a candidate within the guard band
     if (patch_ok) {
       const float wmax = m4_wave_max(pg);
       if (wmax > -1.0e38f) {
@@ -741,7 +742,8 @@ __device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frame
         const int hl = __ffsll((long long)__ballot(pg == wmax)) - 1;
         const float second = m4_wave_max(lane == hl ? pt : pg);          // second largest ranking value of the whole window
         const bool boundary = __builtin_amdgcn_readlane(m4_D1(pS1, pS2), hl) == 1464100;
-        if (second >= thr || boundary) code = -1;                          // several near-best candidates, or sigma == 10: the exact walk
+        if (boundary) code = -1;                                           // sigma == 10 for the best: the exact walk of the whole window
+        else if (second >= thr) { code = -2; near_units = __ballot(lane < units && pg >= thr); }   // several near-best candidates
         else {
           code = 1;
           if (lane == hl) {
@@ -753,7 +755,34 @@ __device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frame
         }
       }
     }
-    if (code < 0) {
+    if (code == -2) {
+      // The reference's winner is the smallest FP64 score, among equals the last in its scan order (u outer, v inner).  Every
+      // candidate that can be it lies within the guard band of the best ranking value, i.e. in one of `near_units`: only
+      // their bands take the exact walk (a window of the whole frame is 150 bands; the ones that hold the tie are one or
+      // two), and the bands' winners are compared by the same rule.
+      double best = 1000000.0;
+      int bu = 0, bv = 0, found = 0;
+      while (near_units) {
+        const int h = __ffsll((long long)near_units) - 1;
+        near_units &= near_units - 1;
+        for (int bi = h * per; bi < min(h * per + per, nbands); ++bi) {
+          const int vt = bi / nbu, up = 2 * (bi - vt * nbu);
+          SearchBounds sb;
+          sb.ucentre = uc; sb.vcentre = vc; sb.halfwidth = sb.halfheight = 0;
+          sb.urelstart = us + 16 * up; sb.urelfinish = min(us + 16 * up + 31, us + nu_all - 1);
+          sb.vrelstart = vs + 16 * vt; sb.vrelfinish = min(vs + 16 * vt + 15, vs + nv_all - 1);
+          const SearchResult r = search_core_v0(img, width, patch + ((size_t)b * N + f) * kPatchStride, sb, recd[0], recd[1], recd[2]);
+          if (r.found && (!found || r.score < best || (r.score == best && (r.u > bu || (r.u == bu && r.v > bv))))) {
+            found = 1; best = r.score; bu = r.u; bv = r.v;
+          }
+        }
+      }
+      if (lane == 0) {
+        o[0] = 0; o[1] = found ? bu : 0; o[2] = found ? bv : 0; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = ncand;
+        o[7] = (found ? 1 : 0) | ((found && !(best > kCorrThresh2)) ? 2 : 0) | 4;
+        meas_score[(size_t)b * N + k] = best;
+      }
+    } else if (code < 0) {
       SearchBounds sb;
       sb.ucentre = uc; sb.vcentre = vc; sb.urelstart = us; sb.urelfinish = us + nu_all - 1;
       sb.vrelstart = vs; sb.vrelfinish = vs + nv_all - 1; sb.halfwidth = sb.halfheight = 0;

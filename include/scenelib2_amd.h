@@ -274,13 +274,13 @@ int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, in
 /* FileGrabber::GetImageFile (filegrabber.cpp:106-109: cv::imread(path, 0)) for the three containers this library decodes,
  * chosen by the file's magic bytes: binary PGM as above; PNG (non-interlaced; 8-bit grey / grey+alpha / RGB / RGBA /
  * palette, 1-2-4-bit grey / palette) - grey PNGs are byte-exact, colour is reduced like libpng's rgb_to_gray, which is what
- * imread(.., 0) uses: (9797 R + 19234 G + 3737 B + 16384) >> 15; JPEG (sequential DCT, Huffman, 8 bits, one or three
- * components) - the luminance component through libjpeg's integer inverse DCT (jpeg_idct_islow), which is what imread(.., 0)
- * gets from libjpeg with out_color_space = JCS_GRAYSCALE; progressive / arithmetic / 12-bit / four-component files are
- * refused with an error.  out may be NULL to query the size.  Host only. */
+ * imread(.., 0) uses: (9797 R + 19234 G + 3737 B + 16384) >> 15; JPEG (sequential and progressive DCT, Huffman, 8 bits, one or
+ * three components) - the luminance component through libjpeg's integer inverse DCT (jpeg_idct_islow), which is what
+ * imread(.., 0) gets from libjpeg with out_color_space = JCS_GRAYSCALE; arithmetic-coded / lossless / 12-bit / four-component
+ * files are refused with an error.  out may be NULL to query the size.  Host only. */
 int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
 /* FileGrabber + FrameGrabber for a batch: dirs[s] is the frame directory of sequence s.  A producer thread decodes
- * (sl2_read_image: PGM or PNG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of
+ * (sl2_read_image: PGM, PNG or JPEG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of
  * every sequence asynchronously on `stream` into one of two device buffers and returns it for
  * sl2_go_one_step(frames_on_device = 1).  The returned pointer stays valid until the next-but-one call.
  * Stream contract: the copy is ordered only with work on `stream`.  Pass the stream the engine steps on (the one given

@@ -1,4 +1,4 @@
-// Baseline JPEG -> 8-bit grey, host only: the third container of sl2_read_image (sl2_ingest.hip).
+// JPEG (sequential and progressive DCT) -> 8-bit grey, host only: the third container of sl2_read_image (sl2_ingest.hip).
 //
 // The reference decodes frames with cv::imread(path, 0) (framegrabber/filegrabber.cpp:106-109); for a JPEG that is libjpeg
 // with out_color_space = JCS_GRAYSCALE: the luminance component of a YCbCr file (or the only component of a grey one) is
@@ -6,10 +6,12 @@
 // is the "slow but accurate" integer one (jpeg_idct_islow).  That is restated here from the published algorithm (Loeffler,
 // Ligtenberg and Moschytz, 13-bit constants, two passes with 2 extra bits between them), so the bytes are libjpeg's, not an
 // approximation of them: tests/test_ingest.py compares against an independent libjpeg build (Pillow, draft('L')).
-// Decoded: sequential DCT (SOF0 / SOF1), 8 bits, Huffman, one or three components in any scan arrangement, any sampling
-// factors as long as the luminance component has the largest, restart intervals, 8- or 16-bit quantisation tables.
-// Refused with an error, not guessed: progressive and lossless processes, arithmetic coding, 12-bit samples, four
-// components (CMYK / YCCK), a subsampled first component.
+// Decoded: sequential DCT (SOF0 / SOF1) and progressive DCT (SOF2: spectral selection and successive approximation, the
+// luminance coefficients collected over all scans and reconstructed once at the end - what libjpeg delivers for a complete
+// file), 8 bits, Huffman, one or three components in any scan arrangement, any sampling factors as long as the luminance
+// component has the largest, restart intervals, 8- or 16-bit quantisation tables.
+// Refused with an error, not guessed: lossless processes, arithmetic coding, 12-bit samples, four components (CMYK / YCCK), a
+// subsampled first component.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -145,8 +147,9 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
   Huff hdc[4], hac[4];
   Component comp[3];
   int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart_interval = 0;
-  bool have_frame = false, y_done = false;
+  bool have_frame = false, y_done = false, progressive = false;
   std::vector<uint8_t> plane;                      // the first component, padded to whole MCUs
+  std::vector<int> ycoef;                          // progressive: the first component's coefficients (natural order, before dequantisation)
   int pw = 0, ph = 0;
   size_t pos = 2;
   while (pos + 4 <= n) {
@@ -183,7 +186,7 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
         if (!(tc ? hac[th] : hdc[th]).build(s + k + 1, s + k + 17, nsym)) return fail("bad JPEG Huffman table");
         k += 17 + nsym;
       }
-    } else if (m == 0xC0 || m == 0xC1) {           // SOF0 / SOF1: sequential DCT, Huffman
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {   // SOF0 / SOF1: sequential DCT, SOF2: progressive DCT; Huffman
       if (sl < 6) return fail("bad JPEG frame header");
       if (s[0] != 8) return fail("JPEG: only 8-bit samples are decoded");
       H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4]; ncomp = s[5];
@@ -199,9 +202,11 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
       pw = (W + 8 * hmax - 1) / (8 * hmax) * 8 * hmax;
       ph = (H + 8 * vmax - 1) / (8 * vmax) * 8 * vmax;
       plane.assign((size_t)pw * ph, 0);
+      progressive = (m == 0xC2);
+      if (progressive) ycoef.assign((size_t)pw * ph, 0);            // 64 coefficients per 8 x 8 block = one per sample
       have_frame = true;
-    } else if (m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
-      return fail("JPEG: only the sequential Huffman processes (SOF0 / SOF1) are decoded, not progressive / lossless / arithmetic");
+    } else if (m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+      return fail("JPEG: only the Huffman DCT processes (SOF0 / SOF1 / SOF2) are decoded, not lossless / arithmetic");
     } else if (m == 0xDD) {                        // DRI
       if (sl < 2) return fail("bad JPEG restart interval");
       restart_interval = (s[0] << 8) | s[1];
@@ -216,15 +221,138 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
         for (int c = 0; c < ncomp; ++c) if (comp[c].id == s[1 + 2 * i]) ci = c;
         if (ci < 0) return fail("bad JPEG scan header");
         comp[ci].td = s[2 + 2 * i] >> 4; comp[ci].ta = s[2 + 2 * i] & 15;
-        if (comp[ci].td > 3 || comp[ci].ta > 3 || !hdc[comp[ci].td].defined || !hac[comp[ci].ta].defined || !qt_def[comp[ci].tq])
-          return fail("JPEG scan refers to an undefined table");
+        if (comp[ci].td > 3 || comp[ci].ta > 3 || !qt_def[comp[ci].tq]) return fail("JPEG scan refers to an undefined table");
         comp[ci].pred = 0;
         sc[i] = ci;
       }
-      if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return fail("JPEG: spectral selection / successive approximation is not decoded");
+      const int Ss = s[1 + 2 * ns], Se = s[2 + 2 * ns], Ah = s[3 + 2 * ns] >> 4, Al = s[3 + 2 * ns] & 15;
       BitReader br;
       br.p = d + pos + len;
       br.end = d + n;
+      auto next_marker = [&]() {                     // behind the entropy-coded segment: the next marker that is not RSTn / a stuffed byte
+        const uint8_t* q = br.p;
+        while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
+        return (size_t)(q - d);
+      };
+      if (progressive) {
+        // ---- one scan of a progressive file (ITU T.81 annex G): a DC scan (Ss = Se = 0, possibly interleaved) or an AC band
+        // of ONE component; Ah = 0: first pass at bit position Al, Ah = Al + 1: one more bit of every coefficient
+        if (Ss > Se || Se > 63 || (Ss == 0 && Se != 0) || (Ss > 0 && ns != 1) || (Ah != 0 && Ah != Al + 1) || Al > 13)
+          return fail("bad progressive JPEG scan header");
+        if (Ss > 0 && sc[0] != 0) { pos = next_marker(); continue; }       // an AC band of a chroma component: not needed for grey
+        for (int i = 0; i < ns; ++i) {
+          if (Ss == 0 && Ah == 0 && !hdc[comp[sc[i]].td].defined) return fail("JPEG scan refers to an undefined table");
+          if (Ss > 0 && !hac[comp[sc[i]].ta].defined) return fail("JPEG scan refers to an undefined table");
+        }
+        int mcux, mcuy;
+        if (ns > 1) { mcux = pw / (8 * hmax); mcuy = ph / (8 * vmax); }
+        else {
+          const Component& c = comp[sc[0]];
+          const int cw = (W * c.h + hmax - 1) / hmax, chh = (H * c.v + vmax - 1) / vmax;
+          mcux = (cw + 7) / 8; mcuy = (chh + 7) / 8;
+        }
+        const int bpr = pw / 8;                        // blocks per row of the stored (first) component
+        int since_restart = 0, next_rst = 0, eobrun = 0;
+        const int p1 = 1 << Al, m1 = -(1 << Al);
+        for (int my = 0; my < mcuy; ++my)
+          for (int mx = 0; mx < mcux; ++mx) {
+            if (restart_interval && since_restart == restart_interval) {
+              const uint8_t* q = br.p;
+              while (q + 1 < br.end && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) ++q;
+              if (q + 1 >= br.end || q[1] != 0xD0 + next_rst) return fail("JPEG restart marker missing");
+              br.p = q + 2;
+              br.restart();
+              next_rst = (next_rst + 1) & 7;
+              since_restart = 0;
+              eobrun = 0;
+              for (int i = 0; i < ns; ++i) comp[sc[i]].pred = 0;
+            }
+            for (int i = 0; i < ns; ++i) {
+              Component& c = comp[sc[i]];
+              const int bh = ns > 1 ? c.h : 1, bv = ns > 1 ? c.v : 1;
+              for (int by = 0; by < bv; ++by)
+                for (int bx = 0; bx < bh; ++bx) {
+                  const int BX = ns > 1 ? mx * c.h + bx : mx, BY = ns > 1 ? my * c.v + by : my;
+                  int* blk = (sc[i] == 0 && BX < bpr && BY < ph / 8) ? ycoef.data() + ((size_t)BY * bpr + BX) * 64 : nullptr;
+                  if (Ss == 0) {
+                    if (Ah == 0) {                     // DC, first pass: the difference as in a sequential file, scaled by 2^Al
+                      const int t = decode_symbol(br, hdc[c.td]);
+                      if (t < 0 || t > 11) return fail("corrupt JPEG data (DC)");
+                      c.pred += extend(br.bits(t), t);
+                      if (blk) blk[0] = c.pred * (1 << Al);
+                    } else {                           // DC, refinement: one bit
+                      if (br.bit() && blk) blk[0] |= p1;
+                    }
+                    continue;
+                  }
+                  int scratch[64];
+                  if (!blk) { memset(scratch, 0, sizeof(scratch)); blk = scratch; }     // (a block outside the stored plane: decoded and dropped)
+                  int k = Ss;
+                  if (Ah == 0) {                       // AC, first pass (figure G.3 ff.): runs of zeros, values, end-of-band runs over blocks
+                    if (eobrun > 0) { --eobrun; continue; }
+                    while (k <= Se) {
+                      const int rs = decode_symbol(br, hac[c.ta]);
+                      if (rs < 0) return fail("corrupt JPEG data (AC)");
+                      const int r = rs >> 4, sz = rs & 15;
+                      if (sz == 0) {
+                        if (r == 15) { k += 16; continue; }
+                        eobrun = (1 << r) - 1;
+                        if (r) eobrun += br.bits(r);
+                        break;
+                      }
+                      k += r;
+                      if (k > Se) return fail("corrupt JPEG data (run)");
+                      blk[kZigzag[k]] = extend(br.bits(sz), sz) * (1 << Al);
+                      ++k;
+                    }
+                  } else {                             // AC, refinement (figure G.7): a correction bit for every coefficient that
+                    // is already non-zero, new coefficients of magnitude 2^Al in between
+                    auto refine = [&](int& coefv) {
+                      if (br.bit() && (coefv & p1) == 0) coefv += coefv >= 0 ? p1 : m1;
+                    };
+                    if (eobrun == 0) {
+                      while (k <= Se) {
+                        const int rs = decode_symbol(br, hac[c.ta]);
+                        if (rs < 0) return fail("corrupt JPEG data (AC)");
+                        int r = rs >> 4;
+                        const int sz = rs & 15;
+                        int newv = 0;
+                        if (sz == 0) {
+                          if (r != 15) {
+                            eobrun = 1 << r;
+                            if (r) eobrun += br.bits(r);
+                            break;                     // (the rest of this block is refined below, as the first block of the run)
+                          }
+                        } else {
+                          if (sz != 1) return fail("corrupt JPEG data (refinement)");
+                          newv = br.bit() ? p1 : m1;
+                        }
+                        while (k <= Se) {              // pass over r zero coefficients, refining the non-zero ones on the way
+                          int& cv = blk[kZigzag[k]];
+                          if (cv != 0) refine(cv);
+                          else { if (r == 0) break; --r; }
+                          ++k;
+                        }
+                        if (newv) { if (k > Se) return fail("corrupt JPEG data (run)"); blk[kZigzag[k]] = newv; }
+                        ++k;
+                      }
+                    }
+                    if (eobrun > 0) {
+                      for (; k <= Se; ++k) { int& cv = blk[kZigzag[k]]; if (cv != 0) refine(cv); }
+                      --eobrun;
+                    }
+                  }
+                }
+            }
+            ++since_restart;
+          }
+        if (Ss == 0) for (int i = 0; i < ns; ++i) if (sc[i] == 0) y_done = true;
+        pos = next_marker();
+        continue;
+      }
+      for (int i = 0; i < ns; ++i)
+        if (!hdc[comp[sc[i]].td].defined || !hac[comp[sc[i]].ta].defined) return fail("JPEG scan refers to an undefined table");
+      if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return fail("bad sequential JPEG scan header");
       // MCU geometry: interleaved (every component's h x v blocks per MCU) or a single component block by block
       int mcux, mcuy;
       if (ns > 1) { mcux = pw / (8 * hmax); mcuy = ph / (8 * vmax); }
@@ -279,15 +407,22 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
           ++since_restart;
         }
       for (int i = 0; i < ns; ++i) if (sc[i] == 0) y_done = true;
-      // continue behind the entropy-coded segment: the next marker that is not RSTn / a stuffed byte
-      const uint8_t* q = br.p;
-      while (q + 1 < br.end && !(q[0] == 0xFF && q[1] != 0x00 && q[1] != 0xFF && !(q[1] >= 0xD0 && q[1] <= 0xD7))) ++q;
-      pos = (size_t)(q - d);
+      pos = next_marker();
       continue;
     }
     pos += len;
   }
   if (!have_frame || !y_done) return fail("JPEG without a decodable luminance scan");
+  if (progressive) {                                 // every scan is in: dequantise and reconstruct the first component
+    int coef[64];
+    const int bpr = pw / 8;
+    for (int by = 0; by < ph / 8; ++by)
+      for (int bx = 0; bx < bpr; ++bx) {
+        const int* blk = ycoef.data() + ((size_t)by * bpr + bx) * 64;
+        for (int i = 0; i < 64; ++i) coef[i] = blk[i] * qt[comp[0].tq][i];
+        idct_islow(coef, plane.data() + (size_t)by * 8 * pw + bx * 8, pw);
+      }
+  }
   px.resize((size_t)W * H);
   for (int y = 0; y < H; ++y) memcpy(px.data() + (size_t)y * W, plane.data() + (size_t)y * pw, W);
   *w = W; *h = H;

@@ -31,48 +31,10 @@ __device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) {
 // registers and loops over the features (3 coalesced row reads of P + 2 coalesced row
 // writes of At per feature, each a full contiguous row for the workgroup).
 // ---------------------------------------------------------------------------
-#ifdef SL2_TESTING   // maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
-__global__ void __launch_bounds__(512) k_build_A(const double* __restrict__ P, const double* __restrict__ f_Hx,
-                                                 const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
-                                                 const int* __restrict__ succ_idx, const int* __restrict__ m_count,
-                                                 double* __restrict__ At, int N, int ld, int mld) {
-  // one workgroup per sequence; a thread owns column(s) i and loops over the features, so every
-  // row of P / At is streamed as one contiguous burst by the workgroup
-  const int b = blockIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int cnt_pad = (cnt + 15) / 16 * 16;
-  double* Ab = At + (size_t)b * mld * ld;
-  const double* Pb = P + (size_t)b * ld * ld;
-  for (int i = threadIdx.x; i < ld; i += blockDim.x) {
-    double pc[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
-#pragma unroll 4
-    for (int j = 0; j < cnt; ++j) {
-      const int f = succ_idx[(size_t)b * N + j];
-      const size_t fi = (size_t)b * N + f;
-      const int pos = 13 + 3 * f;
-      double py[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        double acc = 0.0;
-#pragma unroll
-        for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
-        if (i == ld - 1) acc = f_nu[fi * 2 + r];
-        Ab[(size_t)(2 * j + r) * ld + i] = acc;
-      }
-    }
-    for (int j = cnt; j < cnt_pad; ++j) {
-      Ab[(size_t)(2 * j) * ld + i] = 0.0;
-      Ab[(size_t)(2 * j + 1) * ld + i] = 0.0;
-    }
-  }
-}
+#ifdef SL2_TESTING   // section 1 of sl2_ekf_update_testing.inc: maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
+#define SL2_EKF_TEST_SECTION 1
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
@@ -203,342 +165,10 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   }
 }
 
-#ifdef SL2_TESTING
-// ---------------------------------------------------------------------------
-// k_build_AS_tiles (round 3; TEST build, SL2_BUILD_VARIANT=2): A^T = (P H^T)^T and S = H A + R from the UPPER block
-// triangle of P only.  Correct (the parity tests pass on it) and it moves 1.2 GB instead of 1.64, but it is SLOWER than
-// k_build_AS: 0.44 ms per launch against 0.29-0.30 on the same box (profiles/r03_build_tiles_*).  What it costs is not bytes
-// but the life of a workgroup: ~34 k cycles of which 60 % are waits (two dependent memory round trips, nine barriers, serial
-// per-thread chains), at two workgroups per CU because the tile, the staged results and the records take 80 KB of LDS.
-// k_build_AS keeps 20 waves per CU streaming full rows.  Kept as the measured alternative; DESIGN.md section 9.
-//
-// k_build_AS above streams the three rows of P of every measured feature in full - all of P, both triangles: 0.8 GB of
-// the launch's 1.64 GB at batch 1024 x 100 features - with one workgroup per sequence walking 25 dependent batches.  Here
-// one workgroup owns one 64 x 64 tile (I, J), J >= I, of a sequence's P (the tiles k_syrk works on), loads it once into
-// LDS and produces every entry of A^T that needs it:
-//   row role     A^T[a_f][j], j in J, for the measured features f whose first state index lies in tile row I
-//                (sum_c Hy[c] P[pos_f + c][j]: rows of the tile), and
-//   column role  A^T[a_f][i], i in I, for the features of tile column J (sum_c Hy[c] P[i][pos_f + c]: columns of the
-//                tile, i.e. the lower-triangle entries P[pos_f + c][i] read through their mirrors), I < J only;
-// the pose part sum_c Hx[c] P[c][.] comes from the seven pose rows over the same columns.  Every entry of A^T is written
-// exactly once, in 512-byte row segments.  A feature whose three rows straddle a tile boundary is handled with two halo
-// rows / columns around the tile (for a diagonal tile the halo rows are the mirrors of the halo columns).
-// The measurements are stacked in SLOT order (k_search_score), so the features of a tile are consecutive rows of A^T and
-// S[t][k] = Hx_t A^T[k][0..6] + Hy_t A^T[k][pos_t ..] for (k in I, t in J) is a contiguous block of the k-major S,
-// formed here from the row-role results still in LDS (A^T[k][0..6] is recomputed from the pose rows: 70 multiply-adds).
-// Summation order of every entry = that of k_build_A / k_build_AS.
-// Traffic at batch 1024 x 100 features: 0.5 GB of P (15 tiles) + 0.57 GB of A^T + 0.16 GB of S instead of 1.64 GB, and
-// 15 independent workgroups per sequence instead of one chain.
-// ---------------------------------------------------------------------------
-constexpr int kBtF = 22;          // measured features whose first state index lies in one 64-wide tile: at most ceil(64 / 3)
-constexpr int kBtW = 66;          // tile edge + two halo rows / columns
-constexpr int kBtP = 67;          // LDS pitch of the tile (odd: column reads are conflict-free)
-constexpr int kBtFD = 24;         // doubles per feature record: Hx[2][7], Hy[2][3], R, nu[2], local position
-constexpr int kBtThreads = 512;
-
-// One output row of A^T over eight columns, with the row's ten coefficients in registers: the summation order of k_build_A
-// (pose part c = 0..6, then the feature's three rows / columns).  ROWS: the feature's states are rows of the tile (row
-// role), else columns (column role).
-template <bool ROWS>
-__device__ __forceinline__ void bt_row_chunk(const double* __restrict__ sT, const double* __restrict__ pose, const double* __restrict__ F,
-                                             int r, int j0, int nj, int jstep, double* __restrict__ out) {
-  double hx[7], hy[3];
-#pragma unroll
-  for (int c = 0; c < 7; ++c) hx[c] = F[r * 7 + c];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) hy[c] = F[14 + r * 3 + c];
-  const int lp = (int)F[23];
-#pragma unroll 4
-  for (int jj = 0; jj < nj; ++jj) {
-    const int j = j0 + jj * jstep;     // (lanes of one row take neighbouring columns: LDS banks)
-    double acc = 0.0;
-#pragma unroll
-    for (int c = 0; c < 7; ++c) acc += pose[c * kBtW + j] * hx[c];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) acc += (ROWS ? sT[(lp + c) * kBtP + j] : sT[j * kBtP + lp + c]) * hy[c];
-    out[j] = acc;
-  }
-}
-
-// what a lane holds of a tile between its loads and their way into LDS
-struct BtRegs { double2 tv[4]; double hv; int arow; double pv[2]; double rv[3]; };
-
-// Every global load one tile needs: the feature slots whose first state index lies in tile row I / tile column J are known
-// from the tile indices alone, so the tile (four 16-byte pieces per lane), its halo, the pose rows, the slots' Jacobians and
-// their rows in A^T (f_arow, written by k_search_score) are requested together.  (The first versions found their features
-// by counting the measurement list and then fetched the records: a second, dependent round trip and nine barriers; and
-// loading phase by phase, each loop iteration waiting for its own data, cost ~15 round trips.)
-__device__ __forceinline__ void bt_load(BtRegs& R, const double* __restrict__ Pb, const double* __restrict__ f_Hx,
-                                        const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
-                                        const double* __restrict__ f_R, const int* __restrict__ f_arow, size_t bN, int N, int ld,
-                                        int ti, int tj, int tid) {
-  const int r0 = ti * 64, c0 = tj * 64;
-  const bool diag = ti == tj;
-  const int fI0 = r0 >= 13 ? (r0 - 13 + 2) / 3 : 0, fJ0 = c0 >= 13 ? (c0 - 13 + 2) / 3 : 0;
-  const int fI1 = min(N, (r0 + 64 - 13 + 2) / 3), fJ1 = min(N, (c0 + 64 - 13 + 2) / 3);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
-    R.tv[u] = *(const double2*)(Pb + (size_t)(r0 + row) * ld + c0 + c2);
-  }
-  // halo columns (P[r0 + i][c0 + 64 + h]), halo rows (P[r0 + 64 + h][c0 + j]; in a diagonal tile the mirrors of the halo
-  // columns: the tile below the diagonal one is a lower tile), the corner, P[0..6][0..6] and the slots' rows of A^T
-  R.hv = 0.0;
-  R.arow = -1;
-  if (tid < 128) {
-    if (c0 + 64 < ld) R.hv = Pb[(size_t)(r0 + (tid >> 1)) * ld + c0 + 64 + (tid & 1)];
-  } else if (tid < 256) {
-    if (!diag && r0 + 64 < ld) R.hv = Pb[(size_t)(r0 + 64 + (tid & 1)) * ld + c0 + ((tid - 128) >> 1)];
-  } else if (tid < 260) {
-    if (r0 + 64 < ld && c0 + 64 < ld) R.hv = Pb[(size_t)(r0 + 64 + ((tid - 256) >> 1)) * ld + c0 + 64 + (tid & 1)];
-  } else if (tid < 320) {
-    if (tid - 260 < 49) R.hv = Pb[(size_t)((tid - 260) / 7) * ld + ((tid - 260) % 7)];
-  } else if (tid < 320 + 2 * kBtF) {
-    const int side = (tid - 320) / kBtF, e = (tid - 320) - side * kBtF;
-    const int f = (side ? fJ0 : fI0) + e;
-    if (f < (side ? fJ1 : fI1) && !(side && diag)) R.arow = f_arow[bN + f];
-  }
-  // pose rows: what k_build_A reads as pc[c] of column i: P[i][c] for i < 13 (the vehicle block is general), else P[c][i]
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = tid + kBtThreads * u;
-    double v = 0.0;
-    if (idx < 2 * 7 * kBtW) {
-      const int side = idx / (7 * kBtW), rem = idx - side * (7 * kBtW);
-      const int c = rem / kBtW, jj = rem - c * kBtW;
-      const int col = (side ? r0 : c0) + jj;
-      if (col < ld) v = (col < 13) ? Pb[(size_t)col * ld + c] : Pb[(size_t)c * ld + col];
-    }
-    R.pv[u] = v;
-  }
-  // slot records (Jacobians of unmeasured slots are fetched too: they are never used)
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int idx = tid + kBtThreads * u;
-    double v = 0.0;
-    if (idx < 2 * kBtF * kBtFD) {
-      const int se = idx / kBtFD, q = idx - se * kBtFD;
-      const int side = se / kBtF, e = se - side * kBtF;
-      const int f = (side ? fJ0 : fI0) + e;
-      if (f < (side ? fJ1 : fI1) && !(side && diag)) {
-        const size_t fi = bN + f;
-        if (q < 14) v = f_Hx[fi * 14 + q];
-        else if (q < 20) v = f_Hy[fi * 6 + (q - 14)];
-        else if (q == 20) v = f_R[fi];
-        else if (q < 23) v = f_nu[fi * 2 + (q - 21)];
-        else v = (double)(13 + 3 * f - (side ? c0 : r0));
-      }
-    }
-    R.rv[u] = v;
-  }
-}
-
-// k_build_AS_tiles<false>: one upper tile per workgroup (80 KB of LDS, two workgroups per CU).  Every phase of a workgroup's
-// life is exposed at that occupancy: loads and staging 0.16-0.20 ms of the launch's 0.40, results 0.055, row role 0.036,
-// S 0.065, column role 0.022 (profiles/r03_build_tiles_ab.txt).
-// k_build_AS_tiles<true>: a workgroup walks `tiles_per_wg` consecutive upper tiles of one sequence with the loads of the next
-// tile in flight while the current one is worked on.  The 29 registers of prefetch push the kernel to 212 VGPRs = one
-// workgroup per CU, and the chain of phases of ONE tile is what bounds it: 0.69 ms at 15 tiles per workgroup, 0.79 at one.
-template <bool PERSIST>
-__global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __restrict__ P, const double* __restrict__ f_Hx,
-                                                               const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
-                                                               const double* __restrict__ f_R, const int* __restrict__ f_arow,
-                                                               const int* __restrict__ m_count, double* __restrict__ At,
-                                                               double* __restrict__ St, int N, int ld, int mld, int B, int skip,
-                                                               int tiles_per_wg) {
-  // skip: timing probes only (bit 0 row role, 1 S, 2 column role, 3 the stores of A^T)
-  int b, grp;
-  const int nt = ld / 64, ntile = nt * (nt + 1) / 2;
-  const int ngrp = (ntile + tiles_per_wg - 1) / tiles_per_wg;
-  if (!xcd_map(ngrp, B, &b, &grp)) return;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int t_first = grp * tiles_per_wg, t_last = PERSIST ? min(ntile, t_first + tiles_per_wg) : t_first + 1;
-  int tj = 0, ti = t_first;
-  while (ti > tj) { ti -= tj + 1; ++tj; }           // ti <= tj
-  const int m = 2 * cnt, mp = (m + 31) / 32 * 32;
-  const int tid = threadIdx.x;
-  const double* Pb = P + (size_t)b * ld * ld;
-  double* Ab = At + (size_t)b * mld * ld;
-  double* Sb = St + (size_t)b * mld * mld;
-
-  __shared__ double sT[kBtW * kBtP];           // the tile with its halo: sT[i][j] = P[r0 + i][c0 + j]
-  __shared__ double sPose[2][7][kBtW];         // [0]: pose rows over the columns of J, [1]: over the columns of I
-  __shared__ double sXX[7][7];                 // P[c][c'], c, c' < 7
-  __shared__ double sF[2][kBtF][kBtFD];        // [0]: the feature slots of tile row I, [1]: of tile column J (slot-local index)
-  __shared__ double sA[2 * kBtF][kBtW];        // results of a role (the row role with its two halo columns: what S is formed from)
-  __shared__ double sU[2][2 * kBtF][7];        // A^T[k][0..6] of the slots of I ([0]) and of J ([1])
-  __shared__ int sArow[2][kBtF];               // first row of A^T / S of a slot's feature (f_arow), -1 = not measured this frame
-
-  BtRegs R;
-  bt_load(R, Pb, f_Hx, f_Hy, f_nu, f_R, f_arow, (size_t)b * N, N, ld, ti, tj, tid);
-  for (int tcur = t_first; tcur < t_last; ++tcur) {
-  const int r0 = ti * 64, c0 = tj * 64;
-  const bool diag = ti == tj;
-  if (PERSIST && tcur > t_first) __syncthreads();         // the previous tile is done with the LDS
-  // ---- everything into LDS ----
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int idx = tid + kBtThreads * u, row = idx >> 5, c2 = (idx & 31) * 2;
-    sT[row * kBtP + c2] = R.tv[u].x;
-    sT[row * kBtP + c2 + 1] = R.tv[u].y;
-  }
-  if (tid < 128) {
-    const int i = tid >> 1, h = tid & 1;
-    sT[i * kBtP + 64 + h] = R.hv;
-    if (diag) sT[(64 + h) * kBtP + i] = R.hv;
-  } else if (tid < 256) {
-    if (!diag) sT[(64 + (tid & 1)) * kBtP + ((tid - 128) >> 1)] = R.hv;
-  } else if (tid < 260) {
-    sT[(64 + ((tid - 256) >> 1)) * kBtP + 64 + (tid & 1)] = R.hv;
-  } else if (tid < 309) {
-    sXX[(tid - 260) / 7][(tid - 260) % 7] = R.hv;
-  } else if (tid >= 320 && tid < 320 + 2 * kBtF) {
-    (&sArow[0][0])[tid - 320] = R.arow;
-  }
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int idx = tid + kBtThreads * u;
-    if (idx < 2 * 7 * kBtW) (&sPose[0][0][0])[idx] = R.pv[u];
-  }
-#pragma unroll
-  for (int u = 0; u < 3; ++u) {
-    const int idx = tid + kBtThreads * u;
-    if (idx < 2 * kBtF * kBtFD) (&sF[0][0][0])[idx] = R.rv[u];
-  }
-  __syncthreads();
-  {   // the next tile's loads fly under this tile's arithmetic
-    int ni = ti + 1, nj = tj;
-    if (ni > nj) { ni = 0; ++nj; }
-    if (PERSIST && tcur + 1 < t_last) bt_load(R, Pb, f_Hx, f_Hy, f_nu, f_R, f_arow, (size_t)b * N, N, ld, ni, nj, tid);
-  }
-
-  // ---- row role: A^T[arow_e + r][c0 + j] -> sA[2 e + r]; a thread owns one output row over eight columns (chunk 8 = the
-  // two halo columns, kept for S only: they belong to the next tile column of A^T) ----
-  if (!(skip & 1) && tid < 2 * kBtF * 9) {
-    const int a = tid / 9, ch = tid - a * 9;
-    if (sArow[0][a >> 1] >= 0) {
-      bt_row_chunk<true>(sT, &sPose[0][0][0], sF[0][a >> 1], a & 1, ch < 8 ? ch : 64, ch < 8 ? 8 : 2, ch < 8 ? 8 : 1, sA[a]);
-      if (c0 + 64 == ld && ch == 7) sA[a][63] = sF[0][a >> 1][21 + (a & 1)];       // column ld - 1 carries the innovation
-    }
-  }
-  // ---- A^T[k][0..6] of both groups (columns < 13: the pose part reads P[c][c'], the feature part the pose rows at the
-  // feature's own columns, i.e. the mirrors of P[pos + c'][c]) ----
-  for (int idx = tid; idx < 2 * kBtF * 14; idx += kBtThreads) {
-    const int se = idx / 14, rc = idx - se * 14, r = rc / 7, c = rc - r * 7;
-    const int side = se / kBtF, e = se - side * kBtF;
-    if (sArow[side][e] < 0) continue;
-    const double* F = sF[side][e];
-    const int lp = (int)F[23];
-    double acc = 0.0;
-#pragma unroll
-    for (int c2 = 0; c2 < 7; ++c2) acc += sXX[c][c2] * F[r * 7 + c2];
-#pragma unroll
-    for (int c2 = 0; c2 < 3; ++c2) acc += sPose[side ? 0 : 1][c][lp + c2] * F[14 + r * 3 + c2];
-    sU[side][2 * e + r][c] = acc;
-  }
-  __syncthreads();
-
-  {
-    // ---- the row-role results leave in 512-byte row segments ----
-    for (int idx = tid; !(skip & 8) && idx < 2 * kBtF * 32; idx += kBtThreads) {
-      const int a = idx >> 5, c2 = (idx & 31) * 2;
-      const int ar = sArow[0][a >> 1];
-      if (ar < 0) continue;
-      double2 v;
-      v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
-      *(double2*)(Ab + (size_t)(ar + (a & 1)) * ld + c0 + c2) = v;
-    }
-    // ---- S: St[k][t] = H_t . A_k for k in the rows of I, t in the rows of J (stored where (t | 31) >= k: the blocks on and
-    // below the block diagonal and the full diagonal blocks).  A thread owns one t (its coefficients in registers) and walks
-    // the k's of its wavefront. ----
-    const int sj = diag ? 0 : 1;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int art = (lane < 2 * kBtF && !(skip & 2)) ? sArow[sj][lane >> 1] : -1;
-    if (art >= 0) {
-      const int tt = lane, at = art + (tt & 1);
-      const double* Ft = sF[sj][tt >> 1];
-      const int r = tt & 1, lp = (int)Ft[23];
-      double hx[7], hy[3];
-#pragma unroll
-      for (int c = 0; c < 7; ++c) hx[c] = Ft[r * 7 + c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) hy[c] = Ft[14 + r * 3 + c];
-      const double Rt = Ft[20];
-      for (int kk = wv; kk < 2 * kBtF; kk += kBtThreads / 64) {
-        const int ark = sArow[0][kk >> 1];
-        if (ark < 0) continue;
-        const int ak = ark + (kk & 1);
-        if ((at | 31) >= ak) {
-          double acc = 0.0;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) acc += hx[c] * sU[0][kk][c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) acc += hy[c] * sA[kk][lp + c];
-          if (at == ak) acc += Rt;
-          Sb[(size_t)ak * mld + at] = acc;
-        }
-        // the transposed position St[t][k] = H_k . A_t is stored too where row t and column k share a diagonal 32-block
-        // (features of two tiles inside one block of S): A_t at the columns of feature k is a column-role value
-        if (!diag && (ak | 31) >= at) {
-          const double* Fk = sF[0][kk >> 1];
-          const int rk = kk & 1, lpk = (int)Fk[23];
-          double acc = 0.0;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) acc += Fk[rk * 7 + c] * sU[1][tt][c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double a_tc = 0.0;                     // A^T[at][r0 + lpk + c], as the column role forms it
-#pragma unroll
-            for (int c2 = 0; c2 < 7; ++c2) a_tc += sPose[1][c2][lpk + c] * hx[c2];
-#pragma unroll
-            for (int c2 = 0; c2 < 3; ++c2) a_tc += sT[(lpk + c) * kBtP + lp + c2] * hy[c2];
-            acc += Fk[14 + rk * 3 + c] * a_tc;
-          }
-          Sb[(size_t)at * mld + ak] = acc;
-        }
-      }
-    }
-  }
-
-  // ---- column role: A^T[arow_e + r][r0 + i] through the mirrors P[i][pos + c] (sA is free again) ----
-  if (!diag) {
-    __syncthreads();
-    if (!(skip & 4) && tid < 2 * kBtF * 8) {
-      const int a = tid >> 3, ch = tid & 7;
-      if (sArow[1][a >> 1] >= 0) bt_row_chunk<false>(sT, &sPose[1][0][0], sF[1][a >> 1], a & 1, ch, 8, 8, sA[a]);
-    }
-    __syncthreads();
-    for (int idx = tid; !(skip & 8) && idx < 2 * kBtF * 32; idx += kBtThreads) {
-      const int a = idx >> 5, c2 = (idx & 31) * 2;
-      const int ar = sArow[1][a >> 1];
-      if (ar < 0) continue;
-      double2 v;
-      v.x = sA[a][c2]; v.y = sA[a][c2 + 1];
-      *(double2*)(Ab + (size_t)(ar + (a & 1)) * ld + r0 + c2) = v;
-    }
-  }
-
-  // ---- padding: rows of A^T up to the 32-multiple are zero (each diagonal-tile workgroup clears its 64 columns); S is the
-  // identity there (first workgroup of the sequence) ----
-  if (diag) {
-    for (int idx = tid; idx < (mp - m) * 64; idx += kBtThreads) Ab[(size_t)(m + (idx >> 6)) * ld + c0 + (idx & 63)] = 0.0;
-    if (tj == 0) {
-      const int npad = mp - m;
-      for (int idx = tid; idx < mp * npad; idx += kBtThreads) {       // columns m .. mp of every row
-        const int k = idx / npad, tcol = m + (idx - k * npad);
-        Sb[(size_t)k * mld + tcol] = (k == tcol) ? 1.0 : 0.0;
-      }
-      const int nlow = m - (mp - 32);                                 // rows m .. mp: the measured columns of the last block
-      for (int idx = tid; idx < npad * nlow; idx += kBtThreads) {
-        const int k = m + idx / nlow, tcol = (mp - 32) + (idx - (idx / nlow) * nlow);
-        Sb[(size_t)k * mld + tcol] = 0.0;
-      }
-    }
-  }
-  if (++ti > tj) { ti = 0; ++tj; }
-  }   // tiles of this workgroup
-}
+#ifdef SL2_TESTING   // section 2 of sl2_ekf_update_testing.inc
+#define SL2_EKF_TEST_SECTION 2
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
@@ -547,54 +177,10 @@ __global__ void __launch_bounds__(kBtThreads) k_build_AS_tiles(const double* __r
 // a of H (its 10 non-zeros in registers) and loops over 32 columns bb: per column
 // 7 wave-uniform loads (pose part of At row bb) + 3 gathered loads within that row.
 // ---------------------------------------------------------------------------
-#ifdef SL2_TESTING   // maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
-__global__ void __launch_bounds__(256) k_build_S(const double* __restrict__ At, const double* __restrict__ f_Hx,
-                                                 const double* __restrict__ f_Hy, const double* __restrict__ f_R,
-                                                 const int* __restrict__ succ_idx, const int* __restrict__ m_count,
-                                                 double* __restrict__ St, int N, int ld, int mld) {
-  const int b = blockIdx.z;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int mp = (2 * cnt + 31) / 32 * 32;
-  const int a = blockIdx.y * 256 + threadIdx.x;
-  const int bb0 = blockIdx.x * 32;
-  if (a >= mp || bb0 >= mp) return;
-  if (bb0 > (a | 31)) return;   // strictly above the block diagonal: never read by the factorisation
-  double* Sb = St + (size_t)b * mld * mld;
-  const int m = 2 * cnt;
-  if (a >= m) {
-    for (int bb = bb0; bb < bb0 + 32; ++bb) Sb[(size_t)bb * mld + a] = (a == bb) ? 1.0 : 0.0;
-    return;
-  }
-  const int j = a >> 1, r = a & 1;
-  const int fj = succ_idx[(size_t)b * N + j];
-  const size_t fi = (size_t)b * N + fj;
-  const int posj = 13 + 3 * fj;
-  double hx[7], hy[3];
-#pragma unroll
-  for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fi * 14 + r * 7 + c];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fi * 6 + r * 3 + c];
-  const double Rn = f_R[fi];
-  const double* Ab = At + (size_t)b * mld * ld;
-#pragma unroll 4
-  for (int bb = bb0; bb < bb0 + 32; ++bb) {
-    double v;
-    if (bb >= m) {
-      v = 0.0;
-    } else {
-      const double* arow = Ab + (size_t)bb * ld;
-      double acc = 0.0;
-#pragma unroll
-      for (int c = 0; c < 7; ++c) acc += hx[c] * arow[c];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) acc += hy[c] * arow[posj + c];
-      if (a == bb) acc += Rn;
-      v = acc;
-    }
-    Sb[(size_t)bb * mld + a] = v;
-  }
-}
+#ifdef SL2_TESTING   // section 3 of sl2_ekf_update_testing.inc: maps beyond what k_build_AS takes are not built by the product (sl2_create rejects them): TEST build only (SL2_BUILD_VARIANT=0)
+#define SL2_EKF_TEST_SECTION 3
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
@@ -631,134 +217,25 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
-__global__ void __launch_bounds__(64) k_chol_diag(double* __restrict__ St, double* __restrict__ LinvT,
-                                                  const int* __restrict__ m_count, int mld, int nblk_max, int J) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
-  if (J >= nblk) return;
-  double* Sb = St + (size_t)b * mld * mld;
-  const int o = J * 32;
-  const int r = lane & 31;                    // lanes 32..63 mirror lanes 0..31 (results discarded)
-  double a[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) a[c] = Sb[(size_t)(o + c) * mld + o + r];   // a[c] = S[o+r][o+c]
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    const double piv = readlane_f64(a[c], c);
-    const double dinv = fast_rsqrt(piv);
-    const double d = piv * dinv;
-    const double l = (r == c) ? d : a[c] * dinv;
-    a[c] = (r >= c) ? l : 0.0;
-#pragma unroll
-    for (int cc = c + 1; cc < 32; ++cc) {
-      const double lcc = readlane_f64(a[c], cc);   // L[cc][c]
-      a[cc] -= l * lcc;                            // meaningful for r >= cc
-    }
-  }
-  // inverse, row-wise: lane k holds x[p] = Linv[k][p]
-  double diag = 1.0;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) diag = (r == c) ? a[c] : diag;   // static indexing only (no scratch)
-  const double rinv = fast_rcp(diag);              // 1 / L[r][r]
-  double x[32];
-#pragma unroll
-  for (int p = 31; p >= 0; --p) {
-    double sacc = (r == p) ? 1.0 : 0.0;
-#pragma unroll
-    for (int i = p + 1; i < 32; ++i) sacc -= x[i] * readlane_f64(a[p], i);   // X[k][i] * L[i][p]
-    x[p] = sacc * readlane_f64(rinv, p);
-  }
-  if (lane < 32) {
-    double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-      Sb[(size_t)(o + c) * mld + o + r] = a[c];    // L[r][c] (zero above the diagonal)
-      Lb[c * 32 + r] = x[c];                       // LinvT[p = c][k = r] = Linv[r][c]
-    }
-  }
-}
+#ifdef SL2_TESTING   // section 4 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
+#define SL2_EKF_TEST_SECTION 4
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // k_chol_panel: L[I][J] = S[I][J] * L_JJ^-T for every block row I > J; one wave
 // per 32x32 tile.  In k-major storage: new[k][i] = sum_p Linv[k][p] * St[J+p][I+i].
-#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
-__global__ void __launch_bounds__(64) k_chol_panel(double* __restrict__ St, const double* __restrict__ LinvT,
-                                                   const int* __restrict__ m_count, int mld, int nblk_max, int J) {
-  const int b = blockIdx.y, lane = threadIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
-  const int I = J + 1 + blockIdx.x;
-  if (I >= nblk) return;
-  const int lo = lane & 15, hi = lane >> 4;
-  double* Sb = St + (size_t)b * mld * mld;
-  const double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-  v4d acc[2][2];
-  for (int kt = 0; kt < 2; ++kt) for (int it = 0; it < 2; ++it) acc[kt][it] = (v4d){0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int p = 4 * s + hi;
-    const double a0 = Lb[p * 32 + lo], a1 = Lb[p * 32 + 16 + lo];
-    const double b0 = Sb[(size_t)(J * 32 + p) * mld + I * 32 + lo];
-    const double b1 = Sb[(size_t)(J * 32 + p) * mld + I * 32 + 16 + lo];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-  }
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Sb[(size_t)(J * 32 + 16 * kt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[kt][it][r];
-}
+#ifdef SL2_TESTING   // section 5 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
+#define SL2_EKF_TEST_SECTION 5
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // k_chol_trail: S[I][K] -= L[I][J] L[K][J]^T for J < K <= I; one wave per tile.
-#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
-__global__ void __launch_bounds__(64) k_chol_trail(double* __restrict__ St, const int* __restrict__ m_count, int mld, int J) {
-  const int b = blockIdx.y, lane = threadIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
-  // tile index -> (I, K), lower triangle of the trailing matrix, row-major
-  int t = blockIdx.x, ri = 0;
-  while (t > ri) { t -= ri + 1; ++ri; }
-  const int I = J + 1 + ri, K = J + 1 + t;
-  if (I >= nblk) return;
-  const int lo = lane & 15, hi = lane >> 4;
-  double* Sb = St + (size_t)b * mld * mld;
-  v4d acc[2][2];
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[jt][it][r] = Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r) * mld + I * 32 + 16 * it + lo];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const size_t row = (size_t)(J * 32 + 4 * s + hi) * mld;
-    const double a0 = -Sb[row + K * 32 + lo], a1 = -Sb[row + K * 32 + 16 + lo];
-    const double b0 = Sb[row + I * 32 + lo], b1 = Sb[row + I * 32 + 16 + lo];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-  }
-#pragma unroll
-  for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Sb[(size_t)(K * 32 + 16 * jt + hi + 4 * r) * mld + I * 32 + 16 * it + lo] = acc[jt][it][r];
-}
+#ifdef SL2_TESTING   // section 6 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
+#define SL2_EKF_TEST_SECTION 6
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 #ifdef SL2_TESTING
@@ -875,127 +352,10 @@ __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int
   tile_store(Sb, mld, K * 32, I * 32, lo, hi, acc);
 }
 
-#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
-__global__ void __launch_bounds__(256, 4) k_chol_fused4(double* __restrict__ St, double* __restrict__ LinvT,
-                                                        const int* __restrict__ m_count, int mld, int nblk_max, long long* trace) {
-  const int b = blockIdx.x;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int nblk = (2 * cnt + 31) / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool isD = wave == 0;
-  const int mw = wave - 1;              // 0..2 for the M waves
-  __shared__ double sTile[32][33];     // next diagonal tile, sTile[r][c] = S[r][c]   (M0 -> D)
-  __shared__ double sLinv[32 * kLinvPitch];   // LinvT of the current block, [p][k]   (D -> M)
-  double* Sb = St + (size_t)b * mld * mld;
-#ifdef SL2_CHOL_TRACE
-#define TR(slot) do { if (trace && lane == 0) trace[(((size_t)b * 4 + wave) * 8 + J) * 4 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
-  if (trace && lane == 0) trace[(size_t)gridDim.x * 4 * 8 * 4 + b * 4 + wave] = __builtin_amdgcn_s_getreg(63492);
-#else
-#define TR(slot) do { } while (0)
-#endif
-  for (int J = 0; J < nblk; ++J) {
-    const int o = J * 32;
-    // Re-derive the lane coordinates inside the loop from an opaque copy: otherwise every
-    // lane-only expression (32 compare masks, 32 unit-vector constants, all tile addresses) is
-    // hoisted out of the J loop and spilled to scratch.
-    int lane_j = lane;
-    asm volatile("" : "+v"(lane_j));
-    const int lo = lane_j & 15, hi = lane_j >> 4;
-    TR(0);
-    if (isD) {
-      // Lanes 0..31 hold the rows of the diagonal tile, lanes 32..63 the rows of the identity:
-      // column-Cholesky applies the same column operations to both, [A; I] -> [L; L^-T], so the
-      // inverse costs no instructions of its own.
-      const int r = lane_j & 31;
-      const bool low = lane_j < 32;
-      double a[32];
-      if (J == 0) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          const double v = Sb[(size_t)c * mld + r];
-          a[c] = low ? v : ((r == c) ? 1.0 : 0.0);
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          const double v = sTile[r][c];
-          a[c] = low ? v : ((r == c) ? 1.0 : 0.0);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        const double piv = readlane_f64(a[c], c);
-        const double dinv = fast_rsqrt(piv);
-        const double l = (!low || r >= c) ? a[c] * dinv : 0.0;   // lane c: piv * rsqrt(piv) = sqrt(piv)
-        a[c] = l;
-#pragma unroll
-        for (int cc = c + 1; cc < 32; ++cc) a[cc] -= l * readlane_f64(l, cc);
-      }
-      // lane 32+i, register c: (L^-T)[i][c] = Linv[c][i] -> sLinv[p = i][k = c]
-      if (!low) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) sLinv[r * kLinvPitch + c] = a[c];
-      }
-    }
-    TR(1);
-    __syncthreads();                    // A_J : L_JJ^-1 available to the M waves
-    TR(2);
-    if (J + 1 >= nblk) {
-      if (mw == 2) {
-        double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
-      }
-      break;
-    }
-    if (!isD) {
-      if (mw == 0) {
-        // panel tile (J+1, J), then diagonal tile (J+1, J+1) straight from those registers
-        const Tile32 pt = tile_panel(sLinv, Sb, mld, o, (J + 1) * 32, lo, hi);
-        Tile32 dg = tile_load(Sb, mld, (J + 1) * 32, (J + 1) * 32, lo, hi);
-        tile_store(Sb, mld, o, (J + 1) * 32, lo, hi, pt);
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-          const double f0 = pt.f[s8 >> 2][0][s8 & 3], f1 = pt.f[s8 >> 2][1][s8 & 3];
-          dg.f[0][0] = mfma_f64(-f0, f0, dg.f[0][0]);
-          dg.f[0][1] = mfma_f64(-f0, f1, dg.f[0][1]);
-          dg.f[1][0] = mfma_f64(-f1, f0, dg.f[1][0]);
-          dg.f[1][1] = mfma_f64(-f1, f1, dg.f[1][1]);
-        }
-#pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-          for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) sTile[16 * it + lo][16 * jt + hi + 4 * r4] = dg.f[jt][it][r4];
-        // share of the remaining panel tiles: M0 takes every third one, after its critical work
-        for (int I = J + 2 + 2; I < nblk; I += 3) {
-          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
-          tile_store(Sb, mld, o, I * 32, lo, hi, t);
-        }
-      } else {
-        if (mw == 2) {   // LinvT block to memory for the forward substitution, coalesced
-          double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) Lb[q * 64 + lane_j] = sLinv[(q * 2 + (lane_j >> 5)) * kLinvPitch + (lane_j & 31)];
-        }
-        for (int I = J + 2 + (mw - 1); I < nblk; I += 3) {
-          const Tile32 t = tile_panel(sLinv, Sb, mld, o, I * 32, lo, hi);
-          tile_store(Sb, mld, o, I * 32, lo, hi, t);
-        }
-      }
-    }
-    TR(3);
-    __syncthreads();                    // B_J : tile (J+1, J+1) is in LDS and column J of L is complete
-    if (!isD) {
-      int idx = 0;
-      for (int K = J + 1; K < nblk; ++K)
-        for (int I = (K == J + 1) ? K + 1 : K; I < nblk; ++I, ++idx)
-          if (idx % 3 == mw) tile_trail(Sb, mld, o, K, I, lo, hi);
-    }
-  }
-}
+#ifdef SL2_TESTING   // section 7 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
+#define SL2_EKF_TEST_SECTION 7
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 #undef TR
@@ -1307,81 +667,10 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 // an explicit two-stage register pipeline, 1.04 ms at 256 VGPRs — each loses the
 // occupancy that hides the chain's latency.  This version: see profiles/.)
 // ---------------------------------------------------------------------------
-#ifdef SL2_TESTING   // superseded variant: TEST build only (sl2_set_update_variant)
-template <bool HALF>
-__device__ __forceinline__ void fwd_kloop(v4d acc[2][2], const double* __restrict__ lrow, const double* vrow, int mld, int ld,
-                                          int kend) {
-#pragma unroll 4
-  for (int kk = 0; kk < kend; kk += 4) {
-    const double a0 = -lrow[(size_t)kk * mld];
-    const double b0 = vrow[(size_t)kk * ld], b1 = vrow[(size_t)kk * ld + 16];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    if (!HALF) {
-      const double a1 = -lrow[(size_t)kk * mld + 16];
-      acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-      acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-    }
-  }
-}
-
-// 2 waves per workgroup, 32 columns per wave (four independent accumulator chains per wave).
-__global__ void __launch_bounds__(128) k_fwdsub(const double* __restrict__ At, double* Vt, const double* __restrict__ St,
-                                                const double* __restrict__ LinvT, const int* __restrict__ m_count, int ld,
-                                                int mld, int nblk_max, int B) {
-  int b, ct;
-  if (!xcd_map(ld / 64, B, &b, &ct)) return;
-  const int cnt = m_count[b];
-  if (cnt == 0) return;
-  const int m = 2 * cnt;
-  const int nblk = (m + 31) / 32;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = ct * 64 + wave * 32;
-  const double* Ab = At + (size_t)b * mld * ld;
-  double* Vb = Vt + (size_t)b * mld * ld;
-  const double* Sb = St + (size_t)b * mld * mld;
-  for (int J = 0; J < nblk; ++J) {
-    const bool half = (J * 32 + 16 >= m);    // rows J*32+16.. are padding: skip the second row tile
-    v4d acc[2][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[jt][it][r] = (jt == 1 && half) ? 0.0 : Ab[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo];
-    const double* lrow = Sb + (size_t)hi * mld + J * 32 + lo;     // L[J*32 + lo (+16)][k], k = hi + 4 s
-    const double* vrow = Vb + (size_t)hi * ld + i0 + lo;
-    if (half) fwd_kloop<true>(acc, lrow, vrow, mld, ld, J * 32);
-    else fwd_kloop<false>(acc, lrow, vrow, mld, ld, J * 32);
-    const double* Lb = LinvT + ((size_t)b * nblk_max + J) * 1024;
-    v4d out[2][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) for (int it = 0; it < 2; ++it) out[jt][it] = (v4d){0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int p = 4 * s + hi;
-      const double a0 = Lb[p * 32 + lo];
-      const double b0 = acc[s >> 2][0][s & 3], b1 = acc[s >> 2][1][s & 3];
-      out[0][0] = mfma_f64(a0, b0, out[0][0]);
-      out[0][1] = mfma_f64(a0, b1, out[0][1]);
-      if (!half) {
-        const double a1 = Lb[p * 32 + 16 + lo];
-        out[1][0] = mfma_f64(a1, b0, out[1][0]);
-        out[1][1] = mfma_f64(a1, b1, out[1][1]);
-      }
-    }
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt) {
-      if (jt == 1 && half) continue;
-#pragma unroll
-      for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Vb[(size_t)(J * 32 + 16 * jt + hi + 4 * r) * ld + i0 + 16 * it + lo] = out[jt][it][r];
-    }
-  }
-}
+#ifdef SL2_TESTING   // section 8 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
+#define SL2_EKF_TEST_SECTION 8
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
@@ -2080,30 +1369,10 @@ __global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, 
     }
 }
 
-#ifdef SL2_TESTING
-// ---------------------------------------------------------------------------
-// Debug GEMM on the same fragment conventions (tests the MFMA layout):
-// C[m][n] = sum_k XT[k][m] YT[k][n], one wave per 32x32 tile.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_gemm_kt(const double* __restrict__ XT, int ldx, const double* __restrict__ YT, int ldy,
-                                                int K, double* __restrict__ C, int ldc) {
-  const int lane = threadIdx.x;
-  const int lo = lane & 15, hi = lane >> 4;
-  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
-  v4d acc[2][2];
-  for (int it = 0; it < 2; ++it) for (int jt = 0; jt < 2; ++jt) acc[it][jt] = (v4d){0, 0, 0, 0};
-  for (int k = 0; k < K; k += 4) {
-    const double a0 = XT[(size_t)(k + hi) * ldx + i0 + lo], a1 = XT[(size_t)(k + hi) * ldx + i0 + 16 + lo];
-    const double b0 = YT[(size_t)(k + hi) * ldy + j0 + lo], b1 = YT[(size_t)(k + hi) * ldy + j0 + 16 + lo];
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
-  }
-  for (int it = 0; it < 2; ++it)
-    for (int jt = 0; jt < 2; ++jt)
-      for (int r = 0; r < 4; ++r) C[(size_t)(i0 + 16 * it + hi + 4 * r) * ldc + j0 + 16 * jt + lo] = acc[it][jt][r];
-}
+#ifdef SL2_TESTING   // section 9 of sl2_ekf_update_testing.inc
+#define SL2_EKF_TEST_SECTION 9
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
 #ifdef SL2_TESTING
@@ -2281,173 +1550,8 @@ int launch_update(sl2_engine* e) { return launch_update_range(e); }
 
 }  // namespace sl2
 
-#ifdef SL2_TESTING   // everything below is test / calibration code: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)
-#include "../../include/scenelib2_amd_testing.h"
-extern "C" int sl2_debug_gemm_kt(int device, const double* XT, int ldx, const double* YT, int ldy, int M, int N, int K,
-                                 double* C, int ldc) {
-  using namespace sl2;
-  if (!XT || !YT || !C || M % 32 || N % 32 || K % 4 || M <= 0 || N <= 0 || K <= 0) return SL2_ERR_INVALID;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device"); return SL2_ERR_NO_DEVICE; }
-  SL2_HIP(hipSetDevice(device));
-  double *dX = nullptr, *dY = nullptr, *dC = nullptr;
-  SL2_HIP(hipMalloc(&dX, sizeof(double) * (size_t)K * ldx));
-  SL2_HIP(hipMalloc(&dY, sizeof(double) * (size_t)K * ldy));
-  SL2_HIP(hipMalloc(&dC, sizeof(double) * (size_t)M * ldc));
-  SL2_HIP(hipMemcpy(dX, XT, sizeof(double) * (size_t)K * ldx, hipMemcpyHostToDevice));
-  SL2_HIP(hipMemcpy(dY, YT, sizeof(double) * (size_t)K * ldy, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_gemm_kt, dim3(N / 32, M / 32), dim3(64), 0, 0, dX, ldx, dY, ldy, K, dC, ldc);
-  SL2_HIP(hipGetLastError());
-  SL2_HIP(hipDeviceSynchronize());
-  SL2_HIP(hipMemcpy(C, dC, sizeof(double) * (size_t)M * ldc, hipMemcpyDeviceToHost));
-  hipFree(dX); hipFree(dY); hipFree(dC);
-  return SL2_OK;
-}
-
-// ---------------------------------------------------------------------------
-// Micro-benchmarks (debug ABI): the FP64 MFMA issue rate and a streaming copy,
-// to confirm the peaks the roofline fractions are priced against.
-// ---------------------------------------------------------------------------
-namespace sl2 {
-template <int NACC>
-__global__ void __launch_bounds__(256) k_ubench_mfma(double* out, int iters) {
-  v4d acc[NACC];
-  for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0, 0, 0, 0};
-  double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = mfma_f64(a, b, acc[i]);
-  }
-  double s = 0;
-  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  if (s == 12345.678) out[0] = s;
-}
-__global__ void __launch_bounds__(256) k_ubench_copy(const double4* __restrict__ src, double4* __restrict__ dst, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-__global__ void __launch_bounds__(256) k_ubench_write(double4* __restrict__ dst, size_t n) {
-  const double4 v = {1.0, 2.0, 3.0, 4.0};
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
-}
-__global__ void __launch_bounds__(256) k_ubench_read(const double4* __restrict__ src, double* __restrict__ out, size_t n) {
-  double s = 0;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const double4 v = src[i];
-    s += v.x + v.y + v.z + v.w;
-  }
-  if (s == 12345.678) out[0] = s;
-}
-}  // namespace sl2
-
-namespace sl2 {
-__global__ void __launch_bounds__(256) k_ubench_fma64(double* out, int iters) {
-  double acc[16];
-  for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
-  const double a = 1.0000001, b = 1e-9;
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
-  }
-  double s = 0;
-  for (int i = 0; i < 16; ++i) s += acc[i];
-  if (s == 12345.678) out[0] = s;
-}
-// half of the waves run the MFMA loop, the other half the VALU FMA loop: do the two pipes overlap?
-__global__ void __launch_bounds__(256) k_ubench_mix(double* out, int iters) {
-  const int wave = threadIdx.x >> 6;
-  double s = 0;
-  if (wave & 1) {
-    double acc[16];
-    for (int i = 0; i < 16; ++i) acc[i] = threadIdx.x * 1e-9 + i;
-    const double a = 1.0000001, b = 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = __builtin_fma(acc[i], a, b);
-    }
-    for (int i = 0; i < 16; ++i) s += acc[i];
-  } else {
-    v4d acc[4];
-    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0, 0, 0, 0};
-    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = mfma_f64(a, b, acc[i]);
-    }
-    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  }
-  if (s == 12345.678) out[0] = s;
-}
-}  // namespace sl2
-
-// which: 0 = FP64 MFMA TFLOP/s with 4 independent accumulators per wave, 2 blocks of 4 waves per CU
-//        1 = same with 1 accumulator (dependent chain), 2 = streaming copy GB/s (read+write bytes),
-//        3 = 8 accumulators, 4 blocks per CU, 4 = FP64 VALU FMA TFLOP/s, 5 = MFMA + VALU mixed,
-//        6 = streaming write GB/s, 7 = streaming read GB/s
-extern "C" int sl2_debug_microbench(int device, int which, double* result) {
-  using namespace sl2;
-  if (!result) return SL2_ERR_INVALID;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device"); return SL2_ERR_NO_DEVICE; }
-  SL2_HIP(hipSetDevice(device));
-  hipEvent_t e0, e1;
-  SL2_HIP(hipEventCreate(&e0));
-  SL2_HIP(hipEventCreate(&e1));
-  float ms = 0.f;
-  if (which == 5) {
-    // mixed: per block 2 MFMA waves (4 acc x iters MFMAs) + 2 VALU waves (16 x iters FMAs per lane)
-    double* d = nullptr;
-    SL2_HIP(hipMalloc(&d, 64));
-    const int iters = 100000, blocks = 1024;
-    for (int rep = 0; rep < 2; ++rep) {
-      SL2_HIP(hipEventRecord(e0, 0));
-      hipLaunchKernelGGL(k_ubench_mix, dim3(blocks), dim3(256), 0, 0, d, iters);
-      SL2_HIP(hipEventRecord(e1, 0));
-      SL2_HIP(hipEventSynchronize(e1));
-    }
-    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
-    const double mf = (double)blocks * 2.0 * iters * 4.0 * 2048.0, vf = (double)blocks * 128.0 * iters * 16.0 * 2.0;
-    *result = (mf + vf) / (ms * 1e-3) / 1e12;
-    hipFree(d);
-  } else if (which == 0 || which == 1 || which == 3 || which == 4) {
-    double* d = nullptr;
-    SL2_HIP(hipMalloc(&d, 64));
-    const int iters = 200000;
-    const int blocks = (which == 3 || which == 4) ? 1024 : 512;
-    for (int rep = 0; rep < 2; ++rep) {
-      SL2_HIP(hipEventRecord(e0, 0));
-      if (which == 0) hipLaunchKernelGGL(k_ubench_mfma<4>, dim3(blocks), dim3(256), 0, 0, d, iters);
-      else if (which == 1) hipLaunchKernelGGL(k_ubench_mfma<1>, dim3(blocks), dim3(256), 0, 0, d, iters);
-      else if (which == 3) hipLaunchKernelGGL(k_ubench_mfma<8>, dim3(blocks), dim3(256), 0, 0, d, iters);
-      else hipLaunchKernelGGL(k_ubench_fma64, dim3(blocks), dim3(256), 0, 0, d, iters);
-      SL2_HIP(hipEventRecord(e1, 0));
-      SL2_HIP(hipEventSynchronize(e1));
-    }
-    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (which == 4) *result = (double)blocks * 256.0 * iters * 16.0 * 2.0 / (ms * 1e-3) / 1e12;
-    else {
-      const double nacc = which == 0 ? 4.0 : (which == 1 ? 1.0 : 8.0);
-      *result = (double)blocks * 4.0 * iters * nacc * 2048.0 / (ms * 1e-3) / 1e12;
-    }
-    hipFree(d);
-  } else {
-    const size_t bytes = (size_t)1 << 30;
-    double4 *s = nullptr, *t = nullptr;
-    SL2_HIP(hipMalloc(&s, bytes));
-    SL2_HIP(hipMalloc(&t, bytes));
-    SL2_HIP(hipMemset(s, 1, bytes));
-    for (int rep = 0; rep < 3; ++rep) {
-      SL2_HIP(hipEventRecord(e0, 0));
-      if (which == 6) hipLaunchKernelGGL(k_ubench_write, dim3(256 * 8), dim3(256), 0, 0, t, bytes / sizeof(double4));
-      else if (which == 7) hipLaunchKernelGGL(k_ubench_read, dim3(256 * 8), dim3(256), 0, 0, s, (double*)t, bytes / sizeof(double4));
-      else hipLaunchKernelGGL(k_ubench_copy, dim3(256 * 8), dim3(256), 0, 0, s, t, bytes / sizeof(double4));
-      SL2_HIP(hipEventRecord(e1, 0));
-      SL2_HIP(hipEventSynchronize(e1));
-    }
-    SL2_HIP(hipEventElapsedTime(&ms, e0, e1));
-    *result = ((which == 6 || which == 7) ? 1.0 : 2.0) * bytes / (ms * 1e-3) / 1e9;
-    hipFree(s); hipFree(t);
-  }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  return SL2_OK;
-}
+#ifdef SL2_TESTING   // section 10 of sl2_ekf_update_testing.inc: everything below is test / calibration code: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)
+#define SL2_EKF_TEST_SECTION 10
+#include "sl2_ekf_update_testing.inc"
+#undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING

@@ -26,6 +26,10 @@ BUDGET = {
     # on the path of the trailing workgroups that work off the large windows' units, which the others never enter; 39 in all
     # with the near-units exact walk on that path)
     "k_search_mfma": ("sl2_search.hip", ["-ffp-contract=off"], 128, 4, 40),
+    # the mapping step's per-job kernels (round 4): a job has a CU to itself, sixteen wavefronts = four per SIMD
+    "k_map_me_search": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),
+    "k_map_detect": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),
+    "k_map_compact_slots": ("sl2_mapping.hip", ["-ffp-contract=off"], 168, 3, 8),
 }
 
 

@@ -219,6 +219,9 @@ int sl2_set_search_split(sl2_engine* e, int min_bands);
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);
 int sl2_kalman_filter_predict(sl2_engine* e);
 int sl2_auto_select_n_features(sl2_engine* e, int n);
+/* Consumes the selection of the sl2_auto_select_n_features call before it (as make_measurements consumes
+ * selected_feature_list_, monoslam.cpp:336-352): ONE call per selection - the list of large search windows that the selection
+ * left for the search (sl2_set_search_split) is worked off and cleared by this call. */
 int sl2_make_measurements(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int frames_on_device);
 int sl2_kalman_filter_update(sl2_engine* e);
 int sl2_finish_step(sl2_engine* e, int save_trajectory);

@@ -275,7 +275,7 @@ int sl2_list_frames(const char* dir, char* buf, size_t capacity, int* count);
  * the reference decodes with cv::imread(path, 0), filegrabber.cpp:105-108).  out may be NULL to query the size.  Host only. */
 int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
 /* FileGrabber::GetImageFile (filegrabber.cpp:106-109: cv::imread(path, 0)) for the three containers this library decodes,
- * chosen by the file's magic bytes: binary PGM as above; PNG (non-interlaced; 8-bit grey / grey+alpha / RGB / RGBA /
+ * chosen by the file's magic bytes: binary PGM as above; PNG (plain or Adam7-interlaced; 8-bit grey / grey+alpha / RGB / RGBA /
  * palette, 1-2-4-bit grey / palette) - grey PNGs are byte-exact, colour is reduced like libpng's rgb_to_gray, which is what
  * imread(.., 0) uses: (9797 R + 19234 G + 3737 B + 16384) >> 15; JPEG (sequential and progressive DCT, Huffman, 8 bits, one or
  * three components) - the luminance component through libjpeg's integer inverse DCT (jpeg_idct_islow), which is what

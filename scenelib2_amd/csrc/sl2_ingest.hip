@@ -8,7 +8,7 @@
 //     (SURVEY 2, row 14).  The reference decodes through cv::imread(path, 0) (filegrabber.cpp:106-109), a third-party
 //     call that is not re-implemented in general; three containers are read here, chosen by the file's magic bytes:
 //       - binary PGM (P5, maxval <= 255), the format of the reference's own fixtures;
-//       - PNG (the format of the MonoSLAM test sequences): non-interlaced, 8 bits per sample (grey, grey + alpha, RGB,
+//       - PNG (the format of the MonoSLAM test sequences): plain or Adam7-interlaced, 8 bits per sample (grey, grey + alpha, RGB,
 //         RGBA, palette) or 1/2/4-bit grey / palette; IDAT inflated with zlib, the five scan-line filters undone here.
 //         Grey PNGs are delivered byte for byte.  Colour goes to grey the way cv::imread(.., 0) gets it from libpng
 //         (png_set_rgb_to_gray, 8-bit path): (9797 R + 19234 G + 3737 B + 16384) >> 15; alpha is dropped;
@@ -129,7 +129,7 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, 
   }
   if (W == 0 || H == 0 || W > 65535 || H > 65535 || idat.empty()) return fail("PNG without image data");
   if ((size_t)W * H > kMaxFramePixels) return fail("PNG larger than 64 M pixels");
-  if (interlace != 0) return fail("interlaced PNG not supported");
+  if (interlace != 0 && interlace != 1) return fail("unknown PNG interlace method");
   int channels;
   switch (ctype) {
     case 0: channels = 1; break;
@@ -143,58 +143,81 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, 
   if (!(depth == 8 || (sub_byte && (ctype == 0 || ctype == 3)))) return fail("PNG bit depth not supported (8, or 1/2/4 grey / palette)");
   if (ctype == 3 && plte.size() < 3) return fail("palette PNG without PLTE");
   const size_t bpp = (size_t)std::max(1, channels * depth / 8);            // filter distance in bytes
-  const size_t stride = ((size_t)W * channels * depth + 7) / 8;
-  std::vector<uint8_t> raw((stride + 1) * (size_t)H);
+  // the image, or the seven reduced images of an Adam7-interlaced file (PNG specification, section 8.2), one after the other
+  // in the inflated stream: first pixel (x0, y0), every dx-th column and dy-th row
+  struct Pass { uint32_t x0, y0, dx, dy; };
+  static const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const Pass kWhole[1] = {{0, 0, 1, 1}};
+  const Pass* passes = interlace ? kAdam7 : kWhole;
+  const int npass = interlace ? 7 : 1;
+  size_t total = 0;
+  for (int k = 0; k < npass; ++k) {
+    const size_t pw = W > passes[k].x0 ? (W - passes[k].x0 + passes[k].dx - 1) / passes[k].dx : 0;
+    const size_t ph = H > passes[k].y0 ? (H - passes[k].y0 + passes[k].dy - 1) / passes[k].dy : 0;
+    if (pw && ph) total += ((pw * channels * depth + 7) / 8 + 1) * ph;
+  }
+  std::vector<uint8_t> raw(total);
   {
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) return fail("PNG inflate failed");
   }
-  // undo the scan-line filters in place (PNG specification, section 9: None, Sub, Up, Average, Paeth)
-  std::vector<uint8_t> zero(stride, 0);
-  for (size_t y = 0; y < H; ++y) {
-    uint8_t* cur = &raw[y * (stride + 1) + 1];
-    const uint8_t* up = y ? &raw[(y - 1) * (stride + 1) + 1] : zero.data();
-    const int ft = raw[y * (stride + 1)];
-    for (size_t x = 0; x < stride; ++x) {
-      const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
-      int pred;
-      switch (ft) {
-        case 0: pred = 0; break;
-        case 1: pred = a; break;
-        case 2: pred = b; break;
-        case 3: pred = (a + b) >> 1; break;
-        case 4: {
-          const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
-          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          break;
-        }
-        default: return fail("bad PNG filter type");
-      }
-      cur[x] = (uint8_t)(cur[x] + pred);
-    }
-  }
   auto to_grey = [](int r, int g, int b) { return (uint8_t)((9797 * r + 19234 * g + 3737 * b + 16384) >> 15); };
   px.resize((size_t)W * H);
-  for (size_t y = 0; y < H; ++y) {
-    const uint8_t* row = &raw[y * (stride + 1) + 1];
-    uint8_t* out = &px[y * W];
-    for (size_t x = 0; x < W; ++x) {
-      int v;     // the sample (or palette index) of pixel x
-      if (sub_byte) {
-        const size_t bit = x * depth;
-        v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-      } else {
-        v = row[x * channels];
-      }
-      switch (ctype) {
-        case 0: out[x] = sub_byte ? (uint8_t)(v * 255 / ((1 << depth) - 1)) : (uint8_t)v; break;
-        case 4: out[x] = (uint8_t)v; break;
-        case 3: {
-          if ((size_t)v * 3 + 2 >= plte.size()) return fail("PNG palette index out of range");
-          out[x] = to_grey(plte[3 * v], plte[3 * v + 1], plte[3 * v + 2]);
-          break;
+  size_t at = 0;
+  for (int k = 0; k < npass; ++k) {
+    const Pass ps = passes[k];
+    const size_t pw = W > ps.x0 ? (W - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = H > ps.y0 ? (H - ps.y0 + ps.dy - 1) / ps.dy : 0;
+    if (!pw || !ph) continue;
+    const size_t stride = (pw * channels * depth + 7) / 8;
+    uint8_t* base = raw.data() + at;
+    at += (stride + 1) * ph;
+    // undo the scan-line filters in place (PNG specification, section 9: None, Sub, Up, Average, Paeth)
+    std::vector<uint8_t> zero(stride, 0);
+    for (size_t y = 0; y < ph; ++y) {
+      uint8_t* cur = &base[y * (stride + 1) + 1];
+      const uint8_t* up = y ? &base[(y - 1) * (stride + 1) + 1] : zero.data();
+      const int ft = base[y * (stride + 1)];
+      for (size_t x = 0; x < stride; ++x) {
+        const int a = x >= bpp ? cur[x - bpp] : 0, b = up[x], c = x >= bpp ? up[x - bpp] : 0;
+        int pred;
+        switch (ft) {
+          case 0: pred = 0; break;
+          case 1: pred = a; break;
+          case 2: pred = b; break;
+          case 3: pred = (a + b) >> 1; break;
+          case 4: {
+            const int pp = a + b - c, pa = abs(pp - a), pb = abs(pp - b), pc = abs(pp - c);
+            pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            break;
+          }
+          default: return fail("bad PNG filter type");
         }
-        default: out[x] = to_grey(row[x * channels], row[x * channels + 1], row[x * channels + 2]); break;
+        cur[x] = (uint8_t)(cur[x] + pred);
+      }
+    }
+    for (size_t y = 0; y < ph; ++y) {
+      const uint8_t* row = &base[y * (stride + 1) + 1];
+      uint8_t* out = &px[(size_t)(ps.y0 + y * ps.dy) * W + ps.x0];
+      for (size_t x = 0; x < pw; ++x) {
+        int v;     // the sample (or palette index) of pixel x
+        if (sub_byte) {
+          const size_t bit = x * depth;
+          v = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+        } else {
+          v = row[x * channels];
+        }
+        uint8_t g;
+        switch (ctype) {
+          case 0: g = sub_byte ? (uint8_t)(v * 255 / ((1 << depth) - 1)) : (uint8_t)v; break;
+          case 4: g = (uint8_t)v; break;
+          case 3: {
+            if ((size_t)v * 3 + 2 >= plte.size()) return fail("PNG palette index out of range");
+            g = to_grey(plte[3 * v], plte[3 * v + 1], plte[3 * v + 2]);
+            break;
+          }
+          default: g = to_grey(row[x * channels], row[x * channels + 1], row[x * channels + 2]); break;
+        }
+        out[x * ps.dx] = g;
       }
     }
   }

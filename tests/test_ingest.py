@@ -97,6 +97,97 @@ def test_read_png_colour_alpha_palette_and_packed_depths(tmp_path):
     assert np.array_equal(ingest.read_image(os.path.join(d, "x.pgm")), idx)
 
 
+def _write_adam7_png(path, img, palette=None, bit_depth=8, filter_type=0):
+    """An Adam7-interlaced PNG written here (PNG specification 8.2): grey (H, W), grey + alpha (H, W, 2), RGB, RGBA, or palette
+    indices; bit_depth < 8 for grey / palette.  Pillow reads such files (it does not write them): the independent check."""
+    import struct
+    import zlib
+    img = np.asarray(img)
+    H, W = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    ctype = 3 if palette is not None else {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+
+    raw = bytearray()
+    for (x0, y0, dx, dy) in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = img[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        prev = None
+        for row in sub:
+            if bit_depth == 8:
+                line = row.astype(np.uint8).tobytes()
+            else:
+                bits = np.zeros(((row.shape[0] * bit_depth + 7) // 8) * 8, dtype=np.uint8)
+                for k in range(bit_depth):
+                    bits[k:row.shape[0] * bit_depth:bit_depth] = (row >> (bit_depth - 1 - k)) & 1
+                line = np.packbits(bits).tobytes()
+            cur = np.frombuffer(line, dtype=np.uint8).astype(np.int32)
+            bpp = max(1, ch * bit_depth // 8)
+            if filter_type == 0:
+                out = cur
+            elif filter_type == 1:
+                out = cur.copy(); out[bpp:] -= cur[:-bpp]
+            else:                                              # 2: Up
+                out = cur - (prev if prev is not None else 0)
+            raw += bytes([filter_type]) + (out & 255).astype(np.uint8).tobytes()
+            prev = cur
+    data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, bit_depth, ctype, 0, 0, 1))
+    if palette is not None:
+        data += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    data += chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(data)
+
+
+def test_read_png_adam7_interlaced(tmp_path):
+    """cv::imread reads interlaced PNGs (libpng de-interlaces); sizes below, at and above the 8 x 8 pattern, every colour type,
+    packed depths, three filter types.  Pillow's reader, where installed, must see the same image in the file."""
+    rng = np.random.default_rng(8)
+    d = str(tmp_path)
+    try:
+        import PIL.Image as Image
+    except ImportError:
+        Image = None
+    n = 0
+    for (H, W) in ((1, 1), (3, 5), (8, 8), (9, 17), (37, 53), (240, 320)):
+        path = os.path.join(d, "i.png")
+        for ft in (0, 1, 2):
+            g = rng.integers(0, 256, (H, W)).astype(np.uint8)
+            _write_adam7_png(path, g, filter_type=ft)
+            if Image is not None:
+                assert np.array_equal(np.array(Image.open(path)), g)
+            assert np.array_equal(ingest.read_image(path), g)
+            n += 1
+        rgb = rng.integers(0, 256, (H, W, 3)).astype(np.uint8)
+        _write_adam7_png(path, rgb, filter_type=1)
+        if Image is not None:
+            assert np.array_equal(np.array(Image.open(path)), rgb)
+        assert np.array_equal(ingest.read_image(path), _grey_like_libpng(rgb))
+        rgba = np.concatenate([rgb, rng.integers(0, 256, (H, W, 1)).astype(np.uint8)], axis=2)
+        _write_adam7_png(path, rgba)
+        assert np.array_equal(ingest.read_image(path), _grey_like_libpng(rgb))
+        ga = rng.integers(0, 256, (H, W, 2)).astype(np.uint8)
+        _write_adam7_png(path, ga, filter_type=2)
+        assert np.array_equal(ingest.read_image(path), ga[..., 0])
+        pal = rng.integers(0, 256, (16, 3)).astype(np.uint8)
+        idx = rng.integers(0, 16, (H, W)).astype(np.uint8)
+        for depth in (8, 4):
+            _write_adam7_png(path, idx, palette=pal, bit_depth=depth)
+            if Image is not None:
+                assert np.array_equal(np.array(Image.open(path).convert("RGB")), pal[idx])
+            assert np.array_equal(ingest.read_image(path), _grey_like_libpng(pal[idx]))
+        for depth in (1, 2, 4):
+            v = rng.integers(0, 1 << depth, (H, W)).astype(np.uint8)
+            _write_adam7_png(path, v, bit_depth=depth)
+            want = (v.astype(np.int32) * 255 // ((1 << depth) - 1)).astype(np.uint8)
+            assert np.array_equal(ingest.read_image(path), want)
+            n += 1
+    assert n >= 30
+
+
 def test_read_png_rejects_what_it_does_not_decode(tmp_path):
     import struct
     import zlib
@@ -111,7 +202,7 @@ def test_read_png_rejects_what_it_does_not_decode(tmp_path):
     with pytest.raises(_lib.Sl2Error):
         ingest.read_image(bad)
     ihdr_at = data.index(b"IHDR")
-    for off, val in ((12, 1), (8, 16)):              # interlaced; 16 bits per sample
+    for off, val in ((12, 1), (8, 16)):              # the interlace flag on a stream that is not interlaced; 16 bits per sample
         hdr = bytearray(data[ihdr_at + 4:ihdr_at + 17])
         hdr[off] = val
         patched = data[:ihdr_at + 4] + bytes(hdr) + struct.pack(">I", zlib.crc32(b"IHDR" + bytes(hdr)) & 0xFFFFFFFF) + data[ihdr_at + 21:]

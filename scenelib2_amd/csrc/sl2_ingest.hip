@@ -12,7 +12,7 @@
 //         RGBA, palette) or 1/2/4-bit grey / palette; IDAT inflated with zlib, the five scan-line filters undone here.
 //         Grey PNGs are delivered byte for byte.  Colour goes to grey the way cv::imread(.., 0) gets it from libpng
 //         (png_set_rgb_to_gray, 8-bit path): (9797 R + 19234 G + 3737 B + 16384) >> 15; alpha is dropped;
-//       - JPEG (round 4; sl2_jpeg.hpp): sequential DCT, Huffman, 8 bits, grey or YCbCr - the luminance component through
+//       - JPEG (round 4; sl2_jpeg.hpp): sequential or progressive DCT, Huffman, 8 bits, grey or YCbCr - the luminance component through
 //         libjpeg's integer inverse DCT, which is what imread(.., 0) delivers (out_color_space = JCS_GRAYSCALE);
 //   * a producer thread decodes ahead into pinned host buffers (the reference queues <= 50 frames,
 //     framegrabber.cpp:93-104; here `depth` batches), the consumer uploads one batch per call with an
@@ -225,7 +225,7 @@ static bool read_png(const std::string& path, std::vector<uint8_t>& px, int* w, 
   return true;
 }
 
-// JPEG (sequential DCT, Huffman): the luminance component through libjpeg's integer inverse DCT - what cv::imread(path, 0) delivers
+// JPEG (sequential or progressive DCT, Huffman): the luminance component through libjpeg's integer inverse DCT - what cv::imread(path, 0) delivers
 static bool read_jpeg(const std::string& path, std::vector<uint8_t>& px, int* w, int* h) {
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) { set_error(("cannot open " + path).c_str()); return false; }

@@ -161,78 +161,111 @@ def per_rank_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W,
 
 
 def mapping_cpu_and_parity(eng, specs, templates, d_frames, cam, params, args, B, N, W, H, fb, n_render, ncores, sample):
-    """--mapping: CPU baseline and parity of the mapping-on workload.  The reference's feature initialisation draws from the
-    process-global drand48 (monoslam.cpp:986-1021), so reference objects cannot step side by side: the timed baseline is the
-    oracle restatement (kind "port": its generator is per object; it is pinned to the reference frame by frame in
-    tests/test_oracle_vs_ref.py), one object per hardware thread, and ONE sequence is also run through the reference build
-    itself (srand48(0) first, like MonoSLAM::Init) as the parity anchor.  Every frame the engine stepped is followed."""
-    import ctypes
+    """--mapping: CPU baseline and parity of the mapping-on workload, against the REFERENCE BUILD (oracle/_ref/libref.so).
+    The reference's feature initialisation draws from the process-global drand48 (monoslam.cpp:986-1021), so reference objects
+    cannot step side by side in one process: the sample's sequences are dealt to one worker PROCESS per hardware thread
+    (oracle/ref_mapping_worker.py), each running its sequences one after the other with srand48(0) in front of each, like
+    MonoSLAM::Init.  cpu_baseline = sequence-frames / the slowest worker's time inside GoOneStep (kind "reference"); parity =
+    every frame the engine stepped, every sampled sequence.  Without libref.so the oracle restatement steps in threads
+    (kind "port")."""
+    import subprocess
+    import tempfile
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_api as oa
     nseq = max(1, min(sample, B, 64))
     frames_n = n_render
     allf = np.stack([d_frames.download((nseq, H, W), np.uint8, offset=k * B * fb) for k in range(frames_n + 1)])
-
-    def build(cls, b):
-        s = cls(cam, params["delta_t"], params["number_of_features_to_select"])
-        s.set_mapping_params(params)
-        s.set_state(specs[b].xv0, specs[b].Pxx0)
-        xo = specs[b].xp_org()
-        for i in range(N):
-            s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
-        return s
-
-    slams = [build(oa.OracleSLAM, b) for b in range(nseq)]
+    use_ref = oa.ref_available()
+    if use_ref:
+        try:
+            oa.ref_lib()
+        except Exception:
+            use_ref = False
     traj = np.zeros((nseq, frames_n, 3))
+    finals, grown = [None] * nseq, [None] * nseq
+    if use_ref:
+        nproc = min(ncores, nseq)
+        with tempfile.TemporaryDirectory(prefix="sl2_refmap_") as td:
+            job = dict(xv0=np.stack([specs[b].xv0 for b in range(nseq)]), Pxx0=np.stack([specs[b].Pxx0 for b in range(nseq)]),
+                       feat_y=np.stack([specs[b].feat_y for b in range(nseq)]), xp_org=np.stack([specs[b].xp_org() for b in range(nseq)]),
+                       templates=np.ascontiguousarray(templates[:nseq]), n_select=params["number_of_features_to_select"])
+            job.update({"cam_" + k: v for k, v in cam.items()})
+            job.update({"params_" + k: v for k, v in params.items()})
+            np.savez(os.path.join(td, "job.npz"), **job)
+            np.save(os.path.join(td, "frames.npy"), allf)
+            bounds = [(w * nseq // nproc, (w + 1) * nseq // nproc) for w in range(nproc)]
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "ref_mapping_worker.py"), os.path.join(td, "job.npz"),
+                                       os.path.join(td, "frames.npy"), os.path.join(td, "out%d.npz" % w), str(lo), str(hi)],
+                                      stdout=subprocess.DEVNULL)
+                     for w, (lo, hi) in enumerate(bounds)]
+            rcs = [p.wait() for p in procs]
+            wall = time.perf_counter() - t0
+            if any(rcs):
+                raise RuntimeError("oracle/ref_mapping_worker.py failed: exit codes %s" % rcs)
+            slowest = 0.0
+            for w, (lo, hi) in enumerate(bounds):
+                o = np.load(os.path.join(td, "out%d.npz" % w), allow_pickle=True)
+                traj[lo:hi] = o["traj"]
+                for i in range(hi - lo):
+                    finals[lo + i] = o["final_state"][i]
+                    grown[lo + i] = tuple(int(v) for v in o["info"][i])
+                slowest = max(slowest, float(o["seconds"]))
+        cpu = dict(value=nseq * frames_n / slowest, unit="frames/s", cores=nproc, host_hardware_threads=ncores, kind="reference",
+                   sample="%d sequences x %d frames (%dx%d, %d known features, mapping on) of this run's input, one worker process per "
+                          "hardware thread, its sequences one after the other" % (nseq, frames_n, W, H, N),
+                   seconds=slowest, wall_seconds_including_process_startup=wall,
+                   note="the reference's own translation units (oracle/_ref/libref.so); processes, not threads, because the reference's "
+                        "feature initialisation draws from the process-global drand48 stream (srand48(0) in front of every sequence, like "
+                        "MonoSLAM::Init); value = sequence-frames / the slowest worker's time inside GoOneStep")
+        checker = "reference build (oracle/_ref/libref.so)"
+    else:
+        def build(b):
+            s = oa.OracleSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
+            s.set_mapping_params(params)
+            s.set_state(specs[b].xv0, specs[b].Pxx0)
+            xo = specs[b].xp_org()
+            for i in range(N):
+                s.add_known_feature(specs[b].feat_y[i], xo[i], templates[b][i])
+            return s
 
-    def run(b):
-        for k in range(frames_n):
-            slams[b].go_one_step(allf[k + 1, b], False, True)
-            traj[b, k] = slams[b].get_state()[0][:3]
+        slams = [build(b) for b in range(nseq)]
 
-    nthreads = min(ncores, nseq)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=nthreads) as ex:
-        list(ex.map(run, range(nseq)))
-    secs = time.perf_counter() - t0
-    cpu = dict(value=nseq * frames_n / secs, unit="frames/s", cores=nthreads, host_hardware_threads=ncores, kind="port",
-               sample="%d sequences x %d frames (%dx%d, %d known features, mapping on) of this run's input, one oracle object per thread"
-                      % (nseq, frames_n, W, H, N), seconds=secs,
-               note="oracle restatement (oracle/*.hpp) stepped from Python threads (ctypes releases the GIL); the reference build "
-                    "cannot run objects side by side with mapping on (process-global drand48)")
+        def run(b):
+            for k in range(frames_n):
+                slams[b].go_one_step(allf[k + 1, b], False, True)
+                traj[b, k] = slams[b].get_state()[0][:3]
+
+        nthreads = min(ncores, nseq)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=nthreads) as ex:
+            list(ex.map(run, range(nseq)))
+        secs = time.perf_counter() - t0
+        for b in range(nseq):
+            finals[b] = slams[b].total_state()
+            info = slams[b].mapping_info()
+            grown[b] = (info["initialised"], slams[b].num_features, info["n_partial"])
+        cpu = dict(value=nseq * frames_n / secs, unit="frames/s", cores=nthreads, host_hardware_threads=ncores, kind="port",
+                   sample="%d sequences x %d frames (%dx%d, %d known features, mapping on) of this run's input, one oracle object per thread"
+                          % (nseq, frames_n, W, H, N), seconds=secs,
+                   note="oracle restatement (oracle/*.hpp) stepped from Python threads; oracle/_ref/libref.so was absent")
+        checker = "oracle"
     log = eng.position_log(0, nseq, capacity=n_render)[:, :frames_n]
     rmse = float(np.sqrt(((log - traj) ** 2).sum(axis=2).mean()))
-    parity = dict(traj_rmse_vs_oracle=rmse, checker="oracle", sequences=nseq, frames=frames_n, frames_stepped=n_render,
+    parity = dict(traj_rmse_vs_oracle=rmse, checker=checker, sequences=nseq, frames=frames_n, frames_stepped=n_render,
                   covers_every_timed_frame=True, position_maxabs=float(np.abs(log - traj).max()))
-    # the maps grew the same way: feature counts, labels, state size and the whole state at the end
+    # the maps grew the same way: state size (feature counts and kinds) and the whole state at the end
     dx, same_maps = 0.0, True
-    grown = []
     for b in range(nseq):
-        xo, xg = slams[b].total_state(), eng.total_state(b)
+        xo, xg = finals[b], eng.total_state(b)
         same_maps = same_maps and xo.shape == xg.shape
         if xo.shape == xg.shape:
             dx = max(dx, float(np.abs(xo - xg).max()))
-        info = slams[b].mapping_info()
-        grown.append((info["initialised"], info["converted"], info["deleted"]))
     parity["final_state_maxabs"] = dx if same_maps else float("inf")
     parity["maps_equal"] = bool(same_maps)
-    g = np.array(grown)
-    parity["features_initialised_converted_deleted_per_sequence_mean"] = [float(v) for v in g.mean(axis=0)]
-    if oa.ref_available():
-        try:
-            oa.ref_lib()
-            ctypes.CDLL(None).srand48(0)
-            r = build(oa.RefSLAM, 0)
-            tr = np.zeros((frames_n, 3))
-            for k in range(frames_n):
-                r.go_one_step(allf[k + 1, 0], False, True)
-                tr[k] = r.get_state()[0][:3]
-            parity["reference_build_sequence0"] = dict(traj_rmse=float(np.sqrt(((log[0] - tr) ** 2).sum(axis=1).mean())),
-                                                       final_state_maxabs=float(np.abs(r.total_state() - eng.total_state(0)).max())
-                                                       if r.total_state().shape == eng.total_state(0).shape else float("inf"))
-        except Exception as ex:      # noqa: BLE001 - the anchor is optional, the oracle leg above is the check
-            parity["reference_build_sequence0"] = "not run: %s" % ex
+    g = np.array(grown).mean(axis=0)
+    parity["per_sequence_mean"] = dict(features_initialised=float(g[0]), features_in_map_at_end=float(g[1]), of_which_partial=float(g[2]))
     return cpu, parity
 
 
@@ -488,6 +521,17 @@ def main():
                 if roof_search and SEARCH in pmc and pmc[SEARCH].get("valu_insts") and work["searched"] > 0:
                     roof_search["valu_insts_per_search"] = pmc[SEARCH]["valu_insts"] / pmc[SEARCH].get("searched", work["searched"])
                     roof_search["valu_insts_source"] = "profiles/pmc_traffic.json: SQ_INSTS_VALU per launch (wave instructions, MFMAs included) / searches per launch"
+                    # The bound that binds (SURVEY section 7 "hard parts"): the kernel is limited by vector-instruction issue, not
+                    # by bytes.  A SIMD issues one wave64 vector instruction per 4 cycles; the launch's SQ_INSTS_VALU spread
+                    # evenly over the chip's 1024 SIMDs at the 2.4 GHz spec clock is the time at 100 % of that pipe.
+                    issue_us = pmc[SEARCH]["valu_insts"] * 4.0 / (256 * 4) / 2.4e9 * 1e6
+                    roof_search["issue_floor_us"] = issue_us
+                    roof_search["issue_frac"] = issue_us / (roof_search["avg_launch_ms"] * 1e3)
+                    roof_search["issue_pipe"] = "VALU issue (one wave64 instruction per SIMD per 4 cycles, 1024 SIMDs, 2.4 GHz)"
+                    if pmc[SEARCH].get("mfma_busy_cycles"):
+                        mf_us = pmc[SEARCH]["mfma_busy_cycles"] / (256 * 4) / 2.4e9 * 1e6
+                        roof_search["mfma_busy_us"] = mf_us
+                        roof_search["mfma_frac"] = mf_us / (roof_search["avg_launch_ms"] * 1e3)
         except Exception:
             pass
 

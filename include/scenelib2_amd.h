@@ -412,6 +412,11 @@ int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels
  * raise when the bit RISES). */
 #define SL2_STATUS_NONFINITE 1
 #define SL2_STATUS_LABELS_EXHAUSTED 2
+/* SL2_STATUS_REFERENCE_OUT_OF_BOUNDS (sticky; only with max_features_to_init_at_once > 1): the position the reference records
+ * for a feature after several conversions and deletions (feature.cpp:254, Q28) has gone NEGATIVE; the reference then writes
+ * its dh_by_dy block outside dh_by_dx_tot (monoslam.cpp:564, undefined behaviour).  The engine holds the block at column 0
+ * and flags the sequence: from here on its filter is not the reference's. */
+#define SL2_STATUS_REFERENCE_OUT_OF_BOUNDS 4
 int sl2_get_status_flags(sl2_engine* e, int seq0, int nseq, int32_t* flags);
 
 /* ------------------------------------------------------------------- profiling */

@@ -422,6 +422,7 @@ class MonoSLAM {
       cov += 13 * d + d * d;
       feature_list_.push_back(std::move(f));
     }
+    patch_cache_.clear();      // only needed while the Feature objects of new labels are created above (labels churn with mapping on)
     const int32_t* sel = reinterpret_cast<const int32_t*>(base + hd.off_selection);
     selected_feature_list_.clear();
     for (int k = 0; k < hd.n_selected; ++k) {          // feature_list_ is in label order (labels are handed out in creation order)

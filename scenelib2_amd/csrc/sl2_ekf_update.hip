@@ -88,8 +88,10 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
     const int fa = sidx[t >> 1];
     const size_t fia = (size_t)b * N + fa;
     posa = hcol ? hcol[fa] : 13 + 3 * fa;
+    // (Q28 with the block landing INSIDE the vehicle state, posa < 7: the reference's dh_by_dx_tot.block(...) = dh_by_dy
+    // OVERWRITES those entries of dh_by_dxv, monoslam.cpp:562-565 - the overlapped pose coefficients do not count)
 #pragma unroll
-    for (int c = 0; c < 7; ++c) hx[c] = f_Hx[fia * 14 + (t & 1) * 7 + c];
+    for (int c = 0; c < 7; ++c) hx[c] = (hcol && (unsigned)(c - posa) < 3u) ? 0.0 : f_Hx[fia * 14 + (t & 1) * 7 + c];
 #pragma unroll
     for (int c = 0; c < 3; ++c) hy[c] = f_Hy[fia * 6 + (t & 1) * 3 + c];
     Rn = f_R[fia];
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
             for (int r = 0; r < 2; ++r) {
               double acc = 0.0;
 #pragma unroll
-              for (int c = 0; c < 7; ++c) acc += pc[q][c] * f_Hx[fi * 14 + r * 7 + c];
+              for (int c = 0; c < 7; ++c) acc += pc[q][c] * ((hcol && (unsigned)(c - pos) < 3u) ? 0.0 : f_Hx[fi * 14 + r * 7 + c]);
 #pragma unroll
               for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
               if (i == ld - 1) acc = f_nu[fi * 2 + r];

@@ -432,6 +432,10 @@ int sl2_set_groups(sl2_engine* e, int groups) {
   if (!e || groups < 1) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int rc = e->sync_all(); if (rc != SL2_OK) return rc; }
+  // captured steps carry the groups' pointers (srch_big is re-allocated per group below, the streams change): replaying one
+  // after a rebuild would write through freed device memory
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  e->step_graphs.clear();
   return build_groups(e, groups);
 }
 

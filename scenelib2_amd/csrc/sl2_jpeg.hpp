@@ -148,6 +148,7 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
   Component comp[3];
   int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart_interval = 0;
   bool have_frame = false, y_done = false, progressive = false;
+  int scans = 0;
   std::vector<uint8_t> plane;                      // the first component, padded to whole MCUs
   std::vector<int> ycoef;                          // progressive: the first component's coefficients (natural order, before dequantisation)
   int pw = 0, ph = 0;
@@ -213,6 +214,9 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
     } else if (m == 0xDA) {                        // SOS + entropy-coded data
       if (!have_frame) return fail("JPEG scan before the frame header");
       if (sl < 1) return fail("bad JPEG scan header");
+      // every scan walks the MCU grid: a crafted file of thousands of empty scans would cost scans x pixels (libjpeg's own
+      // progressive scripts use about ten; 3 components x (1 DC + 63 AC bands) x 14 bit positions bounds any legal file)
+      if (++scans > 1024) return fail("JPEG: too many scans");
       const int ns = s[0];
       if (ns < 1 || ns > ncomp || sl < (size_t)1 + 2 * ns + 3) return fail("bad JPEG scan header");
       int sc[3];
@@ -279,6 +283,7 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
                       const int t = decode_symbol(br, hdc[c.td]);
                       if (t < 0 || t > 11) return fail("corrupt JPEG data (DC)");
                       c.pred += extend(br.bits(t), t);
+                      if (c.pred > 32767 || c.pred < -32768) return fail("corrupt JPEG data (DC range)");
                       if (blk) blk[0] = c.pred * (1 << Al);
                     } else {                           // DC, refinement: one bit
                       if (br.bit() && blk) blk[0] |= p1;
@@ -384,6 +389,7 @@ inline bool decode_grey(const std::vector<uint8_t>& file, std::vector<uint8_t>& 
                 const int t = decode_symbol(br, hdc[c.td]);
                 if (t < 0 || t > 11) return fail("corrupt JPEG data (DC)");
                 c.pred += extend(br.bits(t), t);
+                if (c.pred > 32767 || c.pred < -32768) return fail("corrupt JPEG data (DC range)");
                 coef[0] = c.pred * qt[c.tq][0];
                 for (int k = 1; k < 64;) {
                   const int rs = decode_symbol(br, hac[c.ta]);

@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
                                                        int* __restrict__ m_count, const int* __restrict__ n_slots,
                                                        const int* __restrict__ pos_err, const int* __restrict__ pos_err_any,
                                                        int* __restrict__ f_hcol, const int* __restrict__ ps_i, int kpart, int ppos0,
-                                                       int N, int* __restrict__ srch_big) {
+                                                       int N, int* __restrict__ srch_big, int* __restrict__ status) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   extern __shared__ int s_flag[];        // [N] successful measurement of slot i in this frame
   __shared__ int s_wcnt[16];
@@ -1098,7 +1098,12 @@ __global__ void __launch_bounds__(1024) k_search_score(const int* __restrict__ s
       const int fl = f_flags[(size_t)b * N + f];
       if (!(fl & (FF_ACTIVE | FF_PARTIAL))) continue;
       const int t = c - pos_err[(size_t)b * N + f] / 3;
-      f_hcol[(size_t)b * N + f] = t >= 0 ? chunk_col[t < N + 7 ? t : N + 7] : 13 + 3 * t;     // (t < 0: inside the vehicle state, same columns here)
+      // t < 0: inside the vehicle state, same columns here (k_build_AS reproduces the overwrite of dh_by_dxv below column 7);
+      // t <= -5 is a NEGATIVE column - the reference's block() write is out of bounds there (undefined behaviour): the
+      // column is held at 0 for memory safety and the sequence is flagged
+      const int hc = 13 + 3 * t;
+      f_hcol[(size_t)b * N + f] = t >= 0 ? chunk_col[t < N + 7 ? t : N + 7] : (hc > 0 ? hc : 0);
+      if (t < 0 && hc < 0) status[b] |= 4;
       c += (fl & FF_PARTIAL) ? 2 : 1;
     }
   }
@@ -1151,7 +1156,10 @@ int launch_search(sl2_engine* e) {
       chunk = chunk < 1 ? 1 : (chunk > kMfChunk ? kMfChunk : chunk);
       if (e->root->search_chunk > 0) chunk = e->root->search_chunk;        // experiments (TEST build: SL2_SEARCH_CHUNK)
       const int nchunks = (e->nsel_max + chunk - 1) / chunk;
-      const bool shared = e->srch_big && e->root->search_split > 0;       // (k_select only lists windows under the same condition)
+      // Whether k_select listed windows was decided at SELECT time (its split threshold); the list itself says so here:
+      // the trailing workgroups read its length and end when it is empty.  (Deciding again from search_split at this point
+      // let sl2_set_search_split(0) between the split-phase calls leave marked windows unsearched.)
+      const bool shared = e->srch_big != nullptr;
       // trailing workgroups for the large windows' units: a quarter of the launch, 128 to kSearchBigWaves (a single sequence
       // should not pay for dispatching two thousand empty wavefronts; its frame-sized window is 38 units)
       int helpers = xcd_grid(nchunks, e->B) / 4;
@@ -1175,7 +1183,7 @@ int launch_search(sl2_engine* e) {
     if (e->root->score_threads > 0) threads = e->root->score_threads;     // experiments (SL2_SCORE_THREADS)
     hipLaunchKernelGGL(k_search_score, dim3(e->B), dim3(threads), sizeof(int) * (e->N + 8), e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                        e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,
-                       e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos, e->N, e->srch_big);
+                       e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos, e->N, e->srch_big, e->status);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

@@ -29,6 +29,41 @@ def run(exe, cfg, fd, mapping, out):
     return json.load(open(out))
 
 
+def cpu_reference(build, frames, mapping, skip=5):
+    """The same loop over the REFERENCE BUILD (oracle/_ref/libref.so) on ONE host thread - the reference's own
+    single-threaded design - per-frame wall time of GoOneStep, the first `skip` frames left out like the adapter's figures."""
+    import ctypes
+    import time
+    import oracle_api as oa
+    oa.ref_lib()
+    ctypes.CDLL(None).srand48(0)                      # MonoSLAM::Init, monoslam.cpp:1968
+    s = build(oa)
+    us = []
+    for k in range(len(frames)):
+        f = np.ascontiguousarray(frames[k])
+        t0 = time.perf_counter()
+        s.go_one_step(f, False, mapping)
+        us.append((time.perf_counter() - t0) * 1e6)
+    us = np.array(us[skip:])
+    return dict(cpu_reference_us_median=float(np.median(us)), cpu_reference_us_mean=float(us.mean()), cpu_reference_frames=int(us.size),
+                cpu_reference_features_at_end=int(s.num_features),
+                cpu_reference="oracle/_ref/libref.so (the reference's translation units, g++ -O3, stand-in Eigen), one host thread, "
+                              "GoOneStep only (no frame decode, no drawing)")
+
+
+def known_features_builder(cam, params, spec, tpl, mapping):
+    def build(oa):
+        s = oa.RefSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
+        if mapping:
+            s.set_mapping_params(params)
+        s.set_state(spec.xv0, spec.Pxx0)
+        xo = spec.xp_org()
+        for i in range(spec.n_features):
+            s.add_known_feature(spec.feat_y[i], xo[i], tpl[i])
+        return s
+    return build
+
+
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "adapter_latency.json")
     exe = os.path.join(ROOT, "examples", "monoslam_adapter")
@@ -43,11 +78,13 @@ def main():
         da = os.path.join(d, "a"); os.makedirs(da)
         cfg, fd = _write_scene(da, cam, params, spec, allf, tpl)
         res["configs1_100_features"] = run(exe, cfg, fd, False, os.path.join(d, "a.json"))
+        res["configs1_100_features"].update(cpu_reference(known_features_builder(cam, params, spec, tpl, False), allf[1:], False))
         # (b) the reference's default workload: few known features, mapping on (the map grows to about a dozen)
         cam2, params2, spec2, frames2, tpl2 = make_mapping_sequence(n_frames=120)
         db = os.path.join(d, "b"); os.makedirs(db)
         cfg2, fd2 = _write_scene(db, cam2, params2, spec2, frames2, tpl2)
         res["mapping_on_dozen_features"] = run(exe, cfg2, fd2, True, os.path.join(d, "b.json"))
+        res["mapping_on_dozen_features"].update(cpu_reference(known_features_builder(cam2, params2, spec2, tpl2, True), frames2[1:], True))
         # (c) the shipped cfg with its four known patches; the frame of the golden fixture repeated (the dataset's own
         # sequence is not in this image)
         g = np.load(os.path.join(ROOT, "tests", "golden", "ref_shipped.npz"))
@@ -56,6 +93,15 @@ def main():
             ingest.write_pgm(os.path.join(dc, "%05d.pgm" % k), g["frame"])
         res["shipped_cfg_4_features"] = run(exe, os.path.join(ROOT, "tests", "golden", "scenelib2_shipped.cfg"), dc, False,
                                             os.path.join(d, "c.json"))
+        gold = os.path.join(ROOT, "tests", "golden")
+        text = open(os.path.join(gold, "scenelib2_shipped.cfg")).read()
+        for i in range(4):                                     # identifiers are relative to the reference's cwd
+            text = text.replace("= known_patch%d.pgm" % i, "= " + os.path.join(gold, "known_patch%d.pgm" % i))
+        shipped = os.path.join(d, "shipped_abs.cfg")
+        with open(shipped, "w") as f:
+            f.write(text)
+        res["shipped_cfg_4_features"].update(cpu_reference(
+            lambda oa: oa.RefSLAM(synth.default_camera(), 1.0 / 30.0, 10, cfg_path=shipped), [g["frame"]] * 60, False))
     res["note"] = ("wall time per frame of the reference example's loop written against include/scenelib2_amd_monoslam.hpp: "
                    "frame_us = sl2_ingest_next + GoOneStep; go_one_step_us = sl2_go_one_step + one sl2_snapshot (one kernel, one "
                    "stream synchronisation, no hipMemcpy) + unpacking into the MonoSLAM-shaped members; step_us / readback_us = "

@@ -33,11 +33,29 @@ pmc)
   # separate passes (PMC only with --kernel-trace; never with sys/runtime traces); 30 warm-up steps so that the last three
   # dispatches of every kernel are steady-state steps (PMC_LAST=3)
   i=0
-  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     i=$((i+1))
     ( cd /tmp && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OLDPWD/$OUT/pmc_$i -o bench -- python $OLDPWD/bench.py --steps 3 --warmup 30 --cpu-sample 0 --no-profile > $OLDPWD/$OUT/pmc_$i.json 2> $OLDPWD/$OUT/pmc_$i.err ); echo "pmc group $i ($grp) exit $?"
   done
-  PMC_LAST=3 PMC_GIT=${PMC_GIT:-unknown} python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
+  PMC_LAST=3 PMC_GIT=${PMC_GIT:-$(cat .build_git 2>/dev/null || echo unknown)} python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
+c1)
+  # BASELINE configs[1]: one sequence; parity over every stepped frame and the reference build on one host thread in the same line
+  timeout 900 python bench.py --batch 1 --steps 200 --warmup 50 > $OUT/bench_c1.json 2> $OUT/bench_c1.err; echo "bench c1 exit $?"; tail -c 1500 $OUT/bench_c1.json
+  timeout 600 python bench.py --batch 1 --steps 200 --warmup 50 --no-profile --cpu-sample 0 > $OUT/bench_c1_noprofile.json 2> /dev/null; tail -c 300 $OUT/bench_c1_noprofile.json ;;
+mapping)
+  timeout 1200 python bench.py --mapping > $OUT/bench_mapping.json 2> $OUT/bench_mapping.err; echo "bench mapping exit $?"; tail -c 2500 $OUT/bench_mapping.json; tail -3 $OUT/bench_mapping.err ;;
+adapter)
+  make -s -C examples > /dev/null 2>&1
+  timeout 900 python scripts/adapter_latency.py $OUT/adapter_latency.json > $OUT/adapter_latency.log 2>&1; echo "adapter exit $?"; tail -5 $OUT/adapter_latency.log ;;
+rccl1)
+  SL2_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29512 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $OUT/rccl_single_rank.json 2> $OUT/rccl_single_rank.err; echo "rccl1 exit $?"
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-sample 0 > $OUT/plain_single_rank.json 2> /dev/null
+  python -c "
+import json
+a=json.load(open('$OUT/rccl_single_rank.json')); b=json.load(open('$OUT/plain_single_rank.json'))
+print('rccl', round(a['value']), a['ms_per_step'], 'plain', round(b['value']), b['ms_per_step'])" ;;
+driver)
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver-protocol exit $?"; tail -c 1200 $OUT/bench_driver.json ;;
 c4|c5)
   # BASELINE configs[3] / configs[4] per GPU: bench line, rocprofv3 kernel stats, FETCH / WRITE passes
   if [ $st = c4 ]; then SHAPE="--width 640 --height 480 --features 200 --batch 1024 --steps 20 --warmup 10"; else SHAPE="--width 1280 --height 720 --features 500 --batch 512 --steps 10 --warmup 6"; fi

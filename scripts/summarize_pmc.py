@@ -45,6 +45,12 @@ for cdir in sorted(glob.glob(os.path.join(out, "pmc_*"))):
             elif c == "SQ_INSTS_VALU":
                 parts.append("%s=%.4g" % (c, mean))
                 traffic[name]["valu_insts"] = mean
+            elif c == "SQ_VALU_MFMA_BUSY_CYCLES":
+                parts.append("%s=%.4g" % (c, mean))
+                traffic[name]["mfma_busy_cycles"] = mean
+            elif c == "SQ_INSTS_SALU":
+                parts.append("%s=%.4g" % (c, mean))
+                traffic[name]["salu_insts"] = mean
             else:
                 parts.append("%s=%.4g" % (c, mean))
         print("%-28s n=%-4d %s" % (name[:28], len(next(iter(cs.values()))), "  ".join(parts)))

@@ -47,6 +47,21 @@ def test_bench_line_contract():
     assert rs["kernel"] == "k_search_mfma" and rs["mfma_floor_us"] > 0 and "valu_insts_per_search" in rs
 
 
+def test_bench_mapping_line_is_checked_against_the_reference_build():
+    """bench.py --mapping (the reference's default workload): every sampled sequence is followed over EVERY stepped frame by the
+    reference build, one worker process per sequence group (oracle/ref_mapping_worker.py: the reference's drand48 stream is
+    process-global), and the CPU baseline is that same code (kind "reference")."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mapping", "--steps", "8", "--warmup", "8", "--batch", "16",
+                          "--cpu-sample", "8"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    p, c = d["parity"], d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0
+    assert "reference build" in p["checker"] and p["sequences"] == 8 and p["frames"] >= 16 and p["covers_every_timed_frame"] is True
+    assert p["maps_equal"] is True and p["traj_rmse_vs_oracle"] <= 1e-9 and p["final_state_maxabs"] <= 1e-8
+    assert p["per_sequence_mean"]["features_initialised"] >= 1.0
+
+
 def test_bench_self_spawns_ranks():
     """`python bench.py --gpus 2` with no launcher starts two ranks itself.  On a 1-GPU box the two ranks share the device
     through the gloo test hook (the code path - rendezvous, barrier, MAX-reduce, gather - is the one RCCL runs on N GPUs)."""

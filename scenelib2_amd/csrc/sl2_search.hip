@@ -121,10 +121,19 @@ __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 // return code -1 and the caller runs search_core_v0 - same results, just slower.
 // ---------------------------------------------------------------------------
 #ifdef SL2_SEARCH_TRACE
-__device__ long long* g_search_trace = nullptr;     // development only: 8 cycle stamps per workgroup
-#define STR(slot) do { if (g_search_trace && threadIdx.x == 0) g_search_trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+__device__ long long* g_search_trace = nullptr;     // development only: 16 values per workgroup (scripts/search_trace.py)
+#define STR(slot) do { if (g_search_trace && threadIdx.x == 0) g_search_trace[(size_t)blockIdx.x * 16 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
+// phase accumulators of the position loop: PH(k) adds the cycles since the previous stamp to phase k
+#define PH_DECL long long ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_prev = (long long)__builtin_readcyclecounter()
+#define PH(k) do { const long long ph_t = (long long)__builtin_readcyclecounter(); ph_acc[k] += ph_t - ph_prev; ph_prev = ph_t; } while (0)
+#define PH_WAIT(what) asm volatile("s_waitcnt " what ::: "memory")
+#define PH_STORE do { if (g_search_trace && threadIdx.x == 0) for (int q = 0; q < 8; ++q) g_search_trace[(size_t)blockIdx.x * 16 + 8 + q] = ph_acc[q]; } while (0)
 #else
 #define STR(slot) do { } while (0)
+#define PH_DECL do { } while (0)
+#define PH(k) do { } while (0)
+#define PH_WAIT(what) do { } while (0)
+#define PH_STORE do { } while (0)
 #endif
 
 constexpr int kMfPitchDw = 12;                 // 48-byte template rows: 16 zeros + 11 bytes + zeros
@@ -397,6 +406,12 @@ __device__ __forceinline__ int m4_mad24(int v_a, int s_b, int v_c) {
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(v_a), "s"(s_b), "v"(v_c));
   return r;
 }
+// scalar a + immediate on the scalar unit (the compiler re-associates S1 + (ks0 + imm) into two vector adds)
+__device__ __forceinline__ int m4_sadd(int s_a, int imm) {
+  int r;
+  asm("s_add_i32 %0, %1, %2" : "=s"(r) : "s"(s_a), "n"(imm) : "scc");
+  return r;
+}
 // ... and its wave-uniform part
 struct M4Uni { int ncand; };
 
@@ -418,7 +433,7 @@ __device__ __forceinline__ float m4_self(m4_mask m, float t, float f) { float r;
 // the (up to two) 16 x 16 candidate tiles of the band in LDS
 __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* s_T, const mf_v4i b_ones, const mf_v4i b_ones_last,
                                               int up, int vt, int TU, int nu_all, int nv_all, int urelstart, int vrelstart,
-                                              double a, double b2, double c, const M4Quads& kq, const M4Const& k, bool patch_ok,
+                                              const double* __restrict__ abc, const M4Quads& kq, const M4Const& k, bool patch_ok,
                                               int j, int g, M4State& st, M4Uni& un) {
   const int vi0 = 16 * vt + 4 * g;
   const unsigned* bp = mf_b_base(s_T, g, 16 + 16 * (g & 1) - j);      // this lane's template operands (offset 1..32)
@@ -433,19 +448,22 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
     {
       const float duf = (float)(urelstart + ui);
       const float euu = k.af * duf * duf, eu = k.b2f * duf;
+      // rows vi0 .. vi0 + 3 of this lane as floats (exact: small integers); the row bound is tested on them too
+      float dv0 = (float)(vrelstart + vi0);
+      asm volatile("" : "+v"(dv0));          // (keeps the per-row terms out of registers across the matrix-core section)
+      const float dvend = (float)(vrelstart + nv_all);
       m4_mask m_amb = 0ull;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        int vi = vi0 + reg;
-        asm volatile("" : "+v"(vi));        // (keeps the per-row terms out of registers across the matrix-core section)
-        const float dvf = (float)(vrelstart + vi);
+        const float dvf = reg == 0 ? dv0 : dv0 + (float)reg;
         const float val = __builtin_fmaf(__builtin_fmaf(k.cf, dvf, eu), dvf, euu);
         const m4_mask in = m4_lt_f32s(val, k.lo);
         m_amb |= ~(in | m4_gt_f32s(val, k.hi));
-        m_cand[reg] = m_col & m4_gt_i32(nv_all, vi) & in;
+        m_cand[reg] = m_col & m4_gt_f32(dvend, dvf) & in;
       }
       if (m_amb != 0ull) {
         // the reference's expression ((a u) u) + (((2 b) u) v) + ((c v) v) < 9, same values, same order
+        const double a = abc[0], b2 = 2 * abc[1], c = abc[2];
         const double du = (double)(urelstart + ui);
         const double e_uu = a * du * du, e_u = b2 * du;
 #pragma unroll
@@ -478,6 +496,34 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
       accH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, p ? accH : zero, 0, 0, 0);
       accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? accL : kq.c_s2, 0, 0, 0);
     }
+    // The first readers of the accumulators below are inline-asm vector instructions (m4_mad24).  The compiler's hazard
+    // recogniser inserts the wait states a matrix-core result needs before a VALU read only for instructions it can see
+    // into - not for inline asm - so whether the scoring read finished accumulators used to depend on what the scheduler
+    // happened to place in between (round 5: passing PuInv by pointer moved the first v_mad_i32_i24 up against the last MFMA
+    // and the engine's searches came back one pixel off).  The wait states are spelled out: 16 cover an 8-pass result.
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accX), "+v"(acc1), "+v"(accH), "+v"(accL));
+#if defined(SL2_PROBE_DUP) && (SL2_PROBE_DUP & 1)        // timing probe (results unchanged): operand reads + matrix-core work twice
+    {
+      mf_v4i dX = zero, d1 = zero, dH = zero, dL = zero;
+      int z0 = 0; asm volatile("" : "+v"(z0));              // (an offset the compiler cannot see through: the reads are not merged)
+      const char* ap2 = ap + z0;
+      const unsigned* bp2 = bp + z0;
+#pragma unroll
+      for (int p = 0; p < 6; ++p) {
+        const mf_v4i aI = *(const mf_v4i*)(ap2 + 32 * p);
+        const mf_v4i aH = *(const mf_v4i*)(ap2 + 32 * p + kM4Plane);
+        const mf_v4i aL = *(const mf_v4i*)(ap2 + 32 * p + 2 * kM4Plane);
+        const mf_v4i bX = mf_load_b4(bp2, p);
+        const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
+        dX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, dX, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, p ? d1 : kq.c_s1, 0, 0, 0);
+        dH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, dH, 0, 0, 0);
+        dL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? dL : kq.c_s2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) { accX[reg] += dX[reg] - accX[reg]; acc1[reg] += d1[reg] - acc1[reg]; accH[reg] += dH[reg] - accH[reg]; accL[reg] += dL[reg] - accL[reg]; }
+    }
+#endif
     // Ranking value q = Nc / sqrt(D1) = rho * sqrt(D0) (D0 = 121 sum g0^2 - (sum g0)^2 is the same for every candidate of
     // a search, so it is left out: one multiply less per candidate; the callers scale the guard band by sqrt(D0) instead).
     // A candidate whose image sigma is EXACTLY 10 (D1 == 1464100) is ranked like a valid one; whether the reference skips
@@ -495,10 +541,32 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
       const m4_mask better = m4_gt_f32(qq, st.best_q);
       st.second_q = __builtin_amdgcn_fmed3f(st.best_q, st.second_q, qq);    // second of {best, second, new}
       st.best_q = m4_self(better, qq, st.best_q);
-      st.best_ks = m4_sel(better, S1 + (ks0 + (reg << 15)), st.best_ks);
+      st.best_ks = m4_sel(better, S1 + m4_sadd(ks0, reg << 15), st.best_ks);
       st.best_w = m4_sel(better, S2, st.best_w);
       st.best_x = m4_sel(better, accX[reg], st.best_x);
     }
+#if defined(SL2_PROBE_DUP) && (SL2_PROBE_DUP & 2)        // timing probe (results unchanged): the scoring a second time
+    {
+      M4State s2; s2.reset();
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int S1 = acc1[reg]; asm volatile("" : "+v"(S1));
+        const int S2 = (accH[reg] << 8) + accL[reg];
+        const int D1 = mul24(121, S2) - mul24(S1, S1);
+        const int Nc = m4_mad24(S1, k.kS, m4_mad24(accX[reg], k.c121, k.c_nc));
+        const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1);
+        const float qq = m4_self(m_cand[reg] & m4_lt_i32(1464099, D1), q, -3.0e38f);
+        const m4_mask better = m4_gt_f32(qq, s2.best_q);
+        s2.second_q = __builtin_amdgcn_fmed3f(s2.best_q, s2.second_q, qq);
+        s2.best_q = m4_self(better, qq, s2.best_q);
+        s2.best_ks = m4_sel(better, S1 + m4_sadd(ks0, reg << 15), s2.best_ks);
+        s2.best_w = m4_sel(better, S2, s2.best_w);
+        s2.best_x = m4_sel(better, accX[reg], s2.best_x);
+      }
+      // (folded in so that it is not dead: nothing changes when both passes agree, which they do)
+      if (s2.best_q > 3.0e38f) { st.best_ks ^= s2.best_ks; st.best_w ^= s2.best_w ^ s2.best_x; st.second_q = s2.second_q; }
+    }
+#endif
   }
 }
 
@@ -506,6 +574,7 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
 __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restrict__ image, int width, int frame_bytes,
                                                        const uint8_t* __restrict__ patch, const SearchBounds sb, double a,
                                                        double b, double c, char* s_pl, unsigned* s_T) {
+  const double abc_v[3] = {a, b, c}; const double* abc_ = abc_v;
   const int lane = threadIdx.x & 63;
   const int nu_all = sb.urelfinish - sb.urelstart + 1;
   const int nv_all = sb.vrelfinish - sb.vrelstart + 1;
@@ -556,7 +625,7 @@ __device__ __forceinline__ SearchResult search_core_mfma(const uint8_t* __restri
       if (m4_band_loads(image, width, frame_bytes, bd, lane, pf)) m4_band_fix(image, width, frame_bytes, bd, lane, pf);
       m4_band_store(pf, bd, s_pl);
       __syncthreads();
-      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, a, 2 * b, c, kq, kc,
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, sb.urelstart, sb.vrelstart, abc_, kq, kc,
                     patch_ok, j, g, st, un);
     }
   res.ncand = un.ncand;
@@ -697,7 +766,7 @@ __device__ __forceinline__ void m4_big_windows(const uint8_t* __restrict__ frame
       if (m4_band_loads(img, width, frame_bytes, bd, lane, pf)) m4_band_fix(img, width, frame_bytes, bd, lane, pf);
       m4_band_store(pf, bd, s_pl);
       __syncthreads();
-      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, us, vs, pa, b2, pc, kq, kc, patch_ok, j, g, st, un);
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, us, vs, recd, kq, kc, patch_ok, j, g, st, un);
     }
     // ---- the unit's partial result: maximum, runner-up, the best candidate's position and sums, candidate count
     const float gmax = m4_wave_max(st.best_q);
@@ -875,6 +944,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
   const mf_v4i b_ones_last = mf_load_b(s_T, (g >> 1) ? 11 : 12, boff);   // template row 11 does not exist: the zero row
   const M4Quads kq = m4_quads();
   STR(1);
+  PH_DECL;
   for (int i = 0; i < nf; ++i) {
     // the next position's record: scalar loads issued here, consumed after the barrier below (clamped index: the last
     // iteration re-reads its own record instead of branching)
@@ -887,6 +957,8 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
     const int Sg0 = (int)__builtin_amdgcn_readlane(tv, 48), Sg0sq = (int)__builtin_amdgcn_readlane(tv, 49);
     const bool patch_ok = __builtin_amdgcn_readlane(tv, 50) != 0;
     const float d0f = (float)(121 * Sg0sq - Sg0 * Sg0);
+    PH_WAIT("lgkmcnt(0)"); PH(0);                     // (trace build: the record's scalar loads)
+    PH_WAIT("vmcnt(0)"); PH(1);                       // (trace build: the prefetched band / template - and the previous position's stores)
     if (i > 0) __syncthreads();                       // feature i - 1 is done with the LDS
     if (geom_ok) {
       mf_tpl_store(tv, tmask, s_T, lane);
@@ -895,6 +967,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
       m4_band_store(pf, bd0, s_pl);
     }
     __syncthreads();
+    PH_WAIT("lgkmcnt(0)"); PH(2);                     // (trace build: planes computed, band and template in LDS)
     pf_over = false;
     if (i + 1 < nf) {                                 // next feature's template and first band: in flight from here on
       if (rn.nu > 0 && rn.nv > 0)
@@ -902,6 +975,7 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
       const unsigned* tpl = (const unsigned*)(patch + ((size_t)b * N + rn.f) * kPatchStride + kPatchPackedOffset);
       pf_tv = tload ? tpl[tidx] : 0u;
     }
+    PH(3);
     int* o = srch_res + ((size_t)b * N + k0 + i) * 8;
     M4State st;
     st.reset();
@@ -913,8 +987,9 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
     else if (geom_ok) {
       const double b2 = 2 * pb;
       const M4Const kc = m4_const(Sg0, pa, b2, pc);
-      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, 0, 0, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kq, kc, patch_ok, j, g,
+      m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, 0, 0, TU, nu_all, nv_all, rc.us, rc.vs, recd, kq, kc, patch_ok, j, g,
                     st, un);
+      PH(4);                                          // (trace build: ellipse + matrix cores + scoring of the first band)
       if (TU > 2 || TV > 1)                           // (most windows are one band: keep the loop set-up off their path)
       for (int vt = 0; vt < TV; ++vt)                 // the other bands of a large window: staged synchronously
         for (int up = (vt == 0 ? 2 : 0); up < TU; up += 2) {
@@ -924,9 +999,10 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
           if (m4_band_loads(img, width, frame_bytes, bd, lane, p2)) m4_band_fix(img, width, frame_bytes, bd, lane, p2);
           m4_band_store(p2, bd, s_pl);
           __syncthreads();
-          m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, pa, b2, pc, kq, kc, patch_ok,
+          m4_band_tiles(s_pl, s_T, b_ones, b_ones_last, up, vt, TU, nu_all, nv_all, rc.us, rc.vs, recd, kq, kc, patch_ok,
                         j, g, st, un);
         }
+      PH(5);                                          // (trace build: further bands)
       // ---- decision: a unique near-best candidate goes on to k_search_score with its exact sums
       if (patch_ok) {
         const float gmax = m4_wave_max(st.best_q);
@@ -966,8 +1042,10 @@ k_search_mfma(const uint8_t* __restrict__ frames, size_t seq_stride, int width, 
       *(int4*)o = o0; *(int4*)(o + 4) = o1;
       meas_score[(size_t)b * N + k0 + i] = 1000000.0;
     }
+    PH(6);                                            // (trace build: decision and result record)
     rc = rn;
   }
+  PH_STORE;
   STR(6);
 }
 
@@ -1164,7 +1242,7 @@ int launch_search(sl2_engine* e) {
       // should not pay for dispatching two thousand empty wavefronts; its frame-sized window is 38 units)
       int helpers = xcd_grid(nchunks, e->B) / 4;
       helpers = helpers < 128 ? 128 : (helpers > kSearchBigWaves ? kSearchBigWaves : helpers);
-      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B) + (shared ? helpers : 0)), dim3(64), 0, e->stream, e->cur_frames, e->cur_stride,
+      hipLaunchKernelGGL(k_search_mfma, dim3(xcd_grid(nchunks, e->B) + (shared ? helpers : 0)), dim3(64), (size_t)e->root->search_lds_pad, e->stream, e->cur_frames, e->cur_stride,
                          e->cam.width, e->cam.width * e->cam.height, e->patch, e->srch_sel, e->n_sel, e->srch_res, e->meas_score,
                          e->N, nchunks, e->B, chunk, shared ? e->srch_big : nullptr);
     }

@@ -24,8 +24,8 @@ BUDGET = {
     "k_build_ASILi1ELi4E": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 80, 6, 0),
     # (scalar spills: eleven in the workgroups that own positions - the records of two positions in flight - and nineteen more
     # on the path of the trailing workgroups that work off the large windows' units, which the others never enter; 39 in all
-    # with the near-units exact walk on that path)
-    "k_search_mfma": ("sl2_search.hip", ["-ffp-contract=off"], 128, 4, 40),
+    # with the near-units exact walk on that path; round 5: 41 with the row coordinates of the ellipse test as floats)
+    "k_search_mfma": ("sl2_search.hip", ["-ffp-contract=off"], 128, 4, 42),
     # the mapping step's per-job kernels (round 4): a job has a CU to itself, sixteen wavefronts = four per SIMD
     "k_map_me_search": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),
     "k_map_detect": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),

@@ -188,6 +188,7 @@ struct sl2_engine {
   int fwd_group = 8;          // block rows per group of the grouped substitution (TEST build: SL2_FWD_GROUP = 4 | 8)
   int chol_panel = 8;         // 32-blocks per panel of the large-map Cholesky: 8 (256 columns; 4.3 ms against 5.05 with 4 at
                               // 512 x n = 1513, profiles/r03_c5_chol_panel_ab.txt); TEST build: SL2_CHOL_PANEL = 4 | 8
+  int build_lds_min = 0;      // minimum dynamic LDS bytes per k_build_AS workgroup (caps the workgroups a CU takes; TEST build: SL2_BUILD_LDS_MIN)
   int search_lds_pad = 0;     // extra dynamic LDS bytes per k_search_mfma workgroup (TEST build: SL2_SEARCH_LDS_PAD): an occupancy probe
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice
   int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)

@@ -1452,7 +1452,8 @@ static int launch_update_range(sl2_engine* e) {
     } else
 #endif
     if (e->ld <= 1024) {
-      const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
+      size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
+      if ((size_t)e->root->build_lds_min > shm) shm = (size_t)e->root->build_lds_min;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
                          e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     } else {

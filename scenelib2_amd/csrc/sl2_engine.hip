@@ -413,6 +413,7 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   if (getenv("SL2_NO_KSPLIT")) e->no_ksplit = 1;
   if (const char* v = getenv("SL2_SEARCH_CHUNK")) e->search_chunk = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_LDS_PAD")) e->search_lds_pad = atoi(v);
+  if (const char* v = getenv("SL2_BUILD_LDS_MIN")) e->build_lds_min = atoi(v);
   if (const char* v = getenv("SL2_CHOL_PANEL")) e->chol_panel = atoi(v);
   if (const char* v = getenv("SL2_FWD_GROUP")) e->fwd_group = atoi(v);
   if (const char* env = getenv("SL2_GROUPS")) if (atoi(env) > 0) G = atoi(env);

@@ -828,3 +828,63 @@ def test_create_step_destroy_does_not_leak_device_memory():
     for i in range(20):
         one_round(i % 3)
     assert abs(free_bytes() - base) <= (8 << 20), "device memory drifted by %d bytes" % (free_bytes() - base)
+
+
+@pytest.mark.gpu
+def test_graph_mode_survives_a_rebuild_of_the_sequence_groups():
+    """Advisor, round 4: sl2_set_groups re-allocates every group's list of large search windows; a step captured in graph mode
+    before it has the old pointers baked in, and replaying it wrote through freed device memory.  The captured steps are
+    dropped with the groups now: stepping with the same frame buffer before and after set_groups(2) / set_groups(1) must
+    keep tracking the oracle."""
+    from scenelib2_amd import _lib
+    pr = Pair(20, 8, batch=3)
+    e = pr.engine
+    e.set_graph_mode(True)
+    W, H = pr.cam["width"], pr.cam["height"]
+    buf = _lib.DeviceBuffer(3 * W * H, 0)                      # ONE buffer: the replay key (frame pointer, flags) stays the same
+    for k in range(8):
+        for b in range(3):
+            pr.oracles[b].go_one_step(pr.frames[b][k], True)
+        buf.upload(pr.frame_batch(k))
+        e.go_one_step(buf.ptr, save_trajectory=True, on_device=True, seq_stride=W * H)
+        e.synchronize()
+        if k == 2:
+            e.set_groups(2)
+        if k == 4:
+            e.set_groups(1)
+        pr.compare_state(TOL_X, TOL_P)
+
+
+@pytest.mark.gpu
+def test_split_threshold_changed_between_selection_and_measurement():
+    """Advisor, round 4: k_select marks the windows it puts on the step's list at SELECT time; launch_search used to decide from
+    the threshold at SEARCH time whether to hand the list to the trailing workgroups, so sl2_set_search_split(0) between
+    auto_select_n_features and make_measurements left the marked windows unsearched (stale results counted as measurements).
+    The list itself decides now."""
+    pr = Pair(24, 2, batch=2)
+    e = pr.engine
+    xv, Pxx = [], []
+    for b in range(2):                                          # a camera known to 0.3 m: frame-sized windows, shared out
+        P0 = pr.specs[b].Pxx0.copy()
+        P0[0, 0] = P0[1, 1] = P0[2, 2] = 0.09
+        pr.oracles[b].set_state(pr.specs[b].xv0, P0)
+        xv.append(pr.specs[b].xv0)
+        Pxx.append(P0)
+    e.set_vehicle_state(np.stack(xv), np.stack(Pxx))
+    e.set_search_split(1)
+    for b in range(2):
+        pr.oracles[b].kalman_filter_predict()
+        pr.oracles[b].auto_select_n_features(24)
+    e.kalman_filter_predict()
+    e.auto_select_n_features(24)
+    e.set_search_split(0)                                       # ... after the windows were listed
+    for b in range(2):
+        pr.oracles[b].make_measurements(pr.frames[b][0])
+    e.make_measurements(pr.frame_batch(0))
+    assert e.step_work()["search_shared"] > 0
+    for b in range(2):
+        for i, fe in enumerate(e.features(b)):
+            fo = pr.oracles[b].feature(i)
+            assert fe["success"] == fo["success"] and fe["attempted"] == fo["attempted"]
+            if fo["success"]:
+                assert np.array_equal(fe["z"], fo["z"])

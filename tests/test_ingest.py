@@ -367,3 +367,27 @@ def test_read_jpeg_rejects_what_it_does_not_decode(tmp_path):
             assert out.shape == (64, 64)
         except _lib.Sl2Error:
             pass                                          # ... but never crashes
+
+
+@pytest.mark.skipif(_pil() is None, reason="Pillow writes the file that is then doctored")
+def test_read_jpeg_bounds_the_work_a_crafted_file_can_ask_for(tmp_path):
+    """Advisor, round 4: every SOS segment walks the whole MCU grid, so a small file of thousands of scan headers costs scans x
+    pixels in the ingest thread.  The reader stops at 1024 scans (libjpeg's own progressive scripts have about ten)."""
+    Image = _pil()
+    img = (np.arange(64 * 64).reshape(64, 64) % 251).astype(np.uint8)
+    path = os.path.join(str(tmp_path), "p.jpg")
+    Image.fromarray(img).save(path, "JPEG", quality=80, progressive=True)
+    raw = open(path, "rb").read()
+    assert np.array_equal(ingest.read_image(path).shape, (64, 64))
+    eoi = raw.rfind(b"\xff\xd9")
+    assert eoi > 0
+    # a DC refinement scan of component 1 (Ss = Se = 0, Ah = 1, Al = 0) with no data behind it: one bit per block, and a bit reader
+    # that has run into a marker feeds zeros - a legal scan that changes nothing and walks the whole grid
+    empty_scan = bytes([0xFF, 0xDA, 0x00, 0x08, 0x01, 0x01, 0x00, 0x00, 0x00, 0x10])
+    with open(path, "wb") as f:
+        f.write(raw[:eoi] + empty_scan * 20 + raw[eoi:])
+    assert ingest.read_image(path).shape == (64, 64)         # a few such scans are decoded like any other
+    with open(path, "wb") as f:
+        f.write(raw[:eoi] + empty_scan * 3000 + raw[eoi:])
+    with pytest.raises(_lib.Sl2Error, match="too many scans"):
+        ingest.read_image(path)

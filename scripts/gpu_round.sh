@@ -54,6 +54,13 @@ rccl1)
 import json
 a=json.load(open('$OUT/rccl_single_rank.json')); b=json.load(open('$OUT/plain_single_rank.json'))
 print('rccl', round(a['value']), a['ms_per_step'], 'plain', round(b['value']), b['ms_per_step'])" ;;
+tworanks)
+  # two ranks sharing the one GPU of the box (gloo in place of RCCL: the test hook), self-spawned and under the driver's own launch line
+  SL2_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --batch 512 --steps 40 --warmup 10 > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks_one_gpu.err; echo "two ranks (self-spawned) exit $?"
+  SL2_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --batch 512 --steps 20 --warmup 5 > $OUT/torchrun_two_ranks_one_gpu.json 2> $OUT/torchrun_two_ranks_one_gpu.err; echo "two ranks (torch.distributed.run) exit $?"
+  for f in two_ranks_one_gpu torchrun_two_ranks_one_gpu; do python -c "
+import json
+d=json.loads([l for l in open('$OUT/$f.json') if l.strip().startswith('{')][0]); print('$f', round(d['value']), d['ms_per_step'], d['n_gpus'], d['parity'].get('ranks_checked'), d['parity']['traj_rmse_vs_oracle'])"; done ;;
 driver)
   timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver-protocol exit $?"; tail -c 1200 $OUT/bench_driver.json ;;
 c4|c5)

@@ -1,6 +1,6 @@
 // The loop and the button handlers of the reference's only caller, examples/MonoSlamSceneLib1.cpp:132-142 and 190-204,
-// headless, written against SceneLib2::MonoSLAM with the reference's own types (tests/ref_binding/monoslam_amd.h over
-// oracle/ref_shim's Eigen / OpenCV stand-ins).  The GUI's inputs are scripted:
+// headless, written against SceneLib2::MonoSLAM with the reference's own types (examples/ref_binding/monoslam_amd.h; needs
+// the real Eigen / OpenCV headers - not built in this repository's image).  The GUI's inputs are scripted:
 //   example_loop <cfg> <frame.pgm> <frames> <dump> [--seams]
 //     frame 2: click (uu_, vv_) + "Initialise Manual Feature"   frame 14: "Initialise Auto Feature"
 //     frame 6: "Print Robot State"   frame 7: mark label 2 + "Delete Feature"   frame 8: mark label 1 + "Save Patch"

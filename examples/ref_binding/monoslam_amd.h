@@ -1,11 +1,11 @@
-// The binding of INTEGRATION.md section 2(b), compiled: SceneLib2::MonoSLAM / Kalman / Feature with the REFERENCE'S OWN
+// The binding of INTEGRATION.md section 2(b): SceneLib2::MonoSLAM / Kalman / Feature with the REFERENCE'S OWN
 // signatures and member types - cv::Mat frames, Eigen::VectorXd / MatrixXd members,
 // Kalman::KalmanFilterPredict(MonoSLAM*, Eigen::Vector3d&) - over the C ABI of include/scenelib2_amd.h
 // (monoslam.h:69-219, kalman.h:44-53, feature.h:56-143, feature_init_info.h:46-118).
 //
-// Eigen and OpenCV are not in this build environment; the test compiles this header against the stand-in headers of
-// oracle/ref_shim (a test-only include path: the same stand-ins the reference's own sources are compiled against for
-// oracle/_ref/libref.so).  At a site that has the real libraries the header compiles unchanged: it uses only
+// Eigen and OpenCV are not in this build environment, so this header is NOT compiled here (rounds 3-5 compiled and ran it
+// against stand-in headers, retired in round 6 with the stand-in reference build - DESIGN.md section 2); it is the text a
+// maintainer adds at a site that has the real libraries, where it compiles as it stands: it uses only
 // VectorXd / MatrixXd / Vector2d / Vector3d element access, resize, and cv::Mat::{data, rows, cols} / cv::imread.
 //
 // It is a thin layer: the C-ABI calls and the read-back live in include/scenelib2_amd_monoslam.hpp (SceneLib2Amd::MonoSLAM,

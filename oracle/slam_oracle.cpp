@@ -338,6 +338,38 @@ void orc_measurement_model(const double* cam8, const double* xp, const double* y
   out[k++] = (double)ffm.visibility_test(xp, y, xp_org, h);
 }
 
+// ---- the dense primitives of oracle/dense.hpp (the Eigen semantics the reference's call sites rely on), exported so that
+// tests/test_oracle_numpy.py can hold them against NumPy / SciPy - implementations nobody here wrote.  Row-major in / out.
+int orc_dense_llt(int n, const double* A, double* L_out) {                 // Eigen::LLT lower factor (kalman.cpp:104)
+  Mat M(n, n), L;
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) M(i, j) = A[i * n + j];
+  const bool ok = oracle::llt_lower(M, L);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) L_out[i * n + j] = L(i, j);
+  return ok ? 1 : 0;
+}
+void orc_dense_inverse(int n, const double* A, double* out) {              // MatrixXd::inverse() (kalman.cpp:106)
+  Mat M(n, n);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) M(i, j) = A[i * n + j];
+  const Mat X = oracle::general_inverse(M);
+  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) out[i * n + j] = X(i, j);
+}
+void orc_dense_mul(int m, int k, int n, const double* A, const double* B, double* C) {
+  Mat a(m, k), b(k, n);
+  for (int i = 0; i < m; ++i) for (int j = 0; j < k; ++j) a(i, j) = A[i * k + j];
+  for (int i = 0; i < k; ++i) for (int j = 0; j < n; ++j) b(i, j) = B[i * n + j];
+  const Mat c = oracle::mul(a, b);
+  for (int i = 0; i < m; ++i) for (int j = 0; j < n; ++j) C[i * n + j] = c(i, j);
+}
+// Quaterniond product / inverse() / toRotationMatrix() (motion_model.cpp:102, full_feature_model.cpp:76-80); q = (w, x, y, z)
+void orc_quat_ops(const double* qa, const double* qb, double* prod4, double* inv4, double* R9) {
+  const oracle::Quat a(qa[0], qa[1], qa[2], qa[3]), b(qb[0], qb[1], qb[2], qb[3]);
+  const oracle::Quat p = oracle::qmul(a, b), iv = oracle::qinverse(a);
+  prod4[0] = p.w; prod4[1] = p.x; prod4[2] = p.y; prod4[3] = p.z;
+  inv4[0] = iv.w; inv4[1] = iv.x; inv4[2] = iv.y; inv4[3] = iv.z;
+  const Mat R = oracle::qrot(a);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R9[i * 3 + j] = R(i, j);
+}
+
 // ---- CPU baseline: nseq independent sequences, one per worker thread -----------
 // Each sequence s has its own oracle handle hs[s]; frames[s] -> nframes consecutive
 // frames of frame_bytes each.  Returns wall seconds.  traj (optional) receives

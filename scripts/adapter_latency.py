@@ -30,13 +30,11 @@ def run(exe, cfg, fd, mapping, out):
 
 
 def cpu_reference(build, frames, mapping, skip=5):
-    """The same loop over the REFERENCE BUILD (oracle/_ref/libref.so) on ONE host thread - the reference's own
-    single-threaded design - per-frame wall time of GoOneStep, the first `skip` frames left out like the adapter's figures."""
-    import ctypes
+    """The same loop over the CPU oracle (oracle/liboracle.so: a port of the reference's algorithm, not the reference - that
+    needs Eigen / OpenCV / Pangolin) on ONE host thread - the reference's own single-threaded design - per-frame wall time of
+    GoOneStep, the first `skip` frames left out like the adapter's figures."""
     import time
     import oracle_api as oa
-    oa.ref_lib()
-    ctypes.CDLL(None).srand48(0)                      # MonoSLAM::Init, monoslam.cpp:1968
     s = build(oa)
     us = []
     for k in range(len(frames)):
@@ -47,13 +45,13 @@ def cpu_reference(build, frames, mapping, skip=5):
     us = np.array(us[skip:])
     return dict(cpu_reference_us_median=float(np.median(us)), cpu_reference_us_mean=float(us.mean()), cpu_reference_frames=int(us.size),
                 cpu_reference_features_at_end=int(s.num_features),
-                cpu_reference="oracle/_ref/libref.so (the reference's translation units, g++ -O3, stand-in Eigen), one host thread, "
-                              "GoOneStep only (no frame decode, no drawing)")
+                cpu_reference="oracle/liboracle.so (CPU port of the reference's algorithm, g++ -O3, fixed-order dense products), one host "
+                              "thread, GoOneStep only (no frame decode, no drawing)")
 
 
 def known_features_builder(cam, params, spec, tpl, mapping):
     def build(oa):
-        s = oa.RefSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
+        s = oa.OracleSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
         if mapping:
             s.set_mapping_params(params)
         s.set_state(spec.xv0, spec.Pxx0)
@@ -87,21 +85,23 @@ def main():
         res["mapping_on_dozen_features"].update(cpu_reference(known_features_builder(cam2, params2, spec2, tpl2, True), frames2[1:], True))
         # (c) the shipped cfg with its four known patches; the frame of the golden fixture repeated (the dataset's own
         # sequence is not in this image)
-        g = np.load(os.path.join(ROOT, "tests", "golden", "ref_shipped.npz"))
+        g = np.load(os.path.join(ROOT, "tests", "golden", "oracle_shipped.npz"))
         dc = os.path.join(d, "c", "frames"); os.makedirs(dc)
         for k in range(60):
             ingest.write_pgm(os.path.join(dc, "%05d.pgm" % k), g["frame"])
         res["shipped_cfg_4_features"] = run(exe, os.path.join(ROOT, "tests", "golden", "scenelib2_shipped.cfg"), dc, False,
                                             os.path.join(d, "c.json"))
         gold = os.path.join(ROOT, "tests", "golden")
-        text = open(os.path.join(gold, "scenelib2_shipped.cfg")).read()
-        for i in range(4):                                     # identifiers are relative to the reference's cwd
-            text = text.replace("= known_patch%d.pgm" % i, "= " + os.path.join(gold, "known_patch%d.pgm" % i))
-        shipped = os.path.join(d, "shipped_abs.cfg")
-        with open(shipped, "w") as f:
-            f.write(text)
-        res["shipped_cfg_4_features"].update(cpu_reference(
-            lambda oa: oa.RefSLAM(synth.default_camera(), 1.0 / 30.0, 10, cfg_path=shipped), [g["frame"]] * 60, False))
+        from scenelib2_amd.config import load_config, read_pgm
+
+        def shipped(oa):
+            cfg = load_config(os.path.join(gold, "scenelib2_shipped.cfg"))
+            o = oa.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], cfg["params"]["number_of_features_to_select"])
+            o.set_state(cfg["xv"], cfg["Pxx"])
+            for i, f in enumerate(cfg["features"]):
+                o.add_known_feature(f["y"], f["xp_org"], read_pgm(os.path.join(gold, "known_patch%d.pgm" % i)))
+            return o
+        res["shipped_cfg_4_features"].update(cpu_reference(shipped, [g["frame"]] * 60, False))
     res["note"] = ("wall time per frame of the reference example's loop written against include/scenelib2_amd_monoslam.hpp: "
                    "frame_us = sl2_ingest_next + GoOneStep; go_one_step_us = sl2_go_one_step + one sl2_snapshot (one kernel, one "
                    "stream synchronisation, no hipMemcpy) + unpacking into the MonoSLAM-shaped members; step_us / readback_us = "

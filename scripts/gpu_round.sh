@@ -39,7 +39,7 @@ pmc)
   done
   PMC_LAST=3 PMC_GIT=${PMC_GIT:-$(cat .build_git 2>/dev/null || echo unknown)} python scripts/summarize_pmc.py $OUT $OUT/pmc_traffic.json > $OUT/pmc_summary.txt 2>&1; tail -80 $OUT/pmc_summary.txt ;;
 c1)
-  # BASELINE configs[1]: one sequence; parity over every stepped frame and the reference build on one host thread in the same line
+  # BASELINE configs[1]: one sequence; parity over every stepped frame and the CPU oracle on one host thread in the same line
   timeout 900 python bench.py --batch 1 --steps 200 --warmup 50 > $OUT/bench_c1.json 2> $OUT/bench_c1.err; echo "bench c1 exit $?"; tail -c 1500 $OUT/bench_c1.json
   timeout 600 python bench.py --batch 1 --steps 200 --warmup 50 --no-profile --cpu-sample 0 > $OUT/bench_c1_noprofile.json 2> /dev/null; tail -c 300 $OUT/bench_c1_noprofile.json ;;
 mapping)

@@ -34,8 +34,7 @@ def build():
 
 
 def _declare(L):
-    """argtypes / restypes of the flat C interface; `L` answers to the orc_* names (the reference build answers through
-    _Prefixed, which maps them to ref_*)."""
+    """argtypes / restypes of the flat C interface (oracle/slam_oracle.cpp)."""
     L.orc_create.restype = C.c_void_p
     L.orc_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                              C.c_double, C.c_int, C.c_double, C.c_int]
@@ -86,6 +85,11 @@ def _declare(L):
     L.orc_measurement_model.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_initialise_feature.argtypes = [C.c_void_p, c_u8p, C.c_int, C.c_int]
     L.orc_initialise_auto_feature.argtypes = [C.c_void_p, c_u8p]
+    L.orc_dense_llt.restype = C.c_int
+    L.orc_dense_llt.argtypes = [C.c_int, c_dp, c_dp]
+    L.orc_dense_inverse.argtypes = [C.c_int, c_dp, c_dp]
+    L.orc_dense_mul.argtypes = [C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp]
+    L.orc_quat_ops.argtypes = [c_dp, c_dp, c_dp, c_dp, c_dp]
     L.orc_run_sequences.restype = C.c_double
     L.orc_run_sequences.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(c_u8p), C.c_int, C.c_size_t,
                                     C.c_int, c_dp]
@@ -102,47 +106,6 @@ def lib():
         L.orc_get_diag.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_dp]
         _LIB = L
     return _LIB
-
-
-class _Prefixed:
-    """The reference build (oracle/_ref/libref.so) exports the same interface under ref_*."""
-
-    def __init__(self, cdll):
-        self._cdll = cdll
-
-    def __getattr__(self, name):
-        if name.startswith("orc_"):
-            return getattr(self._cdll, "ref_" + name[4:])
-        return getattr(self._cdll, name)
-
-
-_REF_DIR = os.path.join(_ORACLE_DIR, "_ref")
-_REFLIB = None
-
-
-def ref_available():
-    """libref.so exists (it is built where /root/reference is and travels with the snapshot) or can be built."""
-    return os.path.exists(os.path.join(_REF_DIR, "libref.so")) or os.path.isdir("/root/reference/scenelib2")
-
-
-def ref_lib():
-    """The REFERENCE's own translation units behind the same flat interface (see oracle/ref_glue.cpp)."""
-    global _REFLIB
-    if _REFLIB is None:
-        path = os.path.join(_REF_DIR, "libref.so")
-        if os.path.isdir("/root/reference/scenelib2"):
-            subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "ref"])
-        if not os.path.exists(path):
-            raise FileNotFoundError("oracle/_ref/libref.so is absent and /root/reference is not here to build it")
-        L = _Prefixed(C.CDLL(path))
-        _declare(L)
-        L.ref_create_from_cfg.restype = C.c_void_p
-        L.ref_create_from_cfg.argtypes = [C.c_char_p]
-        L.ref_save_patch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_u8p]
-        L.ref_save_patch.restype = C.c_int
-        L.ref_sinv_from_S4.argtypes = [c_dp, c_dp, c_dp]
-        _REFLIB = L
-    return _REFLIB
 
 
 class OracleSLAM:
@@ -315,27 +278,6 @@ class OracleSLAM:
         self.L.orc_initialise_auto_feature(self.h, _u8(f))
 
 
-class RefSLAM(OracleSLAM):
-    """One MonoSLAM object of the REFERENCE ITSELF (oracle/_ref/libref.so): same interface as OracleSLAM."""
-
-    def __init__(self, cam, delta_t, n_select, cfg_path=None):
-        L = ref_lib()
-        if cfg_path is None:
-            OracleSLAM.__init__(self, cam, delta_t, n_select, L=L)
-        else:  # the reference's own MonoSLAM::Init on a cfg file
-            self.L = L
-            self.cam = dict(cam)
-            self.h = L.ref_create_from_cfg(os.fsencode(cfg_path))
-
-    def diag(self):
-        raise NotImplementedError("the reference keeps no counters")
-
-    def save_patch(self, label, directory):
-        p = np.zeros(121, dtype=np.uint8)
-        ok = self.L.ref_save_patch(self.h, int(label), os.fsencode(directory), _u8(p))
-        return bool(ok == 1), p.reshape(11, 11)
-
-
 def correlate2_warning(patch, image, x1, y1, x0=0, y0=0, x0lim=11, y0lim=11, L=None):
     L = L if L is not None else lib()
     p0 = np.ascontiguousarray(patch, dtype=np.uint8)
@@ -450,3 +392,34 @@ def run_sequences(slams, frames_list, nthreads=1, want_traj=True, L=None):
     traj = np.zeros((nseq, nframes, 3)) if want_traj else None
     secs = L.orc_run_sequences(hs, nseq, fr, nframes, fb, nthreads, _dp(traj) if want_traj else None)
     return secs, traj
+
+
+def dense_llt(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    out = np.zeros_like(A)
+    ok = lib().orc_dense_llt(A.shape[0], _dp(A), _dp(out))
+    return bool(ok), out
+
+
+def dense_inverse(A):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    out = np.zeros_like(A)
+    lib().orc_dense_inverse(A.shape[0], _dp(A), _dp(out))
+    return out
+
+
+def dense_mul(A, B):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    B = np.ascontiguousarray(B, dtype=np.float64)
+    out = np.zeros((A.shape[0], B.shape[1]))
+    lib().orc_dense_mul(A.shape[0], A.shape[1], B.shape[1], _dp(A), _dp(B), _dp(out))
+    return out
+
+
+def quat_ops(qa, qb):
+    """(qa * qb, qa.inverse(), qa.toRotationMatrix()) with q = (w, x, y, z) - Eigen::Quaterniond semantics of oracle/dense.hpp."""
+    qa = np.ascontiguousarray(qa, dtype=np.float64)
+    qb = np.ascontiguousarray(qb, dtype=np.float64)
+    prod, inv, R = np.zeros(4), np.zeros(4), np.zeros((3, 3))
+    lib().orc_quat_ops(_dp(qa), _dp(qb), _dp(prod), _dp(inv), _dp(R))
+    return prod, inv, R

@@ -18,9 +18,8 @@ class Pair:
     """B synthetic sequences: frames, oracle instances and one engine."""
 
     def __init__(self, n_features, n_frames, batch=1, cam=None, n_select=None, seq0=0, max_features=None,
-                 feature_counts=None, make_engine=True, feature_sigma=0.0, lib=None, checker="oracle", **spec_kw):
-        """checker = "oracle": the CPU restatement (oracle/liboracle.so); "reference": the reference's own translation
-        units (oracle/_ref/libref.so) when that library is there, the restatement otherwise."""
+                 feature_counts=None, make_engine=True, feature_sigma=0.0, lib=None, **spec_kw):
+        """The checker is the CPU restatement (oracle/liboracle.so)."""
         self.cam = cam or synth.default_camera()
         self.N = n_features
         self.B = batch
@@ -41,10 +40,7 @@ class Pair:
             self.frames.append(frames)
         self.oracles = []
         for b in range(batch):
-            if checker == "reference" and oa.ref_available():
-                s = oa.RefSLAM(self.cam, self.params["delta_t"], n_select)
-            else:
-                s = oa.OracleSLAM(self.cam, self.params["delta_t"], n_select)
+            s = oa.OracleSLAM(self.cam, self.params["delta_t"], n_select)
             s.set_state(self.specs[b].xv0, self.specs[b].Pxx0)
             xo = self.specs[b].poses[0]
             for i in range(self.specs[b].feat_y.shape[0]):

@@ -10,6 +10,13 @@ from mapping_helpers import make_mapping_sequence, oracle_for
 
 pytestmark = pytest.mark.gpu
 
+# FP64 tolerances of the mapping path.  The partially initialised feature's depth comes out of a particle filter (exp(),
+# normalisations over up to 1024 particles) and enters the state at conversion, so one decade is given away against
+# tests/test_gpu_slam.py; measured on MI355X: 3.5e-12 on the final state after 134 frames with ~11 initialisations.
+TOL_X = 1e-11
+TOL_P = 1e-10
+TOL_X_SOAK = 1e-10     # 160-frame soaks: differences are fed back through every update
+
 
 def _engine(cam, params, spec, templates, max_features=32, batch=1):
     from scenelib2_amd import Engine
@@ -56,8 +63,8 @@ def test_mapping_step_by_step_matches_oracle():
         x0, P0 = s.total_state(), s.total_covariance()
         assert eng.total_state_sizes(0, 1)[0] == x0.size, k
         x1, P1 = eng.total_state(0), eng.total_covariance(0)
-        assert np.abs(x1 - x0).max() < 1e-9, (k, np.abs(x1 - x0).max())
-        assert np.linalg.norm(P1 - P0) <= 1e-8 * max(np.linalg.norm(P0), 1e-12), k
+        assert np.abs(x1 - x0).max() < TOL_X, (k, np.abs(x1 - x0).max())
+        assert np.linalg.norm(P1 - P0) <= TOL_P * max(np.linalg.norm(P0), 1e-12), k
         kinds = s.feature_kinds()
         feats = eng.features(0)
         assert [f["label"] for f in feats] == list(kinds[:, 2]) and [f["state_size"] for f in feats] == list(kinds[:, 0]), k
@@ -92,7 +99,7 @@ def test_mapping_with_300_depth_particles():
             if pf["making"]:
                 assert np.array_equal(a[:, 11], b[:, 11]), k
         x0, x1 = s.total_state(), eng.total_state(0)
-        assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, k
+        assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X, k
     assert seen == 300 and s.mapping_info()["initialised"] >= 2
     p3 = dict(params); p3["number_of_particles"] = 2000
     with pytest.raises(_lib.Sl2Error):
@@ -132,7 +139,7 @@ def test_mapping_batch_of_different_sequences():
             assert [got[key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
                    [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], (k, b)
             x0, x1 = s.total_state(), eng.total_state(b)
-            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X, (k, b)
     assert sum(s.mapping_info()["initialised"] for s in oracles) >= 5
     assert not eng.status_flags().any()
 
@@ -161,7 +168,7 @@ def test_mapping_soak_160_frames():
                 x0, x1 = s.total_state(), eng.total_state(b)
                 assert x0.size == x1.size, (k, b)
                 worst = max(worst, float(np.abs(x0 - x1).max()))
-                assert np.abs(x0 - x1).max() < 1e-8, (k, b)
+                assert np.abs(x0 - x1).max() < TOL_X_SOAK, (k, b)
                 feats = eng.features(b)
                 assert [f["label"] for f in feats] == [s.feature(i)["label"] for i in range(s.num_features)]
                 assert [(f["attempted"], f["successful"]) for f in feats] == \
@@ -175,10 +182,10 @@ def test_mapping_soak_160_frames():
 
 
 def test_engine_matches_committed_mapping_golden():
-    """The HIP path against the committed event log of the 40-frame mapping run (tests/golden/ref_mapping.npz)."""
+    """The HIP path against the committed event log of the 40-frame mapping run (tests/golden/oracle_mapping.npz)."""
     from conftest import golden_path
     from scenelib2_amd import Engine
-    g = np.load(golden_path("ref_mapping.npz"))
+    g = np.load(golden_path("oracle_mapping.npz"))
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
     eng = Engine(cam, params, 1, 32)
     eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
@@ -191,8 +198,8 @@ def test_engine_matches_committed_mapping_golden():
         assert got == list(g["events"][k - 1]), k
         xe, _ = eng.get_vehicle_state(0, 1)
         assert np.allclose(xe[0][:3], g["pos"][k - 1], rtol=0, atol=1e-10)
-    assert np.abs(eng.total_state(0) - g["x"]).max() < 1e-9
-    assert rel_fro(eng.total_covariance(0), g["P"]) < 1e-8
+    assert np.abs(eng.total_state(0) - g["x"]).max() < TOL_X
+    assert rel_fro(eng.total_covariance(0), g["P"]) < TOL_P
     # Feature::patch_ of every live feature, the ones cut from the frames by the initialisation included
     s = oracle_for(cam, params, spec, templates, oa)
     for k in range(1, 41):
@@ -233,7 +240,7 @@ def test_slots_are_squeezed_and_labels_stay_the_references():
             if k % 4 == 0 or k == n:
                 x0, x1 = s.total_state(), eng.total_state(b)
                 assert x0.size == x1.size, (k, b)
-                assert np.abs(x0 - x1).max() < 1e-8, (k, b, np.abs(x0 - x1).max())
+                assert np.abs(x0 - x1).max() < TOL_X_SOAK, (k, b, np.abs(x0 - x1).max())
                 feats = eng.features(b)
                 assert [f["label"] for f in feats] == [s.feature(i)["label"] for i in range(s.num_features)], (k, b)
                 assert [(f["attempted"], f["successful"]) for f in feats] == \
@@ -271,7 +278,7 @@ def test_a_full_map_is_loud():
         if int(eng.status_flags()[0]) & 2:
             full_at = k
             break
-        assert np.abs(eng.total_state(0) - s.total_state()).max() < 1e-9, k
+        assert np.abs(eng.total_state(0) - s.total_state()).max() < TOL_X, k
     # (raised at the first frame whose speed gate / visible-feature count call for an initialisation: before the region
     # search that may still find nothing - the oracle has initialised at most one feature by then)
     assert full_at is not None and s.mapping_info()["initialised"] <= 1
@@ -325,8 +332,8 @@ def test_initialise_feature_buttons_match_the_oracle(mode, tmp_path):
         assert got["n_partial"] == info["n_partial"], b
         if info["n_partial"]:
             assert (got["uu"], got["vv"]) == (info["uu"], info["vv"])
-        assert np.abs(eng.total_state(b) - s.total_state()).max() < 1e-9
-        assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-8
+        assert np.abs(eng.total_state(b) - s.total_state()).max() < TOL_X
+        assert rel_fro(eng.total_covariance(b), s.total_covariance()) < TOL_P
     for k in range(7, 23):
         eng.go_one_step(np.tile(frames[k], (B, 1, 1)))
         for b, s in enumerate(oracles):
@@ -335,8 +342,8 @@ def test_initialise_feature_buttons_match_the_oracle(mode, tmp_path):
             assert [got["info"][key] for key in ("n_partial", "converted", "deleted")] == \
                    [info[key] for key in ("n_partial", "converted", "deleted")], (k, b)
             x0, x1 = s.total_state(), eng.total_state(b)
-            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
-            assert rel_fro(eng.total_covariance(b), s.total_covariance()) < 1e-8, (k, b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X, (k, b)
+            assert rel_fro(eng.total_covariance(b), s.total_covariance()) < TOL_P, (k, b)
             if info["n_partial"]:
                 po = s.partial_feature(0)
                 assert got["pf"]["n_particles"] == po["n_particles"] and got["pf"]["attempts"] == po["attempts"]
@@ -392,34 +399,24 @@ def test_slot_squeeze_at_100_features_moves_state_covariance_and_templates_exact
         for b in range(2):
             pr.oracles[b].go_one_step(pr.frames[b][k], False, False)
             x0, x1 = pr.oracles[b].total_state(), eng.total_state(b)
-            assert x0.size == x1.size and np.abs(x0 - x1).max() < 1e-9, (k, b)
-            assert rel_fro(eng.total_covariance(b), pr.oracles[b].total_covariance()) < 1e-8, (k, b)
+            assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X, (k, b)
+            assert rel_fro(eng.total_covariance(b), pr.oracles[b].total_covariance()) < TOL_P, (k, b)
 
 
-@pytest.mark.parametrize("checker", ["reference", "oracle"])
-def test_two_features_initialised_at_once_against_the_reference(checker):
+def test_two_features_initialised_at_once():
     """params.max_features_to_init_at_once = 2 with 200 depth particles (data/SceneLib2.cfg:62 ships 1; the gate is
     monoslam.cpp:163-167): two partially initialised features in flight - twelve extra states, each matched with its own
     particle set - through conversions while the other is still partial.  The reference then moves the LATER feature's
     position_in_total_state_vector_ by 6 instead of 3 (feature.cpp:254, Q28) and from then on stacks that feature's dh_by_dy
     three columns early in H (monoslam.cpp:564): the engine reproduces the recorded positions AND the filter that results,
-    frame by frame, against the reference's own translation units (oracle/_ref/libref.so) and against the oracle."""
+    frame by frame, against the oracle (whose reading of feature.cpp:254 is pinned on the CPU by
+    tests/test_oracle_mapping.py::test_two_features_initialised_at_once_what_the_oracle_does)."""
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60, v_amp=0.5)
     params = dict(params)
     params["max_features_to_init_at_once"] = 2
     params["number_of_particles"] = 200
     params["number_of_features_to_keep_visible"] = 14
-    if checker == "reference" and oa.ref_available():
-        import ctypes
-        oa.ref_lib()
-        ctypes.CDLL(None).srand48(0)                 # MonoSLAM::Init (monoslam.cpp:1968): the reference's generator is the process's
-        s = oa.RefSLAM(cam, params["delta_t"], params["number_of_features_to_select"])
-        s.set_mapping_params(params)
-        s.set_state(spec.xv0, spec.Pxx0)
-        for i in range(spec.n_features):
-            s.add_known_feature(spec.feat_y[i], spec.xp_org()[i], templates[i])
-    else:
-        s = oracle_for(cam, params, spec, templates, oa)
+    s = oracle_for(cam, params, spec, templates, oa)
     eng = _engine(cam, params, spec, templates, max_features=40)
     max_partial, q28, measured_with_q28 = 0, 0, 0
     for k in range(1, 61):
@@ -427,7 +424,7 @@ def test_two_features_initialised_at_once_against_the_reference(checker):
         eng.go_one_step(frames[k][None], save_trajectory=True, enable_mapping=True)
         info = s.mapping_info()
         got = eng.partial_feature(0, capacity=256)["info"]
-        keys = ("initialised", "converted", "deleted", "n_partial") if not isinstance(s, oa.RefSLAM) else ("n_partial",)   # (the reference keeps no event counters)
+        keys = ("initialised", "converted", "deleted", "n_partial")
         assert [got[key] for key in keys] == [info[key] for key in keys], (k, got, info)
         max_partial = max(max_partial, info["n_partial"])
         mine = eng.partial_features(0, capacity=256)
@@ -445,8 +442,8 @@ def test_two_features_initialised_at_once_against_the_reference(checker):
         x0, P0 = s.total_state(), s.total_covariance()
         x1, P1 = eng.total_state(0), eng.total_covariance(0)
         assert x0.size == x1.size, k
-        assert np.abs(x1 - x0).max() < 1e-9, (k, np.abs(x1 - x0).max())
-        assert np.linalg.norm(P1 - P0) <= 1e-8 * max(np.linalg.norm(P0), 1e-12), k
+        assert np.abs(x1 - x0).max() < TOL_X, (k, np.abs(x1 - x0).max())
+        assert np.linalg.norm(P1 - P0) <= TOL_P * max(np.linalg.norm(P0), 1e-12), k
         kinds = s.feature_kinds()
         feats = eng.features(0)
         assert [f["label"] for f in feats] == list(kinds[:, 2]) and [f["state_size"] for f in feats] == list(kinds[:, 0]), k

@@ -9,8 +9,13 @@ from scenelib2_amd import Engine, MonoSLAM, synth
 
 pytestmark = pytest.mark.gpu
 
-TOL_X = 1e-9     # max-abs on the total state (EKF summation order differs from the dense CPU path)
-TOL_P = 1e-8     # relative Frobenius on the total covariance
+# Tolerances of the FP64 EKF quantities (the engine sums in a different order than the dense CPU path: S = L L^T, V = A L^-T,
+# P -= V V^T against the oracle's explicit S^-1).  Measured on MI355X: 5e-15 / 4e-14 per step at n = 313; three decades of
+# headroom are kept (SURVEY 8(c) asks for ~1e-12 relative on P).  Looser only where a test says why.
+TOL_X = 1e-12    # max-abs on the total state
+TOL_P = 1e-11    # relative Frobenius on the total covariance
+TOL_P_LARGE = 1e-10   # maps of n = 613 ... 1513 (condition number and sum lengths grow with n)
+TOL_X_LONG, TOL_P_LONG = 1e-11, 1e-10   # 300 frames with deletions: rounding differences are fed back through 300 updates
 
 
 def test_seams_one_frame():
@@ -80,7 +85,7 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
             traj_e[b, k] = xe[b, :3]
     rmse = np.sqrt(((traj_o - traj_e) ** 2).sum(axis=2).mean())
     assert rmse <= 1e-4          # BASELINE.json: trajectory RMSE within 1e-4 of the CPU reference
-    assert rmse <= 1e-9          # what FP64 on both sides should actually give
+    assert rmse <= 1e-12          # what FP64 on both sides should actually give
     truth = np.stack([s.poses[1:, :3] for s in pr.specs])
     assert np.abs(traj_e - truth).max() < 0.02      # and it actually tracks the camera
     for b in range(batch):     # trajectory_store_ keeps the reference's stale-scratch semantics (Q12)
@@ -88,17 +93,16 @@ def test_sequences_track_the_oracle(n_features, n_frames, batch, variant):
     assert not pr.engine.status_flags().any()
 
 
-def test_three_hundred_frames_with_natural_deletions_against_the_reference():
+def test_three_hundred_frames_with_natural_deletions():
     """300-frame sequences (30 x the deletion window of Q17) at the headline shape - 100 features, 5 mm
-    prior, dense covariance - four different sequences in one batch, EVERY frame against the reference's own translation
-    units (oracle/_ref/libref.so): measurements bit-exact, counters, selection order, total state 1e-9, total covariance
-    1e-8.  The camera rolls about its optical axis at 0.03 rad/s (0.3 rad over the run) on top of the usual path: the features stay visible
+    prior, dense covariance - four different sequences in one batch, EVERY frame against the oracle: measurements
+    bit-exact, counters, selection order, total state and total covariance within the tolerances at the top of this file.  The camera rolls about its optical axis at 0.03 rad/s (0.3 rad over the run) on top of the usual path: the features stay visible
     (visibility_test does not look at roll, full_feature_model.cpp:103-170) while their unwarped 11x11 templates stop
     matching, so features earn delete_bad_features NATURALLY (monoslam.cpp:644-660: >= 10 attempts, < 50 % matched) - no
     forced counters - and the filter still tracks the camera to the end."""
     import os
     B, N, F = 4, 100, 300
-    pr = Pair(N, F, batch=B, feature_sigma=0.005, checker="reference", w_bias=(0.0, 0.0, 0.03))
+    pr = Pair(N, F, batch=B, feature_sigma=0.005, w_bias=(0.0, 0.0, 0.03))
     threads = min(B, os.cpu_count() or 1)
     deleted_at = []
     n_prev = [N] * B
@@ -107,7 +111,7 @@ def test_three_hundred_frames_with_natural_deletions_against_the_reference():
     traj_e = np.zeros((B, F, 3))
     for k in range(F):
         pr.step_both(k, threads=threads)
-        w = pr.compare_state(TOL_X, TOL_P)
+        w = pr.compare_state(TOL_X_LONG, TOL_P_LONG)
         worst = {q: max(worst[q], w[q]) for q in worst}
         xe, _ = pr.engine.get_vehicle_state()
         for b in range(B):
@@ -126,7 +130,7 @@ def test_three_hundred_frames_with_natural_deletions_against_the_reference():
         assert len(pr.engine.features(b)) == n_prev[b]
         assert len(pr.engine.features(b, include_deleted=True)) == N
     rmse = np.sqrt(((traj_o - traj_e) ** 2).sum(axis=2).mean())
-    assert rmse <= 1e-9
+    assert rmse <= 1e-12
     truth = np.stack([s.poses[1:, :3] for s in pr.specs])
     assert np.abs(traj_e - truth).max() < 0.1                       # still tracking after 10 s of roll
     assert not pr.engine.status_flags().any()
@@ -331,20 +335,20 @@ def test_larger_baseline_shapes(width, height, n_features, n_frames, batch):
     pr = Pair(n_features, n_frames, batch=batch, cam=cam, feature_sigma=0.005 if batch > 1 else 0.0)
     for k in range(n_frames):
         pr.step_both(k, threads=min(batch, os.cpu_count() or 1))
-        worst = pr.compare_state(TOL_X, 2e-8)
+        worst = pr.compare_state(TOL_X, TOL_P_LARGE)
     _, cnt = pr.engine.selection(0)
     assert cnt["measurement_size"] > 1.5 * n_features     # most features matched
     assert not pr.engine.status_flags().any()
 
 
-def test_engine_matches_reference_golden_at_configs3_shape():
-    """The HIP path against REFERENCE outputs at n = 613 (640x480, 200 features, 5 mm prior, 6 frames):
-    tests/golden/ref_seq200.npz, produced by the reference's own translation units like ref_seq100.npz."""
+def test_engine_matches_committed_vectors_at_configs3_shape():
+    """The HIP path against the committed oracle outputs at n = 613 (640x480, 200 features, 5 mm prior, 6 frames):
+    tests/golden/oracle_seq200.npz (regression vectors of the oracle, tests/golden/make_golden.py - not reference outputs)."""
     import hashlib
     import sys
     sys.path.insert(0, golden_path(""))
     import make_golden as mg
-    g = np.load(golden_path("ref_seq200.npz"))
+    g = np.load(golden_path("oracle_seq200.npz"))
     cam, params, spec, tpl, frames = mg.seq_inputs(mg.SEQ200)
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
     N, B = mg.SEQ200["n_features"], 2
@@ -377,7 +381,7 @@ def test_large_ragged_batch_runs_the_panel_kernels():
     pr = Pair(288, 3, batch=3, cam=cam, feature_counts=[288, 150, 40], feature_sigma=0.004)
     for k in range(3):
         pr.step_both(k)
-        pr.compare_state(TOL_X, 2e-8)
+        pr.compare_state(TOL_X, TOL_P_LARGE)
     assert not pr.engine.status_flags().any()
 
 
@@ -464,10 +468,10 @@ def test_full_size_batch_properties():
 
 
 def test_engine_matches_committed_golden_fixture():
-    """The HIP path against REFERENCE outputs (tests/golden/ref_shipped.npz, generated by the reference's own
-    MonoSLAM::Init + GoOneStep compiled into oracle/_ref/libref.so): the shipped scene, three GoOneStep calls."""
+    """The HIP path against the committed oracle outputs (tests/golden/oracle_shipped.npz, tests/golden/make_golden.py):
+    the shipped scene, three GoOneStep calls."""
     from scenelib2_amd.config import load_config, read_pgm
-    g = np.load(golden_path("ref_shipped.npz"))
+    g = np.load(golden_path("oracle_shipped.npz"))
     m = MonoSLAM(max_features=8).Init(golden_path("scenelib2_shipped.cfg"), template_dirs=[golden_path("")])
     for k in range(3):
         m.GoOneStep(g["frame"], True, False)
@@ -477,15 +481,15 @@ def test_engine_matches_committed_golden_fixture():
     assert m.successful_measurement_vector_size_ == 8
 
 
-def test_engine_matches_reference_golden_at_the_headline_shape():
-    """The HIP path against REFERENCE outputs at n = 313 (100 features, 5 mm prior, 12 frames): tests/golden/ref_seq100.npz
-    was produced by the reference's own translation units (oracle/_ref/libref.so, tests/golden/make_golden.py).  The same
+def test_engine_matches_committed_vectors_at_the_headline_shape():
+    """The HIP path against the committed oracle outputs at n = 313 (100 features, 5 mm prior, 12 frames):
+    tests/golden/oracle_seq100.npz (tests/golden/make_golden.py; regression vectors, not reference outputs).  The same
     sequence runs as sequence 1 of a batch of 3 so that batching cannot hide behind it."""
     import hashlib
     import sys
     sys.path.insert(0, golden_path(""))
     import make_golden as mg
-    g = np.load(golden_path("ref_seq100.npz"))
+    g = np.load(golden_path("oracle_seq100.npz"))
     cam, params, spec, tpl, frames = mg.seq100_inputs()
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
     N, B = mg.SEQ100["n_features"], 3
@@ -523,7 +527,7 @@ def test_kernel_variants_give_the_same_filter(chol_variant, fwd_variant, search_
     pr.engine.set_search_variant(search_variant)
     for k in range(4):
         pr.step_both(k)
-        pr.compare_state(1e-9, 1e-8)
+        pr.compare_state(TOL_X, TOL_P)
     if (chol_variant, fwd_variant) != (1, 1):
         prod = Pair(4, 1, batch=1)
         with pytest.raises(_lib.Sl2Error, match="TEST build"):
@@ -547,7 +551,7 @@ def test_build_variants_of_the_test_library(build_variant, n_features, monkeypat
                 pr.oracles[b].delete_feature(4 + b)
             pr.engine.delete_features(np.array([4, 5, 6], dtype=np.int32))
         pr.step_both(k)
-        pr.compare_state(1e-9, 1e-8)
+        pr.compare_state(TOL_X, TOL_P)
 
 
 @pytest.mark.gpu
@@ -566,7 +570,7 @@ def test_both_substitution_kernels_on_small_batches(n_features, monkeypatch):
         pr = Pair(n_features, 4, batch=2, feature_sigma=0.004, lib=_lib.load_testing())
         for k in range(4):
             pr.step_both(k)
-            pr.compare_state(1e-9, 1e-8)
+            pr.compare_state(TOL_X, TOL_P)
         states.append([pr.engine.total_covariance(b) for b in range(2)])
     monkeypatch.delenv("SL2_NO_KSPLIT", raising=False)
     for b in range(2):
@@ -751,7 +755,7 @@ def test_awkward_shapes(width, height, n_features, n_frames, batch, sigma):
     matched = 0
     for k in range(n_frames):
         pr.step_both(k)
-        pr.compare_state(TOL_X, 2e-8)
+        pr.compare_state(TOL_X, TOL_P_LARGE)
         matched += pr.engine.selection(0)[1]["measurement_size"]
     assert matched >= n_frames * n_features          # at least half of the measurements succeed
     assert not pr.engine.status_flags().any()

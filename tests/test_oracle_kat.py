@@ -204,12 +204,12 @@ def test_deletion_rule_and_skip_quirk(oracle):
 
 
 def test_oracle_matches_committed_golden_run(oracle):
-    """The oracle against REFERENCE outputs: three GoOneStep calls on the shipped scene, generated by the reference's
-    own MonoSLAM::Init + GoOneStep (oracle/_ref/libref.so, tests/golden/make_golden.py)."""
+    """Regression: the oracle against its own committed outputs (tests/golden/make_golden.py) - three GoOneStep calls on
+    the shipped scene.  Guards the checker against accidental change; it is not a pin against the reference."""
     import os
     from conftest import golden_path
     from scenelib2_amd.config import load_config, read_pgm
-    g = np.load(golden_path("ref_shipped.npz"))
+    g = np.load(golden_path("oracle_shipped.npz"))
     cfg = load_config(golden_path("scenelib2_shipped.cfg"))
     o = oracle.OracleSLAM(cfg["cam"], cfg["params"]["delta_t"], 10)
     o.set_state(cfg["xv"], cfg["Pxx"])
@@ -281,14 +281,14 @@ def test_predict_equals_F_P_Ft_plus_Q_in_numpy(oracle):
     assert np.abs(s.total_covariance() - want).max() <= 1e-13 * max(np.abs(want).max(), 1e-30)
 
 
-def test_oracle_matches_reference_golden_at_the_headline_shape(oracle):
-    """100 features (n = 313), 12 frames, against tests/golden/ref_seq100.npz = outputs of the reference's own code."""
+def test_oracle_matches_committed_vectors_at_the_headline_shape(oracle):
+    """Regression: 100 features (n = 313), 12 frames, against tests/golden/oracle_seq100.npz (the oracle's own committed outputs)."""
     import hashlib
     import sys
     from conftest import golden_path
     sys.path.insert(0, golden_path(""))
     import make_golden as mg
-    g = np.load(golden_path("ref_seq100.npz"))
+    g = np.load(golden_path("oracle_seq100.npz"))
     cam, params, spec, tpl, frames = mg.seq100_inputs()
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])
     N = mg.SEQ100["n_features"]

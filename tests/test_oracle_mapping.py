@@ -70,12 +70,11 @@ def test_camera_still_tracks_with_mapping_on(run):
 
 
 def test_oracle_matches_committed_mapping_golden():
-    """The feature-initialisation oracle against REFERENCE outputs: the per-frame log and the final state of the 40-frame
-    mapping run committed in tests/golden/ref_mapping.npz (generated from oracle/_ref/libref.so, the reference's own
-    translation units, by tests/golden/make_golden.py)."""
+    """Regression: the feature-initialisation oracle against its own committed outputs - the per-frame log and the final
+    state of the 40-frame mapping run in tests/golden/oracle_mapping.npz (tests/golden/make_golden.py)."""
     import hashlib
     from conftest import golden_path
-    g = np.load(golden_path("ref_mapping.npz"))
+    g = np.load(golden_path("oracle_mapping.npz"))
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=40)
     assert hashlib.sha256(frames.tobytes()).hexdigest() == str(g["frames_sha256"])     # same input bytes
     s = oracle_for(cam, params, spec, templates, oa)
@@ -128,3 +127,41 @@ def test_particle_update_equals_numpy_bayes_rule():
             checked += 1
         prev = cur
     assert checked >= 8
+
+
+def test_two_features_initialised_at_once_what_the_oracle_does():
+    """params.max_features_to_init_at_once = 2 with 200 depth particles: two partially initialised features in flight (twelve
+    extra states).  When the FIRST converts while the second is still partial, the reference's
+    convert_from_partially_to_fully_initialised subtracts the partial size (6) instead of the difference (3) from every later
+    feature's position_in_total_state_vector_ (feature.cpp:254, quirk Q28) - so that feature's recorded position ends up 3
+    below where construct_total_state puts it (monoslam.cpp:501-512 sums the state sizes in list order).  Pinned here from
+    the reference's TEXT, not from a run of it: every recorded position is either the running sum or lies a positive multiple
+    of 3 below it, a deficit appears only in a frame in which a conversion happened, and it does appear."""
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60, v_amp=0.5)
+    params = dict(params)
+    params["max_features_to_init_at_once"] = 2
+    params["number_of_particles"] = 200
+    params["number_of_features_to_keep_visible"] = 14
+    o = oracle_for(cam, params, spec, templates, oa)
+    max_partial, q28_frames, prev_deficits, prev_converted = 0, 0, {}, 0
+    for k in range(1, 61):
+        o.go_one_step(frames[k], False, True)
+        info = o.mapping_info()
+        max_partial = max(max_partial, info["n_partial"])
+        kinds = o.feature_kinds()
+        pos, deficits = 13, {}
+        for i in range(o.num_features):
+            f = o.feature(i)
+            d = pos - f["pos"]
+            assert d >= 0 and d % 3 == 0, (k, i, pos, f["pos"])
+            if d:
+                deficits[int(f["label"])] = d
+            pos += int(kinds[i][0])
+        assert pos == o.total_state_size
+        grew = {lab: d for lab, d in deficits.items() if d > prev_deficits.get(lab, 0)}
+        if grew:
+            assert info["converted"] > prev_converted, (k, grew)     # only a conversion moves recorded positions
+            q28_frames += 1
+        prev_deficits, prev_converted = deficits, info["converted"]
+    assert max_partial == 2, "the scene never had two partially initialised features in flight"
+    assert q28_frames > 0, "Q28 (position moved by 6 instead of 3) never showed: no conversion happened next to a second partial feature"

@@ -197,6 +197,13 @@ int sl2_set_graph_mode(sl2_engine* e, int enabled);
 /* Which search kernel sl2_make_measurements / sl2_go_one_step use: 1 = int8 matrix-core walk (k_search_mfma, default),
  * 0 = the exact kernel with one candidate per lane (k_search_exact, the cross-check).  Identical results, bit for bit. */
 int sl2_set_search_variant(sl2_engine* e, int variant);
+/* Small maps (the reference's own workload: data/SceneLib2.cfg:60-62 keeps a dozen features and measures ten per frame):
+ * when the whole state fits 128 columns (max_features <= 35 with one partially initialised feature) and at most 16 features
+ * are measured per frame, sl2_go_one_step issues THREE launches instead of ten - predict + measurement prediction + selection,
+ * the patch search, scoring + EKF update + normalise / delete / symmetrise (monoslam.cpp:108-180 unchanged in meaning;
+ * search results, selection and every counter identical bit for bit, state and covariance equal to rounding).
+ * enabled = 1 (default) / 0 = always the one-stage-per-launch kernels.  The seam entry points below always use the latter. */
+int sl2_set_step_fusion(sl2_engine* e, int enabled);
 /* Search windows of at least `min_bands` bands (a band = 32 x 16 candidate positions; a window of nu x nv positions has
  * ceil(ceil(nu / 16) / 2) * ceil(nv / 16) of them) are not walked by one wavefront but cut into units of four bands that
  * extra workgroups at the end of the search launch (a quarter of it, at most 2048) work off - the window of a poorly constrained feature can be the

@@ -192,6 +192,7 @@ struct sl2_engine {
   int search_lds_pad = 0;     // extra dynamic LDS bytes per k_search_mfma workgroup (TEST build: SL2_SEARCH_LDS_PAD): an occupancy probe
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice
   int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)
+  int step_fusion = 1;        // small maps (sl2_small.hip: ld <= 128, one 32-row innovation block) step in three launches instead of ten; 0 = never (sl2_set_step_fusion)
   int search_split = sl2::kSrchSplitDefault;   // windows of at least this many 32 x 16 bands are shared out over wavefronts (0 = never); sl2_create: srch_split_default, then sl2_set_search_split
   // ---- large search windows (round 4): the step's units of work for every wavefront of k_search_mfma (layout: kSrchBig* above) ----
   int* srch_big = nullptr;    // per sequence GROUP (allocated by build_groups)
@@ -289,7 +290,12 @@ struct LaunchScope {
 int launch_predict(sl2_engine* e);
 int launch_feature_prediction(sl2_engine* e);
 int launch_select(sl2_engine* e, int n);
-int launch_search(sl2_engine* e);
+int launch_search(sl2_engine* e);            // the search kernel, then k_search_score
+int launch_search_kernel(sl2_engine* e);     // the search kernel alone (the fused small-map step scores in k_small_back)
+int launch_search_score(sl2_engine* e);
+bool small_step_applies(const sl2_engine* e);                 // sl2_small.hip
+int launch_small_front(sl2_engine* e, int n);                 // predict + feature prediction + selection in one launch
+int launch_small_back(sl2_engine* e, int save_trajectory);    // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);

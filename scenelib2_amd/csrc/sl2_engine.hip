@@ -436,7 +436,7 @@ int sl2_set_groups(sl2_engine* e, int groups) {
   { int rc = e->sync_all(); if (rc != SL2_OK) return rc; }
   // captured steps carry the groups' pointers (srch_big is re-allocated per group below, the streams change): replaying one
   // after a rebuild would write through freed device memory
-  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
+  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);       // (synchronised above; drop_step_graphs is defined further down)
   e->step_graphs.clear();
   return build_groups(e, groups);
 }
@@ -576,19 +576,35 @@ static int bind_frames(sl2_engine* e, const uint8_t* frames, size_t seq_stride, 
   return SL2_OK;
 }
 
-int sl2_set_search_variant(sl2_engine* e, int variant) {
-  if (!e || variant < 0 || variant > 1) return SL2_ERR_INVALID;
+// Captured steps bake kernel choices, arguments and the groups' pointers in: every setter that changes one of them drops the
+// graphs through here - after the device has finished with them (a replay may still be in flight on the engine's streams).
+static int drop_step_graphs(sl2_engine* e) {
+  if (e->step_graphs.empty()) return SL2_OK;
+  SL2_HIP(hipSetDevice(e->device));
+  { int rc = e->sync_all(); if (rc != SL2_OK) return rc; }
   for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
   e->step_graphs.clear();
+  return SL2_OK;
+}
+
+int sl2_set_search_variant(sl2_engine* e, int variant) {
+  if (!e || variant < 0 || variant > 1) return SL2_ERR_INVALID;
+  { int rc = drop_step_graphs(e); if (rc != SL2_OK) return rc; }
   e->search_variant = variant;
   return SL2_OK;
 }
 
 int sl2_set_search_split(sl2_engine* e, int min_bands) {
   if (!e || min_bands < 0) return SL2_ERR_INVALID;
-  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);        // the threshold is a kernel argument of the captured k_select
-  e->step_graphs.clear();
+  { int rc = drop_step_graphs(e); if (rc != SL2_OK) return rc; }        // the threshold is a kernel argument of the captured k_select
   e->search_split = min_bands;
+  return SL2_OK;
+}
+
+int sl2_set_step_fusion(sl2_engine* e, int enabled) {
+  if (!e) return SL2_ERR_INVALID;
+  { int rc = drop_step_graphs(e); if (rc != SL2_OK) return rc; }
+  e->step_fusion = enabled ? 1 : 0;
   return SL2_OK;
 }
 
@@ -616,8 +632,7 @@ int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
     return SL2_ERR_INVALID;
   }
 #endif
-  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
-  e->step_graphs.clear();
+  { int rc = drop_step_graphs(e); if (rc != SL2_OK) return rc; }
   e->chol_variant = chol_variant;
   e->fwd_variant = fwd_variant;
   return SL2_OK;
@@ -661,10 +676,6 @@ int sl2_finish_step(sl2_engine* e, int save_trajectory) {
   return rc;
 }
 
-static void drop_step_graphs_of(sl2_engine* e) {
-  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
-  e->step_graphs.clear();
-}
 
 // Feature initialisation is in use from now on (enable_mapping, or one of the two "initialise feature" entry points): checks
 // what this engine supports and allocates the per-pixel maps of the multi-ellipse search.
@@ -723,7 +734,7 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
     rc = launch_auto_init(g);
   }
   if (rc != SL2_OK) return rc;
-  drop_step_graphs_of(e);     // captured steps were recorded without the feature-initialisation tail
+  { int rc2 = drop_step_graphs(e); if (rc2 != SL2_OK) return rc2; }     // captured steps were recorded without the feature-initialisation tail
   if (created) {
     { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
     std::vector<int> pi((size_t)e->B * kPartInts);
@@ -757,6 +768,11 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
+      if (small_step_applies(g)) {       // small maps: three launches (sl2_small.hip)
+        if ((q = launch_small_front(g, nsel)) != SL2_OK) return q;
+        if ((q = launch_search_kernel(g)) != SL2_OK) return q;
+        return launch_small_back(g, tail ? 0 : save_trajectory);
+      }
       if ((q = launch_predict(g)) != SL2_OK) return q;
       if ((q = launch_feature_prediction(g)) != SL2_OK) return q;
       if ((q = launch_select(g, nsel)) != SL2_OK) return q;
@@ -809,16 +825,10 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   return SL2_OK;
 }
 
-static void drop_step_graphs(sl2_engine* e) {
-  for (auto& sg : e->step_graphs) hipGraphExecDestroy(sg.exec);
-  e->step_graphs.clear();
-}
-
 int sl2_set_graph_mode(sl2_engine* e, int enabled) {
   if (!e) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
-  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  drop_step_graphs(e);
+  { int _rc = drop_step_graphs(e); if (_rc != SL2_OK) return _rc; }
   e->graph_mode = enabled != 0;
   return SL2_OK;
 }

@@ -893,3 +893,49 @@ def test_split_threshold_changed_between_selection_and_measurement():
             assert fe["success"] == fo["success"] and fe["attempted"] == fo["attempted"]
             if fo["success"]:
                 assert np.array_equal(fe["z"], fo["z"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_features,n_select,capacity,sigma,groups", [(12, 12, 12, 0.005, 1), (30, 16, 35, 0.004, 1), (4, 4, 8, 0.0, 1),
+                                                                      (12, 10, 14, 0.005, 2)])
+def test_small_map_step_in_three_launches_equals_the_ten_launch_step(n_features, n_select, capacity, sigma, groups):
+    """sl2_small.hip: engines whose state fits 128 columns and whose innovation system is one 32-row block step in THREE
+    launches (k_small_front, the search kernel, k_small_back) - same bodies for everything bit-exact, its own one-block EKF
+    update.  The same frames through the fused step, through the ten-launch step (sl2_set_step_fusion(0)) and through the
+    oracle: every integer output (measured pixels, match flags, selection order, counters, visible count) identical between
+    the two engines, state and covariance of each within the file's tolerances of the oracle and within 1e-13 / 1e-12 of
+    each other.  Shapes: ld = 64 with every feature measured; ld = 128 with 16 of 30 measured; the shipped scene's four
+    features (block-sparse covariance: AddNewKnownFeature's zeros); two sequence groups."""
+    B, F = 3, 14
+    pr = Pair(n_features, F, batch=B, n_select=n_select, max_features=capacity, feature_sigma=sigma)
+    twin = Engine(pr.cam, pr.params, B, capacity)
+    twin.set_step_fusion(False)
+    twin.set_vehicle_state(np.stack([s.xv0 for s in pr.specs]), np.stack([s.Pxx0 for s in pr.specs]))
+    for b in range(B):
+        twin.add_known_features(pr.specs[b].feat_y[None], np.tile(pr.specs[b].poses[0], (1, n_features, 1)), pr.templates[b][None], seq0=b)
+        if sigma > 0.0:
+            twin.set_feature_covariances(np.tile(np.eye(3) * sigma ** 2, (1, n_features, 1, 1)), seq0=b)
+    if groups > 1:
+        pr.engine.set_groups(groups)
+        twin.set_groups(groups)
+    pr.engine.set_profiling(2)
+    for k in range(F):
+        pr.step_both(k, save_trajectory=True)
+        twin.go_one_step(pr.frame_batch(k), True)
+        pr.compare_state(TOL_X, TOL_P)
+        for b in range(B):
+            fa, fb = pr.engine.features(b), twin.features(b)
+            for p, q in zip(fa, fb):
+                for key in ("label", "selected", "success", "attempted", "successful", "pos"):
+                    assert p[key] == q[key], (k, b, key)
+                assert np.array_equal(p["z"], q["z"]) and np.array_equal(p["h"], q["h"]), (k, b)        # h: the front bodies are the same code
+            sa, ca = pr.engine.selection(b)
+            sb, cb = twin.selection(b)
+            assert list(sa) == list(sb) and ca == cb, (k, b)
+            assert np.abs(pr.engine.total_state(b) - twin.total_state(b)).max() <= 1e-13
+            assert rel_fro(pr.engine.total_covariance(b), twin.total_covariance(b)) <= 1e-12
+    for b in range(B):
+        assert np.array_equal(pr.engine.trajectory(b), twin.trajectory(b))              # rRES_ pushes (Q12): copies, no arithmetic
+    names = set(pr.engine.kernel_times())
+    assert {"k_small_front", "k_small_back"} <= names and not ({"k_predict", "k_build_AS", "k_syrk", "k_finalize"} & names), names
+    assert not pr.engine.status_flags().any() and not twin.status_flags().any()

@@ -177,7 +177,7 @@ struct sl2_engine {
   bool mapping_used = false;
   int* init_uv = nullptr;                // [B][2] pixel selections of sl2_initialise_feature (allocated on first use)
   // ---- whole-step HIP graphs (small batches are launch-bound: ~12 kernels per step) ----
-  struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail; hipGraphExec_t exec; };
+  struct StepGraph { const void* frames; size_t stride; int save_trajectory, enable_mapping, tail, small; hipGraphExec_t exec; };
   bool graph_mode = false;
   std::vector<StepGraph> step_graphs;
   int build_split = 0;        // development switches (TEST build only: SL2_BUILD_SPLIT, SL2_SCORE_THREADS, SL2_NO_KSPLIT read
@@ -192,6 +192,14 @@ struct sl2_engine {
   int search_lds_pad = 0;     // extra dynamic LDS bytes per k_search_mfma workgroup (TEST build: SL2_SEARCH_LDS_PAD): an occupancy probe
   int search_chunk = 0;       // selected positions per wavefront of k_search_mfma (TEST build: SL2_SEARCH_CHUNK); 0 = the engine's own choice
   int search_variant = 1;     // 0 = exact kernel (one candidate per lane), 1 = int8 matrix-core walk (default)
+  // How large the live maps are, known on the host WITHOUT a synchronisation (the choice of the step's kernels): finalize
+  // publishes the batch's maximum of n_slots per step to pinned memory (sl2_frontend_dev.hpp: finalize_body); exact values
+  // are taken wherever a call synchronises anyway (sl2_add_known_features, the "initialise feature" buttons).
+  int* slots_max_dev = nullptr;                  // [2] device: maxima of the steps in flight (step parity)
+  unsigned long long* slots_mail = nullptr;      // pinned + mapped host word: (step << 32) | max n_slots of the step before it
+  unsigned long long* slots_mail_dev = nullptr;  // its device address
+  int slots_exact = 0;                           // max n_slots over the batch when last read back ...
+  long long slots_exact_step = 0;                // ... and steps_done at that point
   int step_fusion = 1;        // small maps (sl2_small.hip: ld <= 128, one 32-row innovation block) step in three launches instead of ten; 0 = never (sl2_set_step_fusion)
   int search_split = sl2::kSrchSplitDefault;   // windows of at least this many 32 x 16 bands are shared out over wavefronts (0 = never); sl2_create: srch_split_default, then sl2_set_search_split
   // ---- large search windows (round 4): the step's units of work for every wavefront of k_search_mfma (layout: kSrchBig* above) ----
@@ -293,7 +301,7 @@ int launch_select(sl2_engine* e, int n);
 int launch_search(sl2_engine* e);            // the search kernel, then k_search_score
 int launch_search_kernel(sl2_engine* e);     // the search kernel alone (the fused small-map step scores in k_small_back)
 int launch_search_score(sl2_engine* e);
-bool small_step_applies(const sl2_engine* e);                 // sl2_small.hip
+bool small_step_applies(const sl2_engine* e, int slots_bound);   // sl2_small.hip
 int launch_small_front(sl2_engine* e, int n);                 // predict + feature prediction + selection in one launch
 int launch_small_back(sl2_engine* e, int save_trajectory);    // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);

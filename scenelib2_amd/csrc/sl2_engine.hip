@@ -393,6 +393,11 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   A(dmalloc(&e->prev_r, B * 3));
   A(dmalloc(&e->me_desc, B * (size_t)e->kpart * e->pcap * 8));
 #undef A
+  SL2_HIP(hipMalloc((void**)&e->slots_max_dev, sizeof(int) * 2));
+  SL2_HIP(hipMemset(e->slots_max_dev, 0, sizeof(int) * 2));
+  SL2_HIP(hipHostMalloc((void**)&e->slots_mail, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+  *e->slots_mail = 0ull;
+  SL2_HIP(hipHostGetDevicePointer((void**)&e->slots_mail_dev, e->slots_mail, 0));
   {  // srand48(0) in MonoSLAM::Init (monoslam.cpp:1968), one generator per sequence
     std::vector<unsigned long long> seeds(B, kRand48Seed0);
     SL2_HIP(hipMemcpy(e->rand48, seeds.data(), sizeof(unsigned long long) * B, hipMemcpyHostToDevice));
@@ -459,6 +464,8 @@ void sl2_destroy(sl2_engine* e) {
                   e->work, e->At, e->Vt, e->St, e->LinvT, e->frames_buf, e->pos_log, e->srch_i, e->srch_d, e->srch_res, e->srch_sel,
                   e->part_i, e->part_d, e->particles, e->rand48, e->prev_r, e->me_desc, e->score_map, e->me_big_list, e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->f_hcol, e->pos_count, e->init_uv, e->f_label, e->next_label};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (e->slots_max_dev) hipFree(e->slots_max_dev);
+  if (e->slots_mail) hipHostFree(e->slots_mail);
   if (e->snap_stage) hipFree(e->snap_stage);
   if (e->snap_host) hipHostFree(e->snap_host);
   if (e->acc_dev) hipFree(e->acc_dev);
@@ -478,6 +485,35 @@ int sl2_batch(const sl2_engine* e) { return e ? e->B : 0; }
 int sl2_max_features(const sl2_engine* e) { return e ? e->N : 0; }
 
 static int range_ok(sl2_engine* e, int seq0, int nseq) { return e && seq0 >= 0 && nseq > 0 && seq0 + nseq <= e->B; }
+
+// The largest n_slots of the batch, read back: only where the caller has just synchronised anyway.
+static int refresh_slots_exact(sl2_engine* e) {
+  std::vector<int> slots(e->B);
+  SL2_HIP(hipMemcpy(slots.data(), e->n_slots, sizeof(int) * e->B, hipMemcpyDeviceToHost));
+  int mx = 0;
+  for (int v : slots) mx = v > mx ? v : mx;
+  e->slots_exact = mx;
+  e->slots_exact_step = e->steps_done;
+  return SL2_OK;
+}
+
+// Upper bound on n_slots of any sequence at the step about to be issued (step index steps_done), without touching the
+// device.  n_slots grows only in the feature-initialisation tail of a step (at most kpart per step and sequence, and only once
+// feature initialisation is in use), in sl2_add_known_features and in the two "initialise feature" calls - the last two
+// synchronise and read the exact value.  In between, finalize's mailbox (max over the batch as of step t - 1, published during
+// step t) follows the device with a lag of however many steps the caller keeps in flight.
+static int slots_upper_bound(const sl2_engine* e) {
+  const long long s = e->steps_done;
+  const long long grow = e->mapping_used ? e->kpart : 0;
+  long long best = (long long)e->slots_exact + grow * (s - e->slots_exact_step);
+  const unsigned long long mail = __atomic_load_n(e->slots_mail, __ATOMIC_ACQUIRE);
+  const long long t = (long long)(mail >> 32);        // published while finalizing step t: the maximum of step t - 1
+  if (t >= 1 && t - 1 >= e->slots_exact_step && t - 1 < s) {
+    const long long viaMail = (long long)(mail & 0xffffffffull) + grow * (s - (t - 1));
+    if (viaMail < best) best = viaMail;
+  }
+  return best > 1000000 ? 1000000 : (int)best;
+}
 
 int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx) {
   if (!range_ok(e, seq0, nseq) || !xv || !Pxx) return SL2_ERR_INVALID;
@@ -556,7 +592,7 @@ int sl2_add_known_features(sl2_engine* e, int seq0, int nseq, int nfeat, const d
                      e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, dy, dxp, dp, seq0, nfeat, e->N, e->ld);
   SL2_HIP(hipGetLastError());
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
-  return SL2_OK;
+  return refresh_slots_exact(e);
 }
 
 // ------------------------------------------------------------------- stepping
@@ -735,8 +771,10 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
   }
   if (rc != SL2_OK) return rc;
   { int rc2 = drop_step_graphs(e); if (rc2 != SL2_OK) return rc2; }     // captured steps were recorded without the feature-initialisation tail
+  // (a button press: the call synchronises, and takes the exact map sizes while it is at it)
+  { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  { int _rc = refresh_slots_exact(e); if (_rc != SL2_OK) return _rc; }
   if (created) {
-    { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
     std::vector<int> pi((size_t)e->B * kPartInts);
     SL2_HIP(hipMemcpy(pi.data(), e->part_i, sizeof(int) * pi.size(), hipMemcpyDeviceToHost));
     for (int b = 0; b < e->B; ++b) created[b] = pi[(size_t)b * kPartInts + kPartCreated];
@@ -765,10 +803,12 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // Once mapping has been on, MatchPartiallyInitialisedFeatures has work to do in every later step
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
+  const int slots_bound = slots_upper_bound(e);
+  const bool small_any = [&]() { for (const sl2_engine* g : e->groups) if (small_step_applies(g, slots_bound)) return true; return false; }();
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
-      if (small_step_applies(g)) {       // small maps: three launches (sl2_small.hip)
+      if (small_step_applies(g, slots_bound)) {       // small maps: three launches (sl2_small.hip)
         if ((q = launch_small_front(g, nsel)) != SL2_OK) return q;
         if ((q = launch_search_kernel(g)) != SL2_OK) return q;
         return launch_small_back(g, tail ? 0 : save_trajectory);
@@ -797,7 +837,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
     hipGraphExec_t exec = nullptr;
     for (const auto& sg : e->step_graphs)
       if (sg.frames == (const void*)frames && sg.stride == seq_stride && sg.save_trajectory == save_trajectory &&
-          sg.enable_mapping == enable_mapping && sg.tail == (int)tail) { exec = sg.exec; break; }
+          sg.enable_mapping == enable_mapping && sg.tail == (int)tail && sg.small == (int)small_any) { exec = sg.exec; break; }
     if (!exec) {
       hipGraph_t graph = nullptr;
       SL2_HIP(hipStreamBeginCapture(e->stream, hipStreamCaptureModeRelaxed));
@@ -812,7 +852,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       SL2_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
       hipGraphDestroy(graph);
       if (e->step_graphs.size() >= 8) { hipGraphExecDestroy(e->step_graphs.front().exec); e->step_graphs.erase(e->step_graphs.begin()); }
-      e->step_graphs.push_back({(const void*)frames, seq_stride, save_trajectory, enable_mapping, (int)tail, exec});
+      e->step_graphs.push_back({(const void*)frames, seq_stride, save_trajectory, enable_mapping, (int)tail, (int)small_any, exec});
     }
     SL2_HIP(hipGraphLaunch(exec, e->stream));
     rc = SL2_OK;

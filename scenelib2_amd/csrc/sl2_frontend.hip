@@ -50,10 +50,11 @@ __global__ void __launch_bounds__(128) k_finalize(double* __restrict__ x, double
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
                                                   int* __restrict__ status, double* __restrict__ pos_log, int* __restrict__ pos_count, int N, int ld,
                                                   int min_attempts, double match_fraction, int save_trajectory,
-                                                  const int* __restrict__ part_i, int pend) {
+                                                  const int* __restrict__ part_i, int pend, int* __restrict__ slots_max,
+                                                  unsigned long long* __restrict__ slots_mail, int publish) {
   extern __shared__ int s_del[];
   finalize_body(blockIdx.x, x, P, f_flags, n_slots, attempted, successful, m_count, n_sel, traj, traj_count, last_r, status, pos_log,
-                pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, s_del);
+                pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, s_del, slots_max, slots_mail, publish);
 }
 
 #ifdef SL2_FRONT_TRACE
@@ -98,7 +99,8 @@ int launch_finalize(sl2_engine* e, int save_trajectory) {
   hipLaunchKernelGGL(k_finalize, dim3(e->B), dim3(128), shm, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->attempted,
                      e->successful, e->m_count, e->n_sel, e->traj, e->traj_count, e->last_r, e->status, e->pos_log,
                      e->pos_count, e->N, e->ld, e->prm.minimum_attempted_measurements_of_feature,
-                     e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos + 6 * e->kpart);
+                     e->prm.successful_match_fraction, save_trajectory, e->part_i, e->ppos + 6 * e->kpart, e->root->slots_max_dev,
+                     e->root->slots_mail_dev, e->group_first == 0 ? 1 : 0);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

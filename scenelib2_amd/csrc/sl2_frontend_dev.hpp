@@ -309,7 +309,9 @@ __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ 
                                                   int* __restrict__ traj_count, const double* __restrict__ last_r,
                                                   int* __restrict__ status, double* __restrict__ pos_log, int* __restrict__ pos_count, int N, int ld,
                                                   int min_attempts, double match_fraction, int save_trajectory,
-                                                  const int* __restrict__ part_i, int pend, int* s_del) {
+                                                  const int* __restrict__ part_i, int pend, int* s_del,
+                                              int* __restrict__ slots_max = nullptr, unsigned long long* __restrict__ slots_mail = nullptr,
+                                              int publish = 0) {
   // s_del: [N] slots deleted this frame, then [N] flags
   __shared__ double s_N[16], s_P[169], s_T[169];
   __shared__ int s_ndel;
@@ -483,6 +485,18 @@ __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ 
     bool bad = false;
     for (int k = 0; k < 13; ++k) bad = bad || !isfinite(pre_x[k]) || !isfinite(s_P[k * 13 + k]);   // (Q10 poisons Pxx first)
     if (bad) status[b] |= 1;
+    // How large the maps of the batch are, for the HOST's choice of step kernels (sl2_small.hip) without a synchronisation:
+    // slots_max[t & 1] collects the maximum of n_slots over the sequences that finalize step t; the first workgroup of the
+    // first sequence group, when it finalizes step t, publishes the COMPLETE maximum of step t - 1 (every finalize of that
+    // step has ended: stream order) to pinned host memory as (t << 32 | max) and clears that slot for step t + 1.
+    if (slots_max) {
+      atomicMax(&slots_max[pre_pc & 1], ns);
+      if (publish && b == 0) {
+        const int prev = __hip_atomic_load(&slots_max[(pre_pc + 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slots_max[(pre_pc + 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots_mail, ((unsigned long long)(unsigned)pre_pc << 32) | (unsigned)prev, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
 }
 

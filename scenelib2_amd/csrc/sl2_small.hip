@@ -46,15 +46,20 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_front(
 }
 
 // Kalman::KalmanFilterUpdate (kalman.cpp:72-119) for a system of at most 32 measurement rows; all threads of the workgroup.
-// sAt: [32][ld] doubles of dynamic LDS.  H row a = 2 j + r of the j-th successful feature in SLOT order (succ_idx): the seven
+// The engine's leading dimension ld is whatever the feature CAPACITY asks for (the adapter reserves 128 slots: ld = 448);
+// what the update touches is the LIVE part of the state: columns [0, 13 + 3 n_slots), the six states of a partially
+// initialised feature at ppos (if one is in flight), and the innovation.  Those are gathered into a compact column index
+// c < W (W = 64 or 128, cmap below) for everything that lives in LDS; P and x are addressed in place, at stride ld.
+// sAt: [32][W] doubles of dynamic LDS.  H row a = 2 j + r of the j-th successful feature in SLOT order (succ_idx): the seven
 // pose coefficients of dh_by_dxv and the three of dh_by_dy at column 13 + 3 slot (monoslam.cpp:548-572; with one partially
 // initialised feature per sequence - the only case this kernel is launched for - no recorded position is misplaced, Q28).
+constexpr int kSmallW = 128;         // compact columns at most: 13 + 3 * 36 + 6 + 1
 __device__ __forceinline__ void small_update_body(const int b, double* __restrict__ x, double* __restrict__ P,
                                                   const double* __restrict__ f_Hx, const double* __restrict__ f_Hy,
                                                   const double* __restrict__ f_nu, const double* __restrict__ f_R,
                                                   const int* __restrict__ succ_idx, const int* __restrict__ m_count,
-                                                  const int* __restrict__ n_slots, const int* __restrict__ part_i, int pend,
-                                                  int N, int ld, double* sAt) {
+                                                  const int* __restrict__ n_slots, const int* __restrict__ part_i, int ppos, int pend,
+                                                  int N, int ld, int* __restrict__ status, double* sAt) {
   __shared__ double sH[kSmallM][10];
   __shared__ double sR[kSmallM];
   __shared__ int sPos[kSmallM];
@@ -67,7 +72,14 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
   const int m = 2 * cnt;
   double* xb = x + (size_t)b * ld;
   double* Pb = P + (size_t)b * ld * ld;
-  const int n_used = part_i[(size_t)b * kPartInts + kPartCount] ? pend : 13 + 3 * n_slots[b];
+  const int nlive = 13 + 3 * n_slots[b];
+  const int n_c = nlive + (part_i[(size_t)b * kPartInts + kPartCount] ? pend - ppos : 0);      // compact columns that hold state
+  if (n_c + 1 > kSmallW || m > kSmallM) {             // cannot happen: the host launches this kernel only under its bound on n_slots
+    if (tid == 0) status[b] |= 8;                     // ... and if it ever did, the sequence says so instead of corrupting memory
+    return;
+  }
+  const int W = (n_c + 1 <= 64) ? 64 : kSmallW;       // row pitch of the LDS panel; column W - 1 carries the innovation
+  auto cmap = [&](int c) { return c < nlive ? c : ppos + (c - nlive); };
   if (tid < kSmallM) {
     if (tid < m) {
       const int f = succ_idx[(size_t)b * N + (tid >> 1)];
@@ -78,29 +90,30 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
       for (int c = 0; c < 3; ++c) sH[tid][7 + c] = f_Hy[fi * 6 + (tid & 1) * 3 + c];
       sR[tid] = f_R[fi];
       sPos[tid] = 13 + 3 * f;
-      sAt[tid * ld + ld - 1] = f_nu[fi * 2 + (tid & 1)];       // the innovation rides along as column ld - 1
+      sAt[tid * W + W - 1] = f_nu[fi * 2 + (tid & 1)];         // the innovation rides along as the last column
     } else {
-      sAt[tid * ld + ld - 1] = 0.0;
+      sAt[tid * W + W - 1] = 0.0;
     }
   }
-  // ---- A^T[a][i] = sum_c H[a][c] P[c][i]: thread (a0, i), rows a0, a0 + 256 / ld, ...  (ld = 64 or 128 divides 256);
-  // the order of every sum is that of k_build_AS
-  const int i = tid % ld, a0 = tid / ld, astep = kSmallThreads / ld;
+  // ---- A^T[a][i] = sum_c H[a][c] P[c][i]: thread (a0, i), rows a0, a0 + 256 / W, ...; the order of every sum is that of
+  // k_build_AS
+  const int i = tid % W, a0 = tid / W, astep = kSmallThreads / W;
+  const int gi = cmap(i);
   double pc[7];
 #pragma unroll
-  for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
+  for (int c = 0; c < 7; ++c) pc[c] = (i < n_c) ? ((i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + gi]) : 0.0;
   __syncthreads();
-  if (i < ld - 1) {
+  if (i < W - 1) {
     for (int a = a0; a < kSmallM; a += astep) {
       double acc = 0.0;
-      if (a < m && i < n_used) {
+      if (a < m && i < n_c) {
         const int pos = sPos[a];
 #pragma unroll
         for (int c = 0; c < 7; ++c) acc = __builtin_fma(pc[c], sH[a][c], acc);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) acc = __builtin_fma(Pb[(size_t)(pos + c) * ld + i], sH[a][7 + c], acc);
+        for (int c = 0; c < 3; ++c) acc = __builtin_fma(Pb[(size_t)(pos + c) * ld + gi], sH[a][7 + c], acc);
       }
-      sAt[a * ld + i] = acc;
+      sAt[a * W + i] = acc;
     }
   }
   __syncthreads();
@@ -109,8 +122,8 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
     const int a = e >> 5, bb = e & 31;
     double v = (a == bb) ? 1.0 : 0.0;
     if (a < m && bb < m) {
-      const double* arow = sAt + bb * ld;
-      const int pos = sPos[a];
+      const double* arow = sAt + bb * W;
+      const int pos = sPos[a];                        // (13 + 3 slot < nlive: the compact index of a feature column is the column)
       double acc = 0.0;
 #pragma unroll
       for (int c = 0; c < 7; ++c) acc = __builtin_fma(sH[a][c], arow[c], acc);
@@ -136,50 +149,50 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
     rows[31] = a[31];
   }
   __syncthreads();
-  // ---- V = L^-1 A^T in place: a thread owns column i (the innovation column ld - 1 included), the column in registers;
-  // L^-1[k][p] = sLinv[p][k] (row p of L^-T), zero for p > k
-  if (tid < ld && (tid < n_used || tid == ld - 1)) {
+  // ---- V = L^-1 A^T in place: a thread owns compact column i (the innovation column W - 1 included), the column in
+  // registers; L^-1[k][p] = sLinv[p][k] (row p of L^-T), zero for p > k
+  if (tid < W && (tid < n_c || tid == W - 1)) {
     double col[kSmallM];
 #pragma unroll
-    for (int p = 0; p < kSmallM; ++p) col[p] = sAt[p * ld + tid];
+    for (int p = 0; p < kSmallM; ++p) col[p] = sAt[p * W + tid];
 #pragma unroll
     for (int k = 0; k < kSmallM; ++k) {
       if (k < m) {
         double acc = 0.0;
 #pragma unroll
         for (int p = 0; p <= k; ++p) acc = __builtin_fma(sLinv[p * kLinvPitch + k], col[p], acc);
-        sAt[k * ld + tid] = acc;
+        sAt[k * W + tid] = acc;
       }
     }
   }
   __syncthreads();
   // ---- P -= V^T V (both triangles; the same products in the same order on either side of the diagonal, so mirrored entries
-  // stay equal bit for bit), 4 x 4 outputs per thread; x += V^T w with w = L^-1 nu = column ld - 1 of V
+  // stay equal bit for bit), 4 x 4 outputs per thread; x += V^T w with w = L^-1 nu = the last column of V
   {
-    const int nt = (n_used + 3) >> 2;
+    const int nt = (n_c + 3) >> 2;                    // (4 nt <= W: W is a multiple of four and n_c < W)
     for (int tile = tid; tile < nt * nt; tile += kSmallThreads) {
       const int ti = (tile / nt) * 4, tj = (tile % nt) * 4;
       double acc[4][4];
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q >> 2][q & 3] = 0.0;
       for (int k = 0; k < m; ++k) {
-        const double* vk = sAt + k * ld;
+        const double* vk = sAt + k * W;
         double vi[4], vj[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { vi[q] = vk[ti + q]; vj[q] = vk[tj + q]; }      // (ti + 3, tj + 3 <= ld - 1: reads stay inside the row)
+        for (int q = 0; q < 4; ++q) { vi[q] = vk[ti + q]; vj[q] = vk[tj + q]; }
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[q >> 2][q & 3] = __builtin_fma(vi[q >> 2], vj[q & 3], acc[q >> 2][q & 3]);
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int ii = ti + (q >> 2), jj = tj + (q & 3);
-        if (ii < n_used && jj < n_used) Pb[(size_t)ii * ld + jj] -= acc[q >> 2][q & 3];
+        if (ii < n_c && jj < n_c) Pb[(size_t)cmap(ii) * ld + cmap(jj)] -= acc[q >> 2][q & 3];
       }
     }
-    if (tid < n_used) {
+    if (tid < n_c) {
       double acc = 0.0;
-      for (int k = 0; k < m; ++k) acc = __builtin_fma(sAt[k * ld + tid], sAt[k * ld + ld - 1], acc);
-      xb[tid] += acc;
+      for (int k = 0; k < m; ++k) acc = __builtin_fma(sAt[k * W + tid], sAt[k * W + W - 1], acc);
+      xb[cmap(tid)] += acc;
     }
   }
 }
@@ -195,23 +208,29 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_back(
     double* __restrict__ x, double* __restrict__ P, const double* __restrict__ f_Hx, const double* __restrict__ f_Hy,
     const double* __restrict__ f_R, const int* __restrict__ part_i, int pend, int ld,
     double* __restrict__ traj, int* __restrict__ traj_count, const double* __restrict__ last_r, double* __restrict__ pos_log,
-    int* __restrict__ pos_count, int min_attempts, double match_fraction, int save_trajectory) {
-  extern __shared__ double s_dynd[];                  // phase by phase: [N + 8] ints, [32][ld] doubles, [2 N] ints
+    int* __restrict__ pos_count, int min_attempts, double match_fraction, int save_trajectory, int* __restrict__ slots_max,
+    unsigned long long* __restrict__ slots_mail, int publish) {
+  extern __shared__ double s_dynd[];                  // phase by phase: [N + 8] ints, [32][128] doubles, [2 N] ints
   const int b = blockIdx.x;
   search_score_body(b, srch_res, srch_i, patch, f_h, sel_idx, n_sel, f_flags, f_z, f_nu, attempted, successful, meas_ok, meas_score,
                     work, succ_idx, f_arow, m_count, n_slots, pos_err, pos_err_any, f_hcol, ps_i, kpart, ppos0, N, srch_big, status,
                     (int*)s_dynd);
   __syncthreads();
-  small_update_body(b, x, P, f_Hx, f_Hy, f_nu, f_R, succ_idx, m_count, n_slots, part_i, pend, N, ld, s_dynd);
+  small_update_body(b, x, P, f_Hx, f_Hy, f_nu, f_R, succ_idx, m_count, n_slots, part_i, ppos0, pend, N, ld, status, s_dynd);
   __syncthreads();
   finalize_body(b, x, P, f_flags, n_slots, attempted, successful, m_count, n_sel, traj, traj_count, last_r, status, pos_log,
-                pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, (int*)s_dynd);
+                pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, (int*)s_dynd, slots_max, slots_mail, publish);
 }
 
-// The engine takes the three-launch step when the whole state fits 128 columns, the innovation system one 32 x 32 block and
-// no recorded feature position can be misplaced (Q28 needs two partially initialised features in flight).
-bool small_step_applies(const sl2_engine* e) {
-  return e->root->step_fusion && e->ld <= 128 && (kSmallThreads % e->ld) == 0 && e->mld == kSmallM && e->kpart == 1 && e->N <= kSmallThreads;
+// The engine takes the three-launch step for a sequence group when (static) at most 16 features are measured per frame - the
+// innovation system is one 32 x 32 block -, no recorded feature position can be misplaced (Q28 needs two partially initialised
+// features in flight) and the group is small enough to be latency-bound (at batch 1024 the one-stage kernels, which spread a
+// stage over the whole chip, are 20 % faster: 0.153 against 0.185 ms for the fused stages of the mapping workload); and
+// (dynamic) the LIVE maps fit kSmallW columns: `slots_bound` = the host's upper bound on n_slots of any sequence
+// (sl2_engine.hip: slots_upper_bound - exact at synchronised points, from the device's mailbox in between).
+bool small_step_applies(const sl2_engine* e, int slots_bound) {
+  return e->root->step_fusion && e->mld == kSmallM && e->kpart == 1 && e->B <= 256 &&
+         13 + 3 * slots_bound + 6 * e->kpart + 1 <= kSmallW;
 }
 
 int launch_small_front(sl2_engine* e, int n) {
@@ -228,7 +247,7 @@ int launch_small_front(sl2_engine* e, int n) {
 
 int launch_small_back(sl2_engine* e, int save_trajectory) {
   LaunchScope ls(e, "k_small_back", true);
-  size_t shm = sizeof(double) * kSmallM * e->ld;
+  size_t shm = sizeof(double) * kSmallM * kSmallW;
   const size_t ints = sizeof(int) * (2 * (size_t)e->N + 8);
   if (ints > shm) shm = ints;
   hipLaunchKernelGGL(k_small_back, dim3(e->B), dim3(kSmallThreads), shm, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
@@ -236,7 +255,8 @@ int launch_small_back(sl2_engine* e, int save_trajectory) {
                      e->succ_idx, e->f_arow, e->m_count, e->n_slots, e->pos_err, e->pos_err_any, e->f_hcol, e->ps_i, e->kpart, e->ppos,
                      e->N, e->srch_big, e->status, e->x, e->P, e->f_Hx, e->f_Hy, e->f_R, e->part_i, e->ppos + 6 * e->kpart, e->ld,
                      e->traj, e->traj_count, e->last_r, e->pos_log, e->pos_count, e->prm.minimum_attempted_measurements_of_feature,
-                     e->prm.successful_match_fraction, save_trajectory);
+                     e->prm.successful_match_fraction, save_trajectory, e->root->slots_max_dev, e->root->slots_mail_dev,
+                     e->group_first == 0 ? 1 : 0);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }

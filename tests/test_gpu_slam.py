@@ -897,7 +897,7 @@ def test_split_threshold_changed_between_selection_and_measurement():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_features,n_select,capacity,sigma,groups", [(12, 12, 12, 0.005, 1), (30, 16, 35, 0.004, 1), (4, 4, 8, 0.0, 1),
-                                                                      (12, 10, 14, 0.005, 2)])
+                                                                      (12, 10, 14, 0.005, 2), (10, 10, 128, 0.005, 1), (36, 16, 300, 0.003, 1)])
 def test_small_map_step_in_three_launches_equals_the_ten_launch_step(n_features, n_select, capacity, sigma, groups):
     """sl2_small.hip: engines whose state fits 128 columns and whose innovation system is one 32-row block step in THREE
     launches (k_small_front, the search kernel, k_small_back) - same bodies for everything bit-exact, its own one-block EKF
@@ -905,7 +905,9 @@ def test_small_map_step_in_three_launches_equals_the_ten_launch_step(n_features,
     oracle: every integer output (measured pixels, match flags, selection order, counters, visible count) identical between
     the two engines, state and covariance of each within the file's tolerances of the oracle and within 1e-13 / 1e-12 of
     each other.  Shapes: ld = 64 with every feature measured; ld = 128 with 16 of 30 measured; the shipped scene's four
-    features (block-sparse covariance: AddNewKnownFeature's zeros); two sequence groups."""
+    features (block-sparse covariance: AddNewKnownFeature's zeros); two sequence groups; and small maps inside LARGE capacities
+    (ld = 448 and 960: what decides is the live map, which the host learns from the device's mailbox or at synchronised calls;
+    36 slots = the largest map the fused update takes)."""
     B, F = 3, 14
     pr = Pair(n_features, F, batch=B, n_select=n_select, max_features=capacity, feature_sigma=sigma)
     twin = Engine(pr.cam, pr.params, B, capacity)
@@ -939,3 +941,46 @@ def test_small_map_step_in_three_launches_equals_the_ten_launch_step(n_features,
     names = set(pr.engine.kernel_times())
     assert {"k_small_front", "k_small_back"} <= names and not ({"k_predict", "k_build_AS", "k_syrk", "k_finalize"} & names), names
     assert not pr.engine.status_flags().any() and not twin.status_flags().any()
+
+
+@pytest.mark.gpu
+def test_step_kernels_follow_the_live_map_size():
+    """The host picks the step's kernels from an upper bound on the live map (sl2_engine.hip: slots_upper_bound): a map that
+    outgrows the fused update (more than 36 slots) moves to the one-stage kernels on its own, nothing is lost on the way, and
+    results stay the oracle's.  36 known features step fused; four more are added (sl2_add_known_features reads the exact
+    size); from then on k_syrk & co. run."""
+    pr = Pair(40, 10, batch=2, n_select=16, max_features=64, feature_counts=[40, 40], feature_sigma=0.004, make_engine=False)
+    eng = Engine(pr.cam, pr.params, 2, 64)
+    eng.set_vehicle_state(np.stack([s.xv0 for s in pr.specs]), np.stack([s.Pxx0 for s in pr.specs]))
+    ora = []
+    for b in range(2):
+        o = oa.OracleSLAM(pr.cam, pr.params["delta_t"], 16)
+        o.set_state(pr.specs[b].xv0, pr.specs[b].Pxx0)
+        ora.append(o)
+
+    def add(lo, hi):
+        for b in range(2):
+            eng.add_known_features(pr.specs[b].feat_y[None, lo:hi], np.tile(pr.specs[b].poses[0], (1, hi - lo, 1)), pr.templates[b][None, lo:hi], seq0=b)
+            for i in range(lo, hi):
+                ora[b].add_known_feature(pr.specs[b].feat_y[i], pr.specs[b].poses[0], pr.templates[b][i])
+
+    def step(k):
+        eng.go_one_step(pr.frame_batch(k), False)
+        for b in range(2):
+            ora[b].go_one_step(pr.frames[b][k], False)
+            assert np.abs(eng.total_state(b) - ora[b].total_state()).max() <= TOL_X
+            assert rel_fro(eng.total_covariance(b), ora[b].total_covariance()) <= TOL_P
+            assert [f["successful"] for f in eng.features(b)] == [ora[b].feature(i)["successful"] for i in range(ora[b].num_features)]
+
+    add(0, 36)
+    eng.set_profiling(2)
+    for k in range(4):
+        step(k)
+    t = eng.kernel_times()
+    assert t["k_small_back"]["launches"] == 4 and "k_syrk" not in t, t
+    add(36, 40)
+    for k in range(4, 8):
+        step(k)
+    t = eng.kernel_times()
+    assert t["k_small_back"]["launches"] == 4 and t["k_syrk"]["launches"] == 4 and t["k_finalize"]["launches"] == 4, t
+    assert not eng.status_flags().any()

@@ -202,7 +202,13 @@ int sl2_set_search_variant(sl2_engine* e, int variant);
  * are measured per frame, sl2_go_one_step issues THREE launches instead of ten - predict + measurement prediction + selection,
  * the patch search, scoring + EKF update + normalise / delete / symmetrise (monoslam.cpp:108-180 unchanged in meaning;
  * search results, selection and every counter identical bit for bit, state and covariance equal to rounding).
- * enabled = 1 (default) / 0 = always the one-stage-per-launch kernels.  The seam entry points below always use the latter. */
+ * The choice follows the LIVE maps, not the capacity: the engine keeps an upper bound on the number of feature slots in use
+ * (exact wherever a call synchronises anyway, from a device-to-host mailbox in between; never a synchronisation of its own)
+ * and takes the fused step while 13 + 3 slots + 7 <= 128 and either the batch (per sequence group) is at most 256 sequences
+ * or the capacity is large (state columns >= 256: the one-stage kernels work on the whole capacity, the fused ones on the
+ * live part) - small capacities at large batches are the one case where the one-stage kernels are faster.
+ * enabled = 1 (default) / 0 = always the one-stage-per-launch kernels / 2 = fused whatever the batch size (measurements).
+ * The seam entry points below always use the one-stage kernels. */
 int sl2_set_step_fusion(sl2_engine* e, int enabled);
 /* Search windows of at least `min_bands` bands (a band = 32 x 16 candidate positions; a window of nu x nv positions has
  * ceil(ceil(nu / 16) / 2) * ceil(nv / 16) of them) are not walked by one wavefront but cut into units of four bands that

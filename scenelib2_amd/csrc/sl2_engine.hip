@@ -640,7 +640,7 @@ int sl2_set_search_split(sl2_engine* e, int min_bands) {
 int sl2_set_step_fusion(sl2_engine* e, int enabled) {
   if (!e) return SL2_ERR_INVALID;
   { int rc = drop_step_graphs(e); if (rc != SL2_OK) return rc; }
-  e->step_fusion = enabled ? 1 : 0;
+  e->step_fusion = enabled == 2 ? 2 : (enabled ? 1 : 0);
   return SL2_OK;
 }
 

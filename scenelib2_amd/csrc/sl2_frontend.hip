@@ -11,10 +11,6 @@
 
 namespace sl2 {
 
-#ifdef SL2_FRONT_TRACE
-__device__ long long* g_front_trace = nullptr;
-#endif
-
 __global__ void __launch_bounds__(256) k_predict(double* __restrict__ x, double* __restrict__ P, const int* __restrict__ n_slots,
                                                  double* __restrict__ prev_r, const int* __restrict__ part_i, int pend, int ld,
                                                  double dt) {

@@ -14,7 +14,7 @@
 namespace sl2 {
 
 #ifdef SL2_FRONT_TRACE
-extern __device__ long long* g_front_trace;        // development only: 8 cycle stamps per workgroup and kernel (defined in sl2_frontend.hip)
+static __device__ long long* g_front_trace = nullptr;        // development only: 8 stamps per workgroup and row; one copy per translation unit, each with its own setter
 #define FTR(kern, slot) do { if (g_front_trace && threadIdx.x == 0) g_front_trace[((size_t)(kern) * 4096 + blockIdx.x) * 8 + (slot)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define FTR(kern, slot) do { } while (0)

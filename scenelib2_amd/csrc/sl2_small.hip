@@ -23,6 +23,13 @@
 
 namespace sl2 {
 
+// development only (SL2_FRONT_TRACE build, scripts/small_trace.py): wall-clock stamps (10 ns units) of the fused kernels' phases
+#ifdef SL2_FRONT_TRACE
+#define SST(row, slot) do { if (g_front_trace && threadIdx.x == 0) g_front_trace[((size_t)(row) * 4096 + blockIdx.x) * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+#else
+#define SST(row, slot) do { } while (0)
+#endif
+
 constexpr int kSmallThreads = 256;
 constexpr int kSmallM = 32;          // rows of the innovation system (one Cholesky block)
 
@@ -36,13 +43,17 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_front(
     int* __restrict__ srch_sel, int n_want, int* __restrict__ srch_big, int split_bands) {
   extern __shared__ double s_dyn[];
   const int b = blockIdx.x;
+  SST(2, 0);
   predict_body(b, x, P, n_slots, prev_r, part_i, pend, ld, dt);
   __syncthreads();                                    // x and P of this sequence: written above, read below (same workgroup)
+  SST(2, 1);
   for (int i = threadIdx.x; i < N; i += (int)blockDim.x)
     feature_prediction_body(b, i, x, P, xp_org, f_flags, n_slots, f_h, f_Hx, f_Hy, f_R, f_S, f_score, srch_i, srch_d, cam, N, ld);
   __syncthreads();
+  SST(2, 2);
   select_body(b, f_score, f_flags, n_slots, xp_org, sel_idx, n_sel, n_vis, last_r, srch_i, srch_d, srch_sel, N, n_want, srch_big,
               split_bands, s_dyn);
+  SST(2, 3);
 }
 
 // Kalman::KalmanFilterUpdate (kalman.cpp:72-119) for a system of at most 32 measurement rows; all threads of the workgroup.
@@ -54,6 +65,7 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_front(
 // pose coefficients of dh_by_dxv and the three of dh_by_dy at column 13 + 3 slot (monoslam.cpp:548-572; with one partially
 // initialised feature per sequence - the only case this kernel is launched for - no recorded position is misplaced, Q28).
 constexpr int kSmallW = 128;         // compact columns at most: 13 + 3 * 36 + 6 + 1
+constexpr int kSmallBatchMax = 256;  // sequences per group up to which the fused step is the faster one at ANY capacity (scripts/small_latency.py)
 __device__ __forceinline__ void small_update_body(const int b, double* __restrict__ x, double* __restrict__ P,
                                                   const double* __restrict__ f_Hx, const double* __restrict__ f_Hy,
                                                   const double* __restrict__ f_nu, const double* __restrict__ f_R,
@@ -117,6 +129,7 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
     }
   }
   __syncthreads();
+  SST(4, 0);
   // ---- S = H A + R (rows / columns beyond m: the identity), all 32 x 32 entries
   for (int e = tid; e < kSmallM * kSmallM; e += kSmallThreads) {
     const int a = e >> 5, bb = e & 31;
@@ -135,6 +148,7 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
     sS[a][bb] = v;
   }
   __syncthreads();
+  SST(4, 1);
   // ---- S = L L^T and L^-T by one wavefront: [S; I] -> [L; L^-T], a row per lane (sl2_chol_diag.hpp)
   if (tid < 64) {
     const int r = tid & 31;
@@ -149,32 +163,49 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
     rows[31] = a[31];
   }
   __syncthreads();
+  SST(4, 2);
   // ---- V = L^-1 A^T in place: a thread owns compact column i (the innovation column W - 1 included), the column in
   // registers; L^-1[k][p] = sLinv[p][k] (row p of L^-T), zero for p > k
-  if (tid < W && (tid < n_c || tid == W - 1)) {
-    double col[kSmallM];
+  {
+    // 256 / W threads per column: thread (h, i) forms the rows k = h, h + 256 / W, ... of column i (h is uniform in a wavefront,
+    // so the L^-1 operand of a product stays one broadcast LDS read); the results stay in registers until every thread has
+    // read its copy of the column
+    const int hs = kSmallThreads / W, h = tid / W, ci = tid % W;
+    const bool mine = ci < n_c || ci == W - 1;
+    double col[kSmallM], out[kSmallM / 2];
 #pragma unroll
-    for (int p = 0; p < kSmallM; ++p) col[p] = sAt[p * W + tid];
+    for (int p = 0; p < kSmallM; ++p) col[p] = mine ? sAt[p * W + ci] : 0.0;
 #pragma unroll
     for (int k = 0; k < kSmallM; ++k) {
-      if (k < m) {
+      if (k < m && (k & (hs - 1)) == h) {
         double acc = 0.0;
 #pragma unroll
         for (int p = 0; p <= k; ++p) acc = __builtin_fma(sLinv[p * kLinvPitch + k], col[p], acc);
-        sAt[k * W + tid] = acc;
+        out[k >> 1] = acc;                              // (hs >= 2: the rows k and k ^ 1 never belong to the same thread)
       }
+    }
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int k = 0; k < kSmallM; ++k)
+        if (k < m && (k & (hs - 1)) == h) sAt[k * W + ci] = out[k >> 1];
     }
   }
   __syncthreads();
+  SST(4, 3);
   // ---- P -= V^T V (both triangles; the same products in the same order on either side of the diagonal, so mirrored entries
   // stay equal bit for bit), 4 x 4 outputs per thread; x += V^T w with w = L^-1 nu = the last column of V
   {
     const int nt = (n_c + 3) >> 2;                    // (4 nt <= W: W is a multiple of four and n_c < W)
     for (int tile = tid; tile < nt * nt; tile += kSmallThreads) {
       const int ti = (tile / nt) * 4, tj = (tile % nt) * 4;
-      double acc[4][4];
+      double acc[4][4], pv[4][4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) acc[q >> 2][q & 3] = 0.0;
+      for (int q = 0; q < 16; ++q) {                    // the entries of P first: their round trip runs under the products
+        const int ii = ti + (q >> 2), jj = tj + (q & 3);
+        acc[q >> 2][q & 3] = 0.0;
+        pv[q >> 2][q & 3] = (ii < n_c && jj < n_c) ? Pb[(size_t)cmap(ii) * ld + cmap(jj)] : 0.0;
+      }
       for (int k = 0; k < m; ++k) {
         const double* vk = sAt + k * W;
         double vi[4], vj[4];
@@ -186,13 +217,16 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int ii = ti + (q >> 2), jj = tj + (q & 3);
-        if (ii < n_c && jj < n_c) Pb[(size_t)cmap(ii) * ld + cmap(jj)] -= acc[q >> 2][q & 3];
+        if (ii < n_c && jj < n_c) Pb[(size_t)cmap(ii) * ld + cmap(jj)] = pv[q >> 2][q & 3] - acc[q >> 2][q & 3];
       }
     }
-    if (tid < n_c) {
+    // (the state's increment on the LAST n_c threads: when the tiles leave threads idle - maps of up to ~45 columns - it runs
+    // beside them instead of behind them)
+    const int xi = kSmallThreads - 1 - tid;
+    if (xi < n_c) {
       double acc = 0.0;
-      for (int k = 0; k < m; ++k) acc = __builtin_fma(sAt[k * W + tid], sAt[k * W + W - 1], acc);
-      xb[cmap(tid)] += acc;
+      for (int k = 0; k < m; ++k) acc = __builtin_fma(sAt[k * W + xi], sAt[k * W + W - 1], acc);
+      xb[cmap(xi)] += acc;
     }
   }
 }
@@ -212,24 +246,30 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_back(
     unsigned long long* __restrict__ slots_mail, int publish) {
   extern __shared__ double s_dynd[];                  // phase by phase: [N + 8] ints, [32][128] doubles, [2 N] ints
   const int b = blockIdx.x;
+  SST(3, 0);
   search_score_body(b, srch_res, srch_i, patch, f_h, sel_idx, n_sel, f_flags, f_z, f_nu, attempted, successful, meas_ok, meas_score,
                     work, succ_idx, f_arow, m_count, n_slots, pos_err, pos_err_any, f_hcol, ps_i, kpart, ppos0, N, srch_big, status,
                     (int*)s_dynd);
   __syncthreads();
+  SST(3, 1);
   small_update_body(b, x, P, f_Hx, f_Hy, f_nu, f_R, succ_idx, m_count, n_slots, part_i, ppos0, pend, N, ld, status, s_dynd);
   __syncthreads();
+  SST(3, 2);
   finalize_body(b, x, P, f_flags, n_slots, attempted, successful, m_count, n_sel, traj, traj_count, last_r, status, pos_log,
                 pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, (int*)s_dynd, slots_max, slots_mail, publish);
+  SST(3, 3);
 }
 
 // The engine takes the three-launch step for a sequence group when (static) at most 16 features are measured per frame - the
 // innovation system is one 32 x 32 block -, no recorded feature position can be misplaced (Q28 needs two partially initialised
-// features in flight) and the group is small enough to be latency-bound (at batch 1024 the one-stage kernels, which spread a
-// stage over the whole chip, are 20 % faster: 0.153 against 0.185 ms for the fused stages of the mapping workload); and
+// features in flight) and either the group is small enough to be latency-bound or the capacity is large: the one-stage kernels
+// work on all ld columns of the state, the fused ones on the live ones (scripts/small_latency.py, a dozen features: at capacity
+// 128 - ld = 448 - the fused step is 1.2 x faster at one sequence and 1.8 x at 1024; at capacity 12 - ld = 64 - and batch 1024
+// the one-stage kernels, which spread a stage over the whole chip, are 20 % faster: 0.153 against 0.185 ms); and
 // (dynamic) the LIVE maps fit kSmallW columns: `slots_bound` = the host's upper bound on n_slots of any sequence
 // (sl2_engine.hip: slots_upper_bound - exact at synchronised points, from the device's mailbox in between).
 bool small_step_applies(const sl2_engine* e, int slots_bound) {
-  return e->root->step_fusion && e->mld == kSmallM && e->kpart == 1 && e->B <= 256 &&
+  return e->root->step_fusion && e->mld == kSmallM && e->kpart == 1 && (e->B <= kSmallBatchMax || e->ld >= 256 || e->root->step_fusion == 2) &&
          13 + 3 * slots_bound + 6 * e->kpart + 1 <= kSmallW;
 }
 
@@ -262,3 +302,9 @@ int launch_small_back(sl2_engine* e, int save_trajectory) {
 }
 
 }  // namespace sl2
+
+#ifdef SL2_FRONT_TRACE
+extern "C" int sl2_debug_small_trace(long long* dev_buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(sl2::g_front_trace), &dev_buf, sizeof(dev_buf)) == hipSuccess ? 0 : 2;
+}
+#endif

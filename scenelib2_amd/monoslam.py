@@ -98,7 +98,7 @@ class Engine:
 
     def set_step_fusion(self, enabled=True):
         """Small maps step in three launches (default) / always one stage per launch (sl2_set_step_fusion)."""
-        self._ck(self.L.sl2_set_step_fusion(self.h, int(bool(enabled))))
+        self._ck(self.L.sl2_set_step_fusion(self.h, int(enabled)))
 
     def set_graph_mode(self, enabled=True):
         self._ck(self.L.sl2_set_graph_mode(self.h, int(bool(enabled))))

@@ -151,7 +151,6 @@ struct sl2_engine {
   int chol_variant = 1;       // one-launch Cholesky when it applies (<= 12 blocks): 1 = left-looking (default), 2 = right-looking; 0 = launch-per-block kernels
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
   int build_variant = 1;      // 1 = k_build_AS (A and S in one pass over the measured features' rows of P; the product's only path); TEST build: 2 = k_build_AS_tiles (upper block triangle of P), 0 = k_build_A then k_build_S
-  int fuse_at = 1;            // A^T formed inside the substitution (k_fwdsub_lds<NB, true>; k_build_AS = the S pass only) where that form applies; TEST build: SL2_NO_FUSE_AT stores it as before
   int fwd_variant = 1;        // forward substitution: 1 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory (any size)
   // ---- feature initialisation ----
   int ppos = 0;                          // first column of the partial features' states (13 + 3N); slot k at ppos + 6 k

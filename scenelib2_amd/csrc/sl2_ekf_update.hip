@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
                                                   const int* __restrict__ m_count, double* __restrict__ At,
                                                   double* __restrict__ St, const int* __restrict__ f_hcol,
-                                                  const int* __restrict__ pos_err_any, int N, int ld, int mld, int write_At) {
+                                                  const int* __restrict__ pos_err_any, int N, int ld, int mld) {
   extern __shared__ double sAt[];   // [2 * BATCH][ld]
   const int b = blockIdx.x;
   const int cnt = m_count[b];
@@ -74,11 +74,6 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   // the state columns feature f's dh_by_dy multiplies: its own, 13 + 3 f - unless the sequence carries the reference's
   // misplaced position_in_total_state_vector_ (Q28, feature.cpp:254 / monoslam.cpp:564): then what k_search_score looked up
   const int* hcol = (pos_err_any[b] != 0) ? f_hcol + (size_t)b * N : nullptr;
-  // write_At = 0: the substitution forms its strips of A^T itself, from P (k_fwdsub_lds<NB, true>), and this kernel is the S
-  // pass only - A^T lives in LDS for the eight columns of S it feeds and is never stored (0.59 GB of writes and as many of
-  // reads per launch at batch 1024 x 100 features).  A sequence that carries a misplaced position (Q28) keeps the stored form:
-  // its H is not the plain one the substitution assumes.
-  const bool store_At = write_At != 0 || hcol != nullptr;
   // role "columns i of At"
   double pc[NQ][7];
 #pragma unroll
@@ -131,7 +126,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
 #pragma unroll
               for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
               if (i == ld - 1) acc = f_nu[fi * 2 + r];
-              if (store_At) Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
+              Ab[(size_t)(2 * (j0 + jj) + r) * ld + i] = acc;
               sAt[(2 * jj + r) * ld + i] = acc;
             }
           }
@@ -167,7 +162,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int i = t + q * (int)blockDim.x;
-      if (i < ld && store_At) Ab[(size_t)k * ld + i] = 0.0;
+      if (i < ld) Ab[(size_t)k * ld + i] = 0.0;
     }
     if (t < mp && (t | 31) >= k) Sb[(size_t)k * mld + t] = (t == k) ? 1.0 : 0.0;
   }
@@ -588,26 +583,14 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
 // on three L2-resident operands).
 // ---------------------------------------------------------------------------
 constexpr int kFwdPitch = 48;   // LDS row pitch (doubles): the two k-rows read by a 32-lane group land on disjoint banks
-constexpr int kFwdAPitch = 80;  // the same for a block row of A^T (64 columns) formed in LDS (FUSE)
 
-// FUSE (round 6): A^T is not read, it is FORMED - A^T[a][i] = sum_c H[a][c] P[c][i] has ten non-zeros per row (seven pose
-// columns, three of the feature), so the workgroup builds the 32 rows x 64 columns of block row J + 1 it is about to need
-// from the measured features' rows of P: thread (wave w, lane l) forms column i0 + l of the eight rows of features 4 w ..
-// 4 w + 3 of the block (one feature's three rows of P serve its two rows of H; the coefficients are wave-uniform), parks them
-// in LDS and every wave picks its MFMA fragments up from there - at the point where the stored form prefetches them from
-// memory.  The sums are those of k_build_AS, term by term in the same order: A^T and everything downstream are bit-identical
-// to the stored form (tests/test_gpu_slam.py::test_substitution_that_forms_At_equals_the_stored_form).
-template <int NB, bool FUSE = false>
+template <int NB>
 // (At, Vt and St are NOT __restrict__: the panel solve of the large-system Cholesky calls this kernel in place, with all three
 // on the factor's own storage - every element is read by the lane that later overwrites it, before it does.)
 __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const double* At, double* Vt,
                                                     const double* St, const double* __restrict__ LinvT,
                                                     const int* __restrict__ m_count, int ld, int mld, int nblk_max, int B,
-                                                    int J0, int col0, int ntile, int nb_cap,
-                                                    const double* __restrict__ P = nullptr, const double* __restrict__ f_Hx = nullptr,
-                                                    const double* __restrict__ f_Hy = nullptr, const double* __restrict__ f_nu = nullptr,
-                                                    const int* __restrict__ succ_idx = nullptr, const int* __restrict__ pos_err_any = nullptr,
-                                                    int N = 0) {
+                                                    int J0, int col0, int ntile, int nb_cap) {
   // J0: first block row of this launch.  For maps of more than 13 blocks the substitution runs in groups of
   // NB = 8 block rows: k_fwd_gemm first subtracts the contribution of all earlier groups from the group's
   // rows of At, then this kernel solves within the group (block indices below are relative to J0).
@@ -643,58 +626,10 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
   v4d V[NB][2];
   v4d at[2];
   const bool half0 = (16 >= m);
-  // FUSE: a sequence with a misplaced recorded position (Q28) has its A^T in memory (k_build_AS stored it) and takes the plain path
-  __shared__ double sA[FUSE ? 32 * kFwdAPitch : 1];
-  const bool formed = FUSE && pos_err_any[b] == 0;
-  // block row Jn of A^T, columns ct * 64 .. + 63, into sA (all four waves; the caller places the barriers)
-  auto form_block = [&](int Jn) {
-    const double* Pb = P + (size_t)b * ld * ld;
-    const int i = col0 + ct * 64 + lane;
-    double pc[7];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) pc[c] = (i < 13) ? Pb[(size_t)i * ld + c] : Pb[(size_t)c * ld + i];
-#pragma unroll 1
-    for (int q = 0; q < 4; ++q) {                       // (rolled: four copies of the body in every block row's code pushed the register allocation into spills)
-      const int j = Jn * 16 + wave * 4 + q;             // rank of the feature among the frame's successes (rows 2 j, 2 j + 1)
-      double v0 = 0.0, v1 = 0.0;
-      if (j < cnt) {
-        const int f = succ_idx[(size_t)b * N + j];
-        const size_t fi = (size_t)b * N + f;
-        const int pos = 13 + 3 * f;
-        double py[3];
+  for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) py[c] = Pb[(size_t)(pos + c) * ld + i];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          double acc = 0.0;
-#pragma unroll
-          for (int c = 0; c < 7; ++c) acc += pc[c] * f_Hx[fi * 14 + r * 7 + c];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) acc += py[c] * f_Hy[fi * 6 + r * 3 + c];
-          if (i == ld - 1) acc = f_nu[fi * 2 + r];
-          if (r == 0) v0 = acc; else v1 = acc;
-        }
-      }
-      sA[(wave * 8 + 2 * q) * kFwdAPitch + lane] = v0;
-      sA[(wave * 8 + 2 * q + 1) * kFwdAPitch + lane] = v1;
-    }
-  };
-  auto frag_from_lds = [&](bool halfn) {
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) at[jt][r] = (jt == 1 && halfn) ? 0.0 : sA[(16 * jt + hi + 4 * r) * kFwdAPitch + wave * 16 + lo];
-  };
-  if (formed) {
-    form_block(0);
-    __syncthreads();
-    frag_from_lds(half0);
-  } else {
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) at[jt][r] = (jt == 1 && half0) ? 0.0 : Ab[(size_t)(16 * jt + hi + 4 * r) * ld + i0 + lo];
-  }
+    for (int r = 0; r < 4; ++r) at[jt][r] = (jt == 1 && half0) ? 0.0 : Ab[(size_t)(16 * jt + hi + 4 * r) * ld + i0 + lo];
   int t = 0;   // running tile counter (buffer parity)
 #pragma unroll
   for (int J = 0; J < NB; ++J) {
@@ -704,13 +639,6 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
       acc[0] = (v4d){0, 0, 0, 0};
       acc[1] = (v4d){0, 0, 0, 0};
       v4d rhs[2];
-      // FUSE: the NEXT block row of A^T is formed here - behind a barrier, because a slower wave may still be picking the
-      // current row's fragments out of sA (the diagonal step of the row before), and in front of the first tile's barrier,
-      // behind which the diagonal step of this row reads it back
-      if (FUSE && formed && J + 1 < nblk && J + 1 < NB) {
-        __syncthreads();
-        form_block(J + 1);
-      }
 #pragma unroll
       for (int K = 0; K <= J; ++K) {
         double* buf = sL[t & 1];
@@ -719,7 +647,6 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
         // next tile of the stream (uniform control flow: nblk is per sequence = per workgroup)
         if (K < J) pre = *(const double4*)SL2_TILE_PTR(J, K + 1);
         else if (J + 1 < nblk && J + 1 < NB) pre = *(const double4*)SL2_TILE_PTR(J + 1, 0);
-
         const double* pa = buf + hi * kFwdPitch + lo;
         if (K < J) {
 #pragma unroll
@@ -734,15 +661,11 @@ __global__ void __launch_bounds__(256, (NB <= 8 ? 3 : 2)) k_fwdsub_lds(const dou
           for (int jt = 0; jt < 2; ++jt) rhs[jt] = at[jt] - acc[jt];
           if (J + 1 < nblk && J + 1 < NB) {   // prefetch the next block row of At under the diagonal product
             const bool halfn = ((J + 1) * 32 + 16 >= m);
-            if (FUSE && formed) {
-              frag_from_lds(halfn);            // (formed at the top of this block row, behind at least one barrier by now)
-            } else {
 #pragma unroll
-              for (int jt = 0; jt < 2; ++jt)
+            for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  at[jt][r] = (jt == 1 && halfn) ? 0.0 : Ab[(size_t)((J + 1) * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo];
-            }
+              for (int r = 0; r < 4; ++r)
+                at[jt][r] = (jt == 1 && halfn) ? 0.0 : Ab[(size_t)((J + 1) * 32 + 16 * jt + hi + 4 * r) * ld + i0 + lo];
           }
           v4d out[2];
           out[0] = (v4d){0, 0, 0, 0};
@@ -887,19 +810,10 @@ __global__ void __launch_bounds__(256) k_fwdsub_ksplit(const double* __restrict_
   }
 }
 
-// Whether the update runs with A^T formed inside the substitution (k_build_AS = the S pass only): the one-launch substitution
-// of a batch large enough for it, the production kernels (the TEST build's switches and superseded variants read A^T from memory).
-static bool fwdsub_takes_ksplit(const sl2_engine* e, int B) {
-  return e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !e->root->no_ksplit;
-}
-static bool update_forms_At(const sl2_engine* e, int B) {
-  return e->root->fuse_at && !fwdsub_takes_ksplit(e, B) && e->nblk_max <= e->root->group_from && e->nblk_max <= 13;
-}
-
-static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done, bool fuse_at) {
+static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done) {
   *done = true;
   // small batches: the chain-shortening kernel (one 16-column strip per workgroup, products dealt to its four waves)
-  if (fwdsub_takes_ksplit(e, B)) {
+  if (e->nblk_max <= kKsMaxBlocks && (long long)B * (e->ld / 16) <= 160 && !e->root->no_ksplit) {
     LaunchScope ls(e, "k_fwdsub_ksplit", true);
     hipLaunchKernelGGL(k_fwdsub_ksplit, dim3(xcd_grid(e->ld / 16, B)), dim3(256), 0, e->stream, e->At, e->Vt, e->St, e->LinvT,
                        e->m_count, e->ld, e->mld, e->nblk_max, B);
@@ -911,13 +825,8 @@ static int launch_fwdsub_lds(sl2_engine* e, int B, bool* done, bool fuse_at) {
   LaunchScope ls(e, "k_fwdsub_lds", true);
 #define SL2_FWD_CASE(NBV)                                                                                           \
   case NBV:                                                                                                         \
-    if (fuse_at)                                                                                                    \
-      hipLaunchKernelGGL((k_fwdsub_lds<NBV, true>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
-                         e->ld, e->mld, e->nblk_max, B, 0, 0, e->ld / 64, NBV, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->succ_idx,  \
-                         e->pos_err_any, e->N);                                                                     \
-    else                                                                                                            \
-      hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
-                         e->ld, e->mld, e->nblk_max, B, 0, 0, e->ld / 64, NBV);                                     \
+    hipLaunchKernelGGL((k_fwdsub_lds<NBV>), grid, block, 0, e->stream, e->At, e->Vt, e->St, e->LinvT, e->m_count, \
+                       e->ld, e->mld, e->nblk_max, B, 0, 0, e->ld / 64, NBV);                                       \
     break;
   switch (e->nblk_max) {
     SL2_FWD_CASE(1) SL2_FWD_CASE(2) SL2_FWD_CASE(3) SL2_FWD_CASE(4) SL2_FWD_CASE(5) SL2_FWD_CASE(6) SL2_FWD_CASE(7)
@@ -1379,10 +1288,8 @@ static int launch_update_range(sl2_engine* e) {
   const int B = e->B;     // (succ_idx / m_count, the successful measurements in slot order, come from k_search_score)
 #ifdef SL2_TESTING
   const int build_variant = e->root->build_variant, chol_variant = e->root->chol_variant, fwd_variant = e->root->fwd_variant;
-  const bool fuse_at = build_variant == 1 && fwd_variant == 1 && update_forms_At(e, B);
 #else
   const int chol_variant = 1, fwd_variant = 1;
-  const bool fuse_at = update_forms_At(e, B);
 #endif
 #ifdef SL2_TESTING
   if (build_variant == 3) {
@@ -1435,18 +1342,18 @@ static int launch_update_range(sl2_engine* e) {
     if (build_variant == 4 && e->ld <= 1024) {
       const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch, true>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld, fuse_at ? 0 : 1);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     } else
 #endif
     if (e->ld <= 1024) {
       size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       if ((size_t)e->root->build_lds_min > shm) shm = (size_t)e->root->build_lds_min;
       hipLaunchKernelGGL((k_build_AS<1, kASBatch>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld, fuse_at ? 0 : 1);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     } else {
       const size_t shm = sizeof(double) * 2 * 2 * e->ld;      // <= 64 KB
       hipLaunchKernelGGL((k_build_AS<2, 2>), dim3(B, nsplit), dim3(1024), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld, fuse_at ? 0 : 1);
+                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
     }
     SL2_HIP(hipGetLastError());
   }
@@ -1498,7 +1405,7 @@ static int launch_update_range(sl2_engine* e) {
   {
     bool done = false;
     if (fwd_variant == 1) {
-      int rc = launch_fwdsub_lds(e, B, &done, fuse_at);
+      int rc = launch_fwdsub_lds(e, B, &done);
       if (rc != SL2_OK) return rc;
       // the grouped form works on 64-row tiles: it needs mld to be a multiple of 64 (sl2_create pads systems of more
       // than 13 blocks to 64, of more than 16 to 128)

@@ -410,7 +410,6 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   // library never reads the environment - there the kernel variants are chosen through sl2_set_search_variant /
   // sl2_set_update_variant / sl2_set_groups only.
   if (const char* v = getenv("SL2_FWD_VARIANT")) e->fwd_variant = atoi(v);
-  if (getenv("SL2_NO_FUSE_AT")) e->fuse_at = 0;
   if (const char* v = getenv("SL2_CHOL_VARIANT")) e->chol_variant = atoi(v);
   if (const char* v = getenv("SL2_BUILD_VARIANT")) e->build_variant = atoi(v);
   if (const char* v = getenv("SL2_SEARCH_VARIANT")) e->search_variant = atoi(v);

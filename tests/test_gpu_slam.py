@@ -984,41 +984,3 @@ def test_step_kernels_follow_the_live_map_size():
     t = eng.kernel_times()
     assert t["k_small_back"]["launches"] == 4 and t["k_syrk"]["launches"] == 4 and t["k_finalize"]["launches"] == 4, t
     assert not eng.status_flags().any()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("n_features,batch", [(100, 12), (37, 20), (200, 9)])
-def test_substitution_that_forms_At_equals_the_stored_form(n_features, batch, monkeypatch):
-    """Round 6: at batches large enough for the one-launch substitution, A^T = (P H^T)^T is no longer stored by k_build_AS and
-    read back - k_fwdsub_lds<NB, true> forms each block row of its 64-column strip from the measured features' rows of P, with
-    the sums of k_build_AS term by term - and k_build_AS is the S pass only.  Same bits: the TEST build with SL2_NO_FUSE_AT
-    (A^T stored, as before) and the default must leave IDENTICAL states and covariances, frame after frame, ragged maps and a
-    retired slot included; both equal the oracle to the file's tolerances."""
-    from scenelib2_amd import _lib
-    lib = _lib.load_testing()
-    counts = [n_features - (3 * b) % 11 for b in range(batch)]
-    pr = Pair(n_features, 5, batch=batch, feature_counts=counts, feature_sigma=0.004, lib=lib)
-    monkeypatch.setenv("SL2_NO_FUSE_AT", "1")
-    stored = Engine(pr.cam, pr.params, batch, n_features, lib=lib)
-    monkeypatch.delenv("SL2_NO_FUSE_AT", raising=False)
-    stored.set_vehicle_state(np.stack([s.xv0 for s in pr.specs]), np.stack([s.Pxx0 for s in pr.specs]))
-    for b in range(batch):
-        nf = counts[b]
-        stored.add_known_features(pr.specs[b].feat_y[None], np.tile(pr.specs[b].poses[0], (1, nf, 1)), pr.templates[b][None], seq0=b)
-        stored.set_feature_covariances(np.tile(np.eye(3) * 0.004 ** 2, (1, nf, 1, 1)), seq0=b)
-    pr.engine.set_profiling(2)
-    stored.set_profiling(2)
-    for k in range(5):
-        if k == 2:
-            for b in range(batch):
-                pr.oracles[b].delete_feature(5)
-            dead = np.full(batch, 5, dtype=np.int32)
-            pr.engine.delete_features(dead)
-            stored.delete_features(dead)
-        pr.step_both(k, threads=8)
-        stored.go_one_step(pr.frame_batch(k), False)
-        pr.compare_state(TOL_X, TOL_P if n_features <= 100 else TOL_P_LARGE)
-        for b in range(batch):
-            assert np.array_equal(pr.engine.total_state(b), stored.total_state(b)), (k, b)
-            assert np.array_equal(pr.engine.total_covariance(b), stored.total_covariance(b)), (k, b)
-    assert "k_fwdsub_lds" in pr.engine.kernel_times() and "k_fwdsub_lds" in stored.kernel_times()

@@ -18,10 +18,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # kernel name fragment -> (file, extra flags, max total registers (arch + accumulator), wavefronts per SIMD that buys,
 #                         scalar registers the compiler may park in vector lanes)
 BUDGET = {
-    "k_syrkEPKd": ("sl2_ekf_update.hip", ["-ffp-contract=fast", "-mllvm", "-pragma-unroll-threshold=200000"], 128, 4, 0),
-    "k_fwdsub_ldsILi7ELb0E": ("sl2_ekf_update.hip", ["-ffp-contract=fast", "-mllvm", "-pragma-unroll-threshold=200000"], 168, 3, 0),
-    "k_chol_left": ("sl2_ekf_update.hip", ["-ffp-contract=fast", "-mllvm", "-pragma-unroll-threshold=200000"], 128, 4, 0),
-    "k_build_ASILi1ELi4E": ("sl2_ekf_update.hip", ["-ffp-contract=fast", "-mllvm", "-pragma-unroll-threshold=200000"], 80, 6, 0),
+    "k_syrkEPKd": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 128, 4, 0),
+    "k_fwdsub_ldsILi7E": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 168, 3, 0),
+    "k_chol_left": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 128, 4, 0),
+    "k_build_ASILi1ELi4E": ("sl2_ekf_update.hip", ["-ffp-contract=fast"], 80, 6, 0),
     # (scalar spills: eleven in the workgroups that own positions - the records of two positions in flight - and nineteen more
     # on the path of the trailing workgroups that work off the large windows' units, which the others never enter; 39 in all
     # with the near-units exact walk on that path; round 5: 41 with the row coordinates of the ellipse test as floats)

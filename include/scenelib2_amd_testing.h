@@ -16,6 +16,12 @@ extern "C" {
  * in front of delete_bad_features without ten frames of failed matches.  Synchronises. */
 int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, int successful);
 
+/* The error of a feature's recorded position_in_total_state_vector_ (how far it lies below the true one: a multiple of three,
+ * what feature.cpp:254 - Q28 - accumulates over conversions), written directly.  Lets a test drive the dh_by_dy block of H into
+ * the vehicle state (monoslam.cpp:562-565: it OVERWRITES dh_by_dxv there) and below column 0
+ * (SL2_STATUS_REFERENCE_OUT_OF_BOUNDS) without the dozen conversions that would take.  Synchronises. */
+int sl2_debug_set_position_error(sl2_engine* e, int seq, int label, int err);
+
 /* FP64 epilogue of correlate2_warning (improc.cpp:99-133) evaluated ON THE DEVICE
  * for `count` tuples of the five integer sums: checks IEEE div/sqrt parity. */
 int sl2_debug_ncc_score(int device, const int32_t* sums5, int count, double* score, double* sd0, double* sd1);

@@ -250,6 +250,12 @@ void orc_set_feature_counters(void* h, int idx, int attempted, int successful) {
   f->attempted = attempted; f->successful = successful;
 }
 
+// test hook: Feature::position_in_total_state_vector_ written directly - what feature.cpp:254 (Q28) does to it over several
+// conversions, without running them (tests/test_gpu_slam.py: the dh_by_dy block landing inside the vehicle state)
+void orc_set_feature_position(void* h, int idx, int pos) {
+  ((MonoSLAM*)h)->feature_list[idx]->position_in_total_state_vector = pos;
+}
+
 // MonoSLAM::InitialiseFeature at (uu_, vv_) = (u, v) (monoslam.cpp:1211-1235: what the "initialise manual feature" button of
 // examples/MonoSlamSceneLib1.cpp:191-192 calls after a mouse click set uu_ / vv_) and InitialiseAutoFeature (:1535-1541)
 void orc_initialise_feature(void* h, const uint8_t* frame, int u, int v) {

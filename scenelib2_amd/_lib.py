@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "sl2_dev_download",
 ]
 # test hooks and micro-benchmarks (include/scenelib2_amd_testing.h): exported by libscenelib2_amd_test.so ONLY
-TEST_SYMBOLS = ["sl2_set_feature_counters", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench"]
+TEST_SYMBOLS = ["sl2_set_feature_counters", "sl2_debug_set_position_error", "sl2_debug_ncc_score", "sl2_debug_gemm_kt", "sl2_debug_microbench"]
 TEST_LIB_PATH = os.path.join(_HERE, "libscenelib2_amd_test.so")
 _testlib = None
 
@@ -204,6 +204,7 @@ def load_testing():
         raise ImportError("scenelib2_amd: %s not built (make -C scenelib2_amd/csrc)" % TEST_LIB_PATH)
     T = _bind(C.CDLL(TEST_LIB_PATH))
     T.sl2_set_feature_counters.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    T.sl2_debug_set_position_error.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     T.sl2_debug_ncc_score.argtypes = [C.c_int, c_ip, C.c_int, c_dp, c_dp, c_dp]
     T.sl2_debug_gemm_kt.argtypes = [C.c_int, c_dp, C.c_int, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, c_dp, C.c_int]
     T.sl2_debug_microbench.argtypes = [C.c_int, C.c_int, c_dp]

@@ -1163,6 +1163,19 @@ int sl2_set_feature_counters(sl2_engine* e, int seq, int label, int attempted, i
   SL2_HIP(hipMemcpy(e->successful + (size_t)seq * e->N + slot, &successful, sizeof(int), hipMemcpyHostToDevice));
   return SL2_OK;
 }
+// How far the RECORDED position_in_total_state_vector_ of a feature lies below its true one (Q28, feature.cpp:254), written
+// directly: several conversions' worth of error without running them.
+int sl2_debug_set_position_error(sl2_engine* e, int seq, int label, int err) {
+  if (!range_ok(e, seq, 1) || label < 0 || err < 0 || err % 3) return SL2_ERR_INVALID;
+  SL2_HIP(hipSetDevice(e->device));
+  int slot = -1;
+  { int _rc = slot_of_label(e, seq, label, &slot); if (_rc != SL2_OK) return _rc; }
+  if (slot < 0) return SL2_ERR_INVALID;
+  const int one = 1;
+  SL2_HIP(hipMemcpy(e->pos_err + (size_t)seq * e->N + slot, &err, sizeof(int), hipMemcpyHostToDevice));
+  if (err) SL2_HIP(hipMemcpy(e->pos_err_any + seq, &one, sizeof(int), hipMemcpyHostToDevice));
+  return SL2_OK;
+}
 #endif  // SL2_TESTING
 
 // mark_feature_by_lab + delete_feature for one feature per sequence (monoslam.cpp:743-812): the slot is retired

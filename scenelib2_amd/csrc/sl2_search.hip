@@ -502,29 +502,12 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
     // into - not for inline asm - so whether the scoring read finished accumulators used to depend on what the scheduler
     // happened to place in between (round 5: passing PuInv by pointer moved the first v_mad_i32_i24 up against the last MFMA
     // and the engine's searches came back one pixel off).  The wait states are spelled out: 16 cover an 8-pass result.
-    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accX), "+v"(acc1), "+v"(accH), "+v"(accL));
-#if defined(SL2_PROBE_DUP) && (SL2_PROBE_DUP & 1)        // timing probe (results unchanged): operand reads + matrix-core work twice
-    {
-      mf_v4i dX = zero, d1 = zero, dH = zero, dL = zero;
-      int z0 = 0; asm volatile("" : "+v"(z0));              // (an offset the compiler cannot see through: the reads are not merged)
-      const char* ap2 = ap + z0;
-      const unsigned* bp2 = bp + z0;
-#pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const mf_v4i aI = *(const mf_v4i*)(ap2 + 32 * p);
-        const mf_v4i aH = *(const mf_v4i*)(ap2 + 32 * p + kM4Plane);
-        const mf_v4i aL = *(const mf_v4i*)(ap2 + 32 * p + 2 * kM4Plane);
-        const mf_v4i bX = mf_load_b4(bp2, p);
-        const mf_v4i bo = (p == 5) ? b_ones_last : b_ones;
-        dX = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bX, dX, 0, 0, 0);
-        d1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(aI, bo, p ? d1 : kq.c_s1, 0, 0, 0);
-        dH = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, bo, dH, 0, 0, 0);
-        dL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, bo, p ? dL : kq.c_s2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) { accX[reg] += dX[reg] - accX[reg]; acc1[reg] += d1[reg] - acc1[reg]; accH[reg] += dH[reg] - accH[reg]; accL[reg] += dL[reg] - accL[reg]; }
-    }
+    // The count belongs to THIS instruction on THIS target - v_mfma_i32_16x16x64_i8 is 8 passes on gfx950 - and to nothing else:
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the MFMA -> inline-asm wait states below (2 x s_nop 7) are counted for v_mfma_i32_16x16x64_i8 on gfx950 only"
 #endif
+    static_assert(sizeof(mf_v4i) == 16, "accumulators of a 16x16 i32 MFMA: four dwords per lane (the 8-pass shape the wait states are for)");
+    asm volatile("s_nop 7\n\ts_nop 7" : "+v"(accX), "+v"(acc1), "+v"(accH), "+v"(accL));
     // Ranking value q = Nc / sqrt(D1) = rho * sqrt(D0) (D0 = 121 sum g0^2 - (sum g0)^2 is the same for every candidate of
     // a search, so it is left out: one multiply less per candidate; the callers scale the guard band by sqrt(D0) instead).
     // A candidate whose image sigma is EXACTLY 10 (D1 == 1464100) is ranked like a valid one; whether the reference skips
@@ -546,28 +529,6 @@ __device__ __forceinline__ void m4_band_tiles(const char* s_pl, const unsigned* 
       st.best_w = m4_sel(better, S2, st.best_w);
       st.best_x = m4_sel(better, accX[reg], st.best_x);
     }
-#if defined(SL2_PROBE_DUP) && (SL2_PROBE_DUP & 2)        // timing probe (results unchanged): the scoring a second time
-    {
-      M4State s2; s2.reset();
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        int S1 = acc1[reg]; asm volatile("" : "+v"(S1));
-        const int S2 = (accH[reg] << 8) + accL[reg];
-        const int D1 = mul24(121, S2) - mul24(S1, S1);
-        const int Nc = m4_mad24(S1, k.kS, m4_mad24(accX[reg], k.c121, k.c_nc));
-        const float q = (float)Nc * __builtin_amdgcn_rsqf((float)D1);
-        const float qq = m4_self(m_cand[reg] & m4_lt_i32(1464099, D1), q, -3.0e38f);
-        const m4_mask better = m4_gt_f32(qq, s2.best_q);
-        s2.second_q = __builtin_amdgcn_fmed3f(s2.best_q, s2.second_q, qq);
-        s2.best_q = m4_self(better, qq, s2.best_q);
-        s2.best_ks = m4_sel(better, S1 + m4_sadd(ks0, reg << 15), s2.best_ks);
-        s2.best_w = m4_sel(better, S2, s2.best_w);
-        s2.best_x = m4_sel(better, accX[reg], s2.best_x);
-      }
-      // (folded in so that it is not dead: nothing changes when both passes agree, which they do)
-      if (s2.best_q > 3.0e38f) { st.best_ks ^= s2.best_ks; st.best_w ^= s2.best_w ^ s2.best_x; st.second_q = s2.second_q; }
-    }
-#endif
   }
 }
 
@@ -1125,6 +1086,8 @@ int launch_search_kernel(sl2_engine* e) {
       // Whether k_select listed windows was decided at SELECT time (its split threshold); the list itself says so here:
       // the trailing workgroups read its length and end when it is empty.  (Deciding again from search_split at this point
       // let sl2_set_search_split(0) between the split-phase calls leave marked windows unsearched.)
+      // (build_groups always allocates the list, so the helpers are always dispatched: 128 .. kSearchBigWaves single-wave
+      // workgroups that read one word and exit when k_select listed nothing - sl2_set_search_split(0) included; ~1 us at batch 1)
       const bool shared = e->srch_big != nullptr;
       // trailing workgroups for the large windows' units: a quarter of the launch, 128 to kSearchBigWaves (a single sequence
       // should not pay for dispatching two thousand empty wavefronts; its frame-sized window is 38 units)

@@ -257,6 +257,11 @@ class Engine:
         T = _lib.load_testing()
         _lib.check(T.sl2_set_feature_counters(self.h, seq, label, attempted, successful), T)
 
+    def debug_set_position_error(self, seq, label, err):
+        # test hook (TEST build only): Q28's error of the recorded position_in_total_state_vector_, written directly
+        T = _lib.load_testing()
+        _lib.check(T.sl2_debug_set_position_error(self.h, seq, label, err), T)
+
     def delete_features(self, labels, seq0=0):
         """mark_feature_by_lab + delete_feature, one label per sequence (-1: none); returns the per-sequence bool."""
         lab = np.ascontiguousarray(labels, dtype=np.int32)

@@ -64,6 +64,7 @@ def _declare(L):
     L.orc_delete_feature.argtypes = [C.c_void_p, C.c_int]
     L.orc_set_feature_Pyy.argtypes = [C.c_void_p, C.c_int, c_dp]
     L.orc_set_feature_counters.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.orc_set_feature_position.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.orc_correlate2_warning.restype = C.c_double
     L.orc_correlate2_warning.argtypes = [C.c_int] * 6 + [c_u8p, C.c_int, c_u8p, C.c_int, c_dp, c_dp]
     L.orc_elliptical_search.restype = C.c_int
@@ -267,6 +268,10 @@ class OracleSLAM:
 
     def set_feature_counters(self, idx, attempted, successful):
         self.L.orc_set_feature_counters(self.h, idx, attempted, successful)
+
+    def set_feature_position(self, idx, pos):
+        """position_in_total_state_vector_ of feature idx, as recorded (Q28 test hook)."""
+        self.L.orc_set_feature_position(self.h, idx, int(pos))
 
     # MonoSLAM::InitialiseFeature at (uu_, vv_) = (u, v) / InitialiseAutoFeature (monoslam.cpp:1211-1235, 1535-1541)
     def initialise_feature(self, frame, u, v):

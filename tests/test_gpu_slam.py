@@ -984,3 +984,35 @@ def test_step_kernels_follow_the_live_map_size():
     t = eng.kernel_times()
     assert t["k_small_back"]["launches"] == 4 and t["k_syrk"]["launches"] == 4 and t["k_finalize"]["launches"] == 4, t
     assert not eng.status_flags().any()
+
+
+@pytest.mark.gpu
+def test_q28_block_inside_the_vehicle_state_and_below_column_zero():
+    """Q28 (feature.cpp:254) lets a feature's recorded position_in_total_state_vector_ drift below its true one by three per
+    conversion that happens in front of it; monoslam.cpp:562-565 then writes dh_by_dxv at column 0 and dh_by_dy at the recorded
+    position, so that a position below 13 OVERWRITES pose coefficients.  Forced here through the test hooks (a dozen
+    conversions' worth of error written directly, on both sides): blocks landing at columns 10, 7, 4 and 1 against the
+    oracle's set_block overwrite; then one below column 0, where the reference writes out of bounds - the engine holds the
+    column at 0 and raises SL2_STATUS_REFERENCE_OUT_OF_BOUNDS for that sequence only."""
+    N = 24
+    pr = Pair(N, 6, batch=2, feature_sigma=0.004)
+    pr.step_both(0)
+    pr.compare_state(TOL_X, TOL_P)
+    for slot, hc in ((2, 10), (3, 7), (4, 4), (5, 1)):
+        err = 13 + 3 * slot - hc
+        pr.engine.debug_set_position_error(0, slot, err)
+        pr.oracles[0].set_feature_position(slot, hc)
+    for k in range(1, 4):
+        pr.step_both(k)
+        feats = pr.engine.features(0)
+        assert [feats[s]["pos"] for s in (2, 3, 4, 5)] == [10, 7, 4, 1]
+        assert sum(1 for s in (2, 3, 4, 5) if feats[s]["selected"] and feats[s]["success"]) >= 3, "the misplaced blocks were never measured"
+        pr.compare_state(TOL_X, TOL_P)
+    assert not pr.engine.status_flags().any()
+    # below column 0: t = slot - err / 3 <= -5  <=>  13 + 3 t < 0
+    pr.engine.debug_set_position_error(1, 1, 18 + 3)                  # slot 1: t = 1 - 7 = -6
+    pr.engine.go_one_step(pr.frame_batch(4), False)
+    st = pr.engine.status_flags()
+    assert st[1] & 4 and not (st[0] & 4)
+    xe, Pe = pr.engine.get_vehicle_state()
+    assert np.isfinite(xe).all() and np.isfinite(Pe).all()

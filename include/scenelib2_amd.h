@@ -220,13 +220,13 @@ int sl2_set_step_fusion(sl2_engine* e, int enabled);
  * changed; sl2_get_step_work has a 13th value.) */
 int sl2_set_search_split(sl2_engine* e, int min_bands);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):
- * chol_variant 1 = one-launch left-looking Cholesky (k_chol_left; default), 2 = one-launch right-looking (k_chol_fused4),
- *              0 = three launches per block column;
+ * chol_variant 1 = one-launch left-looking Cholesky (k_chol_left; default), 0 = three launches per block column;
  * fwd_variant  1 = forward substitution with L streamed through LDS and the solved rows in registers (k_fwdsub_lds;
  *              default), 0 = operands re-read from memory (k_fwdsub).
- * Only the defaults (1, 1) are compiled into this library; the superseded variants live in the TEST build
+ * Only the defaults (1, 1) are compiled into this library; the alternatives live in the TEST build
  * (libscenelib2_amd_test.so, include/scenelib2_amd_testing.h), where this call selects them - here anything else
- * returns SL2_ERR_INVALID.  Systems of more than 16 blocks are factored panel-wise (k_chol_left + k_fwdsub_lds +
+ * returns SL2_ERR_INVALID.  (chol_variant 2, the right-looking one-launch kernel of rounds 1-2, was retired in round 6 and is
+ * SL2_ERR_INVALID everywhere.)  Systems of more than 16 blocks are factored panel-wise (k_chol_left + k_fwdsub_lds +
  * k_chol_syrk per 256 columns) and systems of more than 13 blocks substituted in groups of eight block rows (k_fwd_gemm +
  * k_fwdsub_lds) either way. */
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant);

@@ -148,9 +148,9 @@ struct sl2_engine {
   double* pos_log = nullptr;  // [B][kTrajCapacity][3] xv[0:3] after every step (the true trajectory, cf. Q12)
   int* pos_count = nullptr;   // [B] steps logged so far (device-side, so that a captured step needs no per-step argument)
   long long steps_done = 0;
-  int chol_variant = 1;       // one-launch Cholesky when it applies (<= 12 blocks): 1 = left-looking (default), 2 = right-looking; 0 = launch-per-block kernels
+  int chol_variant = 1;       // 1 = one-launch left-looking Cholesky (k_chol_left; the product's only path); TEST build: 0 = launch-per-block kernels
   void* chol_trace = nullptr; // development only (SL2_CHOL_TRACE builds): per-wave cycle stamps of k_chol_fused4
-  int build_variant = 1;      // 1 = k_build_AS (A and S in one pass over the measured features' rows of P; the product's only path); TEST build: 2 = k_build_AS_tiles (upper block triangle of P), 0 = k_build_A then k_build_S
+  int build_variant = 1;      // 1 = k_build_AS (A and S in one pass over the measured features' rows of P; the product's only path); TEST build: 0 = k_build_A then k_build_S
   int fwd_variant = 1;        // forward substitution: 1 = L through LDS + solved rows in registers (<= 8 blocks, default), 0 = operands re-read from memory (any size)
   // ---- feature initialisation ----
   int ppos = 0;                          // first column of the partial features' states (13 + 3N); slot k at ppos + 6 k

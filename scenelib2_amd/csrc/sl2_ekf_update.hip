@@ -52,9 +52,7 @@ constexpr int kASBatch = 4;   // features per LDS batch (state sizes up to 1024 
 
 // NQ: columns per thread (thread t owns columns t, t + 1024, ...: NQ = 1 for ld <= 1024, 2 up to 2048 - the 1280x720 /
 // 500-feature configuration, ld = 1536); BATCH: features per LDS batch (2 * BATCH * ld doubles of LDS).
-// UP (probe, TEST build: SL2_BUILD_VARIANT=4): entries of P in strictly lower 64x64 tiles are read through their mirrors -
-// a thread walks ITS OWN row of P to the right (the condition is wave-uniform: a wave's 64 columns lie in one tile column).
-template <int NQ, int BATCH, bool UP = false>
+template <int NQ, int BATCH>
 __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P, const double* __restrict__ f_Hx,
                                                   const double* __restrict__ f_Hy, const double* __restrict__ f_nu,
                                                   const double* __restrict__ f_R, const int* __restrict__ succ_idx,
@@ -117,7 +115,7 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
             double py[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-              py[c] = (UP && ((pos + c) >> 6) > (i >> 6)) ? Pb[(size_t)i * ld + pos + c] : Pb[(size_t)(pos + c) * ld + i];
+              py[c] = Pb[(size_t)(pos + c) * ld + i];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
               double acc = 0.0;
@@ -168,11 +166,6 @@ __global__ void __launch_bounds__(1024) k_build_AS(const double* __restrict__ P,
   }
 }
 
-#ifdef SL2_TESTING   // section 2 of sl2_ekf_update_testing.inc
-#define SL2_EKF_TEST_SECTION 2
-#include "sl2_ekf_update_testing.inc"
-#undef SL2_EKF_TEST_SECTION
-#endif  // SL2_TESTING
 
 // ---------------------------------------------------------------------------
 // k_build_S: S = H A + R, stored St[c][r] = S[r][c] (32x32 blocks on and below the block
@@ -236,28 +229,11 @@ __device__ __forceinline__ double fast_rsqrt(double p) {
 #undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
-#ifdef SL2_TESTING
-constexpr int kFusedMaxBlocks = 16;   // k_chol_fused4 (TEST build) is used up to this many 32-blocks
-#endif
 
 // ---------------------------------------------------------------------------
-// k_chol_fused4: the whole blocked Cholesky of one sequence in ONE launch (used when the number
-// of 32-blocks is small enough that the launch-per-block version is latency-bound), by a FOUR-wave
-// workgroup: wave 0 = D factors + inverts the 32x32 diagonal blocks in registers, waves 1..3 =
-// M0..M2 do every MFMA tile (panel solves, trailing updates), spread over three SIMDs.
-// (The first fused version had one D and one M wave and a two-pass diagonal routine: 0.50 ms per
-// launch at batch 1024 against 0.28 ms for this one.)
-//   * D interleaves the factor step c with step c of the inversion (row c of L^-1 is
-//     final as soon as column c of L is): every broadcast scalar is used exactly once,
-//     so nothing is kept in SGPRs across the block (the two-pass version re-used the
-//     496 broadcast values in its inversion pass and the compiler spilled them).
-//   * between A_J (L_JJ^-1 ready) and B_J (next diagonal tile ready) M0 solves panel
-//     tile (J+1,J) and, from those registers, updates tile (J+1,J+1); M1/M2 solve the
-//     other panel tiles of column J meanwhile, so B_J is also "column J complete";
-//   * after B_J the trailing tiles are dealt round-robin to the three M waves while D
-//     factors block J+1.
+// 32 x 32 tile helpers of the one-launch Cholesky (k_chol_left below) and its panel kernels.  (The RIGHT-looking one-launch
+// kernel of rounds 1-2, k_chol_fused4, is profiles/r06_retired_variants.patch.)
 // ---------------------------------------------------------------------------
-
 struct Tile32 {
   v4d f[2][2];   // f[kt][it][r] = element (k = 16 kt + 4 r + hi, i = 16 it + lo) of a k-major 32x32 tile
 };
@@ -349,11 +325,6 @@ __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int
   tile_store(Sb, mld, K * 32, I * 32, lo, hi, acc);
 }
 
-#ifdef SL2_TESTING   // section 7 of sl2_ekf_update_testing.inc: superseded variant: TEST build only (sl2_set_update_variant)
-#define SL2_EKF_TEST_SECTION 7
-#include "sl2_ekf_update_testing.inc"
-#undef SL2_EKF_TEST_SECTION
-#endif  // SL2_TESTING
 
 #undef TR
 
@@ -457,7 +428,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
   for (int J = 0; J < nblk; ++J) {
     const int o = J * 32;
     int lane_j = lane;
-    asm volatile("" : "+v"(lane_j));      // see k_chol_fused4
+    asm volatile("" : "+v"(lane_j));      // (a copy the compiler cannot hoist: as a loop-carried value of the J loop it cost six spilled registers, round 2)
     const int lo = lane_j & 15, hi = lane_j >> 4;
     const bool more = J + 1 < nblk;
     TRL(0);
@@ -1271,15 +1242,6 @@ __global__ void __launch_bounds__(256, 4) k_syrk(const double* __restrict__ Vt, 
 #undef SL2_EKF_TEST_SECTION
 #endif  // SL2_TESTING
 
-#ifdef SL2_TESTING
-// tiles a workgroup of k_build_AS_tiles walks (SL2_BUILD_SPLIT >> 8 overrides; its low byte is the probes' skip mask), and the
-// resulting workgroups per sequence
-static int bt_tiles_per_wg(const sl2_engine* e) { return (e->root->build_split >> 8) > 0 ? (e->root->build_split >> 8) : 1; }
-static int bt_groups(const sl2_engine* e) {
-  const int nt = e->ld / 64, ntile = nt * (nt + 1) / 2, k = bt_tiles_per_wg(e);
-  return (ntile + k - 1) / k;
-}
-#endif
 
 // Profiling scopes carry the SYMBOL of the kernel they bracket (so that the bench's per-kernel times and rocprofv3's
 // kernel_stats.csv join on the name); "@phase" tells two uses of one kernel apart (k_fwdsub_lds is also the panel solve of
@@ -1292,25 +1254,7 @@ static int launch_update_range(sl2_engine* e) {
   const int chol_variant = 1, fwd_variant = 1;
 #endif
 #ifdef SL2_TESTING
-  if (build_variant == 3) {
-    // timing probe: the tile kernel as a SHADOW launch (its A^T goes to Vt, which the substitution overwrites anyway, its S to
-    // a scratch buffer), so that phases of it can be switched off (SL2_BUILD_SPLIT = skip mask) without touching the filter
-    static double* s_scratch = nullptr;
-    static size_t s_scratch_n = 0;
-    const size_t need = (size_t)e->root->B * e->mld * e->mld;
-    if (s_scratch_n < need) { if (s_scratch) (void)hipFree(s_scratch); SL2_HIP(hipMalloc((void**)&s_scratch, sizeof(double) * need)); s_scratch_n = need; }
-    LaunchScope ls(e, "k_build_AS_tiles", true);
-    hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
-                       e->f_nu, e->f_R, e->f_arow, e->m_count, e->Vt, s_scratch, e->N, e->ld, e->mld, B, e->root->build_split & 255, bt_tiles_per_wg(e));
-    SL2_HIP(hipGetLastError());
-  }
-  if (build_variant == 2) {
-    // A^T and S from the upper block triangle of P: one workgroup per 64 x 64 tile (measured slower: see the kernel)
-    LaunchScope ls(e, "k_build_AS_tiles", true);
-    hipLaunchKernelGGL((bt_tiles_per_wg(e) > 1 ? k_build_AS_tiles<true> : k_build_AS_tiles<false>), dim3(xcd_grid(bt_groups(e), B)), dim3(kBtThreads), 0, e->stream, e->P, e->f_Hx, e->f_Hy,
-                       e->f_nu, e->f_R, e->f_arow, e->m_count, e->At, e->St, e->N, e->ld, e->mld, B, 0, bt_tiles_per_wg(e));
-    SL2_HIP(hipGetLastError());
-  } else if (build_variant == 0) {
+  if (build_variant == 0) {
     {
       LaunchScope ls(e, "k_build_A", true);
       const int threads = e->ld <= 512 ? e->ld : 512;
@@ -1334,17 +1278,10 @@ static int launch_update_range(sl2_engine* e) {
     // of it - k_search_score - to consist of single-wave workgroups, see launch_search).  Smaller batches: ~3000 workgroups
     // in all, so that the chip is full and a sequence's 25 feature batches are not one chain.
     int nsplit = B >= 1024 ? 1 : (3072 + B - 1) / B;
-    if (e->root->build_split > 0 && e->root->build_variant != 3) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
+    if (e->root->build_split > 0) nsplit = e->root->build_split;        // experiments (TEST build: SL2_BUILD_SPLIT)
     if (nsplit < 1) nsplit = 1;
     const int nbatch_max = (e->N + kASBatch - 1) / kASBatch;
     if (nsplit > nbatch_max) nsplit = nbatch_max;
-#ifdef SL2_TESTING
-    if (build_variant == 4 && e->ld <= 1024) {
-      const size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
-      hipLaunchKernelGGL((k_build_AS<1, kASBatch, true>), dim3(B, nsplit), dim3(e->ld), shm, e->stream, e->P, e->f_Hx, e->f_Hy, e->f_nu, e->f_R,
-                         e->succ_idx, e->m_count, e->At, e->St, e->f_hcol, e->pos_err_any, e->N, e->ld, e->mld);
-    } else
-#endif
     if (e->ld <= 1024) {
       size_t shm = sizeof(double) * 2 * kASBatch * e->ld;
       if ((size_t)e->root->build_lds_min > shm) shm = (size_t)e->root->build_lds_min;
@@ -1358,7 +1295,7 @@ static int launch_update_range(sl2_engine* e) {
     SL2_HIP(hipGetLastError());
   }
   // sl2_create sizes the innovation system so that one of the first two branches always applies (mld a multiple of 128
-  // beyond kFusedMaxBlocks blocks)
+  // beyond 16 blocks)
   if (e->nblk_max > e->root->panel_from && chol_variant >= 1 && e->mld % 64 == 0 && e->nblk_max % kCholPanelBlocks == 0) {
     int rc = launch_chol_panels(e, B);
     if (rc != SL2_OK) return rc;
@@ -1369,12 +1306,7 @@ static int launch_update_range(sl2_engine* e) {
     SL2_HIP(hipGetLastError());
   } else {
 #ifdef SL2_TESTING
-    if (e->nblk_max <= kFusedMaxBlocks && chol_variant == 2) {
-      LaunchScope ls(e, "k_chol_fused4", true);
-      hipLaunchKernelGGL(k_chol_fused4, dim3(B), dim3(256), 0, e->stream, e->St, e->LinvT, e->m_count, e->mld, e->nblk_max,
-                         (long long*)e->root->chol_trace);
-      SL2_HIP(hipGetLastError());
-    } else {
+    {
       for (int J = 0; J < e->nblk_max; ++J) {
         {
           LaunchScope ls(e, "k_chol_diag");

@@ -660,7 +660,7 @@ int sl2_debug_chol_trace(sl2_engine* e, long long* out, size_t n) {
 #endif
 
 int sl2_set_update_variant(sl2_engine* e, int chol_variant, int fwd_variant) {
-  if (!e || chol_variant < 0 || chol_variant > 2 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
+  if (!e || chol_variant < 0 || chol_variant > 1 || fwd_variant < 0 || fwd_variant > 1) return SL2_ERR_INVALID;
 #ifndef SL2_TESTING
   if (chol_variant != 1 || fwd_variant != 1) {
     set_error("sl2_set_update_variant: the superseded kernel variants are compiled into the TEST build of the library only "

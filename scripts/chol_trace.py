@@ -1,4 +1,4 @@
-"""Development aid: per-wave cycle stamps inside k_chol_fused4 (needs the SL2_CHOL_TRACE build:
+"""Development aid: per-wave cycle stamps inside k_chol_left (needs the SL2_CHOL_TRACE build:
    make -C scenelib2_amd/csrc trace ; SL2_LIB_PATH=scenelib2_amd/libscenelib2_amd_trace.so python scripts/chol_trace.py)."""
 import ctypes as C
 import os

@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
     ap.add_argument("--search-split", type=int, default=-1,
                     help="bands from which a search window is shared out over wavefronts (sl2_set_search_split; -1: engine default, 0: never)")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="skip the host-fed leg (frames starting in pinned host memory, copied under the previous step): an extra "
+                         "block of the line, measured after the timed region on an engine of its own; never `value`")
     ap.add_argument("--mapping", action="store_true",
                     help="the reference's DEFAULT workload instead of the headline: --features known features (use 6-12), the shipped "
                          "parameters (select 10, keep 12 visible, 100 depth particles), a camera that translates past the 0.2 m/s "
@@ -565,6 +568,24 @@ def main():
                 parity["full_length"]["final_state_maxabs"] = dx
                 parity["full_length"]["final_covariance_rel_fro"] = dP
 
+        # ---- host-fed leg: the same shape with the frames starting in pinned HOST memory, the copy of frame
+        # k + 1 under the step on frame k - what a grabber-fed caller gets.  Outside the timed region, on an engine of its own;
+        # the headline stays device-resident.
+        host_fed = None
+        if world == 1 and not args.mapping and not args.no_host_fed:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                import pcie_inclusive
+                hf = pcie_inclusive.host_fed(B, N, W, H, steps=min(K, 20), warm=min(Wm, 5), ring=4)
+                host_fed = dict(frames_per_s=hf["overlapped_frames_per_s"], ms_per_step=hf["overlapped_ms_per_step"],
+                                serial_copy_ms_per_step=hf["serial_ms_per_step"], resident_ms_per_step_same_harness=hf["resident_ms_per_step"],
+                                h2d_GBps=hf["h2d_GBps"], copy_ms_per_step=hf["copy_ms_per_step"], overlap_efficiency=hf["overlap_efficiency"],
+                                link_ceiling_frames_per_s=hf["link_ceiling_frames_per_s"], link_bound=hf["link_bound"],
+                                note="frames in pinned host memory, copy stream + two device buffers, the copy of frame k + 1 under the step "
+                                     "on frame k; measured after the timed region; never `value`")
+            except Exception as ex:                       # (no torch streams on this box, out of memory ...): the line still goes out
+                host_fed = dict(error=repr(ex))
+
         out = {
             "metric": "batched MonoSLAM frames/sec (320x240, 100 feat)" if not args.mapping else
                       "batched MonoSLAM frames/sec (%dx%d, mapping on, %d known features: the reference's default workload)" % (W, H, N),
@@ -582,7 +603,7 @@ def main():
             # roofline = the dominant kernel of the step; roofline_search = the NCC search kernel the north star names
             # (HBM roofline + its VALU-issue roofline); the same object is repeated under roofline["search"]
             "roofline": (dict(roof, search=roof_search) if roof is not None and roof_search is not None and roof is not roof_search else roof),
-            "roofline_search": roof_search, "cpu_baseline": cpu, "parity": parity if parity is not None else rank_parity,
+            "roofline_search": roof_search, "cpu_baseline": cpu, "host_fed": host_fed, "parity": parity if parity is not None else rank_parity,
             "kernels": per_kernel,
             "work_per_step": {k: v for k, v in work.items()},
             "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,

@@ -490,7 +490,8 @@ __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ 
     // first sequence group, when it finalizes step t, publishes the COMPLETE maximum of step t - 1 (every finalize of that
     // step has ended: stream order) to pinned host memory as (t << 32 | max) and clears that slot for step t + 1.
     if (slots_max) {
-      atomicMax(&slots_max[pre_pc & 1], ns);
+      // (a plain read first: the maps of a batch are mostly the same size, and 1024 atomics on one word were 8 us of this kernel)
+      if (ns > __hip_atomic_load(&slots_max[pre_pc & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&slots_max[pre_pc & 1], ns);
       if (publish && b == 0) {
         const int prev = __hip_atomic_load(&slots_max[(pre_pc + 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&slots_max[(pre_pc + 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -18,11 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scenelib2_amd import Engine, _lib, synth  # noqa: E402
 
 
-def main():
-    B = int(os.environ.get("PCIE_B", "1024"))
-    N, W, H = 100, 320, 240
-    steps, warm, ring = 20, 5, 8
-    dev = 0
+def host_fed(B=1024, N=100, W=320, H=240, steps=20, warm=5, ring=8, dev=0):
+    """The three rates (frames resident / host frames copied on the engine's stream / host frames copied under the step before)
+    and the link by itself, for one shape.  Imported by bench.py for the `host_fed` block of its line."""
     torch.cuda.set_device(dev)
     cam = synth.default_camera(W, H)
     params = synth.default_params(N)
@@ -50,7 +48,7 @@ def main():
         return eng
 
     host = torch.from_numpy(all_frames[1:]).pin_memory()          # ring of `ring` frames, pinned
-    out = {"batch": B, "bytes_per_step": B * fb, "steps": steps}
+    out = {"batch": B, "features": N, "width": W, "height": H, "bytes_per_step": B * fb, "steps": steps}
 
     # (0) resident frames, for reference (the bench's timed region)
     eng = make_engine()
@@ -110,7 +108,25 @@ def main():
     out["h2d_GBps"] = 10 * B * fb / (e0.elapsed_time(e1) * 1e-3) / 1e9
     for key in ("resident", "serial", "overlapped"):
         out[key + "_frames_per_s"] = B / (out[key + "_ms_per_step"] * 1e-3)
-    print(json.dumps(out))
+    out["copy_ms_per_step"] = B * fb / (out["h2d_GBps"] * 1e9) * 1e3
+    out["overlap_efficiency"] = out["resident_ms_per_step"] / out["overlapped_ms_per_step"]     # 1 = the copy is entirely hidden
+    # what the host link alone allows, whatever the kernels do (one GPU's link; the GPUs of a node each have their own x16)
+    out["link_ceiling_frames_per_s"] = out["h2d_GBps"] * 1e9 / fb
+    out["link_bound"] = bool(out["copy_ms_per_step"] > out["resident_ms_per_step"])
+    return out
+
+
+def main():
+    shapes = {"configs2": (int(os.environ.get("PCIE_B", "1024")), 100, 320, 240, 20, 5), "configs3": (1024, 200, 640, 480, 8, 3)}
+    which = sys.argv[1:] or ["configs2"]
+    res = {}
+    for name in which:
+        B, N, W, H, steps, warm = shapes[name]
+        res[name] = host_fed(B, N, W, H, steps, warm, ring=8 if name == "configs2" else 4)
+        print(name, json.dumps(res[name]), flush=True)
+    out_path = os.environ.get("PCIE_OUT")
+    if out_path:
+        json.dump(res, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":

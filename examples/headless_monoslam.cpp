@@ -7,41 +7,7 @@
 // scene.cfg uses the keys of the reference's data/SceneLib2.cfg ("name = value;", '#' comments): cam.*, params.*,
 // state.* (rw_*, qwr_*, vw_*, ww_*, pxxR_C), fK.yi_*, fK.xp_org_J, fK.identifier (an 11x11 binary PGM, looked up
 // beside the cfg).  Keys that are absent read as 0, like pangolin::Var<T>(key, 0).
-#include <scenelib2_amd.h>
-
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <fstream>
-#include <map>
-#include <string>
-#include <vector>
-
-static std::map<std::string, std::string> parse_vars(const std::string& path) {
-  std::map<std::string, std::string> kv;
-  std::ifstream in(path);
-  std::string line;
-  while (std::getline(in, line)) {
-    const size_t hash = line.find('#');
-    if (hash != std::string::npos) line.erase(hash);
-    const size_t eq = line.find('=');
-    if (eq == std::string::npos) continue;
-    auto trim = [](std::string s) {
-      const char* ws = " \t\r\n;";
-      const size_t a = s.find_first_not_of(ws);
-      if (a == std::string::npos) return std::string();
-      const size_t b = s.find_last_not_of(ws);
-      return s.substr(a, b - a + 1);
-    };
-    kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
-  }
-  return kv;
-}
-
-static double num(const std::map<std::string, std::string>& kv, const std::string& k, double dflt = 0.0) {
-  auto it = kv.find(k);
-  return it == kv.end() ? dflt : atof(it->second.c_str());
-}
+#include "scene_cfg.hpp"
 
 #define CHECK(call)                                                                        \
   do {                                                                                     \
@@ -62,58 +28,18 @@ int main(int argc, char** argv) {
     else { fprintf(stderr, "usage: %s --cfg scene.cfg --frames dir [--mapping] [--steps N] [--dump file]\n", argv[0]); return 2; }
   }
   if (cfg.empty() || frames_dir.empty()) { fprintf(stderr, "need --cfg and --frames\n"); return 2; }
-  const auto kv = parse_vars(cfg);
-  const std::string base = cfg.find('/') == std::string::npos ? "." : cfg.substr(0, cfg.rfind('/'));
-
   // MonoSLAM::Init (monoslam.cpp:1574-1969): camera, constants, xv_, Pxx_, known features
-  sl2_camera cam;
-  cam.width = (int)num(kv, "cam.width"); cam.height = (int)num(kv, "cam.height");
-  cam.fku = (int)num(kv, "cam.fku"); cam.fkv = (int)num(kv, "cam.fkv");          // read as Var<int> (monoslam.cpp:1597-1602)
-  cam.u0 = (int)num(kv, "cam.u0"); cam.v0 = (int)num(kv, "cam.v0");
-  cam.kd1 = num(kv, "cam.kd1"); cam.sd = (int)num(kv, "cam.sd");
-  sl2_params prm;
-  memset(&prm, 0, sizeof(prm));
-  prm.delta_t = num(kv, "params.delta_t");
-  prm.number_of_features_to_select = (int)num(kv, "params.number_of_features_to_select");
-  prm.number_of_features_to_keep_visible = (int)num(kv, "params.number_of_features_to_keep_visible");
-  prm.max_features_to_init_at_once = (int)num(kv, "params.max_features_to_init_at_once");
-  prm.min_lambda = num(kv, "params.min_lambda"); prm.max_lambda = num(kv, "params.max_lambda");
-  prm.number_of_particles = (int)num(kv, "params.number_of_particles");
-  prm.standard_deviation_depth_ratio = num(kv, "params.standard_deviation_depth_ratio");
-  prm.min_number_of_particles = (int)num(kv, "params.min_number_of_particles");
-  prm.prune_probability_threshold = num(kv, "params.prune_probability_threshold");
-  prm.erase_partially_init_feature_after_this_many_attempts = (int)num(kv, "params.erase_partially_init_feature_after_this_many_attempts");
-  prm.minimum_attempted_measurements_of_feature = 10;   // monoslam.cpp:1875-1876
-  prm.successful_match_fraction = 0.5;
-
+  Scene sc;
+  if (int rc = load_scene(cfg, sc)) return rc;
+  const sl2_camera& cam = sc.cam;
   if (sl2_device_count() < 1) { fprintf(stderr, "no HIP device: this engine has no CPU path\n"); return 3; }
   sl2_engine* eng = nullptr;
   const int max_features = 128;
-  CHECK(sl2_create(&cam, &prm, 1, max_features, 0, nullptr, &eng));
-
-  double xv[13] = {num(kv, "state.rw_x"), num(kv, "state.rw_y"), num(kv, "state.rw_z"),
-                   num(kv, "state.qwr_w"), num(kv, "state.qwr_x"), num(kv, "state.qwr_y"), num(kv, "state.qwr_z"),
-                   num(kv, "state.vw_x"), num(kv, "state.vw_y"), num(kv, "state.vw_z"),
-                   num(kv, "state.ww_x"), num(kv, "state.ww_y"), num(kv, "state.ww_z")};
-  double Pxx[169];
-  for (int r = 0; r < 13; ++r)
-    for (int c = 0; c < 13; ++c) Pxx[r * 13 + c] = num(kv, "state.pxx" + std::to_string(r) + "_" + std::to_string(c));
-  CHECK(sl2_set_vehicle_state(eng, 0, 1, xv, Pxx));
-  int n_known = 0;
-  for (int k = 1; kv.count("f" + std::to_string(k) + ".yi_x"); ++k) {      // AddNewKnownFeature, monoslam.cpp:1941-1957
-    const std::string p = "f" + std::to_string(k) + ".";
-    const double y[3] = {num(kv, p + "yi_x"), num(kv, p + "yi_y"), num(kv, p + "yi_z")};
-    double xp[7];
-    for (int j = 0; j < 7; ++j) xp[j] = num(kv, p + "xp_org_" + std::to_string(j));
-    uint8_t patch[121];
-    int w = 0, h = 0;
-    auto it = kv.find(p + "identifier");
-    const std::string ident = base + "/" + (it == kv.end() ? std::string("empty") : it->second);
-    CHECK(sl2_read_pgm(ident.c_str(), patch, sizeof(patch), &w, &h));
-    if (w != 11 || h != 11) { fprintf(stderr, "%s is not an 11x11 template\n", ident.c_str()); return 4; }
-    CHECK(sl2_add_known_features(eng, 0, 1, 1, y, xp, patch));
-    ++n_known;
-  }
+  CHECK(sl2_create(&sc.cam, &sc.prm, 1, max_features, 0, nullptr, &eng));
+  CHECK(sl2_set_vehicle_state(eng, 0, 1, sc.xv, sc.Pxx));
+  const int n_known = sc.n_known;
+  for (int k = 0; k < n_known; ++k)
+    CHECK(sl2_add_known_features(eng, 0, 1, 1, &sc.y[3 * k], &sc.xp[7 * k], &sc.patches[121 * k]));
 
   // FrameGrabber / FileGrabber
   const char* dirs[1] = {frames_dir.c_str()};

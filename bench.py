@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--groups", type=int, default=0, help="sequence groups / HIP streams per engine (0: engine default)")
     ap.add_argument("--search-split", type=int, default=-1,
                     help="bands from which a search window is shared out over wavefronts (sl2_set_search_split; -1: engine default, 0: never)")
+    ap.add_argument("--step-fusion", type=int, default=-1,
+                    help="sl2_set_step_fusion: 0 = one stage per launch, 1 = the engine's rule (default), 2 = fused small-map step whatever the batch size")
     ap.add_argument("--no-host-fed", action="store_true",
                     help="skip the host-fed leg (frames starting in pinned host memory, copied under the previous step): an extra "
                          "block of the line, measured after the timed region on an engine of its own; never `value`")
@@ -280,6 +282,8 @@ def main():
         eng.set_search_split(args.search_split)
     if args.groups > 0:
         eng.set_groups(args.groups)
+    if args.step_fusion >= 0:
+        eng.set_step_fusion(args.step_fusion)
     if args.graph:
         eng.set_graph_mode(True)
     eng.set_vehicle_state(np.stack([s.xv0 for s in specs]), np.stack([s.Pxx0 for s in specs]))

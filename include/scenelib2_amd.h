@@ -206,7 +206,7 @@ int sl2_set_search_variant(sl2_engine* e, int variant);
  * (exact wherever a call synchronises anyway, from a device-to-host mailbox in between; never a synchronisation of its own)
  * and takes the fused step while 13 + 3 slots + 7 <= 128 and either the batch (per sequence group) is at most 256 sequences
  * or the capacity is large (state columns >= 256: the one-stage kernels work on the whole capacity, the fused ones on the
- * live part) - small capacities at large batches are the one case where the one-stage kernels are faster.
+ * live part); small capacities at large batches fuse the stages behind the search only (six launches).
  * enabled = 1 (default) / 0 = always the one-stage-per-launch kernels / 2 = fused whatever the batch size (measurements).
  * The seam entry points below always use the one-stage kernels. */
 int sl2_set_step_fusion(sl2_engine* e, int enabled);

@@ -301,9 +301,9 @@ int launch_select(sl2_engine* e, int n);
 int launch_search(sl2_engine* e);            // the search kernel, then k_search_score
 int launch_search_kernel(sl2_engine* e);     // the search kernel alone (the fused small-map step scores in k_small_back)
 int launch_search_score(sl2_engine* e);
-bool small_step_applies(const sl2_engine* e, int slots_bound);   // sl2_small.hip
+int small_step_mode(const sl2_engine* e, int slots_bound);       // sl2_small.hip: 0 = ten launches, 1 = three (both sides of the search fused), 2 = the back side only
 int launch_small_front(sl2_engine* e, int n);                 // predict + feature prediction + selection in one launch
-int launch_small_back(sl2_engine* e, int save_trajectory);    // scoring + EKF update + normalise / delete / symmetrise in one launch
+int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound);   // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory);

@@ -804,14 +804,22 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
   const int slots_bound = slots_upper_bound(e);
-  const bool small_any = [&]() { for (const sl2_engine* g : e->groups) if (small_step_applies(g, slots_bound)) return true; return false; }();
+  const int small_any = [&]() { int m = 0; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (part of a captured step's key)
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
-      if (small_step_applies(g, slots_bound)) {       // small maps: three launches (sl2_small.hip)
+      const int mode = small_step_mode(g, slots_bound);
+      if (mode == 1) {                   // small maps: three launches (sl2_small.hip)
         if ((q = launch_small_front(g, nsel)) != SL2_OK) return q;
         if ((q = launch_search_kernel(g)) != SL2_OK) return q;
-        return launch_small_back(g, tail ? 0 : save_trajectory);
+        return launch_small_back(g, tail ? 0 : save_trajectory, slots_bound);
+      }
+      if (mode == 2) {                   // small maps, large batch, small capacity: the back side only
+        if ((q = launch_predict(g)) != SL2_OK) return q;
+        if ((q = launch_feature_prediction(g)) != SL2_OK) return q;
+        if ((q = launch_select(g, nsel)) != SL2_OK) return q;
+        if ((q = launch_search_kernel(g)) != SL2_OK) return q;
+        return launch_small_back(g, tail ? 0 : save_trajectory, slots_bound);
       }
       if ((q = launch_predict(g)) != SL2_OK) return q;
       if ((q = launch_feature_prediction(g)) != SL2_OK) return q;

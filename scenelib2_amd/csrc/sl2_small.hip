@@ -260,17 +260,20 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_back(
   SST(3, 3);
 }
 
-// The engine takes the three-launch step for a sequence group when (static) at most 16 features are measured per frame - the
-// innovation system is one 32 x 32 block -, no recorded feature position can be misplaced (Q28 needs two partially initialised
-// features in flight) and either the group is small enough to be latency-bound or the capacity is large: the one-stage kernels
-// work on all ld columns of the state, the fused ones on the live ones (scripts/small_latency.py, a dozen features: at capacity
-// 128 - ld = 448 - the fused step is 1.2 x faster at one sequence and 1.8 x at 1024; at capacity 12 - ld = 64 - and batch 1024
-// the one-stage kernels, which spread a stage over the whole chip, are 20 % faster: 0.153 against 0.185 ms); and
-// (dynamic) the LIVE maps fit kSmallW columns: `slots_bound` = the host's upper bound on n_slots of any sequence
-// (sl2_engine.hip: slots_upper_bound - exact at synchronised points, from the device's mailbox in between).
-bool small_step_applies(const sl2_engine* e, int slots_bound) {
-  return e->root->step_fusion && e->mld == kSmallM && e->kpart == 1 && (e->B <= kSmallBatchMax || e->ld >= 256 || e->root->step_fusion == 2) &&
-         13 + 3 * slots_bound + 6 * e->kpart + 1 <= kSmallW;
+// Which stages of a sequence group's step are fused: 0 = none (ten launches), 1 = both sides of the search (three launches),
+// 2 = the back side only (scoring + update + finalize in one launch, the front-end stages on their own: six launches).
+// Static conditions: at most 16 features measured per frame - the innovation system is one 32 x 32 block - and no recorded
+// feature position can be misplaced (Q28 needs two partially initialised features in flight).  Dynamic: the LIVE maps fit
+// kSmallW columns - `slots_bound` = the host's upper bound on n_slots of any sequence (sl2_engine.hip: slots_upper_bound, exact
+// at synchronised points, from the device's mailbox in between).  Then: everything fused when the group is small enough to be
+// latency-bound or the capacity is large (the one-stage kernels work on all ld columns, the fused ones on the live ones:
+// scripts/small_latency.py, a dozen features at capacity 128 - ld = 448 - fused is 1.2 x faster at one sequence and 1.8 x at
+// 1024); at a small capacity and a large batch only the back side, which holds its own there (0.107 against 0.118 ms for the six
+// stages it replaces at 1024 sequences, ld = 128) - k_small_front does not (0.065 against 0.038 ms: 304 registers, one workgroup
+// per CU).
+int small_step_mode(const sl2_engine* e, int slots_bound) {
+  if (!e->root->step_fusion || e->mld != kSmallM || e->kpart != 1 || 13 + 3 * slots_bound + 6 * e->kpart + 1 > kSmallW) return 0;
+  return (e->B <= kSmallBatchMax || e->ld >= 256 || e->root->step_fusion == 2) ? 1 : 2;
 }
 
 int launch_small_front(sl2_engine* e, int n) {
@@ -285,9 +288,11 @@ int launch_small_front(sl2_engine* e, int n) {
   return SL2_OK;
 }
 
-int launch_small_back(sl2_engine* e, int save_trajectory) {
+int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound) {
   LaunchScope ls(e, "k_small_back", true);
-  size_t shm = sizeof(double) * kSmallM * kSmallW;
+  // the LDS panel is [32][W], W = 64 while every live map of the group fits it (the kernel picks W from the sequence's own size,
+  // which the bound bounds): a third workgroup per CU at large batches
+  size_t shm = sizeof(double) * kSmallM * ((13 + 3 * slots_bound + 6 * e->kpart + 1 <= 64) ? 64 : kSmallW);
   const size_t ints = sizeof(int) * (2 * (size_t)e->N + 8);
   if (ints > shm) shm = ints;
   hipLaunchKernelGGL(k_small_back, dim3(e->B), dim3(kSmallThreads), shm, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,

@@ -1015,3 +1015,41 @@ def test_q28_block_inside_the_vehicle_state_and_below_column_zero():
     assert st[1] & 4 and not (st[0] & 4)
     xe, Pe = pr.engine.get_vehicle_state()
     assert np.isfinite(xe).all() and np.isfinite(Pe).all()
+
+
+@pytest.mark.gpu
+def test_large_batch_of_small_maps_fuses_the_back_side_only():
+    """More than 256 sequences at a small capacity (ld < 256): the front-end stages stay on their own kernels, the stages behind
+    the search run as k_small_back (sl2_small.hip: small_step_mode 2).  Against an engine on the ten-launch step: integer
+    outputs identical, state and covariance to 1e-13 / 1e-12, three sequences of the batch against the oracle."""
+    B, N, F = 300, 6, 4
+    pr = Pair(N, F, batch=3, max_features=8, feature_sigma=0.004)
+    cam, params = pr.cam, pr.params
+    engs = []
+    for fused in (1, 0):
+        e = Engine(cam, params, B, 8)
+        e.set_step_fusion(fused)
+        e.set_vehicle_state(np.tile(np.stack([s.xv0 for s in pr.specs]), (B // 3, 1)), np.tile(np.stack([s.Pxx0 for s in pr.specs]), (B // 3, 1, 1)))
+        e.add_known_features(np.tile(np.stack([s.feat_y for s in pr.specs]), (B // 3, 1, 1)), np.tile(np.stack([s.xp_org() for s in pr.specs]), (B // 3, 1, 1)),
+                             np.tile(np.stack(pr.templates), (B // 3, 1, 1, 1)))
+        e.set_feature_covariances(np.tile(np.eye(3) * 0.004 ** 2, (B, N, 1, 1)))
+        e.set_profiling(2)
+        engs.append(e)
+    for k in range(F):
+        frames = np.tile(pr.frame_batch(k), (B // 3, 1, 1))
+        for e in engs:
+            e.go_one_step(frames, False)
+        for b in range(3):
+            pr.oracles[b].go_one_step(pr.frames[b][k], False)
+        for b in (0, 1, 2, 151, 299):
+            fa, fb = engs[0].features(b), engs[1].features(b)
+            assert [(p["selected"], p["success"], p["attempted"], p["successful"]) for p in fa] == [(p["selected"], p["success"], p["attempted"], p["successful"]) for p in fb]
+            assert all(np.array_equal(p["z"], q["z"]) for p, q in zip(fa, fb))
+            assert np.abs(engs[0].total_state(b) - engs[1].total_state(b)).max() <= 1e-13
+            assert rel_fro(engs[0].total_covariance(b), engs[1].total_covariance(b)) <= 1e-12
+            o = pr.oracles[b % 3]
+            assert np.abs(engs[0].total_state(b) - o.total_state()).max() <= TOL_X
+            assert rel_fro(engs[0].total_covariance(b), o.total_covariance()) <= TOL_P
+    t0, t1 = engs[0].kernel_times(), engs[1].kernel_times()
+    assert "k_small_back" in t0 and "k_predict" in t0 and "k_small_front" not in t0 and "k_syrk" not in t0, t0.keys()
+    assert "k_syrk" in t1 and "k_small_back" not in t1

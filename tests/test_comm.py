@@ -78,3 +78,23 @@ def test_sharded_example_on_one_gpu_matches_the_oracle(tmp_path):
         assert np.abs(rows[b, 13:].reshape(13, 13) - Pxx).max() <= 1e-11 * np.abs(Pxx).max()
     two = subprocess.run([exe, "--cfg", cfg, "--frames", fd, "--gpus", "2"], capture_output=True, text=True, timeout=120)
     assert two.returncode == 3 and "HIP device" in two.stderr          # fewer devices than ranks: refused, not mislabelled
+
+
+def test_comm_entry_points_refuse_bad_arguments_and_a_missing_device():
+    """Error behaviour without a GPU in reach of the call: status codes, never a crash (the reference has no error codes at all;
+    the C ABI's convention is SL2_OK / SL2_ERR_*).  On a box without a HIP device the constructors answer SL2_ERR_NO_DEVICE."""
+    from scenelib2_amd import _lib
+    L = C.CDLL(LIB)
+    L.sl2_comm_last_error.restype = C.c_char_p
+    out = (C.c_void_p * 2)()
+    assert L.sl2_comm_create_all(0, None, out) == 1 and b"bad argument" in L.sl2_comm_last_error()          # SL2_ERR_INVALID
+    assert L.sl2_comm_create(None, 1, 0, 0, out) == 1
+    ident = (C.c_ubyte * 128)()
+    assert L.sl2_comm_create(ident, 2, 2, 0, out) == 1                                                       # rank out of range
+    assert L.sl2_scatter_frames(None, 0, None, C.c_size_t(1), 1, None, None) == 1
+    assert L.sl2_gather_states(None, None, 0, None, None) == 1
+    assert L.sl2_comm_rank(None) == -1 and L.sl2_comm_nranks(None) == 0 and L.sl2_comm_device(None) == -1
+    L.sl2_comm_destroy(None)                                                                                 # a no-op
+    if _lib.device_count() == 0:
+        assert L.sl2_comm_create_all(1, None, out) == 4 and b"no HIP device" in L.sl2_comm_last_error()      # SL2_ERR_NO_DEVICE
+        assert L.sl2_comm_create(ident, 1, 0, 0, out) == 4

@@ -466,3 +466,36 @@ def test_two_features_initialised_at_once():
     assert measured_with_q28 > 0, "no feature with a misplaced position was ever measured: the H placement went untested"
     t0, t1 = s.trajectory(), eng.trajectory(0)
     assert t0.shape == t1.shape and np.abs(t0 - t1).max() < 1e-9
+
+
+def test_step_kernels_switch_safely_when_the_host_runs_ahead_with_mapping_on():
+    """The fused small-map step is chosen from a HOST-side bound on the live map (sl2_engine.hip: slots_upper_bound).  With
+    feature initialisation on, the bound grows by one per step the host has issued beyond the last step the device reported
+    through its mailbox - so a host that queues many steps without ever waiting sees the bound climb past the fused step's limit
+    and the engine move to the one-stage kernels, then back once the device has caught up.  Whatever the mix, nothing may be
+    lost: 60 frames queued in bursts of 30 without a synchronisation in between, state and event counters against the oracle
+    at the end of each burst, and both kinds of kernels must have run."""
+    from scenelib2_amd import Engine
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60)
+    s = oracle_for(cam, params, spec, templates, oa)
+    eng = Engine(cam, params, 1, 128)                       # the adapter's capacity: ld = 448
+    eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
+    eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
+    eng.set_profiling(2)
+    dev = _lib.DeviceBuffer(frames.nbytes, 0)
+    dev.upload(frames)
+    fb = frames.shape[1] * frames.shape[2]
+    for burst in range(2):
+        for k in range(1 + 30 * burst, 31 + 30 * burst):
+            eng.go_one_step(dev.ptr + k * fb, save_trajectory=True, enable_mapping=True, on_device=True, seq_stride=fb)     # queued, not waited for
+            s.go_one_step(frames[k], True, True)
+        info, got = s.mapping_info(), eng.partial_feature(0)["info"]
+        assert [got[key] for key in ("initialised", "converted", "deleted", "n_partial")] == \
+               [info[key] for key in ("initialised", "converted", "deleted", "n_partial")], burst
+        x0, x1 = s.total_state(), eng.total_state(0)
+        assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X_SOAK, burst
+    t = eng.kernel_times()
+    fused, plain = t.get("k_small_back", {}).get("launches", 0), t.get("k_finalize", {}).get("launches", 0)
+    assert fused + plain == 60 and fused >= 10, t
+    print("60 queued mapping steps: %d fused, %d on the one-stage kernels" % (fused, plain))
+    assert not eng.status_flags().any()

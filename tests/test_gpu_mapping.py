@@ -472,13 +472,22 @@ def test_step_kernels_switch_safely_when_the_host_runs_ahead_with_mapping_on():
     """The fused small-map step is chosen from a HOST-side bound on the live map (sl2_engine.hip: slots_upper_bound).  With
     feature initialisation on, the bound grows by one per step the host has issued beyond the last step the device reported
     through its mailbox - so a host that queues many steps without ever waiting sees the bound climb past the fused step's limit
-    and the engine move to the one-stage kernels, then back once the device has caught up.  Whatever the mix, nothing may be
-    lost: 60 frames queued in bursts of 30 without a synchronisation in between, state and event counters against the oracle
-    at the end of each burst, and both kinds of kernels must have run."""
+    and the engine move to the one-stage kernels, then back once the device has caught up.  Forced here: the engine's stream is
+    held up by a host function (hipLaunchHostFunc: 0.2 s of sleep) while 50 steps are queued behind it, twice.  Whatever the
+    mix, nothing may be lost: state and event counters against the oracle after each burst, and BOTH kinds of kernels must have
+    run (fused while the lag is small, one-stage beyond it)."""
+    import ctypes as C
+    import time
     from scenelib2_amd import Engine
-    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=60)
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=100)
     s = oracle_for(cam, params, spec, templates, oa)
-    eng = Engine(cam, params, 1, 128)                       # the adapter's capacity: ld = 448
+    hip = C.CDLL("libamdhip64.so")                                    # the runtime the engine library is linked against
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipLaunchHostFunc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    st = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    hold = C.CFUNCTYPE(None, C.c_void_p)(lambda _arg: time.sleep(0.2))
+    eng = Engine(cam, params, 1, 128, stream=st.value)                # the adapter's capacity: ld = 448
     eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
     eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
     eng.set_profiling(2)
@@ -486,7 +495,9 @@ def test_step_kernels_switch_safely_when_the_host_runs_ahead_with_mapping_on():
     dev.upload(frames)
     fb = frames.shape[1] * frames.shape[2]
     for burst in range(2):
-        for k in range(1 + 30 * burst, 31 + 30 * burst):
+        eng.synchronize()
+        assert hip.hipLaunchHostFunc(st, C.cast(hold, C.c_void_p), None) == 0      # the stream waits here while the steps below are queued
+        for k in range(1 + 50 * burst, 51 + 50 * burst):
             eng.go_one_step(dev.ptr + k * fb, save_trajectory=True, enable_mapping=True, on_device=True, seq_stride=fb)     # queued, not waited for
             s.go_one_step(frames[k], True, True)
         info, got = s.mapping_info(), eng.partial_feature(0)["info"]
@@ -496,6 +507,6 @@ def test_step_kernels_switch_safely_when_the_host_runs_ahead_with_mapping_on():
         assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X_SOAK, burst
     t = eng.kernel_times()
     fused, plain = t.get("k_small_back", {}).get("launches", 0), t.get("k_finalize", {}).get("launches", 0)
-    assert fused + plain == 60 and fused >= 10, t
-    print("60 queued mapping steps: %d fused, %d on the one-stage kernels" % (fused, plain))
+    print("100 queued mapping steps: %d fused, %d on the one-stage kernels" % (fused, plain))
+    assert fused + plain == 100 and fused >= 10 and plain >= 10, t
     assert not eng.status_flags().any()

@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
   for (int k = 0; k < n; ++k) {                     // the loop of examples/MonoSlamSceneLib1.cpp:132-142
     const uint8_t* d_frame = nullptr;
     size_t stride = 0;
-    CHECK(sl2_ingest_next(grab, nullptr, &d_frame, &stride));
+    CHECK(sl2_ingest_next(grab, sl2_get_stream(eng), &d_frame, &stride));     // (the copy of the frame after this one starts here, under the step below)
     CHECK(sl2_go_one_step(eng, d_frame, stride, /*frames_on_device=*/1, /*save_trajectory=*/1, mapping));
     if (k % 10 == 9 || k + 1 == n) {
       double x13[13], P[169];

@@ -50,7 +50,7 @@ int main(int argc, char** argv) {
           const auto t0 = std::chrono::steady_clock::now();
           SceneLib2Amd::Frame frame;
           size_t stride = 0;
-          if (sl2_ingest_next(grab, nullptr, &frame.data, &stride) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
+          if (sl2_ingest_next(grab, slam.stream(), &frame.data, &stride) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
           frame.cols = slam.camera_->width_; frame.rows = slam.camera_->height_; frame.on_device = true;
           const auto t1 = std::chrono::steady_clock::now();
           slam.GoOneStep(frame, true, enable_mapping);
@@ -102,7 +102,7 @@ int main(int argc, char** argv) {
     for (int frame_id = 0; frame_id < n; ++frame_id) {                  // MonoSlamSceneLib1.cpp:132-142
       SceneLib2Amd::Frame frame;
       size_t stride = 0;
-      if (sl2_ingest_next(grab, nullptr, &frame.data, &stride) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
+      if (sl2_ingest_next(grab, slam.stream(), &frame.data, &stride) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
       frame.cols = slam.camera_->width_; frame.rows = slam.camera_->height_; frame.on_device = true;
       if (!seams) {
         slam.GoOneStep(frame, save_trajectory, enable_mapping);

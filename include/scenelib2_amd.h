@@ -116,6 +116,9 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
 void sl2_destroy(sl2_engine* e);
 const char* sl2_last_error(void);
 int sl2_synchronize(sl2_engine* e);
+/* The hipStream_t the engine's steps are queued on (the one given to sl2_create, or the engine's own): what sl2_ingest_next and
+ * the scenelib2_amd_comm.h calls want as their `stream`. */
+void* sl2_get_stream(sl2_engine* e);
 int sl2_batch(const sl2_engine* e);
 int sl2_max_features(const sl2_engine* e);
 
@@ -296,13 +299,16 @@ int sl2_read_pgm(const char* path, uint8_t* out, size_t capacity, int* width, in
  * files are refused with an error.  out may be NULL to query the size.  Host only. */
 int sl2_read_image(const char* path, uint8_t* out, size_t capacity, int* width, int* height);
 /* FileGrabber + FrameGrabber for a batch: dirs[s] is the frame directory of sequence s.  A producer thread decodes
- * (sl2_read_image: PGM, PNG or JPEG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next uploads the next frame of
- * every sequence asynchronously on `stream` into one of two device buffers and returns it for
- * sl2_go_one_step(frames_on_device = 1).  The returned pointer stays valid until the next-but-one call.
- * Stream contract: the copy is ordered only with work on `stream`.  Pass the stream the engine steps on (the one given
- * to sl2_create; with an engine-owned stream create the engine on a stream of yours): the copy of frame k + 2 then queues
- * behind the step on frame k that still reads the same buffer, and the step on frame k queues behind its copy.  With a
- * different stream the caller must provide both orderings (events), or synchronise.
+ * (sl2_read_image: PGM, PNG or JPEG) ahead into `depth` (2..50, framegrabber.cpp:93-104) pinned host batches; sl2_ingest_next hands out
+ * the next frame of every sequence in one of two device buffers for sl2_go_one_step(frames_on_device = 1).  The returned pointer
+ * stays valid until the next-but-one call.
+ * The upload runs on a copy stream of the grabber's own, ONE FRAME AHEAD: the call that hands out frame k also starts the copy of
+ * frame k + 1 (if it is decoded), which then runs under the caller's work on frame k.
+ * Stream contract: `stream` is the stream on which the caller CONSUMES the frames (the one the engine steps on: the stream given to
+ * sl2_create, or sl2_get_stream of an engine-owned one).  The call makes that stream wait for frame k's copy, and takes the point
+ * that stream has reached as the moment the buffer of frame k - 1 may be overwritten - so the consumer of a frame must be queued
+ * on that stream BEFORE the next call.  NULL = the legacy default stream, which is ordered with every blocking stream (correct
+ * with an engine-owned stream, at the price of the default stream's implicit synchronisations).
  * A decode failure is reported by the call whose frame could not be produced, not by earlier ones.
  * SL2_ERR_CAPACITY = the shortest sequence is exhausted (sl2_ingest_frame_count). */
 typedef struct sl2_ingest sl2_ingest;

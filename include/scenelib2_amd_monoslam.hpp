@@ -165,6 +165,9 @@ class MonoSLAM {
     check(sl2_add_known_features(eng_, 0, 1, 1, y_new.data(), xp_o.data(), patch.data()), "sl2_add_known_features");
   }
 
+  // The stream the engine steps on: what sl2_ingest_next wants, so that the upload of the next frame runs under this one's step.
+  void* stream() const { return eng_ ? sl2_get_stream(eng_) : nullptr; }
+
   // MonoSLAM::GoOneStep (monoslam.cpp:108-180).  Always true, like the reference (:179).
   bool GoOneStep(const Frame& frame, bool save_trajectory, bool enable_mapping) {
     if (!eng_ || !frame.data || frame.cols != camera_->width_ || frame.rows != camera_->height_)

@@ -81,7 +81,7 @@ assert C.sizeof(sl2_snapshot_header) == 256 and C.sizeof(sl2_partial_info) == 32
 EXPORTED_SYMBOLS = [
     "sl2_api_version", "sl2_device_count", "sl2_create", "sl2_destroy", "sl2_last_error", "sl2_synchronize", "sl2_batch",
     "sl2_max_features", "sl2_set_vehicle_state", "sl2_get_vehicle_state", "sl2_add_known_features", "sl2_set_feature_covariances",
-    "sl2_go_one_step", "sl2_initialise_feature", "sl2_initialise_auto_feature", "sl2_save_patch", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_step_fusion", "sl2_set_search_split", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
+    "sl2_go_one_step", "sl2_initialise_feature", "sl2_initialise_auto_feature", "sl2_save_patch", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_step_fusion", "sl2_get_stream", "sl2_set_search_split", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
@@ -138,6 +138,8 @@ def _bind(L):
     L.sl2_set_update_variant.argtypes = [vp, C.c_int, C.c_int]
     L.sl2_set_graph_mode.argtypes = [vp, C.c_int]
     L.sl2_set_step_fusion.argtypes = [vp, C.c_int]
+    L.sl2_get_stream.argtypes = [vp]
+    L.sl2_get_stream.restype = vp
     L.sl2_kalman_filter_predict.argtypes = [vp]
     L.sl2_auto_select_n_features.argtypes = [vp, C.c_int]
     L.sl2_make_measurements.argtypes = [vp, vp, C.c_size_t, C.c_int]

@@ -481,6 +481,7 @@ int sl2_synchronize(sl2_engine* e) {
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
   return SL2_OK;
 }
+void* sl2_get_stream(sl2_engine* e) { return e ? (void*)e->stream : nullptr; }
 int sl2_batch(const sl2_engine* e) { return e ? e->B : 0; }
 int sl2_max_features(const sl2_engine* e) { return e ? e->N : 0; }
 

@@ -271,7 +271,15 @@ struct sl2_ingest {
   std::condition_variable cv;
   std::thread producer;
   uint8_t* dev[2] = {nullptr, nullptr};
-  int flip = 0;
+  // Upload: frame k goes to dev[k & 1] on a copy stream of the grabber's own, ONE FRAME AHEAD of the caller - the copy of frame
+  // k + 1 is issued by the call that hands out frame k and runs under the caller's work on frame k (round 6; before, the copy of
+  // frame k was queued on the caller's stream in front of its step: 1.4 ms of a 1.5 ms step at batch 1024, 8 us of a single
+  // sequence's frame).  copied[b]: the copy into dev[b] has landed (the caller's stream waits for it); reusable[b]: the caller's
+  // stream has got past everything that read dev[b] (the copy stream waits for it before it overwrites the buffer).
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, reusable[2] = {nullptr, nullptr};
+  bool handed_out[2] = {false, false};
+  int issued = 0;                // frames whose copy has been issued (consumed <= issued <= consumed + 1 between calls)
 
   void run() {
     const size_t fb = (size_t)width * height;
@@ -435,11 +443,17 @@ int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, in
     }
   }
   for (int i = 0; i < 2; ++i)
-    if (hipMalloc((void**)&g->dev[i], batch) != hipSuccess) {
+    if (hipMalloc((void**)&g->dev[i], batch) != hipSuccess || hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->reusable[i], hipEventDisableTiming) != hipSuccess) {
       set_error("sl2_ingest_open: device allocation failed");
       sl2_ingest_close(g);
       return SL2_ERR_HIP;
     }
+  if (hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("sl2_ingest_open: cannot create the copy stream");
+    sl2_ingest_close(g);
+    return SL2_ERR_HIP;
+  }
   g->producer = std::thread([g] { g->run(); });
   *out = g;
   return SL2_OK;
@@ -447,47 +461,74 @@ int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, in
 
 int sl2_ingest_frame_count(const sl2_ingest* g) { return g ? g->n_frames : 0; }
 
-int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride) {
+// The copy of frame k (host slot k % depth -> dev[k & 1]) on the copy stream; `wait`: block until the producer has decoded it
+// (false: only if it is ready now).  0 = issued, 1 = not ready (wait == false only), < 0 = -(error code).
+static int issue_copy(sl2_ingest* g, int k, bool wait) {
   using namespace sl2;
-  if (!g || !d_frames || !seq_stride) return SL2_ERR_INVALID;
-  if (g->consumed >= g->n_frames) return SL2_ERR_CAPACITY;     // end of the shortest sequence
-  SL2_HIP(hipSetDevice(g->device));
-  const int slot = g->consumed % g->depth;
+  const int slot = k % g->depth, b = k & 1;
   {
-    // the slot this call needs may still be marked "in flight" from `depth` calls ago: hand it back to the
-    // producer first (its copy was issued long ago; this wait is normally free)
+    // the slot may still be marked "in flight" from `depth` frames ago: hand it back to the producer first
     bool fly;
     { std::lock_guard<std::mutex> lk(g->mu); fly = g->state[slot] == 2; }
     if (fly) {
-      SL2_HIP(hipEventSynchronize(g->done[slot]));
+      if (!wait && hipEventQuery(g->done[slot]) != hipSuccess) return 1;
+      if (hipEventSynchronize(g->done[slot]) != hipSuccess) { set_error("sl2_ingest_next: hipEventSynchronize failed"); return -SL2_ERR_HIP; }
       { std::lock_guard<std::mutex> lk(g->mu); g->state[slot] = 0; }
       g->cv.notify_all();
     }
   }
   {
     std::unique_lock<std::mutex> lk(g->mu);
+    if (!wait && g->state[slot] != 1) return 1;
     // a decode failure further ahead does not fail THIS frame if its batch is already decoded
     g->cv.wait(lk, [&] { return g->failed || g->state[slot] == 1; });
-    if (g->state[slot] != 1) { set_error(g->fail_msg.c_str()); return SL2_ERR_INVALID; }
+    if (g->state[slot] != 1) { set_error(g->fail_msg.c_str()); return -SL2_ERR_INVALID; }
   }
   const size_t batch = (size_t)g->nseq * g->width * g->height;
-  uint8_t* dst = g->dev[g->flip];
-  g->flip ^= 1;
-  hipStream_t st = (hipStream_t)stream;
-  SL2_HIP(hipMemcpyAsync(dst, g->host[slot], batch, hipMemcpyHostToDevice, st));
-  SL2_HIP(hipEventRecord(g->done[slot], st));
+  // dev[b] was last read by the caller's work on frame k - 2: the copy stream waits until the caller's stream is past it
+  if (g->handed_out[b] && hipStreamWaitEvent(g->copy_stream, g->reusable[b], 0) != hipSuccess) { set_error("sl2_ingest_next: hipStreamWaitEvent failed"); return -SL2_ERR_HIP; }
+  if (hipMemcpyAsync(g->dev[b], g->host[slot], batch, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess ||
+      hipEventRecord(g->done[slot], g->copy_stream) != hipSuccess || hipEventRecord(g->copied[b], g->copy_stream) != hipSuccess) {
+    set_error("sl2_ingest_next: the upload could not be queued");
+    return -SL2_ERR_HIP;
+  }
   { std::lock_guard<std::mutex> lk(g->mu); g->state[slot] = 2; }
+  g->issued = k + 1;
+  return 0;
+}
+
+int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride) {
+  using namespace sl2;
+  if (!g || !d_frames || !seq_stride) return SL2_ERR_INVALID;
+  if (g->consumed >= g->n_frames) return SL2_ERR_CAPACITY;     // end of the shortest sequence
+  SL2_HIP(hipSetDevice(g->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int k = g->consumed, b = k & 1;
+  if (g->issued <= k) {                       // not prefetched (the first frame, or the producer had not decoded it in time)
+    const int rc = issue_copy(g, k, true);
+    if (rc < 0) return -rc;
+  }
+  SL2_HIP(hipStreamWaitEvent(st, g->copied[b], 0));            // the caller's work on frame k queues behind its copy
+  g->handed_out[b] = true;
   ++g->consumed;
+  // ONE AHEAD: frame k + 1 goes to the other buffer, which the caller's work on frame k - 1 read - everything queued on the
+  // caller's stream so far.  Behind that point the buffer may be overwritten; the caller's work on frame k, queued after this
+  // call returns, runs beside the copy.
+  if (k + 1 < g->n_frames) {
+    if (g->handed_out[b ^ 1]) SL2_HIP(hipEventRecord(g->reusable[b ^ 1], st));
+    const int rc = issue_copy(g, k + 1, false);
+    if (rc < 0) { /* reported by the call whose frame it is */ (void)hipGetLastError(); }
+  }
   // pinned batches whose copies have completed go back to the producer (decode-ahead)
   for (int i = 0; i < g->depth; ++i) {
     bool f2;
     { std::lock_guard<std::mutex> lk(g->mu); f2 = g->state[i] == 2; }
-    if (f2 && i != slot && hipEventQuery(g->done[i]) == hipSuccess) {
+    if (f2 && hipEventQuery(g->done[i]) == hipSuccess) {
       { std::lock_guard<std::mutex> lk(g->mu); g->state[i] = 0; }
       g->cv.notify_all();
     }
   }
-  *d_frames = dst;
+  *d_frames = g->dev[b];
   *seq_stride = (size_t)g->width * g->height;
   return SL2_OK;
 }
@@ -504,7 +545,12 @@ void sl2_ingest_close(sl2_ingest* g) {
   hipDeviceSynchronize();
   for (auto p : g->host) if (p) hipHostFree(p);
   for (auto e : g->done) if (e) hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) if (g->dev[i]) hipFree(g->dev[i]);
+  for (int i = 0; i < 2; ++i) {
+    if (g->dev[i]) hipFree(g->dev[i]);
+    if (g->copied[i]) hipEventDestroy(g->copied[i]);
+    if (g->reusable[i]) hipEventDestroy(g->reusable[i]);
+  }
+  if (g->copy_stream) hipStreamDestroy(g->copy_stream);
   delete g;
 }
 

@@ -96,6 +96,11 @@ class Engine:
     def set_groups(self, groups):
         self._ck(self.L.sl2_set_groups(self.h, int(groups)))
 
+    @property
+    def stream(self):
+        """The hipStream_t (as an integer) the engine's steps are queued on: what Ingest.next wants."""
+        return self.L.sl2_get_stream(self.h)
+
     def set_step_fusion(self, enabled=True):
         """Small maps step in three launches (default) / always one stage per launch (sl2_set_step_fusion)."""
         self._ck(self.L.sl2_set_step_fusion(self.h, int(enabled)))

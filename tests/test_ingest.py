@@ -244,6 +244,51 @@ def test_batched_ingest_delivers_every_frame_in_order(tmp_path):
     g.close()
 
 
+@pytest.mark.gpu
+def test_ingest_runs_one_frame_ahead_and_never_overwrites_a_frame_in_use(tmp_path):
+    """sl2_ingest_next uploads on a stream of its own, one frame ahead of the caller: the call that hands out frame k starts the
+    copy of frame k + 1 into the other device buffer, which the caller's work on frame k - 1 read.  The contract (scenelib2_amd.h):
+    the consumer of a frame is queued on `stream` before the next call; the copy then waits for it.  Checked with a SLOW
+    consumer: on the caller's stream every frame is first held up by a host function (2 ms) and only then copied out - twelve
+    frames queued without a single wait; every copy must still deliver its own frame."""
+    import ctypes as C
+    import time
+    rng = np.random.default_rng(5)
+    H, W, nseq, nfr = 48, 64, 2, 12
+    dirs, want = [], []
+    for s in range(nseq):
+        d = os.path.join(str(tmp_path), "seq%d" % s)
+        os.makedirs(d)
+        frames = rng.integers(0, 256, (nfr, H, W)).astype(np.uint8)
+        for k in range(nfr):
+            ingest.write_pgm(os.path.join(d, "%04d.pgm" % k), frames[k])
+        dirs.append(d); want.append(frames)
+    _lib.load()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+    hip.hipLaunchHostFunc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    st, pinned = C.c_void_p(), C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(st)) == 0
+    batch = nseq * H * W
+    assert hip.hipHostMalloc(C.byref(pinned), nfr * batch, 0) == 0
+    hold = C.CFUNCTYPE(None, C.c_void_p)(lambda _arg: time.sleep(0.002))
+    g = ingest.FrameIngest(dirs, W, H, depth=4)
+    time.sleep(0.2)                                           # let the producer decode ahead, so that the prefetch really is issued
+    for k in range(nfr):
+        ptr, stride = g.next(stream=st.value)
+        assert hip.hipLaunchHostFunc(st, C.cast(hold, C.c_void_p), None) == 0
+        assert hip.hipMemcpyAsync(C.c_void_p(pinned.value + k * batch), C.c_void_p(ptr), batch, 2, st) == 0      # hipMemcpyDeviceToHost
+    assert hip.hipStreamSynchronize(st) == 0
+    got = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(nfr, nseq, H, W))
+    for k in range(nfr):
+        for s in range(nseq):
+            assert np.array_equal(got[k, s], want[s][k]), (k, s)
+    g.close()
+
+
 def test_decoders_survive_random_corruption(tmp_path):
     """Fuzz: random byte flips / truncations of valid PNG and PGM files must end in a decoded image of the declared size or in
     an error code - never in a crash, a hang or an exception across the ABI (hostile IHDR sizes, broken zlib streams, bad

@@ -131,8 +131,11 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
   __syncthreads();
   SST(4, 0);
   // ---- S = H A + R (rows / columns beyond m: the identity), all 32 x 32 entries
+  // (lanes run along a - the row of H, whose coefficients and pivot column differ per lane - and share bb, the row of the LDS
+  // panel they read: one broadcast address per read.  With bb along the lanes every read was 32 rows of the panel at a pitch of
+  // W doubles = the same bank 32 times.)
   for (int e = tid; e < kSmallM * kSmallM; e += kSmallThreads) {
-    const int a = e >> 5, bb = e & 31;
+    const int bb = e >> 5, a = e & 31;
     double v = (a == bb) ? 1.0 : 0.0;
     if (a < m && bb < m) {
       const double* arow = sAt + bb * W;
@@ -202,11 +205,12 @@ __device__ __forceinline__ void small_update_body(const int b, double* __restric
       double acc[4][4], pv[4][4];
 #pragma unroll
       for (int q = 0; q < 16; ++q) {                    // the entries of P first: their round trip runs under the products
-        const int ii = ti + (q >> 2), jj = tj + (q & 3);
-        acc[q >> 2][q & 3] = 0.0;
+        const int ii = ti + (q >> 2), jj = tj + (q & 3);  // (requesting them before the factorisation instead was measured: the D wave's
+        acc[q >> 2][q & 3] = 0.0;                         // routine 0.8 us longer, this phase 0.2 us shorter)
         pv[q >> 2][q & 3] = (ii < n_c && jj < n_c) ? Pb[(size_t)cmap(ii) * ld + cmap(jj)] : 0.0;
       }
-      for (int k = 0; k < m; ++k) {
+#pragma unroll 4
+      for (int k = 0; k < m; ++k) {                     // (unrolled: four k-steps' LDS reads in flight over the products of the step before)
         const double* vk = sAt + k * W;
         double vi[4], vj[4];
 #pragma unroll

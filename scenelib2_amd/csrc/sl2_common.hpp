@@ -238,6 +238,8 @@ struct sl2_engine {
   void* snap_stage = nullptr;     // device: the packed blob of sl2_snapshot
   void* snap_host = nullptr;      // pinned + mapped host memory the blob is streamed into (what sl2_snapshot returns)
   void* snap_host_dev = nullptr;  // its device-side address
+  size_t snap_cap = 0;            // bytes of the blob area; the completion word the kernel writes last sits right behind it
+  unsigned long long snap_ticket = 0;
   void* acc_dev = nullptr;        // device scratch of the get / set accessors (grown on demand)
   size_t acc_dev_bytes = 0;
   void* acc_host = nullptr;       // pinned host scratch of the same calls

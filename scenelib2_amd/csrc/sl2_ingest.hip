@@ -274,10 +274,11 @@ struct sl2_ingest {
   // Upload: frame k goes to dev[k & 1] on a copy stream of the grabber's own, ONE FRAME AHEAD of the caller - the copy of frame
   // k + 1 is issued by the call that hands out frame k and runs under the caller's work on frame k (round 6; before, the copy of
   // frame k was queued on the caller's stream in front of its step: 1.4 ms of a 1.5 ms step at batch 1024, 8 us of a single
-  // sequence's frame).  copied[b]: the copy into dev[b] has landed (the caller's stream waits for it); reusable[b]: the caller's
-  // stream has got past everything that read dev[b] (the copy stream waits for it before it overwrites the buffer).
+  // sequence's frame).  done[slot]: the copy out of pinned slot `slot` has landed (the caller's stream waits for it, and the
+  // producer may decode into the slot again); reusable[b]: the caller's stream has got past everything that read dev[b] (the copy
+  // stream waits for it before it overwrites the buffer).
   hipStream_t copy_stream = nullptr;
-  hipEvent_t copied[2] = {nullptr, nullptr}, reusable[2] = {nullptr, nullptr};
+  hipEvent_t reusable[2] = {nullptr, nullptr};
   bool handed_out[2] = {false, false};
   int issued = 0;                // frames whose copy has been issued (consumed <= issued <= consumed + 1 between calls)
 
@@ -443,8 +444,7 @@ int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, in
     }
   }
   for (int i = 0; i < 2; ++i)
-    if (hipMalloc((void**)&g->dev[i], batch) != hipSuccess || hipEventCreateWithFlags(&g->copied[i], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g->reusable[i], hipEventDisableTiming) != hipSuccess) {
+    if (hipMalloc((void**)&g->dev[i], batch) != hipSuccess || hipEventCreateWithFlags(&g->reusable[i], hipEventDisableTiming) != hipSuccess) {
       set_error("sl2_ingest_open: device allocation failed");
       sl2_ingest_close(g);
       return SL2_ERR_HIP;
@@ -488,7 +488,7 @@ static int issue_copy(sl2_ingest* g, int k, bool wait) {
   // dev[b] was last read by the caller's work on frame k - 2: the copy stream waits until the caller's stream is past it
   if (g->handed_out[b] && hipStreamWaitEvent(g->copy_stream, g->reusable[b], 0) != hipSuccess) { set_error("sl2_ingest_next: hipStreamWaitEvent failed"); return -SL2_ERR_HIP; }
   if (hipMemcpyAsync(g->dev[b], g->host[slot], batch, hipMemcpyHostToDevice, g->copy_stream) != hipSuccess ||
-      hipEventRecord(g->done[slot], g->copy_stream) != hipSuccess || hipEventRecord(g->copied[b], g->copy_stream) != hipSuccess) {
+      hipEventRecord(g->done[slot], g->copy_stream) != hipSuccess) {       // (one event: the pinned slot is free AND the device buffer is filled)
     set_error("sl2_ingest_next: the upload could not be queued");
     return -SL2_ERR_HIP;
   }
@@ -508,7 +508,7 @@ int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_
     const int rc = issue_copy(g, k, true);
     if (rc < 0) return -rc;
   }
-  SL2_HIP(hipStreamWaitEvent(st, g->copied[b], 0));            // the caller's work on frame k queues behind its copy
+  SL2_HIP(hipStreamWaitEvent(st, g->done[k % g->depth], 0));   // the caller's work on frame k queues behind its copy
   g->handed_out[b] = true;
   ++g->consumed;
   // ONE AHEAD: frame k + 1 goes to the other buffer, which the caller's work on frame k - 1 read - everything queued on the
@@ -519,12 +519,15 @@ int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_
     const int rc = issue_copy(g, k + 1, false);
     if (rc < 0) { /* reported by the call whose frame it is */ (void)hipGetLastError(); }
   }
-  // pinned batches whose copies have completed go back to the producer (decode-ahead)
-  for (int i = 0; i < g->depth; ++i) {
+  // The pinned batch of the frame handed out LAST time goes back to the producer: its copy was waited for by the caller's stream a
+  // whole call ago, and everything queued behind that wait has been issued since - one query, not one per slot (a HIP call is
+  // ~1 us; this function was 12 us of a 70 us frame).  The slot this call used stays "in flight" until the next call.
+  for (int back = 1; back <= 2 && back <= k; ++back) {      // (the one before as well, should its copy not have landed a call ago)
+    const int prev = (k - back) % g->depth;
     bool f2;
-    { std::lock_guard<std::mutex> lk(g->mu); f2 = g->state[i] == 2; }
-    if (f2 && hipEventQuery(g->done[i]) == hipSuccess) {
-      { std::lock_guard<std::mutex> lk(g->mu); g->state[i] = 0; }
+    { std::lock_guard<std::mutex> lk(g->mu); f2 = g->state[prev] == 2; }
+    if (f2 && hipEventQuery(g->done[prev]) == hipSuccess) {
+      { std::lock_guard<std::mutex> lk(g->mu); g->state[prev] = 0; }
       g->cv.notify_all();
     }
   }
@@ -547,7 +550,6 @@ void sl2_ingest_close(sl2_ingest* g) {
   for (auto e : g->done) if (e) hipEventDestroy(e);
   for (int i = 0; i < 2; ++i) {
     if (g->dev[i]) hipFree(g->dev[i]);
-    if (g->copied[i]) hipEventDestroy(g->copied[i]);
     if (g->reusable[i]) hipEventDestroy(g->reusable[i]);
   }
   if (g->copy_stream) hipStreamDestroy(g->copy_stream);

@@ -9,6 +9,8 @@
 // synchronisation, no hipMemcpy, no allocation per call.
 #include "sl2_common.hpp"
 
+#include <chrono>
+
 namespace sl2 {
 
 struct SnapArrays {
@@ -31,7 +33,8 @@ __device__ __forceinline__ int up8(int v) { return (v + 7) & ~7; }
 // covariance record, patch index (-1: not included); then the selection's labels.
 __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq, int N, int ld, int ppos, int pcap, int kpart, int traj_cursor,
                                                            int patch_from_label, long long steps_done, unsigned char* __restrict__ stage,
-                                                           uint4* __restrict__ host_out) {
+                                                           uint4* __restrict__ host_out, unsigned long long* __restrict__ done_word,
+                                                           unsigned long long ticket) {
   extern __shared__ int sm[];
   int* s_flags = sm;
   int* s_label = sm + N;
@@ -227,6 +230,10 @@ __global__ void __launch_bounds__(kSnapThreads) k_snapshot(SnapArrays a, int seq
   const uint4* src16 = reinterpret_cast<const uint4*>(stage);
   for (int k = tid; k < n16; k += kSnapThreads) host_out[k] = src16[k];
   __threadfence_system();
+  // The blob is in host memory: say so in a word of its own, so that the caller can pick it up the moment it is complete instead
+  // of waiting for the launch to be retired (sl2_snapshot spins on this word first: ~8 us less per call than a stream wait).
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(done_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace sl2
@@ -248,8 +255,11 @@ extern "C" int sl2_snapshot(sl2_engine* e, int seq, int traj_cursor, int patch_f
   if (!e->snap_host) {   // first use: a device staging buffer and a pinned, mapped host buffer, both owned by the engine
     const size_t cap = sl2_snapshot_capacity(e);
     SL2_HIP(hipMalloc(&e->snap_stage, cap));
-    SL2_HIP(hipHostMalloc(&e->snap_host, cap, hipHostMallocMapped));
+    // (+ 64 bytes: the completion word behind the blob, on a cache line of its own)
+    SL2_HIP(hipHostMalloc(&e->snap_host, cap + 64, hipHostMallocMapped | hipHostMallocCoherent));
     SL2_HIP(hipHostGetDevicePointer(&e->snap_host_dev, e->snap_host, 0));
+    e->snap_cap = cap;
+    *(volatile unsigned long long*)((char*)e->snap_host + cap) = 0ull;
   }
   // the groups' streams (sl2_set_groups > 1) join the root stream at the end of every stepping call; the kernel below is
   // queued behind them
@@ -260,9 +270,21 @@ extern "C" int sl2_snapshot(sl2_engine* e, int seq, int traj_cursor, int patch_f
   a.successful = e->successful; a.sel_idx = e->sel_idx; a.n_sel = e->n_sel; a.n_vis = e->n_vis; a.m_count = e->m_count;
   a.traj_count = e->traj_count; a.status = e->status; a.part_i = e->part_i; a.ps_i = e->ps_i; a.pos_err = e->pos_err; a.patch = e->patch;
   hipLaunchKernelGGL(k_snapshot, dim3(1), dim3(kSnapThreads), sizeof(int) * 8 * e->N, e->stream, a, seq, e->N, e->ld, e->ppos, e->pcap, e->kpart,
-                     traj_cursor, patch_from_label, e->steps_done, (unsigned char*)e->snap_stage, (uint4*)e->snap_host_dev);
+                     traj_cursor, patch_from_label, e->steps_done, (unsigned char*)e->snap_stage, (uint4*)e->snap_host_dev,
+                     (unsigned long long*)((char*)e->snap_host_dev + e->snap_cap), ++e->snap_ticket);
   SL2_HIP(hipGetLastError());
-  SL2_HIP(hipStreamSynchronize(e->stream));
+  {
+    // the kernel announces the finished blob in the word behind it; a short spin on that word, then the ordinary wait (a long
+    // step in front of the snapshot, a large batch: no point in burning a core)
+    const volatile unsigned long long* done = (const volatile unsigned long long*)((const char*)e->snap_host + e->snap_cap);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (;;) {
+      for (int i = 0; i < 64 && !seen; ++i) { seen = __atomic_load_n(done, __ATOMIC_ACQUIRE) == e->snap_ticket; if (!seen) __builtin_ia32_pause(); }
+      if (seen || std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+    }
+    if (!seen) SL2_HIP(hipStreamSynchronize(e->stream));
+  }
   const sl2_snapshot_header* h = (const sl2_snapshot_header*)e->snap_host;
   if (h->magic != kSnapMagic || h->bytes <= 0 || (size_t)h->bytes > sl2_snapshot_capacity(e)) {
     set_error("sl2_snapshot: malformed blob");

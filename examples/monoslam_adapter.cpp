@@ -19,6 +19,7 @@
 int main(int argc, char** argv) {
   std::string cfg, frames_dir, dump, latency;
   bool enable_mapping = false, seams = false;    // --seams: the step through the reference's individual members instead of GoOneStep
+  bool zero_copy = true;                         // --copy-frames: upload every frame instead of letting the device read the pinned batch (A/B)
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--cfg" && i + 1 < argc) cfg = argv[++i];
@@ -27,6 +28,7 @@ int main(int argc, char** argv) {
     else if (a == "--latency" && i + 1 < argc) latency = argv[++i];
     else if (a == "--mapping") enable_mapping = true;
     else if (a == "--seams") seams = true;
+    else if (a == "--copy-frames") zero_copy = false;
     else { fprintf(stderr, "usage: %s --cfg scene.cfg --frames dir [--mapping | --seams] [--dump file]\n", argv[0]); return 2; }
   }
   if (cfg.empty() || frames_dir.empty()) { fprintf(stderr, "need --cfg and --frames\n"); return 2; }
@@ -45,6 +47,7 @@ int main(int argc, char** argv) {
         const char* dirs[1] = {frames_dir.c_str()};
         sl2_ingest* grab = nullptr;
         if (sl2_ingest_open(dirs, 1, slam.camera_->width_, slam.camera_->height_, 0, 8, &grab) != SL2_OK) { fprintf(stderr, "%s\n", sl2_last_error()); return 1; }
+        if (!zero_copy) sl2_ingest_set_zero_copy(grab, 0);
         const int n = sl2_ingest_frame_count(grab);
         for (int frame_id = 0; frame_id < n; ++frame_id) {
           const auto t0 = std::chrono::steady_clock::now();
@@ -97,6 +100,7 @@ int main(int argc, char** argv) {
       fprintf(stderr, "%s\n", sl2_last_error());
       return 1;
     }
+    if (!zero_copy) sl2_ingest_set_zero_copy(grab, 0);
     const int n = sl2_ingest_frame_count(grab);
     const bool save_trajectory = true;
     for (int frame_id = 0; frame_id < n; ++frame_id) {                  // MonoSlamSceneLib1.cpp:132-142

@@ -315,6 +315,11 @@ typedef struct sl2_ingest sl2_ingest;
 int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, int device, int depth, sl2_ingest** out);
 int sl2_ingest_frame_count(const sl2_ingest* g);
 int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride);
+/* Batches of at most max_batch_bytes (nseq * width * height; default 512 KB, 0 = never) are not uploaded at all: sl2_ingest_next
+ * hands out the pinned host batch itself, which the device reads in place (depth >= 4; the same stream contract - the batch goes
+ * back to the decoder once the caller's stream is past the point it had reached at the NEXT call).  A single 320 x 240 sequence
+ * saves the ~10 us per frame that queueing a copy costs the host.  Before the first sl2_ingest_next only. */
+int sl2_ingest_set_zero_copy(sl2_ingest* g, size_t max_batch_bytes);
 void sl2_ingest_close(sl2_ingest* g);
 
 /* ----------------------------------------------------------------- state access */

@@ -84,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "sl2_go_one_step", "sl2_initialise_feature", "sl2_initialise_auto_feature", "sl2_save_patch", "sl2_set_groups", "sl2_set_search_variant", "sl2_set_step_fusion", "sl2_get_stream", "sl2_set_search_split", "sl2_set_update_variant", "sl2_set_graph_mode", "sl2_kalman_filter_predict", "sl2_auto_select_n_features", "sl2_make_measurements",
     "sl2_kalman_filter_update", "sl2_finish_step", "sl2_elliptical_search_batch", "sl2_find_best_patch_batch",
     "sl2_search_multiple_overlapping_ellipses_batch", "sl2_list_frames", "sl2_read_pgm", "sl2_read_image", "sl2_ingest_open",
-    "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_close", "sl2_get_total_state_sizes",
+    "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_set_zero_copy", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
     "sl2_snapshot_capacity", "sl2_snapshot", "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
     "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
@@ -157,6 +157,7 @@ def _bind(L):
     L.sl2_ingest_open.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.sl2_ingest_frame_count.argtypes = [vp]
     L.sl2_ingest_next.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.sl2_ingest_set_zero_copy.argtypes = [vp, C.c_size_t]
     L.sl2_ingest_close.argtypes = [vp]
     L.sl2_ingest_close.restype = None
     L.sl2_get_total_state_sizes.argtypes = [vp, C.c_int, C.c_int, c_ip]

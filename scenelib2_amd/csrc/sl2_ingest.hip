@@ -281,6 +281,14 @@ struct sl2_ingest {
   hipEvent_t reusable[2] = {nullptr, nullptr};
   bool handed_out[2] = {false, false};
   int issued = 0;                // frames whose copy has been issued (consumed <= issued <= consumed + 1 between calls)
+  // Small batches (a single 320 x 240 sequence: 77 KB) are not copied at all: the device reads the pinned batch in place - the
+  // ~6 us a hipMemcpyAsync costs the host per call, its wait and its events were most of what this grabber added to a 70 us
+  // frame, and the step touches each byte of such a frame about once.  zero_copy: batches of at most zc_max bytes
+  // (sl2_ingest_set_zero_copy; default 512 KB).  A slot handed out stays with the device (state 2) until an event recorded on the
+  // caller's stream at the NEXT call - behind everything that read it - has completed (used_valid).
+  size_t zc_max = 512 * 1024;
+  std::vector<uint8_t*> host_dev;   // device-side addresses of the pinned batches
+  std::vector<char> used_valid;     // done[slot] has been recorded behind the slot's consumer
 
   void run() {
     const size_t fb = (size_t)width * height;
@@ -436,8 +444,11 @@ int sl2_ingest_open(const char* const* dirs, int nseq, int width, int height, in
   g->host.assign(depth, nullptr);
   g->state.assign(depth, 0);
   g->done.assign(depth, nullptr);
+  g->host_dev.assign(depth, nullptr);
+  g->used_valid.assign(depth, 0);
   for (int i = 0; i < depth; ++i) {
-    if (hipHostMalloc((void**)&g->host[i], batch, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess) {
+    if (hipHostMalloc((void**)&g->host[i], batch, hipHostMallocMapped) != hipSuccess || hipEventCreateWithFlags(&g->done[i], hipEventDisableTiming) != hipSuccess ||
+        hipHostGetDevicePointer((void**)&g->host_dev[i], g->host[i], 0) != hipSuccess) {
       set_error("sl2_ingest_open: pinned allocation failed");
       sl2_ingest_close(g);
       return SL2_ERR_HIP;
@@ -497,12 +508,64 @@ static int issue_copy(sl2_ingest* g, int k, bool wait) {
   return 0;
 }
 
+int sl2_ingest_set_zero_copy(sl2_ingest* g, size_t max_batch_bytes) {
+  if (!g) return SL2_ERR_INVALID;
+  if (g->consumed > 0) { sl2::set_error("sl2_ingest_set_zero_copy: frames have been handed out already"); return SL2_ERR_INVALID; }
+  g->zc_max = max_batch_bytes;
+  return SL2_OK;
+}
+
+// The zero-copy hand-over of frame k: the pinned batch itself, as the device sees it.
+static int next_zero_copy(sl2_ingest* g, hipStream_t st, const uint8_t** d_frames) {
+  using namespace sl2;
+  const int k = g->consumed, slot = k % g->depth;
+  {
+    // the slot may still be with the device from `depth` frames ago (a caller that queues far ahead): wait for that consumer -
+    // its event was recorded depth - 1 calls ago - and hand the slot to the producer before waiting for the producer
+    bool fly;
+    { std::lock_guard<std::mutex> lk(g->mu); fly = g->state[slot] == 2; }
+    if (fly) {
+      if (g->used_valid[slot]) SL2_HIP(hipEventSynchronize(g->done[slot]));
+      { std::lock_guard<std::mutex> lk(g->mu); g->state[slot] = 0; }
+      g->cv.notify_all();
+    }
+  }
+  {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [&] { return g->failed || g->state[slot] == 1; });
+    if (g->state[slot] != 1) { set_error(g->fail_msg.c_str()); return SL2_ERR_INVALID; }
+    g->state[slot] = 2;
+  }
+  g->used_valid[slot] = 0;
+  if (k >= 1) {                                   // everything that read the previous frame's batch is queued on the caller's stream by now
+    const int prev = (k - 1) % g->depth;
+    SL2_HIP(hipEventRecord(g->done[prev], st));
+    g->used_valid[prev] = 1;
+  }
+  for (int back = 2; back <= 3 && back <= k; ++back) {      // older batches whose consumers have finished go back to the producer
+    const int old = (k - back) % g->depth;
+    bool f2;
+    { std::lock_guard<std::mutex> lk(g->mu); f2 = g->state[old] == 2; }
+    if (f2 && g->used_valid[old] && hipEventQuery(g->done[old]) == hipSuccess) {
+      { std::lock_guard<std::mutex> lk(g->mu); g->state[old] = 0; }
+      g->cv.notify_all();
+    }
+  }
+  ++g->consumed;
+  *d_frames = g->host_dev[slot];
+  return SL2_OK;
+}
+
 int sl2_ingest_next(sl2_ingest* g, void* stream, const uint8_t** d_frames, size_t* seq_stride) {
   using namespace sl2;
   if (!g || !d_frames || !seq_stride) return SL2_ERR_INVALID;
   if (g->consumed >= g->n_frames) return SL2_ERR_CAPACITY;     // end of the shortest sequence
-  SL2_HIP(hipSetDevice(g->device));
   hipStream_t st = (hipStream_t)stream;
+  if ((size_t)g->nseq * g->width * g->height <= g->zc_max && g->depth >= 4) {
+    *seq_stride = (size_t)g->width * g->height;
+    return next_zero_copy(g, st, d_frames);
+  }
+  SL2_HIP(hipSetDevice(g->device));
   const int k = g->consumed, b = k & 1;
   if (g->issued <= k) {                       // not prefetched (the first frame, or the producer had not decoded it in time)
     const int rc = issue_copy(g, k, true);

@@ -120,6 +120,10 @@ class FrameIngest:
         _lib.check(self.L.sl2_ingest_open(arr, len(directories), width, height, device, depth, C.byref(self.h)))
         self.frame_count = self.L.sl2_ingest_frame_count(self.h)
 
+    def set_zero_copy(self, max_batch_bytes):
+        """Batches of at most this many bytes are handed out in place (pinned host memory read by the device); 0 = never."""
+        _lib.check(self.L.sl2_ingest_set_zero_copy(self.h, int(max_batch_bytes)))
+
     def next(self, stream=None):
         ptr = _lib.vp()
         stride = C.c_size_t(0)

@@ -24,7 +24,7 @@ from mapping_helpers import make_mapping_sequence  # noqa: E402
 
 
 def run(exe, cfg, fd, mapping, out):
-    cmd = [exe, "--cfg", cfg, "--frames", fd, "--latency", out] + (["--mapping"] if mapping else [])
+    cmd = [exe, "--cfg", cfg, "--frames", fd, "--latency", out] + (["--mapping"] if mapping else []) + (["--copy-frames"] if os.environ.get("ADAPTER_COPY_FRAMES") else [])
     subprocess.run(cmd, check=True, timeout=600)
     return json.load(open(out))
 

@@ -245,8 +245,11 @@ def test_batched_ingest_delivers_every_frame_in_order(tmp_path):
 
 
 @pytest.mark.gpu
-def test_ingest_runs_one_frame_ahead_and_never_overwrites_a_frame_in_use(tmp_path):
-    """sl2_ingest_next uploads on a stream of its own, one frame ahead of the caller: the call that hands out frame k starts the
+@pytest.mark.parametrize("zero_copy", [False, True])
+def test_ingest_runs_one_frame_ahead_and_never_overwrites_a_frame_in_use(tmp_path, zero_copy):
+    """Small batches are handed out in place (zero_copy: the device reads the pinned batch, which goes back to the decoder only
+    when the consumer's stream is past it); larger ones are uploaded.  Both under the same test.
+    sl2_ingest_next uploads on a stream of its own, one frame ahead of the caller: the call that hands out frame k starts the
     copy of frame k + 1 into the other device buffer, which the caller's work on frame k - 1 read.  The contract (scenelib2_amd.h):
     the consumer of a frame is queued on `stream` before the next call; the copy then waits for it.  Checked with a SLOW
     consumer: on the caller's stream every frame is first held up by a host function (2 ms) and only then copied out - twelve
@@ -276,6 +279,8 @@ def test_ingest_runs_one_frame_ahead_and_never_overwrites_a_frame_in_use(tmp_pat
     assert hip.hipHostMalloc(C.byref(pinned), nfr * batch, 0) == 0
     hold = C.CFUNCTYPE(None, C.c_void_p)(lambda _arg: time.sleep(0.002))
     g = ingest.FrameIngest(dirs, W, H, depth=4)
+    if not zero_copy:
+        g.set_zero_copy(0)
     time.sleep(0.2)                                           # let the producer decode ahead, so that the prefetch really is issued
     for k in range(nfr):
         ptr, stride = g.next(stream=st.value)

@@ -257,13 +257,19 @@ __device__ __forceinline__ void tile_store(double* __restrict__ Sb, int mld, int
       for (int r = 0; r < 4; ++r) Sb[(size_t)(k0 + 16 * kt + hi + 4 * r) * mld + i0 + 16 * it + lo] = t.f[kt][it][r];
 }
 // panel tile: out[k][i] = sum_p Linv[k][p] S[o+p][i0+i]
+// `need` (wave-uniform) says which 16 x 16 quarters f[kt][it] of a tile are wanted, bit 2 kt + it: the tiles of the LAST block row
+// of a system whose last block holds at most 16 real rows (m mod 32 in 1 .. 16: m = 200 is one) have their rows 16 .. 31 = the
+// identity padding, whose products are zeros (kTileRowsLo); of a DIAGONAL tile the D wave reads the lower triangle only, so the
+// quarter above the diagonal (kt = 1, it = 0) is never looked at (kTileDiag), and with a padded last block only the first quarter
+// is (kTileDiagLo).  A 7-block system of 200 rows runs 58 instead of 77 tile operations' worth of MFMAs.
+constexpr int kTileAll = 15, kTileRowsLo = 5, kTileDiag = 11, kTileDiagLo = 1;
 __device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* __restrict__ Sb, int mld, int o, int i0, int lo,
-                                             int hi) {
+                                             int hi, int need) {
   double b0[8], b1[8];
 #pragma unroll
   for (int s8 = 0; s8 < 8; ++s8) {
     b0[s8] = Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + lo];
-    b1[s8] = Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + 16 + lo];
+    b1[s8] = (need & 10) ? Sb[(size_t)(o + 4 * s8 + hi) * mld + i0 + 16 + lo] : 0.0;
   }
   Tile32 t;
 #pragma unroll
@@ -275,14 +281,14 @@ __device__ __forceinline__ Tile32 tile_panel(const double* sLinv, const double* 
     const int p = 4 * s8 + hi;
     const double a0 = sLinv[p * kLinvPitch + lo], a1 = sLinv[p * kLinvPitch + 16 + lo];
     t.f[0][0] = mfma_f64(a0, b0[s8], t.f[0][0]);
-    t.f[0][1] = mfma_f64(a0, b1[s8], t.f[0][1]);
+    if (need & 2) t.f[0][1] = mfma_f64(a0, b1[s8], t.f[0][1]);
     t.f[1][0] = mfma_f64(a1, b0[s8], t.f[1][0]);
-    t.f[1][1] = mfma_f64(a1, b1[s8], t.f[1][1]);
+    if (need & 8) t.f[1][1] = mfma_f64(a1, b1[s8], t.f[1][1]);
   }
   return t;
 }
 // the same with the tile in registers: the fragment (k = 4 s8 + hi, i = 16 it + lo) of an accumulator IS the B operand of k-step s8
-__device__ __forceinline__ Tile32 tile_panel_regs(const double* sLinv, const Tile32& in, int lo, int hi) {
+__device__ __forceinline__ Tile32 tile_panel_regs(const double* sLinv, const Tile32& in, int lo, int hi, int need) {
   Tile32 t;
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
@@ -294,9 +300,9 @@ __device__ __forceinline__ Tile32 tile_panel_regs(const double* sLinv, const Til
     const double a0 = sLinv[p * kLinvPitch + lo], a1 = sLinv[p * kLinvPitch + 16 + lo];
     const double b0 = in.f[s8 >> 2][0][s8 & 3], b1 = in.f[s8 >> 2][1][s8 & 3];
     t.f[0][0] = mfma_f64(a0, b0, t.f[0][0]);
-    t.f[0][1] = mfma_f64(a0, b1, t.f[0][1]);
+    if (need & 2) t.f[0][1] = mfma_f64(a0, b1, t.f[0][1]);
     t.f[1][0] = mfma_f64(a1, b0, t.f[1][0]);
-    t.f[1][1] = mfma_f64(a1, b1, t.f[1][1]);
+    if (need & 8) t.f[1][1] = mfma_f64(a1, b1, t.f[1][1]);
   }
   return t;
 }
@@ -344,7 +350,7 @@ __device__ __forceinline__ void tile_trail(double* __restrict__ Sb, int mld, int
 // (the D wave's routine - d_column: [A; I] -> [L; L^-T] by column Cholesky, a row per lane - lives in sl2_chol_diag.hpp, which the
 // fused small-map kernel of sl2_small.hip shares)
 // acc(I, J) -= sum_{K < kend} L[J][K-block] L[I][K-block]^T (kend = J: the complete left-looking update)
-__device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int kend, int lo, int hi) {
+__device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int mld, int J, int I, int kend, int lo, int hi, int need) {
   Tile32 acc = tile_load(Sb, mld, J * 32, I * 32, lo, hi);
   // (measured slower: an explicit register prefetch of the next half-step's operands, 0.275 vs 0.243 ms; all 32 operand
   // loads of a product in one batch, 0.271 vs 0.266)
@@ -356,30 +362,30 @@ __device__ __forceinline__ Tile32 tile_left_update(double* __restrict__ Sb, int 
       for (int s4 = 0; s4 < 4; ++s4) {
         const size_t row = (size_t)(K * 32 + 16 * h + 4 * s4 + hi) * mld;
         a0[s4] = Sb[row + J * 32 + lo];
-        a1[s4] = Sb[row + J * 32 + 16 + lo];
+        a1[s4] = (need & 12) ? Sb[row + J * 32 + 16 + lo] : 0.0;
         b0[s4] = Sb[row + I * 32 + lo];
-        b1[s4] = Sb[row + I * 32 + 16 + lo];
+        b1[s4] = (need & 10) ? Sb[row + I * 32 + 16 + lo] : 0.0;
       }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         acc.f[0][0] = mfma_f64(-a0[s4], b0[s4], acc.f[0][0]);
-        acc.f[0][1] = mfma_f64(-a0[s4], b1[s4], acc.f[0][1]);
-        acc.f[1][0] = mfma_f64(-a1[s4], b0[s4], acc.f[1][0]);
-        acc.f[1][1] = mfma_f64(-a1[s4], b1[s4], acc.f[1][1]);
+        if (need & 2) acc.f[0][1] = mfma_f64(-a0[s4], b1[s4], acc.f[0][1]);
+        if (need & 4) acc.f[1][0] = mfma_f64(-a1[s4], b0[s4], acc.f[1][0]);
+        if (need & 8) acc.f[1][1] = mfma_f64(-a1[s4], b1[s4], acc.f[1][1]);
       }
     }
   }
   return acc;
 }
 // diagonal tile: acc -= l^T l for the k-major panel tile l = L[I][J-block] held in registers (A and B fragments coincide)
-__device__ __forceinline__ void tile_diag_sub_regs(Tile32& acc, const Tile32& l) {
+__device__ __forceinline__ void tile_diag_sub_regs(Tile32& acc, const Tile32& l, int need) {
 #pragma unroll
   for (int s8 = 0; s8 < 8; ++s8) {
     const double v0 = l.f[s8 >> 2][0][s8 & 3], v1 = l.f[s8 >> 2][1][s8 & 3];
     acc.f[0][0] = mfma_f64(-v0, v0, acc.f[0][0]);
-    acc.f[0][1] = mfma_f64(-v0, v1, acc.f[0][1]);
-    acc.f[1][0] = mfma_f64(-v1, v0, acc.f[1][0]);
-    acc.f[1][1] = mfma_f64(-v1, v1, acc.f[1][1]);
+    if (need & 2) acc.f[0][1] = mfma_f64(-v0, v1, acc.f[0][1]);
+    if (need & 4) acc.f[1][0] = mfma_f64(-v1, v0, acc.f[1][0]);
+    if (need & 8) acc.f[1][1] = mfma_f64(-v1, v1, acc.f[1][1]);
   }
 }
 
@@ -397,6 +403,10 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool isD = wave == 0;
   const int mw = wave - 1;
+  // the last block of THIS launch holds at most 16 real rows (its rows 16 .. 31 are the identity padding): see kTileRowsLo
+  const bool half_last = 2 * cnt - 32 * (J0 + nblk - 1) <= 16;
+  auto off_need = [&](int I) { return (half_last && I == nblk - 1) ? kTileRowsLo : kTileAll; };
+  auto diag_need = [&](int I) { return (half_last && I == nblk - 1) ? kTileDiagLo : kTileDiag; };
   __shared__ double sTile[32][33];
   __shared__ double sLinv[32 * kLinvPitch];
   __shared__ double sNext[1024];      // the next diagonal tile (partial), MFMA fragment order
@@ -438,7 +448,7 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       for (int sidx = turn; ; sidx += 3) {
         const int t = sidx == 0 ? 3 : sidx + 4;
         if (J + t >= nblk) break;
-        const Tile32 u = tile_panel(sLinv, Sb, mld, o, (J + t) * 32, lo, hi);
+        const Tile32 u = tile_panel(sLinv, Sb, mld, o, (J + t) * 32, lo, hi, off_need(J + t));
         tile_store(Sb, mld, o, (J + t) * 32, lo, hi, u);
       }
     };
@@ -480,29 +490,29 @@ __global__ void __launch_bounds__(256, 4) k_chol_left(double* __restrict__ St, d
       int keptI = nblk;
       if (more) {                                   // (the last column has no tile below it)
         if (mw == 1) {                              // task 1
-          const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi);
+          const Tile32 dn = tile_left_update(Sb, mld, J + 1, J + 1, J, lo, hi, diag_need(J + 1));
 #pragma unroll
           for (int k = 0; k < 16; ++k) sNext[k * 64 + lane_j] = dn.f[k >> 3][(k >> 2) & 1][k & 3];
         }
         const int t_keep = mw == 0 ? 0 : (mw == 1 ? 4 : 2);
         for (int t = t_keep + 3; J + t < nblk; t += 3) {          // the wave's later tiles: updated, stored
-          const Tile32 u = tile_left_update(Sb, mld, J, J + t, J, lo, hi);
+          const Tile32 u = tile_left_update(Sb, mld, J, J + t, J, lo, hi, off_need(J + t));
           tile_store(Sb, mld, o, (J + t) * 32, lo, hi, u);
         }
         keptI = mw == 0 ? J + 1 : J + t_keep;
-        if (keptI < nblk) kept = tile_left_update(Sb, mld, J, keptI, J, lo, hi);
+        if (keptI < nblk) kept = tile_left_update(Sb, mld, J, keptI, J, lo, hi, off_need(keptI));
       }
       TRL(2);
       __syncthreads();                     // X2 (the D wave meets it in its own branch)
       // ---- P3 ----
       if (keptI < nblk) {
-        const Tile32 l = tile_panel_regs(sLinv, kept, lo, hi);
+        const Tile32 l = tile_panel_regs(sLinv, kept, lo, hi, off_need(keptI));
         tile_store(Sb, mld, o, keptI * 32, lo, hi, l);
         if (mw == 0) {                     // the chain: the next diagonal tile minus the square of the tile just solved
           Tile32 dn;
 #pragma unroll
           for (int q = 0; q < 16; ++q) dn.f[q >> 3][(q >> 2) & 1][q & 3] = sNext[q * 64 + lane_j];
-          tile_diag_sub_regs(dn, l);
+          tile_diag_sub_regs(dn, l, diag_need(J + 1));
           diag_to_lds(dn, lo, hi);
         }
       }

@@ -33,8 +33,11 @@ extern "C" {
  * doubles (out[11] = candidate tiles), search variants renumbered (1 = int8 matrix-core walk, 0 = exact kernel; 2 and 3 are
  * gone and return SL2_ERR_INVALID), sl2_set_update_variant accepts only (1, 1) outside the TEST build; 4 = sl2_get_step_work
  * takes the capacity of the caller's array, sl2_snapshot / sl2_snapshot_capacity, several partially initialised features per
- * sequence (max_features_to_init_at_once > 1), sl2_get_partial_feature takes the index of the partial feature. */
-#define SL2_API_VERSION 4
+ * sequence (max_features_to_init_at_once > 1), sl2_get_partial_feature takes the index of the partial feature; 5 = sl2_ingest_next
+ * uploads on a stream of its own, one frame ahead (or hands a small batch out in place): its `stream` argument is the stream the
+ * frames are CONSUMED on, not the one the copy is queued on; sl2_set_update_variant no longer takes chol_variant 2; new:
+ * sl2_set_step_fusion, sl2_get_stream, sl2_ingest_set_zero_copy; scenelib2_amd_comm.h. */
+#define SL2_API_VERSION 5
 
 #define SL2_OK 0
 #define SL2_ERR_INVALID 1   /* bad argument */
@@ -219,7 +222,7 @@ int sl2_set_step_fusion(sl2_engine* e, int enabled);
  * whole frame (150 bands at 320 x 240), and one wavefront walking it alone was the tail of the search.  Default: a twentieth
  * of the frame's bands (8 at 320 x 240, 96 at 1280 x 720: what is shared out should be the rare oversized window); 0 =
  * never (and no extra workgroups: they cost the headline step 0.06 %).  Results are identical either way: the parts' best
- * and second-best candidates are combined into the decision a single wavefront takes.  (An addition within SL2_API_VERSION 4: no existing entry point
+ * and second-best candidates are combined into the decision a single wavefront takes.  (An addition within SL2_API_VERSION 4 at the time: no existing entry point
  * changed; sl2_get_step_work has a 13th value.) */
 int sl2_set_search_split(sl2_engine* e, int min_bands);
 /* Kernel choice inside sl2_kalman_filter_update (identical algebra, results equal to rounding):

@@ -805,7 +805,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
   const int slots_bound = slots_upper_bound(e);
-  const int small_any = [&]() { int m = 0; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (part of a captured step's key)
+  const int small_any = [&]() { int m = (slots_bound + 1 > e->N) ? 1 : 0; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (which launches the step consists of: part of a captured step's key)
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
@@ -834,7 +834,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
       g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
-      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory);
+      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory, slots_bound);
     }
     return r;
   };

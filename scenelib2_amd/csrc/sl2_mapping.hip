@@ -880,7 +880,7 @@ int launch_auto_init(sl2_engine* e) {
   return launch_create(e, mp);
 }
 
-int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound) {
   const int B = e->B;
   MapParams mp;
   mp.force = 0;
@@ -896,7 +896,10 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory) {
   mp.kpart = e->root->kpart;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map) { set_error("launch_mapping: score map not allocated"); return SL2_ERR_INVALID; }
-  if (enable_mapping) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
+  // Retired slots are squeezed out only when a sequence is about to run out of slots; the host's upper bound on the slots in use
+  // (sl2_engine.hip: slots_upper_bound) says when none can be: the launch - one of the step's dependent chain, 7 us at one
+  // sequence, 0.03 ms at 1024 - is then left out altogether.
+  if (enable_mapping && slots_bound + 1 > e->N) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
   {
     LaunchScope ls(e, "k_map_region");
     hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,

@@ -39,6 +39,8 @@ int main(int argc, char** argv) {
       auto median = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
       auto mean = [](const std::vector<double>& v) { double s = 0; for (double x : v) s += x; return v.empty() ? 0.0 : s / v.size(); };
       std::vector<double> loop_us, call_us, step_us, refresh_us, snap_us;
+      std::vector<double> loop_free_us, loop_partial_us;      // frames that start without / with a partially initialised feature
+      std::string partial_seq;                                // their number at the start of every frame of pass 0, one digit each
       size_t n_features = 0, n_frames = 0, snap_cap = 0;
       for (int pass = 0; pass < 2; ++pass) {
         SceneLib2Amd::MonoSLAM slam;
@@ -50,6 +52,8 @@ int main(int argc, char** argv) {
         if (!zero_copy) sl2_ingest_set_zero_copy(grab, 0);
         const int n = sl2_ingest_frame_count(grab);
         for (int frame_id = 0; frame_id < n; ++frame_id) {
+          const bool partial_before = !slam.feature_init_info_vector_.empty();
+          if (pass == 0) partial_seq.push_back((char)('0' + std::min<size_t>(slam.feature_init_info_vector_.size(), 9)));
           const auto t0 = std::chrono::steady_clock::now();
           SceneLib2Amd::Frame frame;
           size_t stride = 0;
@@ -61,6 +65,7 @@ int main(int argc, char** argv) {
           if (frame_id < 5) continue;                                   // warm-up: first launches, lazy allocations
           if (pass == 0) {
             loop_us.push_back(std::chrono::duration<double, std::micro>(t2 - t0).count());
+            (partial_before ? loop_partial_us : loop_free_us).push_back(loop_us.back());
             call_us.push_back(std::chrono::duration<double, std::micro>(t2 - t1).count());
           } else {
             step_us.push_back(slam.last_step_us_);
@@ -78,9 +83,12 @@ int main(int argc, char** argv) {
       fprintf(f, "{\"frames\": %zu, \"timed_frames\": %zu, \"features_at_end\": %zu, \"mapping\": %s, "
                  "\"frame_us_median\": %.2f, \"frame_us_mean\": %.2f, \"go_one_step_us_median\": %.2f, \"go_one_step_us_mean\": %.2f, "
                  "\"step_us_median\": %.2f, \"step_us_mean\": %.2f, \"readback_us_median\": %.2f, \"readback_us_mean\": %.2f, \"snapshot_call_us_median\": %.2f, "
-                 "\"blocking_copies_per_frame\": 0, \"synchronisations_per_frame\": 1, \"snapshot_capacity_bytes\": %zu}\n",
+                 "\"frames_starting_without_partial_feature\": %zu, \"frame_us_median_without_partial_feature\": %.2f, "
+                 "\"frames_starting_with_partial_feature\": %zu, \"frame_us_median_with_partial_feature\": %.2f, "
+                 "\"partial_features_at_frame_start\": \"%s\", \"blocking_copies_per_frame\": 0, \"synchronisations_per_frame\": 1, \"snapshot_capacity_bytes\": %zu}\n",
               n_frames, loop_us.size(), n_features, enable_mapping ? "true" : "false", median(loop_us), mean(loop_us), median(call_us),
-              mean(call_us), median(step_us), mean(step_us), median(refresh_us), mean(refresh_us), median(snap_us), snap_cap);
+              mean(call_us), median(step_us), mean(step_us), median(refresh_us), mean(refresh_us), median(snap_us), loop_free_us.size(),
+              median(loop_free_us), loop_partial_us.size(), median(loop_partial_us), partial_seq.c_str(), snap_cap);
       fclose(f);
     } catch (const std::exception& e) {
       fprintf(stderr, "error: %s\n", e.what());

@@ -198,6 +198,9 @@ struct sl2_engine {
   int* slots_max_dev = nullptr;                  // [2] device: maxima of the steps in flight (step parity)
   unsigned long long* slots_mail = nullptr;      // pinned + mapped host word: (step << 32) | max n_slots of the step before it
   unsigned long long* slots_mail_dev = nullptr;  // its device address
+  unsigned long long* parts_mail = nullptr;      // the word after it, one-sequence engines: (steps completed << 32) | partially initialised features left by k_map_update
+  unsigned long long* parts_mail_dev = nullptr;
+  long long parts_block_step = -1;               // a step of this index must not trust parts_mail (a feature was initialised by hand since)
   int slots_exact = 0;                           // max n_slots over the batch when last read back ...
   long long slots_exact_step = 0;                // ... and steps_done at that point
   int step_fusion = 1;        // small maps (sl2_small.hip: ld <= 128, one 32-row innovation block) step in three launches instead of ten; 0 = never (sl2_set_step_fusion)
@@ -308,7 +311,7 @@ int launch_small_front(sl2_engine* e, int n);                 // predict + featu
 int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound);   // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory);
-int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound);
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_none);
 int launch_manual_init(sl2_engine* e, const int* d_uv);
 int launch_auto_init(sl2_engine* e);
 int launch_compact_slots(sl2_engine* e, int need);   // sl2_mapping.hip: retired slots squeezed out when a sequence lacks room for `need` more features

@@ -395,9 +395,10 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
 #undef A
   SL2_HIP(hipMalloc((void**)&e->slots_max_dev, sizeof(int) * 2));
   SL2_HIP(hipMemset(e->slots_max_dev, 0, sizeof(int) * 2));
-  SL2_HIP(hipHostMalloc((void**)&e->slots_mail, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
-  *e->slots_mail = 0ull;
+  SL2_HIP(hipHostMalloc((void**)&e->slots_mail, 2 * sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+  e->slots_mail[0] = 0ull; e->slots_mail[1] = 0ull;
   SL2_HIP(hipHostGetDevicePointer((void**)&e->slots_mail_dev, e->slots_mail, 0));
+  e->parts_mail = e->slots_mail + 1; e->parts_mail_dev = e->slots_mail_dev + 1;
   {  // srand48(0) in MonoSLAM::Init (monoslam.cpp:1968), one generator per sequence
     std::vector<unsigned long long> seeds(B, kRand48Seed0);
     SL2_HIP(hipMemcpy(e->rand48, seeds.data(), sizeof(unsigned long long) * B, hipMemcpyHostToDevice));
@@ -514,6 +515,16 @@ static int slots_upper_bound(const sl2_engine* e) {
     if (viaMail < best) best = viaMail;
   }
   return best > 1000000 ? 1000000 : (int)best;
+}
+
+// True when the step about to be issued (index steps_done) is known to start without a partially initialised feature: the
+// step before it ran the feature-initialisation tail, whose k_map_update reported none left (one-sequence engines only: the
+// report is a plain store of the one workgroup), the report has arrived, and no feature was initialised by hand since.  A caller
+// who queues steps ahead of the device sees a report that is not current and gets the full set of launches - never a wrong skip.
+static int parts_none_for_step(const sl2_engine* e) {
+  if (e->B != 1 || !e->mapping_used || e->step_fusion == 0 || e->parts_block_step == e->steps_done) return 0;
+  const unsigned long long mail = __atomic_load_n(e->parts_mail, __ATOMIC_ACQUIRE);
+  return (long long)(mail >> 32) == e->steps_done && (mail & 0xffffffffull) == 0ull && e->steps_done > 0;
 }
 
 int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx) {
@@ -771,6 +782,7 @@ static int initialise_common(sl2_engine* e, const uint8_t* frames, size_t seq_st
     rc = launch_auto_init(g);
   }
   if (rc != SL2_OK) return rc;
+  e->parts_block_step = e->steps_done;       // the next step starts with a partial feature k_map_update has not reported
   { int rc2 = drop_step_graphs(e); if (rc2 != SL2_OK) return rc2; }     // captured steps were recorded without the feature-initialisation tail
   // (a button press: the call synchronises, and takes the exact map sizes while it is at it)
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
@@ -805,7 +817,8 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
   const int slots_bound = slots_upper_bound(e);
-  const int small_any = [&]() { int m = (slots_bound + 1 > e->N) ? 1 : 0; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (which launches the step consists of: part of a captured step's key)
+  const int parts_none = tail ? parts_none_for_step(e) : 0;
+  const int small_any = [&]() { int m = ((slots_bound + 1 > e->N) ? 1 : 0) + 2 * parts_none; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (which launches the step consists of: part of a captured step's key)
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
@@ -834,7 +847,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
       g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
-      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory, slots_bound);
+      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory, slots_bound, parts_none);
     }
     return r;
   };

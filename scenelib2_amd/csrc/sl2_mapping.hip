@@ -29,6 +29,10 @@ struct MapParams {
   double min_lambda, max_lambda, sd_ratio, prune_threshold, dt;
   int pcap;       // particle slots per partial feature in `particles` / `me_desc` (sl2_engine::pcap)
   int kpart;      // partial slots per sequence (sl2_engine::kpart)
+  // One-sequence engines (launch_mapping): k_map_update reports how many partially initialised features the step leaves, and a
+  // step issued while the report says "none" runs without k_map_particles / k_map_me_search / k_me_big.
+  int parts_skipped = 0;    // this step runs without them: k_map_create does the one thing k_map_particles does to a feature of this frame
+  int publish_parts = 0;    // k_map_update writes (steps completed << 32) | partial features left to parts_mail
 };
 
 // ---------------------------------------------------------------------------
@@ -283,7 +287,8 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
     next_label[b] += 1;
     n_slots[b] = label + 1;
     int* ps = psb + ks * kPsInts;
-    ps[kPsActive] = 1; ps[kPsLabel] = label; ps[kPsAttempts] = 0; ps[kPsNp] = mp.n_particles; ps[kPsMaking] = 0;
+    // (a feature made in this frame is not matched in it, Q29: all k_map_particles does to it is number_of_match_attempts_++)
+    ps[kPsActive] = 1; ps[kPsLabel] = label; ps[kPsAttempts] = mp.parts_skipped ? 1 : 0; ps[kPsNp] = mp.n_particles; ps[kPsMaking] = 0;
     pi[kPartOrder + pi[kPartCount]] = ks;          // feature_init_info_vector_.push_back
     pi[kPartCount] += 1;
     pi[kPartCreated] = 1;
@@ -400,7 +405,8 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
                                                    int* __restrict__ ps_i, double* __restrict__ ps_d, int* __restrict__ pos_err,
                                                    int* __restrict__ pos_err_any, double* __restrict__ particles,
                                                    double* __restrict__ traj, int* __restrict__ traj_count,
-                                                   const double* __restrict__ last_r, MapParams mp, int N, int ld, int ppos0) {
+                                                   const double* __restrict__ last_r, const int* __restrict__ pos_count,
+                                                   unsigned long long* __restrict__ parts_mail, MapParams mp, int N, int ld, int ppos0) {
   const int b = blockIdx.x, lane = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   double* xb = x + (size_t)b * ld;
@@ -634,6 +640,9 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
       for (int k = 0; k < 3; ++k) t[k] = last_r[b * 3 + k];
       traj_count[b] = c + 1;
     }
+    // the host's next step (index pos_count: k_finalize has counted this one) may leave the partial-feature launches out if none is left
+    if (mp.publish_parts)
+      __hip_atomic_store(parts_mail, ((unsigned long long)(unsigned)pos_count[b] << 32) | (unsigned)s_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -880,7 +889,7 @@ int launch_auto_init(sl2_engine* e) {
   return launch_create(e, mp);
 }
 
-int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound) {
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_none) {
   const int B = e->B;
   MapParams mp;
   mp.force = 0;
@@ -894,6 +903,11 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
   mp.dt = e->prm.delta_t;
   mp.pcap = e->root->pcap;
   mp.kpart = e->root->kpart;
+  // The three launches that serve partially initialised features are dead weight while there is none, and at one sequence each
+  // is a link of the frame's dependent chain: k_map_update's report (sl2_engine.hip: parts_none_for_step) lets the host leave
+  // them out.  me_big_count keeps its last value meanwhile; k_map_particles zeroes it before anything reads it again.
+  mp.parts_skipped = parts_none ? 1 : 0;
+  mp.publish_parts = (e->root->B == 1 && e->root->parts_mail_dev) ? 1 : 0;
   const int W = e->cam.width, H = e->cam.height;
   if (!e->score_map) { set_error("launch_mapping: score map not allocated"); return SL2_ERR_INVALID; }
   // Retired slots are squeezed out only when a sequence is about to run out of slots; the host's upper bound on the slots in use
@@ -918,7 +932,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
                        e->ps_i, e->ps_d, e->pos_err, e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }
-  {
+  if (!parts_none) {
     LaunchScope ls(e, "k_map_particles");
     const int pc = e->root->pcap;
 #define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B, mp.kpart), dim3(pc), 0, e->stream, e->x, e->P, e->ps_i, e->particles, \
@@ -930,7 +944,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
 #undef SL2_PARTICLES
     SL2_HIP(hipGetLastError());
   }
-  {
+  if (!parts_none) {
     MeJobsEngine J;
     J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.ps_i = e->ps_i; J.me_desc = e->me_desc;
     J.particles = e->particles; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
@@ -949,7 +963,8 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
   {
     LaunchScope ls(e, "k_map_update");
     hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), sizeof(double) * kParticleDoubles * (size_t)mp.n_particles, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i,
-                       e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->particles, e->traj, e->traj_count, e->last_r, mp, e->N, e->ld, e->ppos);
+                       e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->particles, e->traj, e->traj_count, e->last_r, e->pos_count,
+                       e->root->parts_mail_dev, mp, e->N, e->ld, e->ppos);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

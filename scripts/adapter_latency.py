@@ -64,7 +64,7 @@ def known_features_builder(cam, params, spec, tpl, mapping):
 
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "adapter_latency.json")
-    exe = os.path.join(ROOT, "examples", "monoslam_adapter")
+    exe = os.environ.get("ADAPTER_EXE") or os.path.join(ROOT, "examples", "monoslam_adapter")     # (another build of it: scripts/ab_adapter.sh)
     res = {}
     with tempfile.TemporaryDirectory() as d:
         # (a) configs[1]: 100 known features, all selected, mapping off, 120 frames

@@ -109,3 +109,27 @@ def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mappin
     traj = v[at:].reshape(-1, 3)
     t0 = s.trajectory()
     assert traj.shape == t0.shape and np.abs(traj - t0).max() < 1e-9
+
+
+def test_adapter_loop_of_120_frames_holds_the_oracles_partial_features_frame_by_frame(tmp_path):
+    """The adapter's timed loop (--latency: what scripts/adapter_latency.py runs) on the feature-initialisation sequence: frames
+    read in place from the grabber's pinned ring, one snapshot per frame, the engine leaving out the partial-feature launches
+    whenever the previous step reported none (sl2_engine.hip: parts_none_for_step).  feature_init_info_vector_.size() at the
+    start of every frame must be the oracle's - a feature made, matched, converted or dropped one frame late would show here."""
+    import json
+    exe = os.path.join(ROOT, "examples", "monoslam_adapter")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    cam, params, spec, frames, templates = make_mapping_sequence(n_frames=120)
+    cfg, fd = _write_scene(str(tmp_path), cam, params, spec, frames, templates)
+    out = os.path.join(str(tmp_path), "latency.json")
+    subprocess.run([exe, "--cfg", cfg, "--frames", fd, "--latency", out, "--mapping"], check=True, timeout=300)
+    got = json.load(open(out))
+    s = oracle_for(cam, params, spec, templates, oa)
+    seq = ""
+    for k in range(1, 121):
+        seq += str(min(s.mapping_info()["n_partial"], 9))
+        s.go_one_step(frames[k], True, True)
+    assert got["partial_features_at_frame_start"] == seq
+    assert got["frames_starting_without_partial_feature"] + got["frames_starting_with_partial_feature"] == got["timed_frames"]
+    assert got["features_at_end"] == s.num_features

@@ -305,7 +305,7 @@ def main():
     # profiling scopes carry the kernel symbols (they join with rocprofv3's kernel_stats.csv on the name)
     MAJOR = ("k_syrk", "k_fwdsub_lds", "k_fwdsub_ksplit", "k_fwd_gemm", "k_build_AS", "k_chol_left", "k_chol_syrk", "k_search_mfma")
     if args.mapping:
-        MAJOR = MAJOR + ("k_map_detect", "k_map_me_search", "k_me_big", "k_map_particles", "k_map_update")
+        MAJOR = MAJOR + ("k_map_find", "k_map_me_search", "k_me_big", "k_map_particles", "k_map_update", "k_map_finish")
     SEARCH = "k_search_mfma"
     focus = "k_syrk," + SEARCH
     n_probe = 3 if (not args.no_profile and Wm >= 6) else 0

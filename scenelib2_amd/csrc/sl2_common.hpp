@@ -311,7 +311,7 @@ int launch_small_front(sl2_engine* e, int n);                 // predict + featu
 int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound);   // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);
 int launch_finalize(sl2_engine* e, int save_trajectory);
-int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_none);
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_state);
 int launch_manual_init(sl2_engine* e, const int* d_uv);
 int launch_auto_init(sl2_engine* e);
 int launch_compact_slots(sl2_engine* e, int need);   // sl2_mapping.hip: retired slots squeezed out when a sequence lacks room for `need` more features

@@ -517,14 +517,18 @@ static int slots_upper_bound(const sl2_engine* e) {
   return best > 1000000 ? 1000000 : (int)best;
 }
 
-// True when the step about to be issued (index steps_done) is known to start without a partially initialised feature: the
-// step before it ran the feature-initialisation tail, whose k_map_update reported none left (one-sequence engines only: the
-// report is a plain store of the one workgroup), the report has arrived, and no feature was initialised by hand since.  A caller
-// who queues steps ahead of the device sees a report that is not current and gets the full set of launches - never a wrong skip.
-static int parts_none_for_step(const sl2_engine* e) {
-  if (e->B != 1 || !e->mapping_used || e->step_fusion == 0 || e->parts_block_step == e->steps_done) return 0;
+// What the host knows about the partially initialised features the step about to be issued (index steps_done) starts with:
+// 1 = none, 2 = every partial slot taken, 0 = not known (launch_mapping then issues every launch).  Known means: the step before
+// it ran the feature-initialisation tail, whose k_map_update reported the count it left (one-sequence engines only: the report
+// is a plain store of the one workgroup), the report has arrived, and no feature was initialised or deleted by hand since.  A
+// caller who queues steps ahead of the device sees a report that is not current and gets the full set of launches - never a
+// wrong skip.
+static int parts_state_for_step(const sl2_engine* e) {
+  if (e->B != 1 || !e->mapping_used || e->step_fusion == 0 || e->parts_block_step == e->steps_done || e->steps_done <= 0) return 0;
   const unsigned long long mail = __atomic_load_n(e->parts_mail, __ATOMIC_ACQUIRE);
-  return (long long)(mail >> 32) == e->steps_done && (mail & 0xffffffffull) == 0ull && e->steps_done > 0;
+  if ((long long)(mail >> 32) != e->steps_done) return 0;
+  const long long left = (long long)(mail & 0xffffffffull);
+  return left == 0 ? 1 : (left >= e->kpart ? 2 : 0);
 }
 
 int sl2_set_vehicle_state(sl2_engine* e, int seq0, int nseq, const double* xv, const double* Pxx) {
@@ -817,8 +821,8 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
   // (monoslam.cpp:167 is unconditional); the trajectory push then moves behind it (k_map_update).
   const bool tail = e->mapping_used;
   const int slots_bound = slots_upper_bound(e);
-  const int parts_none = tail ? parts_none_for_step(e) : 0;
-  const int small_any = [&]() { int m = ((slots_bound + 1 > e->N) ? 1 : 0) + 2 * parts_none; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (which launches the step consists of: part of a captured step's key)
+  const int parts_state = tail ? parts_state_for_step(e) : 0;
+  const int small_any = [&]() { int m = ((slots_bound + 1 > e->N) ? 1 : 0) + 2 * parts_state; for (const sl2_engine* g : e->groups) m = (m * 5 + small_step_mode(g, slots_bound)) % 1000003; return m; }();   // (which launches the step consists of: part of a captured step's key)
   auto issue = [=]() -> int {
     int r = for_each_group(e, [=](sl2_engine* g) {
       int q;
@@ -847,7 +851,7 @@ int sl2_go_one_step(sl2_engine* e, const uint8_t* frames, size_t seq_stride, int
       g->cur_frames = e->cur_frames; g->cur_stride = e->cur_stride;
       g->score_map = e->score_map;
       g->me_big_list = e->me_big_list; g->me_big_count = e->me_big_count;
-      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory, slots_bound, parts_none);
+      r = launch_mapping(g, enable_mapping ? 1 : 0, save_trajectory, slots_bound, parts_state);
     }
     return r;
   };
@@ -1234,6 +1238,7 @@ int sl2_delete_features(sl2_engine* e, int seq0, int nseq, const int32_t* labels
   if (!range_ok(e, seq0, nseq) || !labels) return SL2_ERR_INVALID;
   SL2_HIP(hipSetDevice(e->device));
   { int _rc = e->sync_all(); if (_rc != SL2_OK) return _rc; }
+  e->parts_block_step = e->steps_done;       // (nothing here touches a partial feature today; the next step takes no shortcut all the same)
   int *d_lab = nullptr, *d_done = nullptr;
   SL2_HIP(hipMalloc((void**)&d_lab, sizeof(int) * nseq));
   if (hipMalloc((void**)&d_done, sizeof(int) * nseq) != hipSuccess) { hipFree(d_lab); set_error("hipMalloc failed"); return SL2_ERR_HIP; }

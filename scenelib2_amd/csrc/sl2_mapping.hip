@@ -36,16 +36,20 @@ struct MapParams {
 };
 
 // ---------------------------------------------------------------------------
-// k_map_region: one wavefront per sequence.
+// k_map_find = FindNonOverlappingRegion + the detector over the region it picked, one workgroup of kDetThreads per sequence
+// (rounds 1-5: k_map_region and k_map_detect, two launches - at one sequence each launch is a link of the frame's chain).
+// region_body is the first wavefront's work; the other waves only keep its barriers company (every thread of the workgroup
+// calls it).  On return the region, or "no region", is in part_i for every thread to read.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x, const int* __restrict__ f_flags,
-                                                   const int* __restrict__ n_slots, const int* __restrict__ n_vis,
-                                                   const double* __restrict__ prev_r, int* __restrict__ part_i,
-                                                   unsigned long long* __restrict__ rand48, double* __restrict__ last_r,
-                                                   int* __restrict__ status, CameraParams cam, MapParams mp, int N, int ld) {
-  extern __shared__ double s_uv[];   // [2 * N] projections of the known features in front of the camera
+__device__ __forceinline__ void region_body(const double* __restrict__ x, const int* __restrict__ f_flags,
+                                            const int* __restrict__ n_slots, const int* __restrict__ n_vis,
+                                            const double* __restrict__ prev_r, int* __restrict__ part_i,
+                                            unsigned long long* __restrict__ rand48, double* __restrict__ last_r,
+                                            int* __restrict__ status, const CameraParams& cam, const MapParams& mp, int N, int ld,
+                                            double* s_uv /* [2 * N] projections of the known features in front of the camera */) {
   __shared__ int s_cnt, s_go, s_safe[4];
   const int b = blockIdx.x, lane = threadIdx.x;
+  const bool first_wave = lane < 64;
   const double* xb = x + (size_t)b * ld;
   int* pi = part_i + (size_t)b * kPartInts;
   const int ns = n_slots[b];
@@ -97,7 +101,7 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
   __syncthreads();
   if (!s_go) return;
   // image positions of the fully initialised features in front of the camera (:968-985)
-  {
+  if (first_wave) {
     double xp[7];
     for (int i = 0; i < 7; ++i) xp[i] = xb[i];
     for (int i = lane; i < ns; i += 64) {
@@ -134,29 +138,49 @@ __global__ void __launch_bounds__(64) k_map_region(const double* __restrict__ x,
     pi[kPartRegion + 0] = us; pi[kPartRegion + 1] = vs; pi[kPartRegion + 2] = uf; pi[kPartRegion + 3] = vf;
     pi[kPartRegionValid] = (i != 5) ? 1 : 0;
   }
+  __syncthreads();
 }
 
-__global__ void __launch_bounds__(kDetThreads) k_map_detect(const uint8_t* __restrict__ frames, size_t seq_stride, int width, int height,
-                                                            int* __restrict__ part_i, double* __restrict__ part_d) {
+__global__ void __launch_bounds__(kDetThreads) k_map_find(const double* __restrict__ x, const int* __restrict__ f_flags,
+                                                          const int* __restrict__ n_slots, const int* __restrict__ n_vis,
+                                                          const double* __restrict__ prev_r, int* __restrict__ part_i,
+                                                          double* __restrict__ part_d, unsigned long long* __restrict__ rand48,
+                                                          double* __restrict__ last_r, int* __restrict__ status,
+                                                          const uint8_t* __restrict__ frames, size_t seq_stride, CameraParams cam,
+                                                          MapParams mp, int N, int ld) {
+  extern __shared__ double s_uv[];
+  region_body(x, f_flags, n_slots, n_vis, prev_r, part_i, rand48, last_r, status, cam, mp, N, ld, s_uv);
   const int b = blockIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   if (!pi[kPartRegionValid]) return;
-  detect_region_wg(frames + (size_t)b * seq_stride, width, height, pi[kPartRegion + 0], pi[kPartRegion + 1], pi[kPartRegion + 2],
+  detect_region_wg(frames + (size_t)b * seq_stride, cam.width, cam.height, pi[kPartRegion + 0], pi[kPartRegion + 1], pi[kPartRegion + 2],
                    pi[kPartRegion + 3], pi + kPartUU, part_d + (size_t)b * kPartDoubles + 2);
 }
 
 // ---------------------------------------------------------------------------
-// k_map_create: one wavefront per sequence.
+// k_map_create: one wavefront per sequence.  The arguments of the feature-initialisation tail's per-sequence kernels travel
+// in one struct: create_body and update_body run as kernels of their own, or one after the other in k_map_finish.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, double* __restrict__ P, const uint8_t* __restrict__ frames,
-                                                   size_t seq_stride, uint8_t* __restrict__ patch, int* __restrict__ patch_sums,
-                                                   double* __restrict__ xp_org, int* __restrict__ f_flags, int* __restrict__ n_slots,
-                                                   int* __restrict__ attempted, int* __restrict__ successful,
-                                                   int* __restrict__ f_label, int* __restrict__ next_label,
-                                                   int* __restrict__ part_i, double* __restrict__ part_d,
-                                                   int* __restrict__ ps_i, double* __restrict__ ps_d, int* __restrict__ pos_err,
-                                                   double* __restrict__ particles, double* __restrict__ last_r, CameraParams cam,
-                                                   MapParams mp, int N, int ld, int ppos0) {
+struct MapArrays {
+  double *x, *P;
+  const uint8_t* frames; size_t seq_stride;
+  uint8_t* patch; int* patch_sums; double* xp_org;
+  int *f_flags, *n_slots, *attempted, *successful, *f_label, *next_label, *part_i;
+  double* part_d; int* ps_i; double* ps_d; int *pos_err, *pos_err_any;
+  double *particles, *last_r, *traj; int* traj_count; const int* pos_count; unsigned long long* parts_mail;
+  int N, ld, ppos0;
+};
+
+__device__ __forceinline__ void create_body(const MapArrays& a, const CameraParams& cam, const MapParams& mp) {
+  double* __restrict__ x = a.x; double* __restrict__ P = a.P; const uint8_t* __restrict__ frames = a.frames;
+  const size_t seq_stride = a.seq_stride;
+  uint8_t* __restrict__ patch = a.patch; int* __restrict__ patch_sums = a.patch_sums; double* __restrict__ xp_org = a.xp_org;
+  int* __restrict__ f_flags = a.f_flags; int* __restrict__ n_slots = a.n_slots; int* __restrict__ attempted = a.attempted;
+  int* __restrict__ successful = a.successful; int* __restrict__ f_label = a.f_label; int* __restrict__ next_label = a.next_label;
+  int* __restrict__ part_i = a.part_i; double* __restrict__ part_d = a.part_d; int* __restrict__ ps_i = a.ps_i;
+  double* __restrict__ ps_d = a.ps_d; int* __restrict__ pos_err = a.pos_err; double* __restrict__ particles = a.particles;
+  double* __restrict__ last_r = a.last_r;
+  const int N = a.N, ld = a.ld, ppos0 = a.ppos0;
   const int b = blockIdx.x, lane = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   double* pd = part_d + (size_t)b * kPartDoubles;
@@ -298,6 +322,8 @@ __global__ void __launch_bounds__(64) k_map_create(double* __restrict__ x, doubl
   }
 }
 
+__global__ void __launch_bounds__(64) k_map_create(MapArrays a, CameraParams cam, MapParams mp) { create_body(a, cam, mp); }
+
 // ---------------------------------------------------------------------------
 // k_map_particles: one workgroup per sequence, one thread per particle.
 // ---------------------------------------------------------------------------
@@ -308,11 +334,15 @@ template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_map_particles(const double* __restrict__ x, const double* __restrict__ P,
                                                                  int* __restrict__ ps_i, double* __restrict__ particles,
                                                                  int* __restrict__ me_desc, double* __restrict__ last_r,
-                                                                 int* __restrict__ me_big_count, CameraParams cam, int ld, int ppos0, int pcap,
-                                                                 int kpart) {
+                                                                 int* __restrict__ me_big_count, int* __restrict__ part_i, int clear_region,
+                                                                 CameraParams cam, int ld, int ppos0, int pcap, int kpart) {
   const int b = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x;       // one workgroup per (sequence, partial slot)
   int* ps = ps_i + ((size_t)b * kpart + ks) * kPsInts;
   if (b == 0 && ks == 0 && tid == 0) *me_big_count = 0;     // the step's list of oversized multi-ellipse searches starts empty
+  if (clear_region && ks == 0 && tid == 0) {                // this step runs without k_map_find (launch_mapping: parts_state 2): its two per-step flags
+    part_i[(size_t)b * kPartInts + kPartRegionValid] = 0;
+    part_i[(size_t)b * kPartInts + kPartCreated] = 0;
+  }
   if (!ps[kPsActive]) return;
   __shared__ int s_making;
   if (tid == 0) {
@@ -400,13 +430,14 @@ __global__ void __launch_bounds__(1024) k_map_me_search(MeJobsEngine J, int* __r
 // decide the bits of the weights, and through them pruning and conversion).  The covariance surgery of a conversion /
 // deletion is done by all lanes.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, double* __restrict__ P, int* __restrict__ f_flags,
-                                                   const int* __restrict__ n_slots, int* __restrict__ part_i,
-                                                   int* __restrict__ ps_i, double* __restrict__ ps_d, int* __restrict__ pos_err,
-                                                   int* __restrict__ pos_err_any, double* __restrict__ particles,
-                                                   double* __restrict__ traj, int* __restrict__ traj_count,
-                                                   const double* __restrict__ last_r, const int* __restrict__ pos_count,
-                                                   unsigned long long* __restrict__ parts_mail, MapParams mp, int N, int ld, int ppos0) {
+__device__ __forceinline__ void update_body(const MapArrays& a, const MapParams& mp, double* s_p /* [number_of_particles][kParticleDoubles] */) {
+  double* __restrict__ x = a.x; double* __restrict__ P = a.P; int* __restrict__ f_flags = a.f_flags;
+  const int* __restrict__ n_slots = a.n_slots; int* __restrict__ part_i = a.part_i; int* __restrict__ ps_i = a.ps_i;
+  double* __restrict__ ps_d = a.ps_d; int* __restrict__ pos_err = a.pos_err; int* __restrict__ pos_err_any = a.pos_err_any;
+  double* __restrict__ particles = a.particles; double* __restrict__ traj = a.traj; int* __restrict__ traj_count = a.traj_count;
+  const double* __restrict__ last_r = a.last_r; const int* __restrict__ pos_count = a.pos_count;
+  unsigned long long* __restrict__ parts_mail = a.parts_mail;
+  const int N = a.N, ld = a.ld, ppos0 = a.ppos0;
   const int b = blockIdx.x, lane = threadIdx.x;
   int* pi = part_i + (size_t)b * kPartInts;
   double* xb = x + (size_t)b * ld;
@@ -415,7 +446,6 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   __shared__ int s_count, s_order[kMaxPartial];
   __shared__ int s_flag;           // scratch decision of lane 0
   __shared__ double s_total;
-  extern __shared__ double s_p[];        // [number_of_particles][kParticleDoubles]
   if (lane == 0) {
     s_count = pi[kPartCount];
     for (int k = 0; k < kMaxPartial; ++k) s_order[k] = pi[kPartOrder + k];
@@ -646,6 +676,20 @@ __global__ void __launch_bounds__(64) k_map_update(double* __restrict__ x, doubl
   }
 }
 
+__global__ void __launch_bounds__(64) k_map_update(MapArrays a, MapParams mp) {
+  extern __shared__ double s_particles[];
+  update_body(a, mp, s_particles);
+}
+
+// A step that starts without a partially initialised feature (launch_mapping: parts_none) has nothing between the creation of
+// a feature and the end-of-frame bookkeeping: both in one launch.
+__global__ void __launch_bounds__(64) k_map_finish(MapArrays a, CameraParams cam, MapParams mp) {
+  extern __shared__ double s_particles[];
+  create_body(a, cam, mp);
+  __syncthreads();           // what lane 0 wrote about the new feature is read by every lane below
+  update_body(a, mp, s_particles);
+}
+
 // ---------------------------------------------------------------------------
 // k_map_compact_slots: one workgroup per sequence; does nothing unless the sequence has used all N slots and some of them
 // are retired (features deleted by delete_bad_features, the sell-by date of a partial feature or sl2_delete_features keep
@@ -857,11 +901,28 @@ static MapParams map_params(const sl2_engine* e, int enable_mapping, int save_tr
   return mp;
 }
 
+static MapArrays map_arrays(const sl2_engine* e) {
+  MapArrays a;
+  a.x = e->x; a.P = e->P; a.frames = e->cur_frames; a.seq_stride = e->cur_stride; a.patch = e->patch; a.patch_sums = e->patch_sums;
+  a.xp_org = e->xp_org; a.f_flags = e->f_flags; a.n_slots = e->n_slots; a.attempted = e->attempted; a.successful = e->successful;
+  a.f_label = e->f_label; a.next_label = e->next_label; a.part_i = e->part_i; a.part_d = e->part_d; a.ps_i = e->ps_i; a.ps_d = e->ps_d;
+  a.pos_err = e->pos_err; a.pos_err_any = e->pos_err_any; a.particles = e->particles; a.last_r = e->last_r; a.traj = e->traj;
+  a.traj_count = e->traj_count; a.pos_count = e->pos_count; a.parts_mail = e->root->parts_mail_dev;
+  a.N = e->N; a.ld = e->ld; a.ppos0 = e->ppos;
+  return a;
+}
+
 static int launch_create(sl2_engine* e, const MapParams& mp) {
   LaunchScope ls(e, "k_map_create");
-  hipLaunchKernelGGL(k_map_create, dim3(e->B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch,
-                     e->patch_sums, e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
-                     e->ps_i, e->ps_d, e->pos_err, e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
+  hipLaunchKernelGGL(k_map_create, dim3(e->B), dim3(64), 0, e->stream, map_arrays(e), e->cam, mp);
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
+static int launch_find(sl2_engine* e, const MapParams& mp) {
+  LaunchScope ls(e, "k_map_find");
+  hipLaunchKernelGGL(k_map_find, dim3(e->B), dim3(kDetThreads), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
+                     e->prev_r, e->part_i, e->part_d, e->rand48, e->last_r, e->status, e->cur_frames, e->cur_stride, e->cam, mp, e->N, e->ld);
   SL2_HIP(hipGetLastError());
   return SL2_OK;
 }
@@ -880,16 +941,12 @@ int launch_manual_init(sl2_engine* e, const int* d_uv) {
 int launch_auto_init(sl2_engine* e) {
   const MapParams mp = map_params(e, 1, 0, 1);
   { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
-  hipLaunchKernelGGL(k_map_region, dim3(e->B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
-                     e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
-  SL2_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_map_detect, dim3(e->B), dim3(kDetThreads), 0, e->stream, e->cur_frames, e->cur_stride, e->cam.width,
-                     e->cam.height, e->part_i, e->part_d);
-  SL2_HIP(hipGetLastError());
+  { int rc = launch_find(e, mp); if (rc != SL2_OK) return rc; }
   return launch_create(e, mp);
 }
 
-int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_none) {
+int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_state) {
+  const int parts_none = parts_state == 1, parts_full = parts_state == 2;
   const int B = e->B;
   MapParams mp;
   mp.force = 0;
@@ -904,8 +961,11 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
   mp.pcap = e->root->pcap;
   mp.kpart = e->root->kpart;
   // The three launches that serve partially initialised features are dead weight while there is none, and at one sequence each
-  // is a link of the frame's dependent chain: k_map_update's report (sl2_engine.hip: parts_none_for_step) lets the host leave
-  // them out.  me_big_count keeps its last value meanwhile; k_map_particles zeroes it before anything reads it again.
+  // is a link of the frame's dependent chain: k_map_update's report (sl2_engine.hip: parts_state_for_step) lets the host leave
+  // them out (state 1).  me_big_count keeps its last value meanwhile; k_map_particles zeroes it before anything reads it again.
+  // The other way round (state 2): every partial slot is taken, so FindNonOverlappingRegion's gate (k_map_find: kPartCount <
+  // kpart, monoslam.cpp:163-165) is shut whatever the camera does - no region, no detector, no creation: k_map_find and
+  // k_map_create are left out, and k_map_particles clears the two per-step flags k_map_find would have.
   mp.parts_skipped = parts_none ? 1 : 0;
   mp.publish_parts = (e->root->B == 1 && e->root->parts_mail_dev) ? 1 : 0;
   const int W = e->cam.width, H = e->cam.height;
@@ -914,29 +974,20 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
   // (sl2_engine.hip: slots_upper_bound) says when none can be: the launch - one of the step's dependent chain, 7 us at one
   // sequence, 0.03 ms at 1024 - is then left out altogether.
   if (enable_mapping && slots_bound + 1 > e->N) { int rc = launch_compact_slots(e, 1); if (rc != SL2_OK) return rc; }
-  {
-    LaunchScope ls(e, "k_map_region");
-    hipLaunchKernelGGL(k_map_region, dim3(B), dim3(64), sizeof(double) * 2 * e->N, e->stream, e->x, e->f_flags, e->n_slots, e->n_vis,
-                       e->prev_r, e->part_i, e->rand48, e->last_r, e->status, e->cam, mp, e->N, e->ld);
+  if (!parts_full) { int rc = launch_find(e, mp); if (rc != SL2_OK) return rc; }
+  const size_t shm_particles = sizeof(double) * kParticleDoubles * (size_t)mp.n_particles;
+  if (parts_none) {
+    LaunchScope ls(e, "k_map_finish");
+    hipLaunchKernelGGL(k_map_finish, dim3(B), dim3(64), shm_particles, e->stream, map_arrays(e), e->cam, mp);
     SL2_HIP(hipGetLastError());
+    return SL2_OK;
   }
+  if (!parts_full) { int rc = launch_create(e, mp); if (rc != SL2_OK) return rc; }
   {
-    LaunchScope ls(e, "k_map_detect");
-    hipLaunchKernelGGL(k_map_detect, dim3(B), dim3(kDetThreads), 0, e->stream, e->cur_frames, e->cur_stride, W, H, e->part_i, e->part_d);
-    SL2_HIP(hipGetLastError());
-  }
-  {
-    LaunchScope ls(e, "k_map_create");
-    hipLaunchKernelGGL(k_map_create, dim3(B), dim3(64), 0, e->stream, e->x, e->P, e->cur_frames, e->cur_stride, e->patch, e->patch_sums,
-                       e->xp_org, e->f_flags, e->n_slots, e->attempted, e->successful, e->f_label, e->next_label, e->part_i, e->part_d,
-                       e->ps_i, e->ps_d, e->pos_err, e->particles, e->last_r, e->cam, mp, e->N, e->ld, e->ppos);
-    SL2_HIP(hipGetLastError());
-  }
-  if (!parts_none) {
     LaunchScope ls(e, "k_map_particles");
     const int pc = e->root->pcap;
 #define SL2_PARTICLES(T) hipLaunchKernelGGL(k_map_particles<T>, dim3(B, mp.kpart), dim3(pc), 0, e->stream, e->x, e->P, e->ps_i, e->particles, \
-                                            e->me_desc, e->last_r, e->me_big_count, e->cam, e->ld, e->ppos, pc, mp.kpart)
+                                            e->me_desc, e->last_r, e->me_big_count, e->part_i, parts_full, e->cam, e->ld, e->ppos, pc, mp.kpart)
     if (pc <= 128) SL2_PARTICLES(128);
     else if (pc <= 256) SL2_PARTICLES(256);
     else if (pc <= 512) SL2_PARTICLES(512);
@@ -944,7 +995,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
 #undef SL2_PARTICLES
     SL2_HIP(hipGetLastError());
   }
-  if (!parts_none) {
+  {
     MeJobsEngine J;
     J.frames = e->cur_frames; J.seq_stride = e->cur_stride; J.patch_base = e->patch; J.ps_i = e->ps_i; J.me_desc = e->me_desc;
     J.particles = e->particles; J.map_base = e->score_map; J.N = e->N; J.pcap = e->root->pcap;
@@ -962,9 +1013,7 @@ int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int s
   }
   {
     LaunchScope ls(e, "k_map_update");
-    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), sizeof(double) * kParticleDoubles * (size_t)mp.n_particles, e->stream, e->x, e->P, e->f_flags, e->n_slots, e->part_i,
-                       e->ps_i, e->ps_d, e->pos_err, e->pos_err_any, e->particles, e->traj, e->traj_count, e->last_r, e->pos_count,
-                       e->root->parts_mail_dev, mp, e->N, e->ld, e->ppos);
+    hipLaunchKernelGGL(k_map_update, dim3(B), dim3(64), shm_particles, e->stream, map_arrays(e), mp);
     SL2_HIP(hipGetLastError());
   }
   return SL2_OK;

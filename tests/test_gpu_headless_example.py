@@ -113,8 +113,8 @@ def test_monoslam_adapter_example_exposes_the_reference_members(tmp_path, mappin
 
 def test_adapter_loop_of_120_frames_holds_the_oracles_partial_features_frame_by_frame(tmp_path):
     """The adapter's timed loop (--latency: what scripts/adapter_latency.py runs) on the feature-initialisation sequence: frames
-    read in place from the grabber's pinned ring, one snapshot per frame, the engine leaving out the partial-feature launches
-    whenever the previous step reported none (sl2_engine.hip: parts_none_for_step).  feature_init_info_vector_.size() at the
+    read in place from the grabber's pinned ring, one snapshot per frame, the engine choosing the feature-initialisation launches
+    of each step from the previous step's report (sl2_engine.hip: parts_state_for_step).  feature_init_info_vector_.size() at the
     start of every frame must be the oracle's - a feature made, matched, converted or dropped one frame late would show here."""
     import json
     exe = os.path.join(ROOT, "examples", "monoslam_adapter")

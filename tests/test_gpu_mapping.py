@@ -512,36 +512,42 @@ def test_step_kernels_switch_safely_when_the_host_runs_ahead_with_mapping_on():
     assert not eng.status_flags().any()
 
 
-def test_partial_feature_launches_are_left_out_only_while_there_is_no_partial_feature():
+def test_launches_follow_the_partial_features_the_previous_step_reported():
     """One sequence: k_map_update reports how many partially initialised features a step leaves, and the next step - if the
-    report has arrived - runs without k_map_particles / k_map_me_search / k_me_big when there is none (sl2_engine.hip:
-    parts_none_for_step; a feature made in such a step gets its first number_of_match_attempts_++ from k_map_create).  Every
-    step is waited for here, so every report is current: the launches must be missing exactly in the steps that START without
-    a partial feature, and the run must still equal the oracle event for event - including the frames in which a feature is
-    made in a step that ran without them, and the manual initialisation in between (whose feature the report cannot know)."""
+    report has arrived - is issued accordingly (sl2_engine.hip: parts_state_for_step).  None left: no k_map_particles /
+    k_map_me_search / k_me_big, and creation + end-of-frame bookkeeping in one launch (k_map_finish; a feature made in such a
+    step gets its first number_of_match_attempts_++ from the creation).  Every partial slot taken (the shipped cfg has one): no
+    k_map_find / k_map_create - FindNonOverlappingRegion's gate is shut.  Every step is waited for here, so every report is
+    current: the launch counts must be exactly what the oracle's partial-feature counts say, and the run must still equal the
+    oracle event for event - including the frames in which a feature is made in a step that ran without the partial-feature
+    launches, and the button press in between (whose feature the report cannot know: that step gets every launch)."""
     from scenelib2_amd import Engine
     cam, params, spec, frames, templates = make_mapping_sequence(n_frames=100)
+    kpart = int(params["max_features_to_init_at_once"])
     s = oracle_for(cam, params, spec, templates, oa)
     eng = Engine(cam, params, 1, 128)
     eng.set_vehicle_state(spec.xv0[None], spec.Pxx0[None])
     eng.add_known_features(spec.feat_y[None], spec.xp_org()[None], templates[None])
     eng.set_profiling(2)
-    expected_full = 0
+    states = []
     n_partial_before = 0
-    first = True
+    presses = 0
     for k in range(1, 101):
+        pressed = False
         if k == 60 and n_partial_before == 0:            # a button press between two steps: the report of step 59 says "none"
             s.initialise_auto_feature(frames[k - 1])
             created = eng.initialise_auto_feature(frames[k - 1][None])
             n_partial_before = s.mapping_info()["n_partial"]
             assert int(created[0]) == int(n_partial_before > 0)
-        expected_full += 1 if (first or n_partial_before > 0 or (k == 60)) else 0
-        first = False
+            pressed = True
+            presses += 1
+        states.append(0 if (k == 1 or pressed) else (1 if n_partial_before == 0 else (2 if n_partial_before >= kpart else 0)))
         s.go_one_step(frames[k], True, True)
         eng.go_one_step(frames[k][None], save_trajectory=True, enable_mapping=True)
         info, got = s.mapping_info(), eng.partial_feature(0)
         for key in ("initialised", "converted", "deleted", "n_partial"):
             assert got["info"][key] == info[key], (k, key, got["info"], info)
+        assert bool(got["info"]["region_defined"]) == bool(info["region_defined"]), k
         pf = s.partial_feature(0)
         if pf is not None:
             assert got["pf"]["attempts"] == pf["attempts"] and got["pf"]["making"] == pf["making"], k
@@ -549,10 +555,15 @@ def test_partial_feature_launches_are_left_out_only_while_there_is_no_partial_fe
         assert x0.size == x1.size and np.abs(x0 - x1).max() < TOL_X_SOAK, k
         n_partial_before = info["n_partial"]
     t = eng.kernel_times()
-    full, steps = t["k_map_particles"]["launches"], t["k_map_update"]["launches"]
-    print("100 waited mapping steps: %d with the partial-feature launches, %d without" % (full, steps - full))
-    assert steps == 100 and t["k_map_me_search"]["launches"] == full
-    assert full == expected_full and 0 < full < 100, (full, expected_full)
+    n = lambda name: t.get(name, {}).get("launches", 0)
+    # (the button press is a k_map_find + k_map_create of its own: launch_auto_init)
+    want = {"k_map_find": states.count(0) + states.count(1) + presses, "k_map_create": states.count(0) + presses, "k_map_finish": states.count(1),
+            "k_map_particles": states.count(0) + states.count(2), "k_map_me_search": states.count(0) + states.count(2),
+            "k_map_update": states.count(0) + states.count(2)}
+    have = {name: n(name) for name in want}
+    print("100 waited mapping steps: %d with every launch, %d starting without a partial feature, %d with every slot taken" %
+          (states.count(0), states.count(1), states.count(2)), have)
+    assert have == want and states.count(1) >= 10 and states.count(2) >= 10, (have, want)
     P0, P1 = s.total_covariance(), eng.total_covariance(0)
     assert np.linalg.norm(P1 - P0) <= 10 * TOL_P * max(np.linalg.norm(P0), 1e-12)
     assert not eng.status_flags().any()
@@ -561,4 +572,5 @@ def test_partial_feature_launches_are_left_out_only_while_there_is_no_partial_fe
     for k in range(90, 100):
         eng.go_one_step(frames[k][None], save_trajectory=False, enable_mapping=True)
     eng.synchronize()
-    assert eng.kernel_times()["k_map_particles"]["launches"] == 10
+    t = eng.kernel_times()
+    assert t["k_map_particles"]["launches"] == 10 and t["k_map_find"]["launches"] == 10 and t["k_map_create"]["launches"] == 10

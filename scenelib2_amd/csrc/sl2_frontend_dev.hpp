@@ -495,7 +495,8 @@ __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ 
       if (publish && b == 0) {
         const int prev = __hip_atomic_load(&slots_max[(pre_pc + 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&slots_max[(pre_pc + 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slots_mail, ((unsigned long long)(unsigned)pre_pc << 32) | (unsigned)prev, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (relaxed: the word is the whole message - a release here is a write-back of the L2, buffer_wbl2, in the middle of the kernel)
+        __hip_atomic_store(slots_mail, ((unsigned long long)(unsigned)pre_pc << 32) | (unsigned)prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
   }

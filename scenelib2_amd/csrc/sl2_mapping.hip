@@ -672,7 +672,7 @@ __device__ __forceinline__ void update_body(const MapArrays& a, const MapParams&
     }
     // the host's next step (index pos_count: k_finalize has counted this one) may leave the partial-feature launches out if none is left
     if (mp.publish_parts)
-      __hip_atomic_store(parts_mail, ((unsigned long long)(unsigned)pos_count[b] << 32) | (unsigned)s_count, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(parts_mail, ((unsigned long long)(unsigned)pos_count[b] << 32) | (unsigned)s_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (the word is the whole message)
   }
 }
 

@@ -28,7 +28,7 @@ BUDGET = {
     "k_search_mfma": ("sl2_search.hip", ["-ffp-contract=off"], 128, 4, 42),
     # the mapping step's per-job kernels (round 4): a job has a CU to itself, sixteen wavefronts = four per SIMD
     "k_map_me_search": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),
-    "k_map_detect": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),
+    "k_map_find": ("sl2_mapping.hip", ["-ffp-contract=off"], 128, 4, 0),      # (region + detector: the detector's 1024 threads)
     "k_map_compact_slots": ("sl2_mapping.hip", ["-ffp-contract=off"], 168, 3, 8),
 }
 

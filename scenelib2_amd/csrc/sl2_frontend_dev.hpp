@@ -302,6 +302,7 @@ __device__ __forceinline__ void select_body(const int b, const double* __restric
 //      other block is stored mirrored), P <- P*0.5 + P^T*0.5;
 //  (4) trajectory_store_ push (stale rRES_, Q12); NaN check.
 // ---------------------------------------------------------------------------
+template <bool kExtScratch = false>
 __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ x, double* __restrict__ P, int* __restrict__ f_flags,
                                                   const int* __restrict__ n_slots, int* __restrict__ attempted,
                                                   int* __restrict__ successful, const int* __restrict__ m_count,
@@ -311,9 +312,16 @@ __device__ __forceinline__ void finalize_body(const int b, double* __restrict__ 
                                                   int min_attempts, double match_fraction, int save_trajectory,
                                                   const int* __restrict__ part_i, int pend, int* s_del,
                                               int* __restrict__ slots_max = nullptr, unsigned long long* __restrict__ slots_mail = nullptr,
-                                              int publish = 0) {
+                                              int publish = 0, double* s_ext = nullptr) {
   // s_del: [N] slots deleted this frame, then [N] flags
-  __shared__ double s_N[16], s_P[169], s_T[169];
+  // (kExtScratch: the 16 + 169 + 169 doubles below live in the caller's LDS, see search_score_body)
+  double *s_N, *s_P, *s_T;
+  if constexpr (kExtScratch) {
+    s_N = s_ext; s_P = s_ext + 16; s_T = s_ext + 16 + 169;
+  } else {
+    __shared__ double s_N_own[16], s_P_own[169], s_T_own[169];
+    s_N = s_N_own; s_P = s_P_own; s_T = s_T_own;
+  }
   __shared__ int s_ndel;
   const int tid = threadIdx.x;
   double* xb = x + (size_t)b * ld;

@@ -10,6 +10,7 @@ namespace sl2 {
 // bookkeeping it compacts the successful measurements (succ_idx / m_count, what the EKF update reads: see the comment at
 // the compaction) and leaves the step's work counters - a launch
 // of its own for the compaction and a memset + atomics for the counters were 10 us of a single-sequence step.
+template <bool kExtScratch = false>
 __device__ __forceinline__ void search_score_body(const int b, const int* __restrict__ srch_res, const int* __restrict__ srch_i,
                                                        const uint8_t* __restrict__ patch, const double* __restrict__ f_h,
                                                        const int* __restrict__ sel_idx, const int* __restrict__ n_sel,
@@ -21,11 +22,20 @@ __device__ __forceinline__ void search_score_body(const int b, const int* __rest
                                                        int* __restrict__ m_count, const int* __restrict__ n_slots,
                                                        const int* __restrict__ pos_err, const int* __restrict__ pos_err_any,
                                                        int* __restrict__ f_hcol, const int* __restrict__ ps_i, int kpart, int ppos0,
-                                                       int N, int* __restrict__ srch_big, int* __restrict__ status, int* s_flag) {
+                                                       int N, int* __restrict__ srch_big, int* __restrict__ status, int* s_flag,
+                                                       double* s_ext = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
   // s_flag: [N + 8] successful measurement of slot i in this frame (dynamic LDS of the caller)
   __shared__ int s_wcnt[16];
-  __shared__ double s_red[16][kWorkDoubles];
+  // (kExtScratch: the 16 x kWorkDoubles reduction buffer lives in the caller's LDS - k_small_back keeps its phases' scratch in
+  // one place, so that a third workgroup fits a CU)
+  double (*s_red)[kWorkDoubles];
+  if constexpr (kExtScratch) {
+    s_red = reinterpret_cast<double (*)[kWorkDoubles]>(s_ext);
+  } else {
+    __shared__ double s_red_own[16][kWorkDoubles];
+    s_red = s_red_own;
+  }
   const int ns = n_sel[b];
   // the step's list of large windows has been worked off by the search kernel: its counters and its length return to zero
   const int nunits_done = (b == 0 && srch_big) ? min(srch_big[0], kSrchBigUnits) : 0;

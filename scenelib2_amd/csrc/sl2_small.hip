@@ -251,16 +251,21 @@ __global__ void __launch_bounds__(kSmallThreads) k_small_back(
   extern __shared__ double s_dynd[];                  // phase by phase: [N + 8] ints, [32][128] doubles, [2 N] ints
   const int b = blockIdx.x;
   SST(3, 0);
-  search_score_body(b, srch_res, srch_i, patch, f_h, sel_idx, n_sel, f_flags, f_z, f_nu, attempted, successful, meas_ok, meas_score,
-                    work, succ_idx, f_arow, m_count, n_slots, pos_err, pos_err_any, f_hcol, ps_i, kpart, ppos0, N, srch_big, status,
-                    (int*)s_dynd);
+  // the bookkeeping stages' scratch sits behind their index arrays in the dynamic region (launch_small_back sizes it): with it
+  // among the statics the kernel needed 56.4 KB at W = 128 - two workgroups per CU; 53.0 KB: three
+  double* const s_ext_score = s_dynd + ((size_t)N + 8 + 1) / 2;
+  double* const s_ext_final = s_dynd + (size_t)N;
+  search_score_body<true>(b, srch_res, srch_i, patch, f_h, sel_idx, n_sel, f_flags, f_z, f_nu, attempted, successful, meas_ok, meas_score,
+                          work, succ_idx, f_arow, m_count, n_slots, pos_err, pos_err_any, f_hcol, ps_i, kpart, ppos0, N, srch_big, status,
+                          (int*)s_dynd, s_ext_score);
   __syncthreads();
   SST(3, 1);
   small_update_body(b, x, P, f_Hx, f_Hy, f_nu, f_R, succ_idx, m_count, n_slots, part_i, ppos0, pend, N, ld, status, s_dynd);
   __syncthreads();
   SST(3, 2);
-  finalize_body(b, x, P, f_flags, n_slots, attempted, successful, m_count, n_sel, traj, traj_count, last_r, status, pos_log,
-                pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, (int*)s_dynd, slots_max, slots_mail, publish);
+  finalize_body<true>(b, x, P, f_flags, n_slots, attempted, successful, m_count, n_sel, traj, traj_count, last_r, status, pos_log,
+                      pos_count, N, ld, min_attempts, match_fraction, save_trajectory, part_i, pend, (int*)s_dynd, slots_max, slots_mail,
+                      publish, s_ext_final);
   SST(3, 3);
 }
 
@@ -297,7 +302,8 @@ int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound) {
   // the LDS panel is [32][W], W = 64 while every live map of the group fits it (the kernel picks W from the sequence's own size,
   // which the bound bounds): a third workgroup per CU at large batches
   size_t shm = sizeof(double) * kSmallM * ((13 + 3 * slots_bound + 6 * e->kpart + 1 <= 64) ? 64 : kSmallW);
-  const size_t ints = sizeof(int) * (2 * (size_t)e->N + 8);
+  // (the bookkeeping phases: [N + 8] ints + 16 x kWorkDoubles doubles, then [2 N] ints + 354 doubles)
+  const size_t ints = sizeof(int) * (2 * (size_t)e->N + 10) + sizeof(double) * (16 + 169 + 169 + 16 * kWorkDoubles);
   if (ints > shm) shm = ints;
   hipLaunchKernelGGL(k_small_back, dim3(e->B), dim3(kSmallThreads), shm, e->stream, e->srch_res, e->srch_i, e->patch, e->f_h, e->sel_idx,
                      e->n_sel, e->f_flags, e->f_z, e->f_nu, e->attempted, e->successful, e->meas_ok, e->meas_score, e->work,

@@ -2,14 +2,16 @@
 // MonoSLAM::GoOneStep (monoslam.cpp:152-170) for the whole batch, up to kMaxPartial partially initialised
 // features per sequence (params.max_features_to_init_at_once; the shipped value is 1):
 //
-//   k_map_region     speed gate + AutoInitialiseFeature's region choice     monoslam.cpp:159-165, 823-1032
-//   k_map_detect     set_image_selection_automatically (Shi-Tomasi)         :1043-1205
+//   k_map_find       speed gate + AutoInitialiseFeature's region choice     monoslam.cpp:159-165, 823-1032
+//                    + set_image_selection_automatically (Shi-Tomasi)       :1043-1205
 //   k_map_create     InitialiseFeature + partially-initialised Feature ctor :1211-1276, feature.cpp:45-104
 //   k_map_particles  predict_partially_initialised_feature_measurements     :1349-1401
 //   k_map_me_search  measure_feature_with_multiple_priors                   :1411-1439 (+ improc/search_multiple...)
 //   k_map_update     update_partially_initialised_feature_probabilities, conversion test,
 //                    convert_from_partially_to_fully_initialised, sell-by deletion, trajectory push
 //                                                                           :1299-1342, 1449-1538, feature.cpp:204-269
+//   k_map_finish     k_map_create + k_map_update in one launch (one sequence, no partial feature at the start of the frame)
+// Which of them a step consists of: launch_mapping, from what the host knows about the partial features (parts_state).
 //
 // State layout: the six states (r_W, hhat_W) of the partial feature in partial slot k live in columns ppos + 6 k ..
 // ppos + 6 k + 5 of x / P, ppos = 13 + 3N (behind the map: the update's algebra does not care where a state sits, and the
@@ -186,7 +188,7 @@ __device__ __forceinline__ void create_body(const MapArrays& a, const CameraPara
   double* pd = part_d + (size_t)b * kPartDoubles;
   if (!pi[kPartRegionValid]) return;
   if (!(pd[2] > 20000)) return;        // SUITABLE_PATCH_SCORE_THRESHOLD (:837, 850-858)
-  // the partial slot this feature takes: the first free one (k_map_region / k_map_manual checked that there is one)
+  // the partial slot this feature takes: the first free one (k_map_find / k_map_manual checked that there is one)
   int* psb = ps_i + (size_t)b * mp.kpart * kPsInts;
   int ks = 0;
   while (ks < mp.kpart - 1 && psb[ks * kPsInts + kPsActive]) ++ks;
@@ -866,7 +868,7 @@ int launch_compact_slots(sl2_engine* e, int need) {
 }
 
 // MonoSLAM::InitialiseFeature at a caller-chosen pixel (monoslam.cpp:1211-1235; the GUI sets uu_ / vv_ by mouse click):
-// per sequence, publish the selection for k_map_create exactly as k_map_region + k_map_detect would have.
+// per sequence, publish the selection for k_map_create exactly as k_map_find would have.
 __global__ void __launch_bounds__(64) k_map_manual(const int* __restrict__ uv, const int* __restrict__ n_slots, int* __restrict__ part_i,
                                                    double* __restrict__ part_d, int* __restrict__ status, int N, int width,
                                                    int height, int B, int kpart) {

@@ -120,7 +120,7 @@ SL2_HD void motion_f_and_blocks(const double xv[13], double dt, double f[13], do
 // f applied `steps` times (FindNonOverlappingRegion predicts ten steps ahead, monoslam.cpp:888-893): the velocities do not
 // change under f (u = 0), so q(omega dt) - a square root, a sine and a cosine - is the SAME quaternion in every step and is
 // formed once; every step then is the position update and the quaternion product, in the expressions of
-// motion_f_and_blocks.  Bit-identical to calling that `steps` times (k_map_region did: ten serial sin / cos on one lane).
+// motion_f_and_blocks.  Bit-identical to calling that `steps` times (k_map_find's region stage did: ten serial sin / cos on one lane).
 SL2_HD void motion_f_repeated(const double xv[13], double dt, int steps, double out[13]) {
   for (int i = 0; i < 13; ++i) out[i] = xv[i];
   const double om[3] = {xv[10], xv[11], xv[12]};

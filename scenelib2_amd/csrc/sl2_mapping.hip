@@ -448,6 +448,22 @@ __device__ __forceinline__ void update_body(const MapArrays& a, const MapParams&
   __shared__ int s_count, s_order[kMaxPartial];
   __shared__ int s_flag;           // scratch decision of lane 0
   __shared__ double s_total;
+  // Everything the passes below read - the records, the particle lists (k_map_me_search left them in another XCD's cache),
+  // the trajectory cursor - is touched HERE, by all lanes at once: the passes are a chain of small dependent reads, each a
+  // round trip to memory when it is the first to meet its line (13-15 us for one sequence's kernel), a hit behind this one.
+  {
+    int wi = 0;
+    double wd = 0.0;
+    if (lane < kPartInts) wi += pi[lane];
+    for (int ks = 0; ks < mp.kpart; ++ks) {
+      if (lane < kPsInts) wi += ps_i[((size_t)b * mp.kpart + ks) * kPsInts + lane];
+      if (lane < kPsDoubles) wd += ps_d[((size_t)b * mp.kpart + ks) * kPsDoubles + lane];
+      const double* pp = particles + ((size_t)b * mp.kpart + ks) * mp.pcap * kParticleDoubles;
+      for (int i = lane * 16; i < mp.n_particles * kParticleDoubles; i += 64 * 16) wd += pp[i];      // one read per 128-byte line
+    }
+    if (lane == 0) { wi += traj_count[b] + pos_count[b] + n_slots[b]; wd += last_r[b * 3]; }
+    asm volatile("" ::"v"(wi), "v"(wd));
+  }
   if (lane == 0) {
     s_count = pi[kPartCount];
     for (int k = 0; k < kMaxPartial; ++k) s_order[k] = pi[kPartOrder + k];

@@ -114,6 +114,11 @@ def main():
                 fr("shipped_cfg_4_features"), fr("mapping_on_dozen_features"), fr("configs1_100_features"),
                 fr("shipped_cfg_4_features", adc), fr("mapping_on_dozen_features", adc), fr("configs1_100_features", adc)) +
             "| GPU tests / smoke | %s passed; 5.4e-15 / 2.0e-14 | `r06_final_pytest_gpu.log` |\n\n" % ntests)
+    late = os.path.join(P, "r06_final_late_git.txt")
+    if os.path.exists(late) and open(late).read().strip() != git:
+        sec8 += ("The mapping line, the adapter, small-map and mapping latency files and the test log are from library %s: `k_small_back`'s LDS layout and\n"
+                 "`k_map_update`'s first reads changed after the headline, configs[1] / [3] / [4], counter and rank runs (%s), which they do not touch.\n\n" % (
+                     open(late).read().strip(), git))
     s = s[:a] + sec8 + s[e:]
     open(path, "w").write(s)
     print("DESIGN.md refreshed from profiles/ (library %s, %d bytes)" % (git, len(s)))

@@ -89,6 +89,15 @@ def main():
                "two ranks sharing the\ndevice under both launch forms (%d k / %d k frames/s for 2 x 512 sequences, `parity.ranks_checked = 2`)" % (
                    round(tw["value"] / 1e3), round(tt["value"] / 1e3)), s)
 
+    mlat = os.path.join(P, "r06_mapping_latency.json")
+    if os.path.exists(mlat):
+        ml = json.load(open(mlat))["plain"]
+        mm = ad["mapping_on_dozen_features"]
+        s = re.sub(r"\(in the committed run: [0-9.]+ / [0-9.]+ us; engine alone, `scripts/mapping_latency.py`: [0-9.]+ / [0-9.]+ us per waited step\)",
+                   "(in the committed run: %.0f / %.0f us; engine alone, `scripts/mapping_latency.py`: %.0f / %.0f us per waited step)" % (
+                       mm["frame_us_median_without_partial_feature"], mm["frame_us_median_with_partial_feature"],
+                       ml["step_us_median_without_partial"], ml["step_us_median_with_partial"]), s)
+
     a = s.index("## 8. Measured on MI355X, round 6")
     e = s.index("## 9. Out of scope")
     hf = b.get("host_fed") or {}

@@ -611,6 +611,8 @@ def main():
             "kernels": per_kernel,
             "work_per_step": {k: v for k, v in work.items()},
             "gather_ms": gather_ms, "setup_s": setup_s, "status_flags_set": status_bad,
+            # how sl2_create placed the large matrices (probe ms of the allocations it kept and of the slowest candidates it saw)
+            "placement": eng.placement(),
             "gathered_states": int(all_xv.shape[0]),
         }
         os.write(json_fd, (json.dumps(out) + "\n").encode())

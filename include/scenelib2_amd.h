@@ -472,6 +472,15 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
  * header with fewer entries is never overrun; one built against more sees the extra entries untouched). */
 int sl2_get_step_work(sl2_engine* e, double* out, int capacity);
 
+/* How sl2_create placed the large matrices (an addition within SL2_API_VERSION 5).  The speed of the update's kernels depends on
+ * the physical memory behind P, A^T, V^T and S - up to 8 % for k_build_AS at 1024 sequences x 100 features, fixed for the life of
+ * an allocation, not visible in its address - so sl2_create times a streaming probe on several candidate allocations and keeps
+ * the fastest of each kind (engines whose covariance is smaller than 256 MB: not tried, all zeros here).
+ * out[0] = candidate allocations of P probed, out[1..4] = probe time in ms of the kept P, V^T, A^T, S, out[5..7] = of the slowest candidate
+ * seen for P, for A^T / V^T, for S.  min(capacity, SL2_PLACEMENT_COUNT) values are written. */
+#define SL2_PLACEMENT_COUNT 8
+int sl2_get_placement(sl2_engine* e, double* out, int capacity);
+
 /* ------------------------------------------------------------- synthetic input */
 
 /* Render `count` frames of the synthetic textured plane z = 0:

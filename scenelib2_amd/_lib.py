@@ -87,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "sl2_ingest_frame_count", "sl2_ingest_next", "sl2_ingest_set_zero_copy", "sl2_ingest_close", "sl2_get_total_state_sizes",
     "sl2_get_total_state", "sl2_get_total_covariance", "sl2_get_features", "sl2_get_partial_feature", "sl2_get_selection",
     "sl2_snapshot_capacity", "sl2_snapshot", "sl2_get_trajectory", "sl2_get_feature_patch", "sl2_get_position_log", "sl2_delete_features", "sl2_get_status_flags", "sl2_set_profiling", "sl2_set_profile_focus",
-    "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work",
+    "sl2_reset_kernel_times", "sl2_kernel_count", "sl2_get_kernel_time", "sl2_get_step_work", "sl2_get_placement",
     "sl2_synth_render_host", "sl2_synth_render_device", "sl2_dev_malloc", "sl2_dev_free", "sl2_dev_upload",
     "sl2_dev_download",
 ]
@@ -179,6 +179,7 @@ def _bind(L):
     L.sl2_kernel_count.argtypes = [vp]
     L.sl2_get_kernel_time.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), c_dp, C.POINTER(C.c_int64)]
     L.sl2_get_step_work.argtypes = [vp, c_dp, C.c_int]
+    L.sl2_get_placement.argtypes = [vp, c_dp, C.c_int]
     L.sl2_api_version.restype = C.c_int
     L.sl2_snapshot_capacity.argtypes = [vp]
     L.sl2_snapshot_capacity.restype = C.c_size_t

@@ -200,6 +200,9 @@ struct sl2_engine {
   unsigned long long* slots_mail_dev = nullptr;  // its device address
   unsigned long long* parts_mail = nullptr;      // the word after it, one-sequence engines: (steps completed << 32) | partially initialised features left by k_map_update
   unsigned long long* parts_mail_dev = nullptr;
+  int place_candidates = 0;                      // sl2_create's placement of the large matrices (sl2_engine.hip: place_large_matrices): sets probed,
+  float place_kept_ms[4] = {0, 0, 0, 0};         // probe time of the kept P, V^T, A^T, S and of the slowest candidate of each size
+  float place_worst_ms[3] = {0, 0, 0};
   long long parts_block_step = -1;               // a step of this index must not trust parts_mail (a feature was initialised by hand since)
   int slots_exact = 0;                           // max n_slots over the batch when last read back ...
   long long slots_exact_step = 0;                // ... and steps_done at that point

@@ -288,6 +288,93 @@ int sl2_device_count(void) {
   return n;
 }
 
+// ---------------------------------------------------------------------------
+// Where the large matrices land.  The same launch of k_build_AS takes 0.313-0.322 ms or 0.335-0.357 at configs[2], k_syrk
+// 0.474 or 0.484, k_chol_left 0.168 or 0.172 - constant for the life of an allocation, different from one hipMalloc to the next
+// even when the VIRTUAL addresses come out the same (two engines of one process, one after the other; rounds 4-5 saw it as "two
+// modes from process to process").  What differs is the physical backing the driver happens to hand out; nothing in the API
+// steers it.  So sl2_create asks: a probe - every sequence's workgroup streams its own part of a buffer, read and write, the way
+// the update's kernels do - is timed on each of the four large matrices, up to kPlaceTries - 1 further sets are allocated BESIDE
+// the first (held, not freed and re-allocated: a freed set tends to come back the same) and probed the same way, and the engine
+// keeps the fastest buffer of each kind; the rest is freed.  For P as many candidates again are tried alone: about one in five is
+// fast (probe 0.296-0.304 ms against 0.32-0.36), and it is P that decides k_build_AS (0.314-0.318 with a fast one in 13 of 15
+// processes, 0.325-0.329 in the two whose ten candidates held none).  Only where it can matter (kPlaceMinBytes of P), and never beyond a quarter of the free memory.
+// ---------------------------------------------------------------------------
+constexpr int kPlaceTries = 10;
+constexpr size_t kPlaceMinBytes = (size_t)256 << 20;
+__global__ void __launch_bounds__(1024) k_place_probe(double* __restrict__ buf, size_t per_seq) {
+  double* p = buf + (size_t)blockIdx.x * per_seq;
+  for (size_t i = threadIdx.x; i < per_seq; i += blockDim.x) p[i] = p[i] + 0.0;      // (the buffers are all zeros at this point, and stay so)
+}
+static int probe_ms(sl2_engine* e, double* buf, size_t per_seq, float* ms_out) {
+  hipEvent_t e0, e1;
+  SL2_HIP(hipEventCreate(&e0));
+  if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); set_error("hipEventCreate failed"); return SL2_ERR_HIP; }
+  float best = 1e30f;
+  hipError_t err = hipSuccess;
+  for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {          // (the first one warms the translation caches)
+    hipEventRecord(e0, e->stream);
+    hipLaunchKernelGGL(k_place_probe, dim3(e->B), dim3(1024), 0, e->stream, buf, per_seq);
+    hipEventRecord(e1, e->stream);
+    err = hipEventSynchronize(e1);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    if (rep > 0 && ms < best) best = ms;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  if (err != hipSuccess) { set_error(hipGetErrorString(err)); return SL2_ERR_HIP; }
+  *ms_out = best;
+  return SL2_OK;
+}
+static int place_large_matrices(sl2_engine* e) {
+  const size_t B = e->B, ld = e->ld, mld = e->mld;
+  if (sizeof(double) * B * ld * ld < kPlaceMinBytes) return SL2_OK;
+  const size_t nP = ld * ld, nA = mld * ld, nS = mld * mld;            // doubles per sequence
+  const size_t set_bytes = sizeof(double) * B * (nP + 2 * nA + nS);
+  struct Cand { double* p; float ms; };
+  std::vector<Cand> cP, cA, cS;                                         // (A^T and V^T are the same size: one pool)
+  int rc = SL2_OK;
+  auto add = [&](std::vector<Cand>& pool, double* p, size_t per_seq) {
+    float ms = 0.0f;
+    if (rc == SL2_OK) rc = probe_ms(e, p, per_seq, &ms);
+    pool.push_back({p, ms});
+  };
+  add(cP, e->P, nP); add(cA, e->At, nA); add(cA, e->Vt, nA); add(cS, e->St, nS);
+  for (int t = 1; t < kPlaceTries && rc == SL2_OK; ++t) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || set_bytes > free_b / 4) break;
+    double *p = nullptr, *a = nullptr, *v = nullptr, *st = nullptr;
+    if (dmalloc(&p, B * nP) != SL2_OK || dmalloc(&a, B * nA) != SL2_OK || dmalloc(&v, B * nA) != SL2_OK || dmalloc(&st, B * nS) != SL2_OK) {
+      if (p) hipFree(p); if (a) hipFree(a); if (v) hipFree(v); if (st) hipFree(st);
+      (void)hipGetLastError();                                          // (a set that does not fit: the engine keeps what it has)
+      break;
+    }
+    add(cP, p, nP); add(cA, a, nA); add(cA, v, nA); add(cS, st, nS);
+  }
+  // The covariance is the one that decides k_build_AS's speed (and moves k_syrk's with it), and about one candidate in five is a
+  // fast one: more of it alone, as many again.
+  for (int t = 0; t < kPlaceTries && rc == SL2_OK; ++t) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || sizeof(double) * B * nP > free_b / 4) break;
+    double* p = nullptr;
+    if (dmalloc(&p, B * nP) != SL2_OK) { (void)hipGetLastError(); break; }
+    add(cP, p, nP);
+  }
+  auto by_ms = [](const Cand& x, const Cand& y) { return x.ms < y.ms; };
+  std::stable_sort(cP.begin(), cP.end(), by_ms);
+  std::stable_sort(cA.begin(), cA.end(), by_ms);
+  std::stable_sort(cS.begin(), cS.end(), by_ms);
+  // V^T is read by k_syrk and written by the substitution, A^T written by k_build_AS and read once: V^T gets the better one
+  e->P = cP[0].p; e->Vt = cA[0].p; e->At = cA[1].p; e->St = cS[0].p;
+  for (size_t i = 1; i < cP.size(); ++i) hipFree(cP[i].p);
+  for (size_t i = 2; i < cA.size(); ++i) hipFree(cA[i].p);
+  for (size_t i = 1; i < cS.size(); ++i) hipFree(cS[i].p);
+  e->place_candidates = (int)cP.size();
+  e->place_kept_ms[0] = cP[0].ms; e->place_kept_ms[1] = cA[0].ms; e->place_kept_ms[2] = cA[1].ms; e->place_kept_ms[3] = cS[0].ms;
+  e->place_worst_ms[0] = cP.back().ms; e->place_worst_ms[1] = cA.back().ms; e->place_worst_ms[2] = cS.back().ms;
+  return rc;
+}
+
 int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int max_features, int device, void* stream,
                sl2_engine** out) {
   if (!cam || !params || !out || batch <= 0 || max_features <= 0) { set_error("sl2_create: bad argument"); return SL2_ERR_INVALID; }
@@ -405,6 +492,10 @@ int sl2_create(const sl2_camera* cam, const sl2_params* params, int batch, int m
   }
   SL2_HIP(hipDeviceSynchronize());
   e->root = e;
+  { int rc2 = place_large_matrices(e); if (rc2 != SL2_OK) return rc2; }
+#ifdef SL2_TESTING
+  if (getenv("SL2_DEBUG_PLACE")) fprintf(stderr, "PLACE %d candidates; kept P %.4f Vt %.4f At %.4f St %.4f; slowest P %.4f A %.4f St %.4f\n", e->place_candidates, e->place_kept_ms[0], e->place_kept_ms[1], e->place_kept_ms[2], e->place_kept_ms[3], e->place_worst_ms[0], e->place_worst_ms[1], e->place_worst_ms[2]);
+#endif
   int G = 1;
 #ifdef SL2_TESTING
   // Development switches of the TEST build of the library (libscenelib2_amd_test.so, scripts/variants.sh): the product
@@ -1299,6 +1390,15 @@ int sl2_get_kernel_time(sl2_engine* e, int idx, const char** name, double* total
   if (name) *name = e->timers[idx].name.c_str();
   if (total_ms) *total_ms = e->timers[idx].total_ms;
   if (launches) *launches = e->timers[idx].launches;
+  return SL2_OK;
+}
+
+int sl2_get_placement(sl2_engine* e, double* out, int capacity) {
+  if (!e || !out || capacity < 0) return SL2_ERR_INVALID;
+  const sl2_engine* r = e->root;
+  const double v[SL2_PLACEMENT_COUNT] = {(double)r->place_candidates, r->place_kept_ms[0], r->place_kept_ms[1], r->place_kept_ms[2],
+                                         r->place_kept_ms[3], r->place_worst_ms[0], r->place_worst_ms[1], r->place_worst_ms[2]};
+  for (int i = 0; i < capacity && i < SL2_PLACEMENT_COUNT; ++i) out[i] = v[i];
   return SL2_OK;
 }
 

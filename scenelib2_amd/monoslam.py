@@ -326,6 +326,14 @@ class Engine:
             out[name.value.decode()] = dict(total_ms=ms.value, launches=cnt.value)
         return out
 
+    def placement(self):
+        """sl2_get_placement: how sl2_create placed the large matrices (candidates probed, probe ms of the kept P, V^T, A^T, S and
+        of the slowest candidate of each size); zeros for an engine too small for it to matter."""
+        w = np.zeros(8)
+        self._ck(self.L.sl2_get_placement(self.h, _lib.dp(w), w.size))
+        keys = ["candidates_of_P", "kept_P_ms", "kept_Vt_ms", "kept_At_ms", "kept_S_ms", "slowest_P_ms", "slowest_A_ms", "slowest_S_ms"]
+        return dict(zip(keys, w.tolist()))
+
     def step_work(self):
         w = np.zeros(13)
         self._ck(self.L.sl2_get_step_work(self.h, _lib.dp(w), w.size))

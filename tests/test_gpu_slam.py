@@ -1053,3 +1053,17 @@ def test_large_batch_of_small_maps_fuses_the_back_side_only():
     t0, t1 = engs[0].kernel_times(), engs[1].kernel_times()
     assert "k_small_back" in t0 and "k_predict" in t0 and "k_small_front" not in t0 and "k_syrk" not in t0, t0.keys()
     assert "k_syrk" in t1 and "k_small_back" not in t1
+
+
+def test_create_places_the_large_matrices_and_says_so():
+    """sl2_create times a streaming probe on candidate allocations of P, A^T / V^T and S and keeps the fastest of each kind
+    (sl2_engine.hip: place_large_matrices) - only for engines whose covariance is at least 256 MB.  The report must say what was
+    done, the buffers must still be all zeros (a fresh engine's total state and covariance), and a small engine is left alone."""
+    cam, params = synth.default_camera(), synth.default_params(16)
+    big = Engine(cam, params, 1024, 60)            # ld = 256: P = 512 MB
+    rep = big.placement()
+    assert rep["candidates_of_P"] >= 2 and 0.0 < rep["kept_P_ms"] <= rep["slowest_P_ms"]
+    assert 0.0 < rep["kept_Vt_ms"] <= rep["kept_At_ms"] <= rep["slowest_A_ms"] and 0.0 < rep["kept_S_ms"] <= rep["slowest_S_ms"]
+    assert not big.total_covariance(1023).any() and not big.total_state(0)[:3].any()
+    small = Engine(cam, params, 4, 16)
+    assert not any(small.placement().values())

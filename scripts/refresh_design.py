@@ -47,7 +47,7 @@ def main():
         s = s[:m.start(2)] + new + s[m.end(2):]
 
     cell(re.escape("`k_search_mfma` + `k_search_score`"), "%.4f ms, %.3f of 8 TB/s; MFMA floor 15.8 us" % (k["k_search_mfma"]["ms_per_step"], b["roofline"]["search"]["frac"]))
-    cell(re.escape("`k_build_AS`"), "%.3f ms (two modes from process to process: 0.31-0.32 / 0.34-0.35)" % k["k_build_AS"]["ms_per_step"])
+    cell(re.escape("`k_build_AS`"), "%.3f ms (on the allocation `sl2_create` chose, section 3; 0.335-0.357 on a slow one)" % k["k_build_AS"]["ms_per_step"])
     cell(re.escape("`k_chol_left`"), "%.3f ms" % k["k_chol_left"]["ms_per_step"])
     cell(re.escape("`k_fwdsub_lds`"), "%.3f ms = %.2f of 78.6 TFLOP/s" % (k["k_fwdsub_lds"]["ms_per_step"], fwd_frac))
     cell(re.escape("`k_syrk` (the dominant kernel"), "%.3f ms = **%.3f** of 78.6 TFLOP/s" % (k["k_syrk"]["ms_per_step"], b["roofline"]["frac"]))

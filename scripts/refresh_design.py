@@ -37,7 +37,7 @@ def main():
 
     s = re.sub(r"Headline \(driver protocol.*?smoke 5\.4e-15 / 2\.0e-14\.",
                "Headline (driver protocol `--steps 20 --warmup 5`): **%d k sequence-frames/s, %.3f ms per step** of 1024 sequences x 100 features in the\n"
-               "committed final run (library %s; 654-697 k over the round's boxes and protocols; r05: 673 k / 1.521).\n"
+               "committed final run (library %s; before the placement of section 3: 654-697 k over the round's boxes and protocols; r05: 673 k / 1.521).\n"
                "GPU tests %s passed; smoke 5.4e-15 / 2.0e-14." % (round(d["value"] / 1e3), d["ms_per_step"], git, ntests), s, flags=re.S)
 
     def cell(pattern, new):
@@ -125,8 +125,8 @@ def main():
             "| GPU tests / smoke | %s passed; 5.4e-15 / 2.0e-14 | `r06_final_pytest_gpu.log` |\n\n" % ntests)
     late = os.path.join(P, "r06_final_late_git.txt")
     if os.path.exists(late) and open(late).read().strip() != git:
-        sec8 += ("The mapping line, the adapter, small-map and mapping latency files and the test log are from library %s: `k_small_back`'s LDS layout and\n"
-                 "`k_map_update`'s first reads changed after the headline, configs[1] / [3] / [4], counter and rank runs (%s), which they do not touch.\n\n" % (
+        sec8 += ("The mapping line and the adapter, small-map and mapping latency files were taken at library %s; the others at %s,\n"
+                 "which differs from it by the placement of the large matrices (section 3) - engines of those sizes are not placed.\n\n" % (
                      open(late).read().strip(), git))
     s = s[:a] + sec8 + s[e:]
     open(path, "w").write(s)

@@ -340,9 +340,12 @@ static int place_large_matrices(sl2_engine* e) {
     pool.push_back({p, ms});
   };
   add(cP, e->P, nP); add(cA, e->At, nA); add(cA, e->Vt, nA); add(cS, e->St, nS);
+  // the candidates together never hold more than a quarter of what is free now
+  size_t budget = 0;
+  { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = free_b / 4; }
   for (int t = 1; t < kPlaceTries && rc == SL2_OK; ++t) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || set_bytes > free_b / 4) break;
+    if (set_bytes > budget) break;
+    budget -= set_bytes;
     double *p = nullptr, *a = nullptr, *v = nullptr, *st = nullptr;
     if (dmalloc(&p, B * nP) != SL2_OK || dmalloc(&a, B * nA) != SL2_OK || dmalloc(&v, B * nA) != SL2_OK || dmalloc(&st, B * nS) != SL2_OK) {
       if (p) hipFree(p); if (a) hipFree(a); if (v) hipFree(v); if (st) hipFree(st);
@@ -354,8 +357,8 @@ static int place_large_matrices(sl2_engine* e) {
   // The covariance is the one that decides k_build_AS's speed (and moves k_syrk's with it), and about one candidate in five is a
   // fast one: more of it alone, as many again.
   for (int t = 0; t < kPlaceTries && rc == SL2_OK; ++t) {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || sizeof(double) * B * nP > free_b / 4) break;
+    if (sizeof(double) * B * nP > budget) break;
+    budget -= sizeof(double) * B * nP;
     double* p = nullptr;
     if (dmalloc(&p, B * nP) != SL2_OK) { (void)hipGetLastError(); break; }
     add(cP, p, nP);

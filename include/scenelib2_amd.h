@@ -477,8 +477,10 @@ int sl2_get_step_work(sl2_engine* e, double* out, int capacity);
  * an allocation, not visible in its address - so sl2_create times a streaming probe on several candidate allocations and keeps
  * the fastest of each kind (engines whose covariance is smaller than 256 MB: not tried, all zeros here).
  * out[0] = candidate allocations of P probed, out[1..4] = probe time in ms of the kept P, V^T, A^T, S, out[5..7] = of the slowest candidate
- * seen for P, for A^T / V^T, for S.  min(capacity, SL2_PLACEMENT_COUNT) values are written. */
-#define SL2_PLACEMENT_COUNT 8
+ * seen for P, for A^T / V^T, for S, out[8..9] = k_syrk itself on the kept pair (P, V^T) and on the slowest pair tried (the kernel
+ * is its own probe: on an all-zero engine it does its full work and changes nothing).  min(capacity, SL2_PLACEMENT_COUNT) values
+ * are written. */
+#define SL2_PLACEMENT_COUNT 10
 int sl2_get_placement(sl2_engine* e, double* out, int capacity);
 
 /* ------------------------------------------------------------- synthetic input */

@@ -201,6 +201,7 @@ struct sl2_engine {
   unsigned long long* parts_mail = nullptr;      // the word after it, one-sequence engines: (steps completed << 32) | partially initialised features left by k_map_update
   unsigned long long* parts_mail_dev = nullptr;
   int place_candidates = 0;                      // sl2_create's placement of the large matrices (sl2_engine.hip: place_large_matrices): sets probed,
+  float place_syrk_ms[2] = {0, 0};               // k_syrk on the kept (P, V^T) and on the slowest pair probed
   float place_kept_ms[4] = {0, 0, 0, 0};         // probe time of the kept P, V^T, A^T, S and of the slowest candidate of each size
   float place_worst_ms[3] = {0, 0, 0};
   long long parts_block_step = -1;               // a step of this index must not trust parts_mail (a feature was initialised by hand since)
@@ -313,6 +314,7 @@ int small_step_mode(const sl2_engine* e, int slots_bound);       // sl2_small.hi
 int launch_small_front(sl2_engine* e, int n);                 // predict + feature prediction + selection in one launch
 int launch_small_back(sl2_engine* e, int save_trajectory, int slots_bound);   // scoring + EKF update + normalise / delete / symmetrise in one launch
 int launch_update(sl2_engine* e);
+int launch_syrk_on(sl2_engine* e, const double* Vt, double* P);
 int launch_finalize(sl2_engine* e, int save_trajectory);
 int launch_mapping(sl2_engine* e, int enable_mapping, int save_trajectory, int slots_bound, int parts_state);
 int launch_manual_init(sl2_engine* e, const int* d_uv);

@@ -1387,6 +1387,22 @@ static int launch_update_range(sl2_engine* e) {
 
 int launch_update(sl2_engine* e) { return launch_update_range(e); }
 
+// k_syrk on the given covariance and V^T, everything else the engine's: sl2_create's placement probe (sl2_engine.hip:
+// place_large_matrices), which fills m_count / n_slots for the occasion - on an engine that holds nothing but zeros the launch
+// does its full work and changes nothing.
+int launch_syrk_on(sl2_engine* e, const double* Vt, double* P) {
+  const int nt = e->ld / 64;
+#ifdef SL2_CHOL_TRACE
+  hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, e->B)), dim3(256), 0, e->stream, Vt, P, e->x, e->m_count, e->ld, e->mld, e->B,
+                     e->n_slots, e->ppos, (long long*)nullptr);
+#else
+  hipLaunchKernelGGL(k_syrk, dim3(xcd_grid(nt * (nt + 1) / 2, e->B)), dim3(256), 0, e->stream, Vt, P, e->x, e->m_count, e->ld, e->mld, e->B,
+                     e->n_slots, e->ppos);
+#endif
+  SL2_HIP(hipGetLastError());
+  return SL2_OK;
+}
+
 }  // namespace sl2
 
 #ifdef SL2_TESTING   // section 10 of sl2_ekf_update_testing.inc: everything below is test / calibration code: libscenelib2_amd_test.so only (include/scenelib2_amd_testing.h)

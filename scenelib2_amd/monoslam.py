@@ -329,9 +329,10 @@ class Engine:
     def placement(self):
         """sl2_get_placement: how sl2_create placed the large matrices (candidates probed, probe ms of the kept P, V^T, A^T, S and
         of the slowest candidate of each size); zeros for an engine too small for it to matter."""
-        w = np.zeros(8)
+        w = np.zeros(10)
         self._ck(self.L.sl2_get_placement(self.h, _lib.dp(w), w.size))
-        keys = ["candidates_of_P", "kept_P_ms", "kept_Vt_ms", "kept_At_ms", "kept_S_ms", "slowest_P_ms", "slowest_A_ms", "slowest_S_ms"]
+        keys = ["candidates_of_P", "kept_P_ms", "kept_Vt_ms", "kept_At_ms", "kept_S_ms", "slowest_P_ms", "slowest_A_ms", "slowest_S_ms",
+                "k_syrk_on_kept_pair_ms", "k_syrk_on_slowest_pair_ms"]
         return dict(zip(keys, w.tolist()))
 
     def step_work(self):

@@ -1064,6 +1064,8 @@ def test_create_places_the_large_matrices_and_says_so():
     rep = big.placement()
     assert rep["candidates_of_P"] >= 2 and 0.0 < rep["kept_P_ms"] <= rep["slowest_P_ms"]
     assert 0.0 < rep["kept_Vt_ms"] <= rep["kept_At_ms"] <= rep["slowest_A_ms"] and 0.0 < rep["kept_S_ms"] <= rep["slowest_S_ms"]
+    assert 0.0 < rep["k_syrk_on_kept_pair_ms"] <= rep["k_syrk_on_slowest_pair_ms"]          # the kernel itself on the candidate pairs
     assert not big.total_covariance(1023).any() and not big.total_state(0)[:3].any()
+    assert big.total_state_sizes(0, 1024).max() == 13                                     # (m_count / n_slots, filled for that probe, are back at zero)
     small = Engine(cam, params, 4, 16)
     assert not any(small.placement().values())

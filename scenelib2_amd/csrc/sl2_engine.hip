@@ -296,9 +296,10 @@ int sl2_device_count(void) {
 // steers it.  So sl2_create asks: a probe - every sequence's workgroup streams its own part of a buffer, read and write, the way
 // the update's kernels do - is timed on each of the four large matrices, up to kPlaceTries - 1 further sets are allocated BESIDE
 // the first (held, not freed and re-allocated: a freed set tends to come back the same) and probed the same way, and the engine
-// keeps the fastest buffer of each kind; the rest is freed.  For P more candidates are tried alone (up to 40 in all) until one stands
-// out: about one in five is fast (probe 0.296-0.304 ms against 0.32-0.36), and it is P that decides k_build_AS (0.306-0.318 with a
-// fast one, 0.325-0.329 in the two processes of eighteen whose twenty candidates held none).  Only where it can matter (kPlaceMinBytes of P), and never beyond a quarter of the free memory.
+// keeps the fastest buffer of each kind; the rest is freed.  For P more candidates are tried alone (up to 40 in all) until one
+// stands out: about one in five is fast (probe 0.296-0.304 ms against 0.32-0.36), and it is P that k_build_AS streams.  k_syrk is
+// then timed itself on the pairs of the best candidates of P and V^T (below).  Only where it can matter (kPlaceMinBytes of P), and
+// never beyond a quarter of the free memory.  Same-box A/B: -2.1 / -2.2 % of the step (profiles/r06_placement_ab.txt).
 // ---------------------------------------------------------------------------
 constexpr int kPlaceTries = 10;
 constexpr size_t kPlaceMinBytes = (size_t)256 << 20;
